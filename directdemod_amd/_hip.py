@@ -1,0 +1,251 @@
+"""
+ctypes binding of the C-ABI in include/directdemod_hip.h (libdirectdemod_hip.so,
+built in-tree by __graft_entry__.build()).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is
+visible when a compute entry point is reached, the call raises.
+"""
+import ctypes as C
+import os
+import threading
+from fractions import Fraction
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdirectdemod_hip.so")
+
+DD_OK = 0
+DD_ERR_INVALID = -1
+DD_ERR_HIP = -2
+DD_ERR_NOMEM = -3
+DD_ERR_UNSUPPORTED = -4
+DD_ERR_NODEVICE = -5
+
+DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
+DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_int = C.c_int
+_sz = C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/directdemod_hip.h declares
+SIGNATURES = {
+    "dd_last_error": (C.c_char_p, []),
+    "dd_version": (C.c_char_p, []),
+    "dd_device_count": (_int, [C.POINTER(_int)]),
+    "dd_set_device": (_int, [_int]),
+    "dd_device_name": (_int, [C.c_char_p, _int]),
+    "dd_malloc": (_int, [_pp, _sz]),
+    "dd_free": (_int, [_p]),
+    "dd_memset": (_int, [_p, _int, _sz, _p]),
+    "dd_host_alloc_pinned": (_int, [_pp, _sz]),
+    "dd_host_free_pinned": (_int, [_p]),
+    "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
+    "dd_memcpy_d2h": (_int, [_p, _p, _sz, _p]),
+    "dd_memcpy_d2d": (_int, [_p, _p, _sz, _p]),
+    "dd_stream_create": (_int, [_pp]),
+    "dd_stream_destroy": (_int, [_p]),
+    "dd_stream_sync": (_int, [_p]),
+    "dd_event_create": (_int, [_pp]),
+    "dd_event_destroy": (_int, [_p]),
+    "dd_event_record": (_int, [_p, _p]),
+    "dd_event_elapsed_ms": (_int, [_p, _p, C.POINTER(C.c_float)]),
+    "dd_u8iq_to_c64": (_int, [_p, _p, _i64, _p]),
+    "dd_nco_c64": (_int, [_p, _p, _i64, _u64, _i64, _p]),
+    "dd_fir_create": (_int, [_pp, C.POINTER(C.c_double), _int]),
+    "dd_fir_destroy": (_int, [_p]),
+    "dd_fir_reset": (_int, [_p, _int, _p, _p]),
+    "dd_fir_c64": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "dd_fir_f64": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "dd_filtfilt_f64": (_int, [C.POINTER(C.c_double), _int, _p, _p, _i64, _int, _p]),
+    "dd_filtfilt_c64": (_int, [C.POINTER(C.c_double), _int, _p, _p, _i64, _p]),
+    "dd_decimate": (_int, [_p, _p, _i64, _int, _int, _int, _pi64, _p]),
+    "dd_fm_create": (_int, [_pp]),
+    "dd_fm_destroy": (_int, [_p]),
+    "dd_fm_reset": (_int, [_p]),
+    "dd_fm_discrim_c64": (_int, [_p, _p, _p, _i64, _int, _pi64, _p]),
+    "dd_fused_process": (_int, [_p, _p, _p, _p, _i64, _int, _u64, _i64, _int, _int, _int, _int, _pi64, _p]),
+    "dd_chain_create": (_int, [_pp, C.POINTER(C.c_double), _int, _u64, _int, _int]),
+    "dd_chain_destroy": (_int, [_p]),
+    "dd_chain_reset": (_int, [_p, _p]),
+    "dd_chain_prime": (_int, [_p, _p, _i64, _i64, _p]),
+    "dd_chain_out_count": (_i64, [_p, _i64]),
+    "dd_chain_process": (_int, [_p, _p, _p, _i64, _pi64, _p]),
+    "dd_chain_path": (_int, [_p]),
+    "dd_resample_fft_f64": (_int, [_p, _p, _i64, _i64, _p]),
+    "dd_am_envelope_f64": (_int, [_p, _p, _i64, _i64, _p]),
+    "dd_xcorr_norm_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
+    "dd_find_peaks_f64": (_int, [_p, _i64, C.c_double, _int, _pi64, _int, C.POINTER(_int), _p]),
+    "dd_f32_to_f64": (_int, [_p, _p, _i64, _p]),
+    "dd_f64_to_f32": (_int, [_p, _p, _i64, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_gpu_checked = False
+_last_path = None
+
+
+def load():
+    """dlopen the C-ABI library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "directdemod_amd: %s is missing -- run `python __graft_entry__.py` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def lib():
+    return _lib if _lib is not None else load()
+
+
+def last_error():
+    return lib().dd_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc == DD_OK:
+        return
+    msg = "%s: %s (code %d)" % (what or "directdemod_hip", last_error(), rc)
+    if rc == DD_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == DD_ERR_NOMEM:
+        raise MemoryError(msg)
+    if rc == DD_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipError(msg)
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run."""
+    global _gpu_checked
+    if _gpu_checked:
+        return
+    n = _int(0)
+    rc = lib().dd_device_count(C.byref(n))
+    if rc != DD_OK or n.value < 1:
+        raise HipError("directdemod_amd needs an AMD MI355X (gfx950) visible to HIP; none found: %s. "
+                       "There is no CPU fallback." % last_error())
+    _gpu_checked = True
+
+
+def device_name():
+    require_gpu()
+    buf = C.create_string_buffer(256)
+    check(lib().dd_device_name(buf, 256), "dd_device_name")
+    return buf.value.decode()
+
+
+def cycles_q64(freq_hz, samp_rate):
+    """frac(f/fs) * 2^64 as an unsigned 64-bit integer, from the exact rational value
+    of the two floats (the reference forms 2*pi*f*n/fs in float64, comm.py:77)."""
+    fr = Fraction(float(freq_hz)) / Fraction(int(samp_rate))
+    q = round(fr * (1 << 64))
+    return int(q) % (1 << 64)
+
+
+def set_last_path(p):
+    global _last_path
+    _last_path = p
+
+
+def last_chain_path():
+    return {None: "none", 0: "direct-f32", 1: "mfma-f16x3"}.get(_last_path, str(_last_path))
+
+
+# ------------------------------------------------------------------ device arrays
+_DT = {
+    "c64": np.dtype(np.complex64), "f32": np.dtype(np.float32),
+    "f64": np.dtype(np.float64), "c128": np.dtype(np.complex128), "u8": np.dtype(np.uint8),
+}
+
+
+class DevArray:
+    """1-D array resident in HBM (owned hipMalloc buffer or a view of one)."""
+
+    __slots__ = ("ptr", "n", "dtype", "_owner", "_base")
+
+    def __init__(self, n, dtype, ptr=None, base=None):
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self._base = base
+        if ptr is None:
+            require_gpu()
+            p = C.c_void_p()
+            check(lib().dd_malloc(C.byref(p), max(16, self.n * self.dtype.itemsize)), "dd_malloc")
+            self.ptr = p.value
+            self._owner = True
+        else:
+            self.ptr = int(ptr)
+            self._owner = False
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def view(self, start, count):
+        return DevArray(count, self.dtype, ptr=self.ptr + start * self.dtype.itemsize,
+                        base=self if self._base is None else self._base)
+
+    @staticmethod
+    def from_host(a, dtype=None, stream=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = DevArray(a.size, a.dtype)
+        if a.size:
+            check(lib().dd_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes, stream), "h2d")
+            check(lib().dd_stream_sync(stream), "sync")
+        return d
+
+    def to_host(self, stream=None):
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            check(lib().dd_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, stream), "d2h")
+            check(lib().dd_stream_sync(stream), "sync")
+        return out
+
+    def free(self):
+        if getattr(self, "_owner", False) and self.ptr:
+            try:
+                lib().dd_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr = 0
+            self._owner = False
+
+    def __del__(self):
+        self.free()
+
+
+def to_device(x, dtype):
+    if isinstance(x, DevArray):
+        if x.dtype != np.dtype(dtype):
+            raise TypeError("device array has dtype %s, expected %s" % (x.dtype, np.dtype(dtype)))
+        return x
+    return DevArray.from_host(np.asarray(x), dtype=dtype)
+
+
+def sync(stream=None):
+    check(lib().dd_stream_sync(stream), "sync")

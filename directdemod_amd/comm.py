@@ -1,0 +1,305 @@
+"""
+commSignal -- device-resident signal container, drop-in for the reference's
+directdemod/comm.py:15-181 (same constructor, fluent methods and properties).
+
+MI355X design.  The reference runs every fluent call as a separate full-array
+NumPy/SciPy pass.  Here the samples live in HBM and the calls that make up the
+per-sample hot path --
+
+    .offsetFreq(f)  .filter(fir)  .bwLim(rate)  .funcApply(fm.demod)
+    (decode_noaa.py:623, decode_fm.py:64-68, tutorial/3_chunking.py:30-37)
+
+-- are *recorded* and executed as ONE fused HIP kernel (dd_fused_process: NCO ->
+LDS-staged FIR -> only the kept outputs -> atan2 discriminator) the moment a result
+is needed.  All bookkeeping the reference does at call time (chunker variables,
+lengths, sample rates, first-chunk quirks) is still done at call time, so the
+observable behaviour is the reference's; only the arithmetic is deferred.  Pending
+work is kept in one global FIFO so operator state (filter history, last FM sample)
+always advances in call order.
+"""
+import numpy as np
+
+from . import _hip, constants
+from ._hip import DevArray
+
+_C64 = np.dtype(np.complex64)
+_F32 = np.dtype(np.float32)
+_F64 = np.dtype(np.float64)
+
+# FIFO of commSignal objects that still have recorded, un-executed operations
+_pending = []
+
+
+def flush_all():
+    """Execute every recorded operation, oldest signal first."""
+    while _pending:
+        s = _pending.pop(0)
+        s._run_ops()
+
+
+class commSignal:
+    '''
+    Stores a signal (in device memory) and its sampling rate
+    '''
+
+    def __init__(self, sampRate, sig=np.array([]), chunker=None):
+        '''Initialize the object
+
+        Args:
+            sampRate (:obj:`int`): sampling rate in Hz, forced to int (comm.py:34)
+            sig (:obj:`numpy array` or device array, optional): one dimensional
+            chunker (:obj:`chunker`, optional): chunking object, if processed in chunks
+        '''
+        self.__chunker = chunker
+        self.__len = len(sig)
+        self.__sampRate = int(sampRate)
+        if self.__sampRate <= 0:
+            raise ValueError("The sampling rate must be greater than zero")
+        self._ops = []
+        self._host = None
+        self._dev = None
+        self._cap = None            # growable device buffer used by extend()
+        self._store(sig, copy=True)
+
+    # ------------------------------------------------------------------ storage
+    def _store(self, sig, copy):
+        if isinstance(sig, DevArray):
+            self._dev = sig
+            self._host = None
+        else:
+            a = np.array(sig) if copy else np.asarray(sig)      # ctor copies (comm.py:38)
+            if a.ndim == 0 or not a.size == a.shape[0]:
+                raise TypeError("The signal array must be 1-D")
+            self._host = a
+            self._dev = None
+        self._cap = None
+        self._ops = []
+
+    def _device(self, want=None):
+        """Device copy of the stored array.  Complex -> complex64, real -> float64
+        unless the array already is float32 on the device (FM output)."""
+        if self._dev is None:
+            a = self._host
+            if np.iscomplexobj(a):
+                dt = _C64
+            else:
+                dt = _F64
+            self._dev = DevArray.from_host(a, dtype=dt)
+        if want is not None and self._dev.dtype != np.dtype(want):
+            self._dev = _convert(self._dev, want)
+            self._host = None
+        return self._dev
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def length(self):
+        ''':obj:`int`: get length of signal'''
+        return self.__len
+
+    @property
+    def sampRate(self):
+        ''':obj:`int`: get sampling rate of signal'''
+        return self.__sampRate
+
+    @property
+    def signal(self):
+        ''':obj:`numpy array`: the samples (downloads from the device when needed).
+        Device float32 results (FM output) are handed out as float64 like the
+        reference's; complex stays complex64 (declared deviation Q6: the reference
+        holds complex128 after ``filter``).'''
+        self._materialise()
+        if self._host is None:
+            a = self._dev.to_host()
+            if a.dtype == _F32:
+                a = a.astype(np.float64)
+            self._host = a
+        return self._host
+
+    @property
+    def device_signal(self):
+        """The samples as a device array (no download)."""
+        self._materialise()
+        return self._device()
+
+    def _materialise(self):
+        if self._ops:
+            flush_all()
+
+    # ------------------------------------------------------------------ hot path (recorded)
+    def _record(self, op):
+        if not self._ops:
+            _pending.append(self)
+        self._ops.append(op)
+
+    def offsetFreq(self, freqOffset):
+        '''Offset signal by a frequency by multiplying a complex envelope (comm.py:63-78)'''
+        if np.ndim(freqOffset) != 0:
+            raise TypeError("per-sample frequency arrays are outside the GPU hot path (decode_funcube only)")
+        offset = 0
+        if self.__chunker is not None:
+            offset = self.__chunker.get(constants.CHUNK_FREQOFFSET, 0)
+            self.__chunker.set(constants.CHUNK_FREQOFFSET, offset + self.length)
+        self._record(("nco", _hip.cycles_q64(freqOffset, self.sampRate), int(offset)))
+        return self
+
+    def filter(self, filt):
+        '''Apply a filter to the signal (comm.py:80-92)'''
+        from . import filters as _f
+        if isinstance(filt, _f.filter) and filt._fusable():
+            self._record(("fir", filt))
+            return self
+        self.updateSignal(filt.applyOn(self._op_input()))
+        return self
+
+    def bwLim(self, tsampRate, strict=False, uniq="abcd"):
+        '''Limit the bandwidth by downsampling (comm.py:94-130)'''
+        if self.__sampRate < tsampRate:
+            raise ValueError("The target sampling rate must be less than current sampling rate")
+        if strict:
+            # Fourier-domain resample of the whole chunk == scipy.signal.resample (comm.py:110-116)
+            from . import _ops
+            num = int(tsampRate * self.length / self.sampRate)
+            self._materialise()
+            self._store(_ops.resample_fft(self._device(), num), copy=False)
+            self.__sampRate = tsampRate
+            self.__len = num
+        else:
+            jumpIndex = int(self.sampRate / tsampRate)
+            offset = 0
+            if self.__chunker is not None:
+                offset = self.__chunker.get(constants.CHUNK_BWLIM + uniq, 0)
+                nextOff = (jumpIndex - (self.length - offset) % jumpIndex) % jumpIndex
+                self.__chunker.set(constants.CHUNK_BWLIM + uniq, nextOff)
+            self._record(("decim", jumpIndex, int(offset)))
+            self.__sampRate = int(self.sampRate / jumpIndex)
+            self.__len = len(range(offset, self.__len, jumpIndex))
+        return self
+
+    def funcApply(self, func):
+        ''' Applies a function to the signal (comm.py:132-144).  Bound ``demod``
+        methods of this package's demodulators stay on the device.'''
+        from . import demod_fm as _dfm
+        owner = getattr(func, "__self__", None)
+        if isinstance(owner, _dfm.demod_fm) and getattr(func, "__name__", "") == "demod":
+            self.__len = owner._note_call(self.__len)
+            self._record(("fm", owner))
+            return self
+        self.updateSignal(func(self._op_input()))
+        return self
+
+    def _op_input(self):
+        """What a foreign operator receives: this package's operators accept device
+        arrays; anything else gets the NumPy array like in the reference."""
+        self._materialise()
+        return self._dev if self._dev is not None else self._host
+
+    # ------------------------------------------------------------------ container ops
+    def extend(self, sig):
+        ''' Adds another signal to this one at the tail end (comm.py:146-164).
+        Device-side append into a geometrically grown buffer (the reference
+        re-concatenates everything each chunk).'''
+        if self.length == 0:
+            self.__sampRate = sig.sampRate
+        if not self.__sampRate == sig.sampRate:
+            raise TypeError("Signals must have same sampling rate to be extended")
+        self._materialise()
+        sig._materialise()
+        if sig.length == 0:
+            return self
+        other = sig._device()
+        if self.__len == 0:
+            mine_dt = other.dtype
+        else:
+            mine_dt = self._device().dtype
+            if mine_dt != other.dtype:
+                # mixed precision (e.g. float32 FM output appended to float64): widen
+                wide = _F64 if (mine_dt.kind == "f" and other.dtype.kind == "f") else _C64
+                if mine_dt != wide:
+                    self._dev = _convert(self._dev, wide)
+                    self._cap = None
+                    mine_dt = wide
+                if other.dtype != wide:
+                    other = _convert(other, wide)
+        need = self.__len + other.n
+        if self._cap is None or self._cap.n < need or self._cap.dtype != mine_dt:
+            cap = DevArray(max(need * 2, 1024), mine_dt)
+            if self.__len:
+                _hip.check(_hip.lib().dd_memcpy_d2d(cap.ptr, self._device().ptr, self.__len * mine_dt.itemsize, None), "d2d")
+            self._cap = cap
+        _hip.check(_hip.lib().dd_memcpy_d2d(self._cap.ptr + self.__len * mine_dt.itemsize, other.ptr,
+                                            other.n * mine_dt.itemsize, None), "d2d")
+        self.__len = need
+        self._dev = self._cap.view(0, need)
+        self._host = None
+        return self
+
+    def updateSignal(self, sig):
+        ''' Updates the signal (comm.py:166-181); copies host arrays like the reference'''
+        self._materialise()
+        if isinstance(sig, DevArray):
+            self._store(sig, copy=False)
+        else:
+            a = np.array(sig)
+            if a.ndim == 0 or not a.size <= a.shape[0]:
+                raise TypeError("The signal array must be 1-D")
+            self._store(a, copy=False)
+        self.__len = len(sig)
+        return self
+
+    # ------------------------------------------------------------------ execution
+    def _run_ops(self):
+        ops, self._ops = self._ops, []
+        from . import _ops
+        x = self._device()
+        i = 0
+        while i < len(ops):
+            kind = ops[i][0]
+            nco = None
+            if kind == "nco" and i + 1 < len(ops) and ops[i + 1][0] == "fir":
+                nco = ops[i]
+                i += 1
+                kind = "fir"
+            if kind == "fir":
+                filt = ops[i][1]
+                j = i + 1
+                decim = (1, 0)
+                fm = None
+                if j < len(ops) and ops[j][0] == "decim":
+                    decim = (ops[j][1], ops[j][2])
+                    j += 1
+                if j < len(ops) and ops[j][0] == "fm":
+                    fm = ops[j][1]
+                    j += 1
+                if x.dtype == _C64:
+                    x = _ops.fused(x, filt, nco, decim, fm)
+                    i = j
+                    continue
+                # real (audio-rate) data: stage by stage in float64
+                x = filt.applyOn(x)
+                i += 1
+                continue
+            if kind == "nco":
+                x = _ops.nco(x, ops[i][1], ops[i][2])
+            elif kind == "decim":
+                x = _ops.decimate(x, ops[i][1], ops[i][2])
+            elif kind == "fm":
+                x = ops[i][1]._demod_device(x)
+            i += 1
+        self._dev = x
+        self._host = None
+        self._cap = None
+
+
+def _convert(d, want):
+    want = np.dtype(want)
+    if d.dtype == want:
+        return d
+    lib = _hip.lib()
+    out = DevArray(d.n, want)
+    if d.dtype == _F32 and want == _F64:
+        _hip.check(lib.dd_f32_to_f64(d.ptr, out.ptr, d.n, None), "f32->f64")
+    elif d.dtype == _F64 and want == _F32:
+        _hip.check(lib.dd_f64_to_f32(d.ptr, out.ptr, d.n, None), "f64->f32")
+    else:
+        out = DevArray.from_host(d.to_host().astype(want))
+    return out

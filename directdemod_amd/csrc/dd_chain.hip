@@ -1,0 +1,648 @@
+// Fused hot path, f32 direct form:  offsetFreq (NCO) -> FIR (state carried) ->
+// bwLim (integer decimation, only kept outputs are computed) -> demod_fm.
+// Reference call sites: decode_noaa.py:623, decode_fm.py:64-68,
+// decode_afsk1200.py:79-94, tutorial/3_chunking.py:24-38; operators comm.py:63-130,
+// filters.py:53-75, demod_fm.py:29-51.
+//
+// Two kernels share the staging / epilogue code:
+//   k_chain_dense  (M == 1)  256 threads x 8 contiguous outputs, register-tiled
+//                            sliding window, planar skewed LDS (conflict-free b32)
+//   k_chain_decim  (M >= 2)  one thread per kept output, float2 skewed LDS
+// Taps are wave-uniform and come through the scalar cache (s_load), so the VALU
+// issues only FMAs and LDS reads.
+#include "dd_chain_kernels.h"
+
+#define DD_DENSE_R 8
+#define DD_DENSE_THREADS 256
+#define DD_DENSE_T (DD_DENSE_R * DD_DENSE_THREADS)
+#define DD_DECIM_THREADS 256
+#define DD_DECIM_SPAN_MAX 6144
+
+// ============================================================================
+// dense kernel
+// ============================================================================
+// LDS: sre[pos(e)], sim[pos(e)], pos(e) = e + (e >> 3)  (thread t reads 9t + ...)
+__global__ void __launch_bounds__(DD_DENSE_THREADS) k_chain_dense(const DDChainParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int R = DD_DENSE_R;
+    const int T = DD_DENSE_T;
+    const int K = P.K;
+    const int niter = (K + R - 1 + R - 1) / R;          // window elements / R, rounded up
+    const int S = T + niter * R;                        // staged elements (incl. slack)
+    const int SP = S + (S >> 3) + 8;                    // skewed length
+    float* sre = reinterpret_cast<float*>(smem);
+    float* sim = sre + SP;
+    float2* w2 = reinterpret_cast<float2*>(sim + SP);   // per-64-group phasors
+    float2* ylast = w2 + ((S + 63) / 64 + 1);           // per-thread last output
+
+    const int t = threadIdx.x;
+    const int b = dd_xcd_tile(blockIdx.x, P.nblocks);
+    const int64_t pfirst = dd_tile_pfirst(P, b);
+    const int64_t ns = pfirst - (K - 1);                // chunk-relative index of staged element 0
+    const bool fm = (P.flags & DD_CHAIN_FM) != 0;
+
+    // ---- per-group NCO phasors
+    const int ngroups = (S + 63) / 64;
+    if (P.flags & DD_CHAIN_NCO) {
+        for (int g = t; g < ngroups; g += DD_DENSE_THREADS) {
+            const uint64_t ph = (uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc;
+            w2[g] = dd_phasor(ph, P.nco_tbl);
+        }
+    }
+    __syncthreads();
+    // ---- stage the tile (coalesced), NCO applied on the way in
+    {
+        const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        for (int e = t; e < S; e += DD_DENSE_THREADS) {
+            float2 ph = make_float2(1.f, 0.f);
+            if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
+            const float2 v = dd_load_sample(P, ns + e, ph);
+            const int p = e + (e >> 3);
+            sre[p] = v.x;
+            sim[p] = v.y;
+        }
+    }
+    __syncthreads();
+
+    // ---- new tail: the last tile holds the chunk's final K-1 (post-NCO) samples
+    if (b == P.nblocks - 1 && P.tail_out) {
+        for (int i = t; i < K - 1; i += DD_DENSE_THREADS) {
+            const int64_t e = (P.L - (K - 1) + i) - ns;
+            const int p = (int)e + ((int)e >> 3);
+            P.tail_out[i] = make_float2(sre[p], sim[p]);
+        }
+    }
+
+    // ---- register-tiled correlation: y[o] = sum_j g[j] s[o + j], o = tR + r
+    float are[DD_DENSE_R], aim[DD_DENSE_R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { are[r] = 0.f; aim[r] = 0.f; }
+    const float* __restrict__ G = P.taps_rev;           // G[i] = g[i - (R-1)], zero padded
+    const int base = 9 * t;                             // pos(tR) = 8t + t
+    for (int it = 0; it < niter; ++it) {
+        float g[2 * DD_DENSE_R - 1];
+#pragma unroll
+        for (int i = 0; i < 2 * R - 1; ++i) g[i] = G[it * R + i];   // uniform -> s_load
+        float vre[DD_DENSE_R], vim[DD_DENSE_R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            vre[i] = sre[base + it * 9 + i];
+            vim[i] = sim[base + it * 9 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // element m = it*R + i pairs with tap j = m - r -> g[(R-1) + i - r]
+                are[r] = fmaf(g[R - 1 + i - r], vre[i], are[r]);
+                aim[r] = fmaf(g[R - 1 + i - r], vim[i], aim[r]);
+            }
+        }
+    }
+
+    // ---- epilogue
+    const int64_t p0 = pfirst + (int64_t)t * R;         // FIR-output index of r = 0
+    if (!fm) {
+        float2* out = reinterpret_cast<float2*>(P.out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t p = p0 + r;
+            if (p < P.Ld) out[p] = make_float2(are[r], aim[r]);
+        }
+        if (P.lasty_out && p0 <= P.Ld - 1 && P.Ld - 1 < p0 + R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (p0 + r == P.Ld - 1) *P.lasty_out = make_float2(are[r], aim[r]);
+        }
+        return;
+    }
+    if (p0 == -1) {            // y[-1] is the carried sample of the previous chunk
+        const float2 ly = *P.lasty_in;
+        are[0] = ly.x;
+        aim[0] = ly.y;
+    }
+    ylast[t] = make_float2(are[R - 1], aim[R - 1]);
+    __syncthreads();
+    float2 prv = (t > 0) ? ylast[t - 1] : make_float2(0.f, 0.f);
+    float* out = reinterpret_cast<float*>(P.out);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t p = p0 + r;
+        const float2 cur = make_float2(are[r], aim[r]);
+        if (p > pfirst && p < P.Ld) {
+            out[p - P.s] = dd_fm_angle(cur, prv);
+            if (p == P.Ld - 1) *P.lasty_out = cur;
+        } else if (p == P.Ld - 1 && p >= 0) {
+            *P.lasty_out = cur;       // single kept sample owned only as "previous"
+        }
+        prv = cur;
+    }
+}
+
+// ============================================================================
+// decimating kernel: one thread per kept output
+// ============================================================================
+__global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = P.K, M = P.M, T = P.T;
+    const int S = (T - 1) * M + K + (M - 1);
+    const int SP = S + (S >> 5) + 4;
+    float2* sx = reinterpret_cast<float2*>(smem);
+    float2* w2 = sx + SP;
+    float2* yblk = w2 + ((S + 63) / 64 + 1);
+
+    const int t = threadIdx.x;
+    const int b = dd_xcd_tile(blockIdx.x, P.nblocks);
+    const int64_t pfirst = dd_tile_pfirst(P, b);
+    const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
+    const bool fm = (P.flags & DD_CHAIN_FM) != 0;
+
+    const int ngroups = (S + 63) / 64;
+    if (P.flags & DD_CHAIN_NCO) {
+        for (int g = t; g < ngroups; g += DD_DECIM_THREADS) {
+            const uint64_t ph = (uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc;
+            w2[g] = dd_phasor(ph, P.nco_tbl);
+        }
+    }
+    __syncthreads();
+    {
+        const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        for (int e = t; e < S; e += DD_DECIM_THREADS) {
+            float2 ph = make_float2(1.f, 0.f);
+            if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
+            sx[e + (e >> 5)] = dd_load_sample(P, ns + e, ph);
+        }
+    }
+    __syncthreads();
+
+    if (b == P.nblocks - 1 && P.tail_out) {
+        for (int i = t; i < K - 1; i += DD_DECIM_THREADS) {
+            const int64_t e = (P.L - (K - 1) + i) - ns;
+            P.tail_out[i] = sx[(int)e + ((int)e >> 5)];
+        }
+    }
+
+    float2 acc = make_float2(0.f, 0.f);
+    const float* __restrict__ G = P.taps_rev + (DD_DENSE_R - 1);   // g[j] = h[K-1-j]
+    if (t < T) {
+        const int e0 = t * M;
+        int j = 0;
+        for (; j + 4 <= K; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + j + u;
+                const float2 v = sx[e + (e >> 5)];
+                const float g = G[j + u];
+                acc.x = fmaf(g, v.x, acc.x);
+                acc.y = fmaf(g, v.y, acc.y);
+            }
+        }
+        for (; j < K; ++j) {
+            const int e = e0 + j;
+            const float2 v = sx[e + (e >> 5)];
+            const float g = G[j];
+            acc.x = fmaf(g, v.x, acc.x);
+            acc.y = fmaf(g, v.y, acc.y);
+        }
+    }
+    const int64_t p = pfirst + t;
+    if (!fm) {
+        if (t < T && p < P.Ld) {
+            reinterpret_cast<float2*>(P.out)[p] = acc;
+            if (P.lasty_out && p == P.Ld - 1) *P.lasty_out = acc;
+        }
+        return;
+    }
+    if (p == -1) acc = *P.lasty_in;
+    if (t < T) yblk[t] = acc;
+    __syncthreads();
+    if (t < T && p >= 0 && p < P.Ld) {
+        if (t > 0) {
+            reinterpret_cast<float*>(P.out)[p - P.s] = dd_fm_angle(acc, yblk[t - 1]);
+        }
+        if (p == P.Ld - 1) *P.lasty_out = acc;
+    }
+}
+
+// rare path (chunk without a kept sample) and shard priming: new tail only
+__global__ void k_tail_update(const DDChainParams P) {
+    const int K = P.K;
+    for (int i = threadIdx.x; i < K - 1; i += blockDim.x) {
+        const int64_t n = P.L - (K - 1) + i;
+        float2 ph = make_float2(1.f, 0.f);
+        if (P.flags & DD_CHAIN_NCO) ph = dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl);
+        P.tail_out[i] = dd_load_sample(P, n, ph);
+    }
+}
+
+__global__ void k_fill_c64(float2* p, int n, float re, float im) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = make_float2(re, im);
+}
+
+// ============================================================================
+// host side
+// ============================================================================
+// MFMA path hooks (dd_mfma.hip)
+int dd_mfma_supported(int K, int M, int flags);
+int dd_mfma_create(void** st, const double* taps, int K);
+void dd_mfma_destroy(void* st);
+int dd_mfma_launch(void* st, const DDChainParams& P, hipStream_t s);
+
+// ---------------------------------------------------------------- dd_fir (taps + history)
+extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
+    DD_REQUIRE(h && taps, "null argument");
+    DD_REQUIRE(ntaps >= 1 && ntaps <= 4096, "ntaps must be in [1, 4096]");
+    if (!dd_nco_table()) {
+        dd_set_error("no usable GPU: the HIP path is mandatory (there is no CPU fallback)");
+        return DD_ERR_NODEVICE;
+    }
+    dd_fir* f = new dd_fir();
+    f->K = ntaps;
+    f->taps.assign(taps, taps + ntaps);
+    f->taps_rev = nullptr;
+    f->tail[0] = f->tail[1] = nullptr;
+    f->parity = 0;
+    f->mfma = nullptr;
+    f->mfma_tried = 0;
+    f->taps_dev = nullptr;
+    f->hist[0] = f->hist[1] = nullptr;
+    f->hpar = 0;
+    f->hist_mode = DD_HIST_ONES;
+    const int R = DD_DENSE_R;
+    const int K = ntaps;
+    // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
+    const int niter = (K + R - 1 + R - 1) / R;
+    const int len = niter * R + 2 * R;
+    std::vector<float> g(len, 0.f);
+    for (int j = 0; j < K; ++j) g[j + R - 1] = (float)taps[K - 1 - j];
+    const size_t tb = sizeof(float2) * (size_t)(K > 1 ? K - 1 : 1);
+    hipError_t e = hipMalloc((void**)&f->taps_rev, len * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(f->taps_rev, g.data(), len * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&f->tail[0], tb);
+    if (e == hipSuccess) e = hipMalloc((void**)&f->tail[1], tb);
+    if (e != hipSuccess) {
+        dd_fir_destroy(f);
+        dd_set_error("dd_fir_create: %s", hipGetErrorString(e));
+        return DD_ERR_HIP;
+    }
+    int rc = dd_fir_reset(f, DD_HIST_ONES, nullptr, nullptr);
+    if (rc != DD_OK) {
+        dd_fir_destroy(f);
+        return rc;
+    }
+    DD_HIP_CHECK(hipDeviceSynchronize());
+    *h = f;
+    return DD_OK;
+}
+
+extern "C" int dd_fir_destroy(dd_fir* f) {
+    if (!f) return DD_OK;
+    if (f->mfma) dd_mfma_destroy(f->mfma);
+    hipFree(f->taps_rev);
+    hipFree(f->tail[0]);
+    hipFree(f->tail[1]);
+    hipFree(f->taps_dev);
+    hipFree(f->hist[0]);
+    hipFree(f->hist[1]);
+    delete f;
+    return DD_OK;
+}
+
+int dd_fir_reset_f64(dd_fir* f, int mode, const float* hist_host, hipStream_t s);   // dd_fir.hip
+
+extern "C" int dd_fir_reset(dd_fir* f, int mode, const float* hist_host, void* stream) {
+    DD_REQUIRE(f, "h");
+    DD_REQUIRE(mode == DD_HIST_ZEROS || mode == DD_HIST_ONES || mode == DD_HIST_GIVEN, "mode");
+    hipStream_t s = dd_stream(stream);
+    const int n = f->K - 1;
+    if (n > 0) {
+        if (mode == DD_HIST_GIVEN) {
+            DD_REQUIRE(hist_host, "hist_host");
+            DD_HIP_CHECK(hipMemcpyAsync(f->tail[f->parity], hist_host, sizeof(float2) * n, hipMemcpyHostToDevice, s));
+            DD_HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            // DD_HIST_ONES: lfilter_zi(b,[1]) unscaled == history of 1.0+0j (filters.py:45, quirk Q1)
+            hipLaunchKernelGGL(k_fill_c64, dim3((n + 255) / 256), dim3(256), 0, s, f->tail[f->parity], n,
+                               mode == DD_HIST_ONES ? 1.f : 0.f, 0.f);
+            DD_LAUNCH_CHECK();
+        }
+    }
+    f->hist_mode = mode;
+    return dd_fir_reset_f64(f, mode, hist_host, s);
+}
+
+// ---------------------------------------------------------------- dd_fm
+extern "C" int dd_fm_create(dd_fm** h) {
+    DD_REQUIRE(h, "h");
+    dd_fm* f = new dd_fm();
+    f->last = nullptr;
+    f->parity = 0;
+    f->has_last = 0;
+    hipError_t e = hipMalloc((void**)&f->last, 2 * sizeof(float2));
+    if (e == hipSuccess) e = hipMemset(f->last, 0, 2 * sizeof(float2));
+    if (e != hipSuccess) {
+        delete f;
+        dd_set_error("dd_fm_create: %s", hipGetErrorString(e));
+        return (e == hipErrorNoDevice) ? DD_ERR_NODEVICE : DD_ERR_HIP;
+    }
+    *h = f;
+    return DD_OK;
+}
+extern "C" int dd_fm_destroy(dd_fm* h) {
+    if (h) {
+        hipFree(h->last);
+        delete h;
+    }
+    return DD_OK;
+}
+extern "C" int dd_fm_reset(dd_fm* h) {
+    DD_REQUIRE(h, "h");
+    h->has_last = 0;
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- fused launch
+static inline int64_t kept_count(int64_t L, int off, int M) {
+    return (L > off) ? (L - off + M - 1) / M : 0;
+}
+
+int64_t dd_fused_out_count(const dd_fm* fm, int64_t n, int M, int off) {
+    const int64_t Ld = kept_count(n, off, M);
+    if (!fm) return Ld;
+    const int64_t no = Ld - (fm->has_last ? 0 : 1);
+    return no > 0 ? no : 0;
+}
+
+int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out, hipStream_t s) {
+    DD_REQUIRE(fir && a.n >= 0 && a.M >= 1 && a.off >= 0 && a.off < a.M, "fused arguments");
+    DDChainParams P;
+    memset(&P, 0, sizeof(P));
+    P.in = a.in;
+    P.out = a.out;
+    P.tail_in = fir->tail[fir->parity];
+    P.tail_out = a.commit ? fir->tail[fir->parity ^ 1] : nullptr;
+    P.taps_rev = fir->taps_rev;
+    P.nco_tbl = dd_nco_table();
+    P.cyc = a.cyc;
+    P.abs0 = a.start_index;
+    P.L = a.n;
+    P.K = fir->K;
+    P.M = a.M;
+    P.off = a.off;
+    P.Ld = kept_count(a.n, a.off, a.M);
+    P.flags = (a.nco ? DD_CHAIN_NCO : 0) | (fm ? DD_CHAIN_FM : 0) | (a.u8 ? DD_CHAIN_U8_INPUT : 0);
+    const bool isfm = fm != nullptr;
+    P.s = (isfm && !fm->has_last) ? 1 : 0;
+    if (isfm) {
+        P.lasty_in = fm->last + fm->parity;
+        P.lasty_out = fm->last + (fm->parity ^ 1);
+    }
+    const int64_t no = dd_fused_out_count(fm, a.n, a.M, a.off);
+    if (n_out) *n_out = no;
+    if (a.n == 0) return DD_OK;
+    DD_REQUIRE(a.in, "in");
+    DD_REQUIRE(a.out || no == 0, "out");
+
+    if (P.Ld == 0) {
+        // no kept sample in this chunk: only the FIR history moves on
+        if (a.commit && fir->K > 1) {
+            hipLaunchKernelGGL(k_tail_update, dim3(1), dim3(256), 0, s, P);
+            DD_LAUNCH_CHECK();
+            fir->parity ^= 1;
+        }
+        return DD_OK;
+    }
+
+    int use_mfma = 0;
+    if (!a.force_direct && dd_mfma_supported(fir->K, a.M, P.flags)) {
+        if (!fir->mfma && !fir->mfma_tried) {
+            fir->mfma_tried = 1;
+            if (dd_mfma_create(&fir->mfma, fir->taps.data(), fir->K) != DD_OK) fir->mfma = nullptr;
+        }
+        use_mfma = fir->mfma != nullptr;
+    }
+    if (use_mfma) {
+        int rc = dd_mfma_launch(fir->mfma, P, s);
+        if (rc != DD_OK) return rc;
+    } else if (a.M == 1) {
+        P.T = DD_DENSE_T;
+        P.nblocks = isfm ? (int)((P.Ld - P.s + (P.T - 2)) / (P.T - 1)) : (int)((P.Ld + P.T - 1) / P.T);
+        if (P.nblocks < 1) P.nblocks = 1;
+        const int R = DD_DENSE_R;
+        const int niter = (P.K + R - 1 + R - 1) / R;
+        const int S = P.T + niter * R;
+        const int SP = S + (S >> 3) + 8;
+        const size_t lds = (size_t)SP * 2 * sizeof(float) + sizeof(float2) * ((S + 63) / 64 + 1) +
+                           sizeof(float2) * DD_DENSE_THREADS;
+        DD_REQUIRE(lds <= 160 * 1024, "filter too long for the dense kernel's LDS tile");
+        if (lds > 64 * 1024)
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chain_dense, dim3(P.nblocks), dim3(DD_DENSE_THREADS), lds, s, P);
+        DD_LAUNCH_CHECK();
+    } else {
+        int T = (DD_DECIM_SPAN_MAX - P.K - (P.M - 1)) / P.M + 1;
+        if (T > DD_DECIM_THREADS) T = DD_DECIM_THREADS;
+        if (T < 2) T = 2;
+        P.T = T;
+        P.nblocks = isfm ? (int)((P.Ld - P.s + (P.T - 2)) / (P.T - 1)) : (int)((P.Ld + P.T - 1) / P.T);
+        if (P.nblocks < 1) P.nblocks = 1;
+        const int S = (T - 1) * P.M + P.K + (P.M - 1);
+        const int SP = S + (S >> 5) + 4;
+        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS);
+        DD_REQUIRE(lds <= 160 * 1024, "filter/decimation too large for the decimating kernel's LDS tile");
+        if (lds > 64 * 1024)
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), lds, s, P);
+        DD_LAUNCH_CHECK();
+    }
+    if (a.commit) fir->parity ^= 1;
+    if (isfm) {
+        fm->parity ^= 1;
+        fm->has_last = 1;
+    }
+    return DD_OK;
+}
+
+extern "C" int dd_fused_process(dd_fir* fir, dd_fm* fm, const void* in, void* out, int64_t n,
+                                int nco, uint64_t cycles_q64, int64_t start_index, int decim, int offset,
+                                int flags, int carry, int64_t* n_out, void* stream) {
+    DD_REQUIRE(fir, "fir");
+    DDFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.out = out;
+    a.n = n;
+    a.nco = nco;
+    a.cyc = cycles_q64;
+    a.start_index = start_index;
+    a.M = decim;
+    a.off = offset;
+    a.u8 = (flags & DD_CHAIN_U8_INPUT) ? 1 : 0;
+    a.commit = carry;
+    a.force_direct = (flags & DD_CHAIN_FORCE_DIRECT) ? 1 : 0;
+    return dd_fused_launch(fir, fm, a, n_out, dd_stream(stream));
+}
+
+// ---------------------------------------------------------------- stand-alone rows
+extern "C" int dd_fir_c64(dd_fir* f, const float* in_c64, float* out_c64, int64_t n, int carry, void* stream) {
+    DD_REQUIRE(f && n >= 0, "h/n");
+    DDFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_c64;
+    a.out = out_c64;
+    a.n = n;
+    a.M = 1;
+    a.commit = carry;
+    return dd_fused_launch(f, nullptr, a, nullptr, dd_stream(stream));
+}
+
+// out[j] = angle(x[j+s] * conj(x[j+s-1])), x[-1] = *last ; s = 1 if no previous sample
+__global__ void __launch_bounds__(256) k_fm(const float2* __restrict__ in, float* __restrict__ out, int64_t n_out, int s,
+                                            const float2* __restrict__ last, float2* __restrict__ last_out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += stride) {
+        const int64_t p = j + s;
+        const float2 cur = in[p];
+        const float2 prv = (p == 0) ? *last : in[p - 1];
+        out[j] = dd_fm_angle(cur, prv);
+    }
+    if (last_out && blockIdx.x == 0 && threadIdx.x == 0) *last_out = in[n - 1];
+}
+
+extern "C" int dd_fm_discrim_c64(dd_fm* h, const float* in_c64, float* out, int64_t n, int carry,
+                                 int64_t* n_out, void* stream) {
+    DD_REQUIRE(h && n >= 0, "h/n");
+    // demod_fm.py:44/48 index sig[-1]: an empty chunk is an IndexError in the reference
+    DD_REQUIRE(!(carry && n == 0), "empty chunk with storeState (IndexError in the reference)");
+    const int s = (carry && h->has_last) ? 0 : 1;
+    const int64_t no = n - s > 0 ? n - s : 0;
+    if (n_out) *n_out = no;
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in_c64 && (out || no == 0), "null buffer");
+    int64_t g = (no + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_fm, dim3((unsigned)g), dim3(256), 0, dd_stream(stream), (const float2*)in_c64, out, no, s,
+                       h->last + h->parity, carry ? h->last + (h->parity ^ 1) : (float2*)nullptr, n);
+    DD_LAUNCH_CHECK();
+    if (carry) {
+        h->parity ^= 1;
+        h->has_last = 1;
+    }
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- dd_chain convenience handle
+// Bundles a filter, an FM demodulator and the chunker variables of one stream
+// (NCO sample index "freqoffset", decimation phase "bwlim", constants.py:38-39).
+struct dd_chain {
+    dd_fir* fir;
+    dd_fm* fm;
+    uint64_t cyc;
+    int M, flags;
+    int64_t abs_index;
+};
+
+extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles_q64,
+                               int decim, int flags) {
+    DD_REQUIRE(h && taps, "null argument");
+    DD_REQUIRE(decim >= 1, "decim must be >= 1");
+    dd_chain* c = new dd_chain();
+    c->fir = nullptr;
+    c->fm = nullptr;
+    c->cyc = cycles_q64;
+    c->M = decim;
+    c->flags = flags;
+    c->abs_index = 0;
+    int rc = dd_fir_create(&c->fir, taps, ntaps);
+    if (rc == DD_OK && (flags & DD_CHAIN_FM)) rc = dd_fm_create(&c->fm);
+    if (rc != DD_OK) {
+        dd_chain_destroy(c);
+        return rc;
+    }
+    *h = c;
+    return DD_OK;
+}
+
+extern "C" int dd_chain_destroy(dd_chain* c) {
+    if (!c) return DD_OK;
+    dd_fir_destroy(c->fir);
+    dd_fm_destroy(c->fm);
+    delete c;
+    return DD_OK;
+}
+
+extern "C" int dd_chain_reset(dd_chain* c, void* stream) {
+    DD_REQUIRE(c, "h");
+    c->abs_index = 0;
+    if (c->fm) dd_fm_reset(c->fm);
+    return dd_fir_reset(c->fir, DD_HIST_ONES, nullptr, stream);
+}
+
+static inline int chain_off(const dd_chain* c) {
+    // kept global indices are the multiples of M (comm.py:123-127, quirk Q4)
+    const int64_t r = c->abs_index % c->M;
+    return (int)((c->M - r) % c->M);
+}
+
+extern "C" int64_t dd_chain_out_count(const dd_chain* c, int64_t n) {
+    if (!c || n < 0) return -1;
+    return dd_fused_out_count(c->fm, n, c->M, chain_off(c));
+}
+
+extern "C" int dd_chain_path(const dd_chain* c) {
+    if (!c) return DD_ERR_INVALID;
+    if (c->flags & DD_CHAIN_FORCE_DIRECT) return 0;
+    const int fl = (c->flags & (DD_CHAIN_NCO | DD_CHAIN_FM | DD_CHAIN_U8_INPUT));
+    return (dd_mfma_supported(c->fir->K, c->M, fl) && (c->fir->mfma || !c->fir->mfma_tried)) ? 1 : 0;
+}
+
+extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t n, int64_t* n_out, void* stream) {
+    DD_REQUIRE(c && n >= 0, "h/n");
+    DDFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.out = out;
+    a.n = n;
+    a.nco = (c->flags & DD_CHAIN_NCO) ? 1 : 0;
+    a.cyc = c->cyc;
+    a.start_index = c->abs_index;
+    a.M = c->M;
+    a.off = chain_off(c);
+    a.u8 = (c->flags & DD_CHAIN_U8_INPUT) ? 1 : 0;
+    a.commit = 1;
+    a.force_direct = (c->flags & DD_CHAIN_FORCE_DIRECT) ? 1 : 0;
+    int rc = dd_fused_launch(c->fir, c->fm, a, n_out, dd_stream(stream));
+    if (rc == DD_OK) c->abs_index += n;
+    return rc;
+}
+
+extern "C" int dd_chain_prime(dd_chain* c, const void* halo_in, int64_t n_halo, int64_t abs_index, void* stream) {
+    DD_REQUIRE(c && n_halo >= 0 && abs_index >= 0, "arguments");
+    DD_REQUIRE(n_halo <= abs_index, "halo longer than the samples that precede abs_index");
+    hipStream_t s = dd_stream(stream);
+    if (abs_index == 0) return dd_chain_reset(c, stream);
+    DD_REQUIRE(halo_in, "halo_in");
+    const bool at_start = (n_halo == abs_index);
+    DD_REQUIRE(at_start || n_halo >= (int64_t)c->fir->K - 1 + c->M,
+               "halo must hold at least ntaps-1+decim samples (or reach back to the stream start)");
+    // Replay the halo as a chunk whose outputs are discarded.  If the halo reaches
+    // the stream start the history is the reference's ones (Q1); otherwise it is
+    // irrelevant: the last kept output and the last K-1 inputs of the halo have
+    // their full windows inside the halo.
+    c->abs_index = abs_index - n_halo;
+    if (c->fm) dd_fm_reset(c->fm);
+    int rc = dd_fir_reset(c->fir, at_start ? DD_HIST_ONES : DD_HIST_ZEROS, nullptr, stream);
+    if (rc != DD_OK) return rc;
+    const int64_t no = dd_chain_out_count(c, n_halo);
+    void* scratch = nullptr;
+    const size_t ob = (size_t)(no > 0 ? no : 1) * ((c->flags & DD_CHAIN_FM) ? sizeof(float) : sizeof(float2));
+    DD_HIP_CHECK(hipMalloc(&scratch, ob));
+    rc = dd_chain_process(c, halo_in, scratch, n_halo, nullptr, stream);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(scratch);
+    if (rc != DD_OK) return rc;
+    DD_HIP_CHECK(e);
+    return DD_OK;
+}

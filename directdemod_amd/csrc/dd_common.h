@@ -1,0 +1,63 @@
+// Internal helpers shared by the gfx950 translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/directdemod_hip.h"
+
+void dd_set_error(const char* fmt, ...);
+
+#define DD_HIP_CHECK(expr)                                                        \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            dd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                         __FILE__, __LINE__);                                     \
+            return (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice)        \
+                       ? DD_ERR_NODEVICE                                          \
+                       : (_e == hipErrorOutOfMemory ? DD_ERR_NOMEM : DD_ERR_HIP); \
+        }                                                                         \
+    } while (0)
+
+#define DD_REQUIRE(cond, msg)                                 \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            dd_set_error("invalid argument: %s", msg);        \
+            return DD_ERR_INVALID;                            \
+        }                                                     \
+    } while (0)
+
+#define DD_LAUNCH_CHECK() DD_HIP_CHECK(hipGetLastError())
+
+static inline hipStream_t dd_stream(void* s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------
+// NCO phase arithmetic (comm.py:77).  phase(n) = frac(n * f/fs) is carried as a
+// 64-bit binary fraction: phase64 = n * cycles_q64 (mod 2^64), exact for any n.
+// exp(-j 2 pi phase) = T[top 12 bits] * exp(-j theta), theta = 2 pi * low bits
+// < 1.6e-3 rad (2-term series).  T is a 4096-entry float2 table computed in
+// float64 on the device at library initialisation.
+// ---------------------------------------------------------------------------
+#define DD_NCO_TBITS 12
+#define DD_NCO_TSIZE (1 << DD_NCO_TBITS)
+
+const float2* dd_nco_table(void);   // device pointer, lazily initialised (host side)
+
+__device__ __forceinline__ float2 dd_cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+__device__ __forceinline__ float2 dd_phasor(uint64_t phase64, const float2* __restrict__ tbl) {
+    const uint32_t k = (uint32_t)(phase64 >> (64 - DD_NCO_TBITS));
+    const uint32_t lo = (uint32_t)(phase64 >> (64 - DD_NCO_TBITS - 32));   // next 32 bits
+    // theta = 2*pi * lo * 2^-(12+32)
+    const float theta = (float)lo * (6.283185307179586f * 5.684341886080802e-14f);   // 2^-44
+    const float t2 = theta * theta;
+    const float c = fmaf(-0.5f, t2, 1.0f);
+    const float s = theta * fmaf(-0.16666667f, t2, 1.0f);
+    const float2 T = tbl[k];                     // (cos, -sin)(2 pi k/4096)
+    // (Tc + j Ts') * (c - j s), Ts' = -sin
+    return make_float2(fmaf(T.x, c, T.y * s), fmaf(T.y, c, -T.x * s));
+}

@@ -1,0 +1,191 @@
+// F1/F3 (stand-alone FIR, filters.py:53-75) and F2 (zero-phase filtfilt,
+// filters.py:72-73) entry points.
+//  - complex64 full-rate data goes through the fused-chain kernels of dd_chain.hip
+//    with NCO/FM/decimation disabled (same LDS-tiled direct form / MFMA path);
+//  - float64 audio-rate data (NOAA tail) uses a plain one-thread-
+//    per-output kernel: sizes there are ~1e5 samples, far from any roofline.
+#include "dd_chain_kernels.h"
+
+__global__ void k_fill_f64(double* p, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static int fir_f64_state(dd_fir* f, hipStream_t s) {
+    if (f->taps_dev) return DD_OK;
+    DD_HIP_CHECK(hipMalloc((void**)&f->taps_dev, sizeof(double) * f->K));
+    DD_HIP_CHECK(hipMemcpy(f->taps_dev, f->taps.data(), sizeof(double) * f->K, hipMemcpyHostToDevice));
+    const int nh = f->K > 1 ? f->K - 1 : 1;
+    DD_HIP_CHECK(hipMalloc((void**)&f->hist[0], sizeof(double) * nh));
+    DD_HIP_CHECK(hipMalloc((void**)&f->hist[1], sizeof(double) * nh));
+    hipLaunchKernelGGL(k_fill_f64, dim3((nh + 255) / 256), dim3(256), 0, s, f->hist[0], nh,
+                       f->hist_mode == DD_HIST_ONES ? 1.0 : 0.0);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// float64 side of dd_fir_reset (called from dd_chain.hip)
+int dd_fir_reset_f64(dd_fir* f, int mode, const float* hist_host, hipStream_t s) {
+    if (!(f->taps_dev || mode == DD_HIST_GIVEN)) return DD_OK;
+    int rc = fir_f64_state(f, s);
+    if (rc != DD_OK) return rc;
+    const int nh = f->K - 1;
+    if (nh <= 0) return DD_OK;
+    if (mode == DD_HIST_GIVEN) {
+        // hist_host holds complex64 pairs; the real path takes the real parts
+        std::vector<double> hr(nh);
+        for (int i = 0; i < nh; ++i) hr[i] = (double)hist_host[2 * i];
+        DD_HIP_CHECK(hipMemcpyAsync(f->hist[f->hpar], hr.data(), sizeof(double) * nh, hipMemcpyHostToDevice, s));
+        DD_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        hipLaunchKernelGGL(k_fill_f64, dim3((nh + 255) / 256), dim3(256), 0, s, f->hist[f->hpar], nh,
+                           mode == DD_HIST_ONES ? 1.0 : 0.0);
+        DD_LAUNCH_CHECK();
+    }
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- float64 real FIR
+__global__ void __launch_bounds__(256) k_fir_f64(const double* __restrict__ in, double* __restrict__ out, int64_t n,
+                                                 const double* __restrict__ taps, int K,
+                                                 const double* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = i - k;
+        const double v = (j >= 0) ? in[j] : hist[(K - 1) + j];
+        acc = fma(taps[k], v, acc);
+    }
+    out[i] = acc;
+}
+__global__ void k_hist_update_f64(const double* __restrict__ in, int64_t n, int K, const double* __restrict__ hold,
+                                  double* __restrict__ hnew) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K - 1) return;
+    const int64_t j = n - (K - 1) + i;
+    hnew[i] = (j >= 0) ? in[j] : hold[(K - 1) + j];
+}
+
+extern "C" int dd_fir_f64(dd_fir* f, const double* in, double* out, int64_t n, int carry, void* stream) {
+    DD_REQUIRE(f && n >= 0, "h/n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in && out, "null buffer");
+    hipStream_t s = dd_stream(stream);
+    int rc = fir_f64_state(f, s);
+    if (rc != DD_OK) return rc;
+    hipLaunchKernelGGL(k_fir_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, f->taps_dev, f->K,
+                       f->hist[f->hpar]);
+    DD_LAUNCH_CHECK();
+    if (carry && f->K > 1) {
+        hipLaunchKernelGGL(k_hist_update_f64, dim3((f->K + 254) / 256), dim3(256), 0, s, in, n, f->K,
+                           f->hist[f->hpar], f->hist[f->hpar ^ 1]);
+        DD_LAUNCH_CHECK();
+        f->hpar ^= 1;
+    }
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- filtfilt
+// scipy.signal.filtfilt(b,[1],x): ext = odd_ext(x, 3K); forward lfilter with the
+// history = ext[0] (zi * x0), reverse, filter again with history = first sample,
+// reverse, crop.  Each pass is a direct FIR whose out-of-range taps read the
+// pass's first input sample.
+template <typename T> struct dd_acc;
+template <> struct dd_acc<double> {
+    __device__ static double zero() { return 0.0; }
+    __device__ static double mad(double t, double v, double a) { return fma(t, v, a); }
+    __device__ static double oddext(double e, double v) { return 2.0 * e - v; }
+};
+template <> struct dd_acc<double2> {
+    __device__ static double2 zero() { return make_double2(0.0, 0.0); }
+    __device__ static double2 mad(double t, double2 v, double2 a) { return make_double2(fma(t, v.x, a.x), fma(t, v.y, a.y)); }
+    __device__ static double2 oddext(double2 e, double2 v) { return make_double2(2.0 * e.x - v.x, 2.0 * e.y - v.y); }
+};
+template <> struct dd_acc<float2> {
+    __device__ static float2 zero() { return make_float2(0.f, 0.f); }
+    __device__ static float2 mad(double t, float2 v, float2 a) { return make_float2(fmaf((float)t, v.x, a.x), fmaf((float)t, v.y, a.y)); }
+    __device__ static float2 oddext(float2 e, float2 v) { return make_float2(2.f * e.x - v.x, 2.f * e.y - v.y); }
+};
+
+// ext[i], i in [0, n + 2*edge): odd extension of x about both ends
+template <typename T>
+__device__ __forceinline__ T dd_ext_at(const T* __restrict__ x, int64_t n, int edge, int64_t i) {
+    if (i < edge) return dd_acc<T>::oddext(x[0], x[edge - i]);
+    if (i < edge + n) return x[i - edge];
+    return dd_acc<T>::oddext(x[n - 1], x[n - 2 - (i - edge - n)]);
+}
+
+// pass 1: y1[i] = sum_k b[k] ext[max(i-k,0)]  for i in [0, N)
+template <typename T>
+__global__ void __launch_bounds__(256) k_filtfilt_fwd(const T* __restrict__ x, T* __restrict__ y1, int64_t n, int edge,
+                                                      const double* __restrict__ taps, int K) {
+    const int64_t N = n + 2 * (int64_t)edge;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    T acc = dd_acc<T>::zero();
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = i - k;
+        acc = dd_acc<T>::mad(taps[k], dd_ext_at(x, n, edge, j > 0 ? j : 0), acc);
+    }
+    y1[i] = acc;
+}
+// pass 2 on the reversed sequence z[i] = y1[N-1-i]; w[i] = sum_k b[k] z[max(i-k,0)];
+// result[m] = w[N-1-(m+edge)] for m in [0, n)
+template <typename T>
+__global__ void __launch_bounds__(256) k_filtfilt_bwd(const T* __restrict__ y1, T* __restrict__ out, int64_t n, int edge,
+                                                      const double* __restrict__ taps, int K) {
+    const int64_t N = n + 2 * (int64_t)edge;
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const int64_t i = N - 1 - (m + edge);
+    T acc = dd_acc<T>::zero();
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = i - k;
+        const int64_t jj = j > 0 ? j : 0;
+        acc = dd_acc<T>::mad(taps[k], y1[N - 1 - jj], acc);
+    }
+    out[m] = acc;
+}
+
+template <typename T>
+static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, int64_t n, hipStream_t s) {
+    const int edge = 3 * K;
+    if (n <= edge) {
+        dd_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
+        return DD_ERR_INVALID;
+    }
+    double* taps = nullptr;
+    T* y1 = nullptr;
+    const int64_t N = n + 2 * (int64_t)edge;
+    DD_HIP_CHECK(hipMalloc((void**)&taps, sizeof(double) * K));
+    hipError_t e = hipMalloc((void**)&y1, sizeof(T) * N);
+    if (e != hipSuccess) {
+        hipFree(taps);
+        dd_set_error("hipMalloc: %s", hipGetErrorString(e));
+        return DD_ERR_NOMEM;
+    }
+    hipMemcpyAsync(taps, taps_host, sizeof(double) * K, hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(k_filtfilt_fwd<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, y1, n, edge, taps, K);
+    hipLaunchKernelGGL(k_filtfilt_bwd<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y1, out, n, edge, taps, K);
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(s);
+    hipFree(taps);
+    hipFree(y1);
+    DD_HIP_CHECK(le);
+    DD_HIP_CHECK(se);
+    return DD_OK;
+}
+
+extern "C" int dd_filtfilt_f64(const double* taps_host, int ntaps, const double* in, double* out,
+                               int64_t n, int is_complex, void* stream) {
+    DD_REQUIRE(taps_host && ntaps >= 1 && in && out && n >= 0, "arguments");
+    if (is_complex) return filtfilt_impl<double2>(taps_host, ntaps, (const double2*)in, (double2*)out, n, dd_stream(stream));
+    return filtfilt_impl<double>(taps_host, ntaps, in, out, n, dd_stream(stream));
+}
+
+extern "C" int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* in_c64, float* out_c64,
+                               int64_t n, void* stream) {
+    DD_REQUIRE(taps_host && ntaps >= 1 && in_c64 && out_c64 && n >= 0, "arguments");
+    return filtfilt_impl<float2>(taps_host, ntaps, (const float2*)in_c64, (float2*)out_c64, n, dd_stream(stream));
+}

@@ -1,0 +1,275 @@
+// Runtime plumbing (memory, streams, events) and the element-wise rows of the
+// hot path: S1 (u8 ingest), N1 (NCO), R1 (decimation gather), D1 (FM
+// discriminator).  gfx950 only.
+#include "dd_common.h"
+#include <stdarg.h>
+#include <mutex>
+
+// ---------------------------------------------------------------- error state
+static thread_local char g_err[512] = "";
+
+void dd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dd_last_error(void) { return g_err; }
+extern "C" const char* dd_version(void) { return "directdemod_hip 0.1 (gfx950)"; }
+
+extern "C" int dd_device_count(int* count) {
+    DD_REQUIRE(count, "count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        dd_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return DD_ERR_NODEVICE;
+    }
+    *count = c;
+    return c > 0 ? DD_OK : DD_ERR_NODEVICE;
+}
+
+extern "C" int dd_set_device(int device) {
+    DD_HIP_CHECK(hipSetDevice(device));
+    return DD_OK;
+}
+
+extern "C" int dd_device_name(char* buf, int buflen) {
+    DD_REQUIRE(buf && buflen > 0, "buf");
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    DD_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return DD_OK;
+}
+
+extern "C" int dd_malloc(void** dptr, size_t bytes) {
+    DD_REQUIRE(dptr, "dptr");
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    DD_HIP_CHECK(hipMalloc(dptr, bytes));
+    return DD_OK;
+}
+extern "C" int dd_free(void* dptr) {
+    if (dptr) DD_HIP_CHECK(hipFree(dptr));
+    return DD_OK;
+}
+extern "C" int dd_memset(void* dptr, int value, size_t bytes, void* stream) {
+    if (bytes) DD_HIP_CHECK(hipMemsetAsync(dptr, value, bytes, dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_host_alloc_pinned(void** hptr, size_t bytes) {
+    DD_REQUIRE(hptr, "hptr");
+    *hptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    DD_HIP_CHECK(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return DD_OK;
+}
+extern "C" int dd_host_free_pinned(void* hptr) {
+    if (hptr) DD_HIP_CHECK(hipHostFree(hptr));
+    return DD_OK;
+}
+extern "C" int dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream) {
+    if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream) {
+    if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_stream_create(void** stream) {
+    DD_REQUIRE(stream, "stream");
+    hipStream_t s;
+    DD_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return DD_OK;
+}
+extern "C" int dd_stream_destroy(void* stream) {
+    if (stream) DD_HIP_CHECK(hipStreamDestroy(dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_stream_sync(void* stream) {
+    DD_HIP_CHECK(hipStreamSynchronize(dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_event_create(void** ev) {
+    DD_REQUIRE(ev, "ev");
+    hipEvent_t e;
+    DD_HIP_CHECK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return DD_OK;
+}
+extern "C" int dd_event_destroy(void* ev) {
+    if (ev) DD_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+    return DD_OK;
+}
+extern "C" int dd_event_record(void* ev, void* stream) {
+    DD_HIP_CHECK(hipEventRecord((hipEvent_t)ev, dd_stream(stream)));
+    return DD_OK;
+}
+extern "C" int dd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+    DD_REQUIRE(ms, "ms");
+    DD_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev_stop));
+    DD_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- NCO table
+__global__ void k_fill_nco_table(float2* t) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < DD_NCO_TSIZE) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)DD_NCO_TSIZE, &s, &c);
+        t[k] = make_float2((float)c, (float)(-s));
+    }
+}
+
+static std::mutex g_tbl_mu;
+static float2* g_tbl[64] = {nullptr};
+
+const float2* dd_nco_table(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tbl_mu);
+    if (!g_tbl[dev]) {
+        float2* p = nullptr;
+        if (hipMalloc((void**)&p, sizeof(float2) * DD_NCO_TSIZE) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(k_fill_nco_table, dim3(DD_NCO_TSIZE / 256), dim3(256), 0, 0, p);
+        if (hipDeviceSynchronize() != hipSuccess) {
+            hipFree(p);
+            return nullptr;
+        }
+        g_tbl[dev] = p;
+    }
+    return g_tbl[dev];
+}
+
+// ---------------------------------------------------------------- S1: u8 -> c64
+// 16 B per lane in (8 samples), 4 x 16 B per lane out.
+__global__ void __launch_bounds__(256) k_u8iq_to_c64(const uint8_t* __restrict__ in, float2* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float4* o = reinterpret_cast<float4*>(out + i * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 r;
+            r.x = (float)(w[j] & 0xff) - 127.5f;
+            r.y = (float)((w[j] >> 8) & 0xff) - 127.5f;
+            r.z = (float)((w[j] >> 16) & 0xff) - 127.5f;
+            r.w = (float)(w[j] >> 24) - 127.5f;
+            o[j] = r;
+        }
+    }
+    // tail
+    const int64_t base = n8 << 3;
+    for (int64_t i = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        out[i] = make_float2((float)in[2 * i] - 127.5f, (float)in[2 * i + 1] - 127.5f);
+    }
+}
+
+static inline int dd_grid_for(int64_t work_items, int block) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+extern "C" int dd_u8iq_to_c64(const uint8_t* in_iq, float* out_c64, int64_t n, void* stream) {
+    DD_REQUIRE(n >= 0, "n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in_iq && out_c64, "null buffer");
+    if (((uintptr_t)in_iq & 15) || ((uintptr_t)out_c64 & 15)) {
+        dd_set_error("dd_u8iq_to_c64: buffers must be 16-byte aligned");
+        return DD_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_u8iq_to_c64, dim3(dd_grid_for(n / 8 + 1, 256)), dim3(256), 0, dd_stream(stream),
+                       in_iq, (float2*)out_c64, n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- N1: NCO
+__global__ void __launch_bounds__(256) k_nco_c64(const float2* __restrict__ in, float2* __restrict__ out, int64_t n,
+                                                 uint64_t cyc, int64_t start, const float2* __restrict__ tbl) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t ph = (uint64_t)(start + i) * cyc;
+        out[i] = dd_cmul(in[i], dd_phasor(ph, tbl));
+    }
+}
+
+extern "C" int dd_nco_c64(const float* in_c64, float* out_c64, int64_t n, uint64_t cycles_q64,
+                          int64_t start_index, void* stream) {
+    DD_REQUIRE(n >= 0, "n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in_c64 && out_c64, "null buffer");
+    const float2* tbl = dd_nco_table();
+    if (!tbl) {
+        dd_set_error("NCO table initialisation failed (no GPU?)");
+        return DD_ERR_NODEVICE;
+    }
+    hipLaunchKernelGGL(k_nco_c64, dim3(dd_grid_for(n, 256)), dim3(256), 0, dd_stream(stream),
+                       (const float2*)in_c64, (float2*)out_c64, n, cycles_q64, start_index, tbl);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- R1: decimation gather
+template <typename T>
+__global__ void __launch_bounds__(256) k_decimate(const T* __restrict__ in, T* __restrict__ out, int64_t n_out, int m, int off) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        out[i] = in[(int64_t)off + i * m];
+    }
+}
+
+extern "C" int dd_decimate(const void* in, void* out, int64_t n, int m, int offset, int elem_bytes,
+                           int64_t* n_out, void* stream) {
+    DD_REQUIRE(n >= 0 && m >= 1 && offset >= 0, "n/m/offset");
+    const int64_t no = (n > offset) ? (n - offset + m - 1) / m : 0;
+    if (n_out) *n_out = no;
+    if (no == 0) return DD_OK;
+    DD_REQUIRE(in && out, "null buffer");
+    const dim3 g(dd_grid_for(no, 256)), b(256);
+    hipStream_t s = dd_stream(stream);
+    switch (elem_bytes) {
+        case 4: hipLaunchKernelGGL(k_decimate<float>, g, b, 0, s, (const float*)in, (float*)out, no, m, offset); break;
+        case 8: hipLaunchKernelGGL(k_decimate<float2>, g, b, 0, s, (const float2*)in, (float2*)out, no, m, offset); break;
+        case 16: hipLaunchKernelGGL(k_decimate<double2>, g, b, 0, s, (const double2*)in, (double2*)out, no, m, offset); break;
+        default: dd_set_error("dd_decimate: elem_bytes must be 4, 8 or 16"); return DD_ERR_INVALID;
+    }
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// ---------------------------------------------------------------- widening / narrowing
+__global__ void __launch_bounds__(256) k_f32_to_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (double)in[i];
+}
+__global__ void __launch_bounds__(256) k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+}
+extern "C" int dd_f32_to_f64(const float* in, double* out, int64_t n, void* stream) {
+    if (n <= 0) return DD_OK;
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(dd_grid_for(n, 256)), dim3(256), 0, dd_stream(stream), in, out, n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+extern "C" int dd_f64_to_f32(const double* in, float* out, int64_t n, void* stream) {
+    if (n <= 0) return DD_OK;
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(dd_grid_for(n, 256)), dim3(256), 0, dd_stream(stream), in, out, n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}

@@ -1,0 +1,227 @@
+"""
+Filters -- drop-in for the reference's directdemod/filters.py (base ``filter`` with
+``applyOn``/``getA``/``getB`` and the ``rollingAverage``, ``blackmanHarris``,
+``hamming``, ``gaussian``, ``butter``, ``remez`` designs; same constructor
+arguments and error behaviour).
+
+Arithmetic.  An FIR (a == [1]) is applied by the LDS-tiled HIP kernels behind
+dd_fir_* / dd_fused_process; its chunk-to-chunk state is the last ntaps-1 input
+samples, kept in HBM inside the C handle.  The reference seeds SciPy's ``lfilter``
+with ``lfilter_zi(b, a)`` *without* scaling by the first sample (filters.py:45);
+for an FIR that is exactly a delay line pre-filled with 1.0, which is how the
+handle is initialised (quirk Q1).  Taps are the raw, un-normalised windows (Q2).
+``zeroPhase`` is SciPy's ``filtfilt`` (odd extension 3*ntaps, forward-backward).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip, _ops, constants
+from ._hip import DevArray, check, lib
+
+_C64 = np.dtype(np.complex64)
+_F32 = np.dtype(np.float32)
+_F64 = np.dtype(np.float64)
+
+
+class filter:
+    '''
+    Parent object of all filters (filters.py:15-89).
+    '''
+
+    def __init__(self, b, a, storeState=True, zeroPhase=False, initOut=None):
+        '''Args:
+            b (:obj:`list`): 'b' constants of filter
+            a (:obj:`list`): 'a' constants of filter
+            storeState (:obj:`bool`, optional): carry the filter state from call to call
+            zeroPhase (:obj:`bool`, optional): forward-backward filtering, no delay
+                (disables 'storeState' and 'initOut', filters.py:38-42)
+            initOut (:obj:`list`, optional): initial condition (past inputs, most recent first)
+        '''
+        self.__storeState = storeState
+        self.__zeroPhase = zeroPhase
+        self.__initOut = initOut
+        if self.__storeState and self.__zeroPhase:
+            self.__storeState = False
+        if (self.__initOut is not None) and self.__zeroPhase:
+            self.__initOut = None
+        self.__b = b
+        self.__a = a
+        self.__h = None
+        self.__seeded = self.__initOut is None      # initOut history still to be loaded?
+        av = np.atleast_1d(np.asarray(a, dtype=np.float64))
+        self.__isFIR = av.size == 1
+        self.__taps = np.atleast_1d(np.asarray(b, dtype=np.float64)) / av[0] if self.__isFIR else None
+
+    # -- device handle ------------------------------------------------------------
+    def _fusable(self):
+        return self.__isFIR and not self.__zeroPhase
+
+    def _handle(self):
+        if self.__h is None:
+            _hip.require_gpu()
+            t = np.ascontiguousarray(self.__taps, dtype=np.float64)
+            p = C.c_void_p()
+            check(lib().dd_fir_create(C.byref(p), t.ctypes.data_as(C.POINTER(C.c_double)), len(t)), "dd_fir_create")
+            self.__h = p
+        return self.__h
+
+    def __del__(self):
+        try:
+            if self.__h is not None:
+                lib().dd_fir_destroy(self.__h)
+        except Exception:
+            pass
+
+    def _prepare_call(self):
+        """Bring the device history to what SciPy's state would be before this call;
+        returns the carry flag."""
+        h = self._handle()
+        if self.__storeState:
+            if not self.__seeded:
+                # lfiltic(b, a, x, initOut) with a=[1]: initOut are the past inputs, most
+                # recent first, zero padded (filters.py:66-67)
+                k1 = len(self.__taps) - 1
+                past = np.zeros(k1, dtype=np.float64)
+                io = np.asarray(self.__initOut, dtype=np.float64).ravel()[:k1]
+                past[:len(io)] = io
+                hist = np.zeros(max(1, k1), dtype=np.complex64)
+                hist[:k1] = past[::-1]
+                check(lib().dd_fir_reset(h, _hip.DD_HIST_GIVEN, hist.ctypes.data, None), "dd_fir_reset")
+                self.__seeded = True
+            return True
+        check(lib().dd_fir_reset(h, _hip.DD_HIST_ZEROS, None, None), "dd_fir_reset")   # plain lfilter (filters.py:75)
+        return False
+
+    # -- public -------------------------------------------------------------------
+    def applyOn(self, x):
+        '''Apply the filter to a given array of signal
+
+        Args:
+            x: numpy array or device array
+
+        Returns:
+            filtered array of the same kind (complex64 / float64; the reference's
+            SciPy path returns complex128 / float64 -- declared deviation Q6)
+        '''
+        from .comm import flush_all
+        flush_all()
+        host = not isinstance(x, DevArray)
+        if host:
+            a = np.asarray(x)
+            d = DevArray.from_host(a, dtype=_C64 if np.iscomplexobj(a) else _F64)
+        else:
+            d = x
+        if not self.__isFIR:
+            raise NotImplementedError("IIR (butter) application is not on the GPU hot path yet (SURVEY.md 8f-3)")
+        if self.__zeroPhase:
+            out = _ops.filtfilt(self.__taps, d)
+        elif d.dtype == _C64:
+            out = _ops.fused(d, self, None, (1, 0), None)
+        else:
+            if d.dtype == _F32:
+                from .comm import _convert
+                d = _convert(d, _F64)
+            carry = self._prepare_call()
+            out = DevArray(d.n, _F64)
+            check(lib().dd_fir_f64(self._handle(), d.ptr, out.ptr, d.n, 1 if carry else 0, None), "dd_fir_f64")
+        return out.to_host() if host else out
+
+    @property
+    def getA(self):
+        ''':obj:`list`: Get 'a' of the filter'''
+        return self.__a
+
+    @property
+    def getB(self):
+        ''':obj:`list`: Get 'b' of the filter'''
+        return self.__b
+
+
+# ------------------------------------------------------------------ window designs
+# Closed forms of scipy.signal.windows.{hamming,blackmanharris,gaussian}(n) (sym=True);
+# the reference passes the raw window as the taps (filters.py:139,199,226).
+def _cosine_sum(n, coeffs):
+    if n == 1:
+        return np.ones(1)
+    ang = 2.0 * np.pi * np.arange(n) / (n - 1)
+    w = np.zeros(n)
+    for k, c in enumerate(coeffs):
+        w += ((-1) ** k) * c * np.cos(k * ang)
+    return w
+
+
+class rollingAverage(filter):
+    '''A simple rolling average filter (filters.py:95-114)'''
+
+    def __init__(self, n=3, storeState=True, zeroPhase=False, initOut=None):
+        self.__n = n
+        super(rollingAverage, self).__init__([1.0 / n] * n, [1], storeState, zeroPhase, initOut)
+
+
+class blackmanHarris(filter):
+    '''Blackman Harris filter (filters.py:120-139)'''
+
+    def __init__(self, n, storeState=True, zeroPhase=False, initOut=None):
+        self.__n = n
+        super(blackmanHarris, self).__init__(_cosine_sum(n, [0.35875, 0.48829, 0.14128, 0.01168]), [1],
+                                             storeState, zeroPhase, initOut)
+
+
+class hamming(filter):
+    '''Hamming filter (filters.py:180-199)'''
+
+    def __init__(self, n, storeState=True, zeroPhase=False, initOut=None):
+        self.__n = n
+        super(hamming, self).__init__(_cosine_sum(n, [0.54, 0.46]), [1], storeState, zeroPhase, initOut)
+
+
+class gaussian(filter):
+    '''Gaussian filter (filters.py:205-226)'''
+
+    def __init__(self, n, sigma, storeState=True, zeroPhase=False, initOut=None):
+        self.__n = n
+        self.__sigma = sigma
+        k = np.arange(n) - (n - 1.0) / 2.0
+        super(gaussian, self).__init__(np.exp(-k ** 2 / (2.0 * sigma * sigma)), [1], storeState, zeroPhase, initOut)
+
+
+class butter(filter):
+    '''Butterworth filter design (filters.py:232-273).  IIR: the recurrence itself is
+    the next item on the hot-path list; design and error behaviour
+    are in place.'''
+
+    def __init__(self, Fs, cutoffA, cutoffB=None, n=6, typeFlt=constants.FLT_LP, storeState=True,
+                 zeroPhase=False, initOut=None):
+        import scipy.signal as signal     # coefficient design only
+        if (typeFlt == constants.FLT_BP or typeFlt == constants.FLT_BS) and cutoffB is None:
+            raise ValueError("CutoffB must be given")
+        nyq = 0.5 * Fs
+        if typeFlt == constants.FLT_LP:
+            b, a = signal.butter(n, cutoffA / nyq, btype='lowpass')
+        elif typeFlt == constants.FLT_HP:
+            b, a = signal.butter(n, cutoffA / nyq, btype='highpass')
+        elif typeFlt == constants.FLT_BP:
+            b, a = signal.butter(n, [cutoffA / nyq, cutoffB / nyq], btype='bandpass')
+        elif typeFlt == constants.FLT_BS:
+            b, a = signal.butter(n, [cutoffA / nyq, cutoffB / nyq], btype='bandstop')
+        else:
+            raise ValueError("Invalid filter type")
+        super(butter, self).__init__(b, a, storeState, zeroPhase, initOut)
+
+
+class remez(filter):
+    '''Remez (Parks-McClellan) band filter (filters.py:279-314)'''
+
+    def __init__(self, Fs, bands, gains, ntaps=128, storeState=True, zeroPhase=False, initOut=None):
+        import scipy.signal as signal     # coefficient design only
+        if len(bands) == 0:
+            raise ValueError("Atleast one band must be given")
+        if bands[-1][1] >= (Fs / 2):
+            raise ValueError("Last band must end before (Fs/2)Hz")
+        flat = []
+        for i in bands:
+            flat.extend(i)
+        if not len(flat) == 2 * len(gains):
+            raise ValueError("Invalid bands/gains values")
+        super(remez, self).__init__(signal.remez(ntaps, flat, gains, fs=Fs), [1], storeState, zeroPhase, initOut)

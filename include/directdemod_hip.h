@@ -1,0 +1,185 @@
+/*
+ * directdemod_hip.h -- C-ABI of the MI355X (gfx950) IQ-sample DSP hot path that
+ * replaces DirectDemod's NumPy/SciPy per-sample path.
+ *
+ * The reference is pure Python (no FFI of its own); every entry point below
+ * replaces one SciPy/NumPy call site of the reference, cited as file:line
+ * relative to the reference tree.  The Python classes in directdemod_amd/
+ * (commSignal, filters.*, demod_fm, demod_am, chunker -- same names/signatures
+ * as the reference's) bind these symbols with ctypes; INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all buffers are DEVICE pointers unless the parameter
+ *     name ends in _host;  complex64 = interleaved float {re,im}.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     compute entry points are asynchronous on that stream; carried state
+ *     lives in device memory inside the handles, so chunk loops need no
+ *     host<->device synchronisation.
+ *   - return value: 0 = DD_OK, <0 = error (never throws); dd_last_error()
+ *     returns a thread-local message.
+ *   - one caller thread per handle (the reference is single-threaded and its
+ *     state carry makes chunk order significant).
+ */
+#ifndef DIRECTDEMOD_HIP_H
+#define DIRECTDEMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_OK               0
+#define DD_ERR_INVALID     -1   /* bad argument (maps to ValueError/TypeError) */
+#define DD_ERR_HIP         -2   /* HIP runtime error */
+#define DD_ERR_NOMEM       -3
+#define DD_ERR_UNSUPPORTED -4
+#define DD_ERR_NODEVICE    -5   /* no MI355X visible: the product path fails loudly */
+
+/* FIR history initialisation (filters.py:44-48, 64-70) */
+#define DD_HIST_ZEROS 0     /* plain lfilter / lfiltic with no past inputs */
+#define DD_HIST_ONES  1     /* lfilter_zi(b,[1]) unscaled == delay line of 1.0+0j (quirk Q1) */
+#define DD_HIST_GIVEN 2     /* explicit past inputs, oldest first */
+
+/* dd_chain_create flags */
+#define DD_CHAIN_NCO        1   /* apply commSignal.offsetFreq        (comm.py:63-78)   */
+#define DD_CHAIN_FM         2   /* apply demod_fm.demod on the output (demod_fm.py:29-51) */
+#define DD_CHAIN_U8_INPUT   4   /* input is interleaved u8 I,Q; source.read fused (source.py:117-118) */
+#define DD_CHAIN_FORCE_DIRECT 8 /* disable the MFMA fast path (f32 direct form only) */
+
+/* ---- runtime ---------------------------------------------------------------- */
+const char* dd_last_error(void);
+const char* dd_version(void);
+int  dd_device_count(int* count);
+int  dd_set_device(int device);
+int  dd_device_name(char* buf, int buflen);
+int  dd_malloc(void** dptr, size_t bytes);
+int  dd_free(void* dptr);
+int  dd_memset(void* dptr, int value, size_t bytes, void* stream);
+int  dd_host_alloc_pinned(void** hptr, size_t bytes);
+int  dd_host_free_pinned(void* hptr);
+int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
+int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int  dd_stream_create(void** stream);
+int  dd_stream_destroy(void* stream);
+int  dd_stream_sync(void* stream);
+int  dd_event_create(void** ev);
+int  dd_event_destroy(void* ev);
+int  dd_event_record(void* ev, void* stream);
+int  dd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* syncs on ev_stop */
+
+/* ---- S1: source.IQwav/IQdat/IQwavAlt.read (source.py:117-118,209-210,303-304) -- */
+/* interleaved uint8 I,Q  ->  complex64 minus (127.5+127.5j) */
+int dd_u8iq_to_c64(const uint8_t* in_iq, float* out_c64, int64_t n, void* stream);
+
+/* ---- N1: commSignal.offsetFreq (comm.py:63-78) ------------------------------ */
+/* out[i] = in[i] * exp(-j 2 pi f (start_index+i)/fs).  `cycles_q64` is
+ * frac(f/fs) * 2^64 (two's complement wrap), computed exactly on the host; the
+ * phase is exact modular integer arithmetic for any start_index.
+ * In place allowed (in == out). */
+int dd_nco_c64(const float* in_c64, float* out_c64, int64_t n, uint64_t cycles_q64,
+               int64_t start_index, void* stream);
+
+/* ---- F1/F3: filters.filter.applyOn, FIR (a=[1]) (filters.py:21-75) ------------ */
+typedef struct dd_fir dd_fir;
+int dd_fir_create(dd_fir** h, const double* taps, int ntaps);
+int dd_fir_destroy(dd_fir* h);
+/* (re)initialise the carried history: DD_HIST_ZEROS / DD_HIST_ONES / DD_HIST_GIVEN
+ * (hist_host: ntaps-1 complex64 (or float for the real path), oldest first). */
+int dd_fir_reset(dd_fir* h, int mode, const float* hist_host, void* stream);
+/* causal FIR, complex64 in -> complex64 out, same length, history carried
+ * (storeState) or not (carry=0: history read but left untouched). */
+int dd_fir_c64(dd_fir* h, const float* in_c64, float* out_c64, int64_t n, int carry, void* stream);
+/* real float64 path used at audio rate (NOAA tail keeps float64) */
+int dd_fir_f64(dd_fir* h, const double* in, double* out, int64_t n, int carry, void* stream);
+
+/* ---- F2: filters.filter zeroPhase -> scipy.signal.filtfilt (filters.py:72-73) -- */
+/* odd extension 3*ntaps, forward/backward with zi*x0; stateless.
+ * is_complex: 0 = float64 real, 1 = complex128 interleaved doubles.  n > 3*ntaps. */
+int dd_filtfilt_f64(const double* taps_host, int ntaps, const double* in, double* out,
+                    int64_t n, int is_complex, void* stream);
+/* complex64 in/out, float32 arithmetic (full-rate IQ windows, decode_noaa.py:852) */
+int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* in_c64, float* out_c64,
+                    int64_t n, void* stream);
+
+/* ---- R1: commSignal.bwLim non-strict (comm.py:118-130) ---------------------- */
+/* out[i] = in[offset + i*m]; elem_bytes in {4,8,16}; n_out = ceil((n-offset)/m) */
+int dd_decimate(const void* in, void* out, int64_t n, int m, int offset, int elem_bytes,
+                int64_t* n_out, void* stream);
+
+/* ---- D1: demod_fm.demod (demod_fm.py:29-51) --------------------------------- */
+typedef struct dd_fm dd_fm;
+int dd_fm_create(dd_fm** h);
+int dd_fm_destroy(dd_fm* h);
+int dd_fm_reset(dd_fm* h);
+/* angle(x[i]*conj(x[i-1])); first call with carry writes n-1 outputs, later calls n
+ * (quirk Q3); carry=0 always n-1.  *n_out receives the count written. */
+int dd_fm_discrim_c64(dd_fm* h, const float* in_c64, float* out, int64_t n, int carry,
+                      int64_t* n_out, void* stream);
+
+/* ---- fused hot path: offsetFreq -> filter(FIR) -> bwLim(M) -> demod_fm -------
+ * (decode_noaa.py:623, decode_fm.py:64-68, decode_afsk1200.py:79-94,
+ *  tutorial/3_chunking.py:24-38).  One kernel per chunk; all carried state (NCO
+ *  sample index, FIR history, decimation phase, last FM sample) is derived from
+ *  the absolute sample index or kept on the device. */
+/* Object-model form: state lives where the reference keeps it -- FIR history in the
+ * filter object (dd_fir), last FM sample in the demodulator (dd_fm, NULL = no FM,
+ * output is complex64), NCO sample index and decimation phase are the chunker
+ * variables "freqoffset"/"bwlim" passed by value (chunker.py:54-84, comm.py:73-76,
+ * 121-125).  nco: 0/1.  offset: chunk-relative index of the first kept sample.
+ * flags: DD_CHAIN_U8_INPUT | DD_CHAIN_FORCE_DIRECT.  carry: storeState of the filter. */
+int dd_fused_process(dd_fir* fir, dd_fm* fm, const void* in, void* out, int64_t n,
+                     int nco, uint64_t cycles_q64, int64_t start_index, int decim, int offset,
+                     int flags, int carry, int64_t* n_out, void* stream);
+
+/* Convenience handle bundling one filter, one FM demodulator and the chunker
+ * variables of one stream (used by bench.py and the sharded multi-GPU driver). */
+typedef struct dd_chain dd_chain;
+int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles_q64,
+                    int decim, int flags);
+int dd_chain_destroy(dd_chain* h);
+/* start a new stream (new chunker object): abs index 0, history ones, no FM state */
+int dd_chain_reset(dd_chain* h, void* stream);
+/* multi-GPU / shard start: establish state as if samples [0, abs_index) had been
+ * processed, from the `n_halo` raw input samples that precede abs_index
+ * (n_halo >= ntaps-1+decim; fewer only if abs_index == n_halo i.e. stream start). */
+int dd_chain_prime(dd_chain* h, const void* halo_in, int64_t n_halo, int64_t abs_index, void* stream);
+/* number of outputs the next dd_chain_process(n) will write (pure host arithmetic) */
+int64_t dd_chain_out_count(const dd_chain* h, int64_t n);
+/* process one chunk of n input samples (complex64, or u8 pairs with DD_CHAIN_U8_INPUT).
+ * out: float32 radians when DD_CHAIN_FM, else complex64. */
+int dd_chain_process(dd_chain* h, const void* in, void* out, int64_t n, int64_t* n_out, void* stream);
+/* which kernel the chain dispatches to: 0 = f32 direct form, 1 = f16-split MFMA Toeplitz */
+int dd_chain_path(const dd_chain* h);
+/* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
+
+/* ---- R2: commSignal.bwLim strict -> scipy.signal.resample (comm.py:110-116) --- */
+/* Fourier-domain resample of one chunk, float64 real: n -> num samples. */
+int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream);
+
+/* ---- A1: demod_am.demod = abs(hilbert(x)) (demod_am.py:18-29) in fixed blocks
+ *      (decode_noaa.py:647-653: 240 000-sample blocks, chunker rule) ----------- */
+int dd_am_envelope_f64(const double* in, double* out, int64_t n, int64_t block, void* stream);
+
+/* ---- X1: decode_noaa.__correlate (decode_noaa.py:659-675) --------------------- */
+/* out[i] = corr_same(h,needle)[i] / sqrt(winenergy_same(h,m)[i] * sum(needle^2)) */
+int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needle_host, int m,
+                      double* out, void* stream);
+
+/* ---- X2: peak pick of decode_noaa.__correlateAndFindPeaks (decode_noaa.py:713-751) */
+/* cor: n float64 on device.  Writes up to max_peaks int64 indices (already shifted
+ * by -needle_len/2, sorted) to peaks_host and their count to n_peaks.  Synchronous. */
+int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate, int needle_len,
+                      int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream);
+
+/* float32 -> float64 / complex64 -> complex128 widening (audio-rate hand-over) */
+int dd_f32_to_f64(const float* in, double* out, int64_t n, void* stream);
+int dd_f64_to_f32(const double* in, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIRECTDEMOD_HIP_H */

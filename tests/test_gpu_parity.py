@@ -1,0 +1,426 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, reached through the
+drop-in classes and through the raw C-ABI, against
+
+  * the golden vectors the reference itself produced (tests/golden/*.npz), and
+  * the oracle (oracle/dd_oracle.py) on other seeded inputs / sizes.
+
+Stated float32 tolerances (the reference computes in float64):
+  NCO   |err| <= 1e-6 * max|x|
+  FIR   |err| <= 2e-6 * max|y|
+  FM    wrapped |dphi| <= 1e-4 rad wherever |y[n] conj y[n-1]| >= 1e-3 * median,
+        and median |dphi| <= 2e-6 rad
+Index/length/rate bookkeeping is exact.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NCO_TOL = 1e-6
+FIR_TOL = 2e-6
+FM_MAX = 1e-4
+FM_MED = 2e-6
+
+
+@pytest.fixture(scope="module")
+def dd():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from directdemod_amd import _hip
+    _hip.require_gpu()
+    import directdemod_amd.comm as comm
+    import directdemod_amd.filters as filters
+    import directdemod_amd.demod_fm as demod_fm
+    import directdemod_amd.demod_am as demod_am
+    import directdemod_amd.chunker as chunker
+    import directdemod_amd._ops as _ops
+
+    class NS:
+        pass
+    ns = NS()
+    ns.hip, ns.comm, ns.filters, ns.demod_fm, ns.demod_am, ns.chunker, ns.ops = \
+        _hip, comm, filters, demod_fm, demod_am, chunker, _ops
+    return ns
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def rel_err(got, ref):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+
+
+def fm_check(got, ref_angle, y_ref_prod_mag=None):
+    got = np.asarray(got, dtype=np.float64)
+    assert got.shape == ref_angle.shape, (got.shape, ref_angle.shape)
+    d = np.abs(np.angle(np.exp(1j * (got - ref_angle))))
+    if y_ref_prod_mag is not None:
+        mask = y_ref_prod_mag >= 1e-3 * np.median(y_ref_prod_mag)
+    else:
+        mask = np.ones(len(d), dtype=bool)
+    assert np.max(d[mask]) <= FM_MAX, "max wrapped FM error %g" % np.max(d[mask])
+    assert np.median(d) <= FM_MED, "median FM error %g" % np.median(d)
+
+
+class _Src:
+    def __init__(self, n):
+        self.length = n
+
+
+@pytest.fixture(params=[0, 1, 2])
+def ops(request, golden_dir):
+    g = _load(golden_dir, "ops_seed%d.npz" % request.param)
+    x = O.grid_c64(O.synth_iq_noise(int(g["L"]), int(g["seed"])))
+    return g, x
+
+
+# ----------------------------------------------------------------------------- N1
+def test_nco_golden(dd, ops):
+    g, x = ops
+    s = dd.comm.commSignal(2400000, x).offsetFreq(25000.0)
+    assert rel_err(s.signal, g["nco_start0"]) < NCO_TOL
+    assert s.signal.dtype == np.complex64
+    ck = dd.chunker.chunker(_Src(len(x)))
+    ck.set("freqoffset", 19999000)
+    s = dd.comm.commSignal(2400000, x, ck).offsetFreq(25000.0)
+    assert rel_err(s.signal, g["nco_start19999000"]) < NCO_TOL
+
+
+@pytest.mark.parametrize("f,fs,start", [(-123456.789, 2048000, 0), (1.0e6, 2400000, 2 ** 40 + 12345),
+                                       (0.0, 1000, 5), (599999.5, 2400000, 123456789)])
+def test_nco_phase_exact_for_large_index(dd, f, fs, start):
+    x = O.grid_c64(O.synth_iq_noise(5000, 9))
+    ck = dd.chunker.chunker(_Src(5000))
+    ck.set("freqoffset", start)
+    got = dd.comm.commSignal(fs, x, ck).offsetFreq(f).signal
+    # oracle with exact rational phase (float64 n*f/fs loses bits at n ~ 2^40)
+    from fractions import Fraction
+    fr = Fraction(float(f)) / Fraction(int(fs))
+    ph = np.array([float((fr * (start + i)) % 1) for i in range(5000)])
+    ref = (x.astype(np.complex128) * np.exp(-2j * np.pi * ph))
+    assert rel_err(got, ref) < NCO_TOL
+
+
+# ----------------------------------------------------------------------------- F1
+@pytest.mark.parametrize("name", ["hamming255", "bh151", "remez127", "gauss51", "rollavg3"])
+def test_fir_stateful_uneven_chunks_golden(dd, ops, name):
+    g, x = ops
+    cuts = g["fir_cuts"]
+    f = dd.filters.filter(g["taps_" + name], [1])
+    y = np.concatenate([f.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(3)])
+    assert y.dtype == np.complex64
+    assert rel_err(y, g["fir_" + name]) < FIR_TOL
+
+
+def test_fir_named_classes_golden(dd, ops):
+    g, x = ops
+    assert rel_err(dd.filters.hamming(255).applyOn(x), g["fir_hamming255"]) < FIR_TOL
+    cuts = g["fir_cuts"]
+    for cls, args, key in ((dd.filters.hamming, (255,), "hamming255"),
+                           (dd.filters.blackmanHarris, (151,), "bh151"),
+                           (dd.filters.gaussian, (51, 5), "gauss51"),
+                           (dd.filters.rollingAverage, (3,), "rollavg3")):
+        f = cls(*args)
+        y = np.concatenate([f.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(3)])
+        assert rel_err(y, g["fir_" + key]) < FIR_TOL
+
+
+def test_fir_q1_first_sample_is_ones_history(dd):
+    # Experiment 3 :276-280 on the device: [1..9] -> first output 1.0 (not 0.5)
+    f = dd.filters.rollingAverage(2)
+    a = f.applyOn(np.arange(1, 10).astype(np.complex64))
+    b = f.applyOn(np.arange(10, 15).astype(np.complex64))
+    assert np.allclose(a.real, [1.0, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5], atol=1e-6)
+    assert np.allclose(b.real, [9.5, 10.5, 11.5, 12.5, 13.5], atol=1e-6)
+    # float64 real path
+    f = dd.filters.rollingAverage(2)
+    a = f.applyOn(np.arange(1, 10).astype(np.float64))
+    b = f.applyOn(np.arange(10, 15).astype(np.float64))
+    assert a.dtype == np.float64
+    assert np.allclose(a, [1.0, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5], atol=1e-12)
+    assert np.allclose(b, [9.5, 10.5, 11.5, 12.5, 13.5], atol=1e-12)
+    # stateless: Experiment 3 :131-132
+    f = dd.filters.rollingAverage(2, storeState=False)
+    assert np.allclose(f.applyOn(np.arange(1, 20).astype(np.float64)), np.arange(1, 20) - 0.5, atol=1e-12)
+    assert np.allclose(f.applyOn(np.arange(10, 15).astype(np.float64))[:2], [5.0, 10.5], atol=1e-12)
+
+
+def test_fir_plain_and_initout_golden(dd, ops):
+    g, x = ops
+    y = dd.filters.hamming(255, storeState=False).applyOn(x)
+    assert rel_err(y, g["fir_plain_hamming255"]) < FIR_TOL
+    y2 = dd.filters.hamming(255, storeState=False).applyOn(x)      # no state leaked
+    assert np.array_equal(y, y2)
+    fi = dd.filters.rollingAverage(4, initOut=[1.0, 2.0, 3.0])
+    y = np.concatenate([fi.applyOn(x[:100].real.astype(np.float64)), fi.applyOn(x[100:300].real.astype(np.float64))])
+    assert rel_err(y, g["fir_initout_rollavg4"]) < 1e-12
+    fi = dd.filters.rollingAverage(4, initOut=[1.0, 2.0, 3.0])
+    y = np.concatenate([fi.applyOn(x[:100].real.astype(np.complex64)), fi.applyOn(x[100:300].real.astype(np.complex64))])
+    assert rel_err(y.real, g["fir_initout_rollavg4"]) < FIR_TOL
+
+
+@pytest.mark.parametrize("L", [1, 2, 7, 253, 254, 255, 2047, 2048, 2049, 4095, 5000])
+def test_fir_ragged_lengths_vs_oracle(dd, L):
+    x = O.grid_c64(O.synth_iq_noise(L + 300, 31 + L))
+    taps = O.win_hamming(255)
+    f = dd.filters.hamming(255)
+    fo = O.FilterState(taps)
+    got = np.concatenate([f.applyOn(x[:L]), f.applyOn(x[L:])])
+    ref = np.concatenate([fo.applyOn(x[:L]), fo.applyOn(x[L:])])
+    assert rel_err(got, ref) < FIR_TOL
+
+
+def test_filtfilt_golden(dd, ops):
+    g, x = ops
+    y = dd.filters.blackmanHarris(151, zeroPhase=True).applyOn(x)
+    assert rel_err(y, g["filtfilt_bh151"]) < 5e-6
+    y = dd.filters.hamming(101, zeroPhase=True).applyOn(x.real.astype(np.float64))
+    assert rel_err(y, g["filtfilt_hamming101_real"]) < 1e-12
+    if "filtfilt_hamming492_real" in g.files:
+        y = dd.filters.hamming(492, zeroPhase=True).applyOn(x.real.astype(np.float64))
+        assert rel_err(y, g["filtfilt_hamming492_real"]) < 1e-12
+    with pytest.raises(ValueError):
+        dd.filters.hamming(492, zeroPhase=True).applyOn(np.zeros(1476))
+
+
+# ----------------------------------------------------------------------------- R1 / D1
+@pytest.mark.parametrize("fs,t,tag", [(2048000, 60000, "m34"), (10000000, 200000, "m50")])
+def test_decimation_carry_golden(dd, ops, fs, t, tag):
+    g, x = ops
+    cuts = g["fir_cuts"]
+    ck = dd.chunker.chunker(_Src(len(x)))
+    outs = []
+    for i in range(3):
+        s = dd.comm.commSignal(fs, x[cuts[i]:cuts[i + 1]], ck).bwLim(t, uniq="First")
+        outs.append(np.array(s.signal))
+        assert s.sampRate == int(g["decim_" + tag + "_rate"])
+    assert np.array_equal(np.concatenate(outs), g["decim_" + tag])     # bit-exact gather
+
+
+def test_fm_golden(dd, ops):
+    g, _ = ops
+    cuts = g["fir_cuts"]
+    y = g["fir_hamming255"]
+    mag = np.abs(y[1:] * np.conj(y[:-1]))
+    fm = dd.demod_fm.demod_fm()
+    got = np.concatenate([fm.demod(y[cuts[i]:cuts[i + 1]]) for i in range(3)])
+    fm_check(got, g["fm_carry"], mag)
+    fm_check(dd.demod_fm.demod_fm(storeState=False).demod(y), g["fm_nostate"], mag)
+
+
+def test_fm_notebook_vectors(dd):
+    # Experiment 5: values and 1-sample carry
+    x = np.array([1 + 1j, 2 - 2j, 3 + 3j, 4 - 4j, 5 + 5j, 6 - 6j])
+    exp = [-np.pi / 2, np.pi / 2, -np.pi / 2, np.pi / 2, -np.pi / 2]
+    assert np.allclose(dd.demod_fm.demod_fm(storeState=False).demod(x), exp, atol=1e-6)
+    fm = dd.demod_fm.demod_fm()
+    a, b = fm.demod(x[:3]), fm.demod(x[3:])
+    assert len(a) == 2 and len(b) == 3
+    assert np.allclose(np.concatenate([a, b]), exp, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- fused chains
+def test_chain_chunked_bh151_m34_golden(dd, ops):
+    g, x = ops
+    L = len(x)
+    ck = dd.chunker.chunker(_Src(L), 600)
+    assert ck.getChunks == g["chain_chunks"].tolist()
+    out = dd.comm.commSignal(2048000)
+    bh = dd.filters.blackmanHarris(151)
+    fm = dd.demod_fm.demod_fm()
+    for a, b in ck.getChunks:
+        s = dd.comm.commSignal(2048000, x[a:b], ck).offsetFreq(30000.0).filter(bh) \
+            .bwLim(60000, uniq="First").funcApply(fm.demod)
+        out.extend(s)
+    assert out.sampRate == int(g["chain_bh151_m34_rate"])
+    # magnitude of the conj-lag product from the oracle's FIR output
+    yo = O.FilterState(O.win_blackmanharris(151)).applyOn(O.nco(x, 30000.0, 2048000))[::34]
+    fm_check(out.signal, g["chain_bh151_m34"], np.abs(yo[1:] * np.conj(yo[:-1])))
+
+
+def test_chain_c2_golden(dd, ops):
+    g, x = ops
+    s = dd.comm.commSignal(2400000, x).offsetFreq(25000.0).filter(dd.filters.hamming(255)) \
+        .funcApply(dd.demod_fm.demod_fm().demod)
+    yo = O.FilterState(O.win_hamming(255)).applyOn(O.nco(x, 25000.0, 2400000))
+    fm_check(s.signal, g["chain_c2"], np.abs(yo[1:] * np.conj(yo[:-1])))
+
+
+def test_fused_equals_unfused_stages(dd):
+    """The fused kernel and the stage-by-stage kernels are the same arithmetic."""
+    L = 30000
+    x = O.grid_c64(O.synth_iq_fm(L, 2.4e6, 5))
+    s = dd.comm.commSignal(2400000, x).offsetFreq(25000.0).filter(dd.filters.hamming(255)) \
+        .bwLim(60000).funcApply(dd.demod_fm.demod_fm().demod)
+    fused = s.signal
+    a = dd.comm.commSignal(2400000, x).offsetFreq(25000.0)
+    _ = a.signal
+    a.filter(dd.filters.hamming(255))
+    _ = a.signal
+    a.bwLim(60000)
+    _ = a.signal
+    a.funcApply(dd.demod_fm.demod_fm().demod)
+    assert fused.shape == a.signal.shape
+    assert np.max(np.abs(np.angle(np.exp(1j * (fused - a.signal))))) < 2e-5
+
+
+@pytest.mark.parametrize("M,K,chunk", [(1, 255, 5000), (1, 31, 777), (2, 64, 1000), (34, 151, 4096),
+                                       (50, 127, 8192), (7, 255, 300), (200, 33, 5000), (32, 100, 3000)])
+def test_fused_chain_vs_oracle_shapes(dd, M, K, chunk):
+    L = 20000
+    fs = 1000000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 40 + M, f_carrier=20e3, f_mod=500.0, dev=3.0))
+    taps = O.win_hamming(K)
+    ck = dd.chunker.chunker(_Src(L), chunk)
+    flt = dd.filters.filter(taps, [1])
+    fm = dd.demod_fm.demod_fm()
+    out = dd.comm.commSignal(fs)
+    for a, b in ck.getChunks:
+        s = dd.comm.commSignal(fs, x[a:b], ck).offsetFreq(20000.0).filter(flt)
+        if M > 1:
+            s.bwLim(fs // M, uniq="First")
+        s.funcApply(fm.demod)
+        out.extend(s)
+    ref, rate = O.audio_chain(lambda a, b: x[a:b], L, fs, 20000.0, taps, fs // M, chunk_size=chunk)
+    assert out.sampRate == rate
+    yo = O.FilterState(taps).applyOn(O.nco(x, 20000.0, fs))[::M]
+    fm_check(out.signal, ref, np.abs(yo[1:] * np.conj(yo[:-1])))
+
+
+def test_fir_complex_output_decimated_vs_oracle(dd):
+    L = 50000
+    x = O.grid_c64(O.synth_iq_noise(L, 77))
+    taps = O.win_blackmanharris(151)
+    ck = dd.chunker.chunker(_Src(L), 7001)
+    flt = dd.filters.blackmanHarris(151)
+    out = dd.comm.commSignal(2048000)
+    fo = O.FilterState(taps)
+    refs = []
+    off = 0
+    for a, b in ck.getChunks:
+        s = dd.comm.commSignal(2048000, x[a:b], ck).filter(flt).bwLim(60000, uniq="q")
+        out.extend(s)
+        y, _, off, _ = O.decimate_carry(fo.applyOn(x[a:b]), 2048000, 60000, off)
+        refs.append(y)
+    assert rel_err(out.signal, np.concatenate(refs)) < FIR_TOL
+
+
+def test_short_first_chunks(dd):
+    """chunks shorter than ntaps-1, chunks without a kept sample"""
+    L = 3000
+    x = O.grid_c64(O.synth_iq_fm(L, 1e6, 3))
+    taps = O.win_hamming(255)
+    cuts = [0, 5, 6, 40, 41, 300, 1000, 1001, 3000]
+    for M in (1, 34):
+        flt = dd.filters.hamming(255)
+        fm = dd.demod_fm.demod_fm()
+        ck = dd.chunker.chunker(_Src(L))
+        out = dd.comm.commSignal(1000000)
+        fo = O.FilterState(taps)
+        last = None
+        off = 0
+        idx = 0
+        refs = []
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            s = dd.comm.commSignal(1000000, x[a:b], ck).offsetFreq(10000.0).filter(flt)
+            y = fo.applyOn(O.nco(x[a:b], 10000.0, 1000000, idx))
+            idx += b - a
+            if M > 1:
+                s.bwLim(1000000 // M, uniq="First")
+                y, _, off, _ = O.decimate_carry(y, 1000000, 1000000 // M, off)
+            if len(y) == 0:
+                continue            # the reference's demod raises IndexError on an empty chunk
+            s.funcApply(fm.demod)
+            out.extend(s)
+            r, last = O.fm_demod(y, last)
+            refs.append(r)
+        ref = np.concatenate(refs)
+        assert out.length == len(ref)
+        d = np.abs(np.angle(np.exp(1j * (out.signal - ref))))
+        assert np.max(d) < 1e-3 and np.median(d) < FM_MED
+
+
+# ----------------------------------------------------------------------------- raw C-ABI
+def test_capi_chain_handle_and_prime(dd):
+    """dd_chain_* handle: chunked == one shot; a primed shard continues the stream."""
+    hip = dd.hip
+    lib = hip.lib()
+    L = 100000
+    fs = 2400000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 11))
+    taps = np.ascontiguousarray(O.win_hamming(255))
+    cyc = hip.cycles_q64(25000.0, fs)
+    tp = taps.ctypes.data_as(C.POINTER(C.c_double))
+    dx = hip.DevArray.from_host(x)
+
+    def run(M, pieces, prime_at=None):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), tp, 255, cyc, M, hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM))
+        outs = []
+        start = 0
+        if prime_at is not None:
+            halo = 254 + M
+            hip.check(lib.dd_chain_prime(h, dx.ptr + (prime_at - halo) * 8, halo, prime_at, None))
+            start = prime_at
+        for a, b in pieces:
+            assert a == start
+            n = b - a
+            no = lib.dd_chain_out_count(h, n)
+            out = hip.DevArray(max(1, no), np.float32)
+            got = C.c_int64(0)
+            hip.check(lib.dd_chain_process(h, dx.ptr + a * 8, out.ptr, n, C.byref(got), None))
+            assert got.value == no
+            outs.append(out.to_host()[:no])
+            start = b
+        lib.dd_chain_destroy(h)
+        return np.concatenate(outs)
+
+    for M in (1, 34):
+        ref, _ = O.audio_chain(lambda a, b: x[a:b], L, fs, 25000.0, taps, fs // M if M > 1 else fs)
+        one = run(M, [(0, L)])
+        yo = O.FilterState(taps).applyOn(O.nco(x, 25000.0, fs))[::M]
+        fm_check(one, ref, np.abs(yo[1:] * np.conj(yo[:-1])))
+        chunked = run(M, [(0, 33333), (33333, 33334), (33334, 90001), (90001, L)])
+        assert np.max(np.abs(np.angle(np.exp(1j * (chunked - one))))) < 2e-5
+        # shard starting at 50 003: equals the tail of the one-shot result
+        cut = 50003
+        shard = run(M, [(cut, L)], prime_at=cut)
+        n_before = len(range(0, cut, M)) - 1        # outputs produced by samples [0, cut)
+        assert len(shard) == len(one) - n_before
+        assert np.max(np.abs(np.angle(np.exp(1j * (shard - one[n_before:]))))) < 2e-5
+
+
+def test_u8_ingest(dd):
+    hip = dd.hip
+    lib = hip.lib()
+    raw = O.synth_iq_noise(10007, 5)
+    d = hip.DevArray.from_host(raw.reshape(-1))
+    out = hip.DevArray(10007, np.complex64)
+    hip.check(lib.dd_u8iq_to_c64(d.ptr, out.ptr, 10007, None))
+    assert np.array_equal(out.to_host(), O.grid_c64(raw))          # exact
+    # fused u8 ingest inside the chain kernel == chain on the converted samples
+    taps = np.ascontiguousarray(O.win_blackmanharris(151))
+    tp = taps.ctypes.data_as(C.POINTER(C.c_double))
+    cyc = hip.cycles_q64(30000.0, 2048000)
+    res = []
+    for flags, src in ((hip.DD_CHAIN_U8_INPUT, d), (0, out)):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), tp, 151, cyc, 34, hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM | flags))
+        no = lib.dd_chain_out_count(h, 10007)
+        o = hip.DevArray(no, np.float32)
+        hip.check(lib.dd_chain_process(h, src.ptr, o.ptr, 10007, None, None))
+        res.append(o.to_host())
+        lib.dd_chain_destroy(h)
+    assert np.array_equal(res[0], res[1])
