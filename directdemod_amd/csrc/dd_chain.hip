@@ -542,6 +542,8 @@ struct dd_chain {
     uint64_t cyc;
     int M, flags;
     int64_t abs_index;
+    void* scratch;          // discarded outputs of dd_chain_prime
+    size_t scratch_bytes;
 };
 
 extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles_q64,
@@ -555,6 +557,8 @@ extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint
     c->M = decim;
     c->flags = flags;
     c->abs_index = 0;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
     int rc = dd_fir_create(&c->fir, taps, ntaps);
     if (rc == DD_OK && (flags & DD_CHAIN_FM)) rc = dd_fm_create(&c->fm);
     if (rc != DD_OK) {
@@ -569,6 +573,7 @@ extern "C" int dd_chain_destroy(dd_chain* c) {
     if (!c) return DD_OK;
     dd_fir_destroy(c->fir);
     dd_fm_destroy(c->fm);
+    hipFree(c->scratch);
     delete c;
     return DD_OK;
 }
@@ -636,13 +641,14 @@ extern "C" int dd_chain_prime(dd_chain* c, const void* halo_in, int64_t n_halo, 
     int rc = dd_fir_reset(c->fir, at_start ? DD_HIST_ONES : DD_HIST_ZEROS, nullptr, stream);
     if (rc != DD_OK) return rc;
     const int64_t no = dd_chain_out_count(c, n_halo);
-    void* scratch = nullptr;
     const size_t ob = (size_t)(no > 0 ? no : 1) * ((c->flags & DD_CHAIN_FM) ? sizeof(float) : sizeof(float2));
-    DD_HIP_CHECK(hipMalloc(&scratch, ob));
-    rc = dd_chain_process(c, halo_in, scratch, n_halo, nullptr, stream);
-    hipError_t e = hipStreamSynchronize(s);
-    hipFree(scratch);
-    if (rc != DD_OK) return rc;
-    DD_HIP_CHECK(e);
-    return DD_OK;
+    if (ob > c->scratch_bytes) {
+        DD_HIP_CHECK(hipStreamSynchronize(s));
+        hipFree(c->scratch);
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+        DD_HIP_CHECK(hipMalloc(&c->scratch, ob));
+        c->scratch_bytes = ob;
+    }
+    return dd_chain_process(c, halo_in, c->scratch, n_halo, nullptr, stream);
 }

@@ -319,7 +319,7 @@ def test_fir_complex_output_decimated_vs_oracle(dd):
 def test_short_first_chunks(dd):
     """chunks shorter than ntaps-1, chunks without a kept sample"""
     L = 3000
-    x = O.grid_c64(O.synth_iq_fm(L, 1e6, 3))
+    x = O.grid_c64(O.synth_iq_fm(L, 1e6, 3, f_carrier=10e3))
     taps = O.win_hamming(255)
     cuts = [0, 5, 6, 40, 41, 300, 1000, 1001, 3000]
     for M in (1, 34):
