@@ -23,6 +23,7 @@
 // 64-byte-strided ds_read_b128 of the A fragments is bank-conflict free
 // (dword index 20 i + 4 h, distinct for the 16 lanes of every b128 lane group).
 #include "dd_chain_kernels.h"
+#include <stdlib.h>
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
@@ -47,151 +48,196 @@ __device__ __forceinline__ float dd_pow2_scale_for(float m) {
     return eb == 0 ? 1.0f : __uint_as_float((uint32_t)se << 23);
 }
 
-template <int NKS>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma(const DDChainParams P, const DDMfmaTaps taps) {
-    constexpr int HALO = 16 * NKS - 32;
-    constexpr int SPAN = MF_T + HALO;                     // staged samples (multiple of 32)
-    constexpr int PLANE = SPAN * 2 + (SPAN / 32) * 16;    // bytes per f16 plane incl. padding
-    constexpr int NIT = (SPAN / 2 + MF_THREADS - 1) / MF_THREADS;
-    constexpr int NGRP = SPAN / 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* planes = smem;
-    float2* w2 = reinterpret_cast<float2*>(smem + 4 * PLANE);
-    float* red = reinterpret_cast<float*>(w2 + NGRP);           // MF_WAVES floats
-    float2* wlast = reinterpret_cast<float2*>(red + MF_WAVES);  // MF_WAVES float2
+// atan2 for the discriminator: odd degree-15 minimax polynomial on [0,1] (max error
+// 4e-8 rad in exact arithmetic, 1.5e-7 rad evaluated in f32) + octant fix-up.
+__device__ __forceinline__ float dd_fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = t * t;
+    float p = -4.054567120e-03f;
+    p = fmaf(p, z, 2.186295773e-02f);
+    p = fmaf(p, z, -5.591232695e-02f);
+    p = fmaf(p, z, 9.642197381e-02f);
+    p = fmaf(p, z, -1.390862959e-01f);
+    p = fmaf(p, z, 1.994656567e-01f);
+    p = fmaf(p, z, -3.332986079e-01f);
+    p = fmaf(p, z, 9.999993356e-01f);
+    float r = p * t;
+    r = (mx == 0.f) ? 0.f : r;                          // atan2(0,0) = 0 like np.angle
+    r = (ay > ax) ? 1.5707963267948966f - r : r;
+    r = (x < 0.f) ? 3.141592653589793f - r : r;
+    return copysignf(r, y);
+}
 
+__device__ __forceinline__ float dd_fm_angle_fast(float cx, float cy, float px, float py) {
+    const float re = fmaf(cx, px, cy * py);
+    const float im = fmaf(cy, px, -cx * py);
+    return dd_fast_atan2(im, re);
+}
+
+// value of the lane one to the left (DPP wave_shr:1); lanes 0/32 are patched by the caller
+__device__ __forceinline__ float dd_lane_left(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dd_readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// bytes of LDS used by one tile's staging (planes + phasors + reduction + strip hand-over)
+#define MF_LDS_TILE_BYTES(NKS) ((4 * MfmaGeom<NKS>::PLANE + 8 * MfmaGeom<NKS>::NGRP + 4 * MF_WAVES + 8 * MF_WAVES + 15) & ~15)
+
+#define MF_BL_SLOTS(NKS) ((((NKS) * 64 + MF_THREADS - 1) / MF_THREADS) * MF_THREADS)
+
+template <int NKS>
+struct MfmaGeom {
+    static constexpr int HALO = 16 * NKS - 32;
+    static constexpr int SPAN = MF_T + HALO;                     // staged samples (multiple of 32)
+    static constexpr int PLANE = SPAN * 2 + (SPAN / 32) * 16;    // bytes per f16 plane incl. padding
+    static constexpr int NIT = (SPAN / 2 + MF_THREADS - 1) / MF_THREADS;
+    static constexpr int NGRP = SPAN / 64;
+};
+
+// A tile is INTERIOR when its whole staged span lies inside the chunk, the input is
+// 16-byte aligned complex64, every output of the tile is emitted and no carried
+// state is touched: no per-element predicates anywhere.
+template <int NKS>
+__device__ __forceinline__ bool dd_tile_interior(const DDChainParams& P, int b) {
+    using G = MfmaGeom<NKS>;
+    const int64_t P0 = (int64_t)b * MF_ADV - 32;
+    const int64_t ns = P0 - G::HALO;
+    return b > 0 && b < P.nblocks - 1 && ns >= 0 && ns + G::SPAN <= P.L && P0 + MF_T <= P.Ld &&
+           !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
+}
+
+// issue the tile's global loads (two consecutive samples per lane per step)
+template <int NKS>
+__device__ __forceinline__ void dd_tile_load(const DDChainParams& P, int b, bool interior, float4 (&raw)[MfmaGeom<NKS>::NIT]) {
+    using G = MfmaGeom<NKS>;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = dd_xcd_tile(blockIdx.x, P.nblocks);
-    const int64_t P0 = (int64_t)b * MF_ADV - 32;          // first FIR output computed by this tile
-    const int64_t ns = P0 - HALO;                         // chunk-relative index of staged element 0
-    const bool fm = (P.flags & DD_CHAIN_FM) != 0;
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    if (interior) {
+        // unconditional loads (a predicated load makes hipcc branch and drain vmcnt per
+        // element): the partial last step re-reads the final pair, its LDS write is masked
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + ns);
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int q = tid + MF_THREADS * it;
+            raw[it] = src[q < G::SPAN / 2 ? q : G::SPAN / 2 - 1];
+        }
+    } else {
+        const bool fast_ok = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int e = 2 * (tid + MF_THREADS * it);
+            const int64_t n = ns + e;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < G::SPAN) {
+                if (fast_ok && n >= 0 && n + 1 < P.L) {
+                    v = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + n);
+                } else {
+                    // stream edges, carried history (already NCO-rotated), u8 ingest
+                    DDChainParams Q = P;
+                    Q.flags &= ~DD_CHAIN_NCO;
+                    const float2 a = dd_load_sample(Q, n, make_float2(1.f, 0.f));
+                    const float2 c = dd_load_sample(Q, n + 1, make_float2(1.f, 0.f));
+                    v = make_float4(a.x, a.y, c.x, c.y);
+                }
+            }
+            raw[it] = v;
+        }
+    }
+}
+
+// phasor of the first sample of this thread's 64-sample group of tile b (threads
+// < NGRP); issued together with the tile's loads so its table fetch is off the
+// critical path
+template <int NKS>
+__device__ __forceinline__ float2 dd_tile_w2(const DDChainParams& P, int b) {
+    using G = MfmaGeom<NKS>;
+    static_assert(G::NGRP <= MF_THREADS, "one group phasor per thread");
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    const int g = threadIdx.x < G::NGRP ? threadIdx.x : G::NGRP - 1;
+    if (!(P.flags & DD_CHAIN_NCO)) return make_float2(1.f, 0.f);
+    return dd_phasor((uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc, P.nco_tbl);
+}
+
+// rotate, scale, split into f16 limbs, write the LDS planes.  Returns the tile's
+// power-of-two scale.  Contains one barrier (max reduction; it also fences the
+// previous tile's LDS reads).
+template <int NKS, bool INTERIOR>
+__device__ __forceinline__ float dd_tile_stage(const DDChainParams& P, int b, const float4 (&raw)[MfmaGeom<NKS>::NIT],
+                                               char* smem, float2 w1a, float2 w1b, float2 w2mine) {
+    using G = MfmaGeom<NKS>;
+    char* planes = smem;
+    float2* w2 = reinterpret_cast<float2*>(smem + 4 * G::PLANE);
+    float* red = reinterpret_cast<float*>(w2 + G::NGRP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
     const int K = P.K;
 
-    // ---- issue the tile's global loads (two consecutive samples per lane per step)
-    float4 raw[NIT];
-    const bool fast_ok = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = 2 * (tid + MF_THREADS * it);
-        const int64_t n = ns + e;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < SPAN) {
-            if (fast_ok && n >= 0 && n + 1 < P.L) {
-                v = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + n);
-            } else {
-                // slow path: stream edges, carried history (already NCO-rotated), u8 ingest
-                DDChainParams Q = P;
-                Q.flags &= ~DD_CHAIN_NCO;
-                const float2 a = dd_load_sample(Q, n, make_float2(1.f, 0.f));
-                const float2 c = dd_load_sample(Q, n + 1, make_float2(1.f, 0.f));
-                v = make_float4(a.x, a.y, c.x, c.y);
-            }
-        }
-        raw[it] = v;
-    }
-
-    // ---- per-64-sample NCO phasors and the tile's max |component|
-    if (nco) {
-        for (int g = tid; g < NGRP; g += MF_THREADS) {
-            const uint64_t ph = (uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc;
-            w2[g] = dd_phasor(ph, P.nco_tbl);
-        }
-    }
     float m = 0.f;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < G::NIT; ++it) {
         m = fmaxf(m, fmaxf(fmaxf(fabsf(raw[it].x), fabsf(raw[it].y)), fmaxf(fabsf(raw[it].z), fabsf(raw[it].w))));
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();                    // previous tile: all LDS reads (planes, w2, red, wlast) are done
     if (lane == 0) red[wave] = m;
+    if (tid < G::NGRP) w2[tid] = w2mine;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float scale = dd_pow2_scale_for(m);
     const float inv_scale = 1.0f / scale;
 
-    // ---- rotate, scale, split into f16 limbs, write the LDS planes
-    {
-        float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+    const int64_t tail_first = P.L - (K - 1);       // first sample of the new history
+    const bool tail_writer = !INTERIOR && (b == P.nblocks - 1) && P.tail_out != nullptr;
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int e = 2 * (tid + MF_THREADS * it);
+        if (e >= G::SPAN) continue;
+        const int64_t n = ns + e;
+        float2 pa = make_float2(scale, 0.f), pb = make_float2(scale, 0.f);
         if (nco) {
-            w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
-            w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
+            const float2 g = w2[e >> 6];
+            const float2 gs = make_float2(g.x * scale, g.y * scale);
+            if (INTERIOR || n >= 0) pa = dd_cmul(gs, w1a);
+            if (INTERIOR || n + 1 >= 0) pb = dd_cmul(gs, w1b);
         }
-        const int64_t tail_first = P.L - (K - 1);       // first sample of the new history
-        const bool tail_writer = (b == P.nblocks - 1) && P.tail_out != nullptr;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = 2 * (tid + MF_THREADS * it);
-            if (e >= SPAN) continue;
-            const int64_t n = ns + e;
-            float2 pa = make_float2(scale, 0.f), pb = make_float2(scale, 0.f);
-            if (nco) {
-                const float2 g = w2[e >> 6];
-                const float2 gs = make_float2(g.x * scale, g.y * scale);
-                if (n >= 0) pa = dd_cmul(gs, w1a);
-                if (n + 1 >= 0) pb = dd_cmul(gs, w1b);
-            }
-            const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
-            const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
-            if (tail_writer) {
-                if (n >= tail_first && n < P.L) P.tail_out[n - tail_first] = make_float2(xa.x * inv_scale, xa.y * inv_scale);
-                if (n + 1 >= tail_first && n + 1 < P.L) P.tail_out[n + 1 - tail_first] = make_float2(xb.x * inv_scale, xb.y * inv_scale);
-            }
-            v2h rh, rl, ih, il;
-            rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
-            ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
-            rl.x = (_Float16)(xa.x - (float)rh.x); rl.y = (_Float16)(xb.x - (float)rh.y);
-            il.x = (_Float16)(xa.y - (float)ih.x); il.y = (_Float16)(xb.y - (float)ih.y);
-            const int off = 2 * e + 16 * (e >> 5);
-            *reinterpret_cast<v2h*>(planes + off) = rh;
-            *reinterpret_cast<v2h*>(planes + PLANE + off) = rl;
-            *reinterpret_cast<v2h*>(planes + 2 * PLANE + off) = ih;
-            *reinterpret_cast<v2h*>(planes + 3 * PLANE + off) = il;
+        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
+        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
+        if (tail_writer) {
+            if (n >= tail_first && n < P.L) P.tail_out[n - tail_first] = make_float2(xa.x * inv_scale, xa.y * inv_scale);
+            if (n + 1 >= tail_first && n + 1 < P.L) P.tail_out[n + 1 - tail_first] = make_float2(xb.x * inv_scale, xb.y * inv_scale);
         }
+        v2h rh, rl, ih, il;
+        rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
+        ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
+        rl.x = (_Float16)(xa.x - (float)rh.x); rl.y = (_Float16)(xb.x - (float)rh.y);
+        il.x = (_Float16)(xa.y - (float)ih.x); il.y = (_Float16)(xb.y - (float)ih.y);
+        const int off = 2 * e + 16 * (e >> 5);
+        *reinterpret_cast<v2h*>(planes + off) = rh;
+        *reinterpret_cast<v2h*>(planes + G::PLANE + off) = rl;
+        *reinterpret_cast<v2h*>(planes + 2 * G::PLANE + off) = ih;
+        *reinterpret_cast<v2h*>(planes + 3 * G::PLANE + off) = il;
     }
-    // ---- Toeplitz tap fragments -> registers (L2 resident, 16 B per lane, coalesced);
-    //      issued here so they do not share the register file with the raw tile
-    v8h bh[NKS], bl[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        bh[ks] = taps.frag[ks * 64 + lane];
-        bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
-    }
-    __syncthreads();
+    return scale;
+}
 
-    // ---- Toeplitz GEMM: 6 MFMAs per k-step (3 limb products x re/im)
-    v16f cre, cim;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-    {
-        const int i = lane & 31, h = lane >> 5;
-        const int sb = wave * MF_STRIP;
-        const char* abase = planes + (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int off = 32 * ks + 16 * (ks >> 1);
-            const v8h arh = *reinterpret_cast<const v8h*>(abase + off);
-            const v8h arl = *reinterpret_cast<const v8h*>(abase + PLANE + off);
-            const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * PLANE + off);
-            const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * PLANE + off);
-            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bh[ks], cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bh[ks], cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, bh[ks], cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, bh[ks], cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bl[ks], cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bl[ks], cim, 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue.  lane (j = lane & 31, h = lane >> 5), register r holds output
-    //      p = P0 + 1024*wave + 32*row + j,  row = (r & 3) + 8 (r >> 2) + 4 h
+// epilogue.  lane (j = lane & 31, h = lane >> 5), register r holds output
+//   p = P0 + 1024*wave + 32*row + j,  row = (r & 3) + 8 (r >> 2) + 4 h
+template <int NKS, bool INTERIOR>
+__device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, v16f& cre, v16f& cim, float unscale, char* smem) {
+    using G = MfmaGeom<NKS>;
+    float2* wlast = reinterpret_cast<float2*>(smem + 4 * G::PLANE + sizeof(float2) * G::NGRP + sizeof(float) * MF_WAVES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
+    const int64_t P0 = (int64_t)b * MF_ADV - 32;
     const int64_t pw = P0 + (int64_t)wave * MF_STRIP;
     const int64_t p_lo = P0 + 32;                          // first output this tile owns
-    const float unscale = inv_scale * taps.inv_tapscale;
+    const bool fm = (P.flags & DD_CHAIN_FM) != 0;
 
     if (!fm) {
         float2* out = reinterpret_cast<float2*>(P.out);
@@ -199,12 +245,13 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma(const DDChainParam
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int64_t p = pw + 32 * row + j;
-            if (p >= p_lo && p < P.Ld) out[p] = make_float2(cre[r] * unscale, cim[r] * unscale);
+            if (INTERIOR ? (wave > 0 || row > 0) : (p >= p_lo && p < P.Ld))
+                out[p] = make_float2(cre[r] * unscale, cim[r] * unscale);
         }
         return;
     }
 
-    if (P.s == 0 && b == 0 && wave == 0 && lane == 31) {   // p == -1: sample carried from the previous chunk
+    if (!INTERIOR && P.s == 0 && b == 0 && wave == 0 && lane == 31) {   // p == -1: sample carried from the previous chunk
         const float2 ly = *P.lasty_in;                     // (any positive scale: only its angle matters)
         cre[0] = ly.x;
         cim[0] = ly.y;
@@ -213,33 +260,151 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma(const DDChainParam
     __syncthreads();
     const float2 prev_strip = (wave > 0) ? wlast[wave - 1] : make_float2(0.f, 0.f);
 
-    float* out = reinterpret_cast<float*>(P.out);
+    // column-0 neighbours: row-1 is register r-1 of lane 31/63, or sits across the
+    // 4-row split of the accumulator layout (register r+3 / r-1 of the other half)
+    float* out = reinterpret_cast<float*>(P.out) + (pw - P.s) + j + 128 * h;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        // neighbour y[p-1]: one lane to the left, except column 0 (lanes 0 and 32)
-        float pre = __shfl_up(cre[r], 1);
-        float pim = __shfl_up(cim[r], 1);
-        // sources for column 0: row-1 lives in (r-1) of lane 31/63, or across the 4-row split
-        float a_re, a_im, c_re, c_im;
+        float pre = dd_lane_left(cre[r]);
+        float pim = dd_lane_left(cim[r]);
+        float a_re, a_im, c_re, c_im;                      // for lane 0 and lane 32
         if ((r & 3) != 0) {
-            a_re = __shfl(cre[r - 1], 31); a_im = __shfl(cim[r - 1], 31);     // lane 0  <- lane 31
-            c_re = __shfl(cre[r - 1], 63); c_im = __shfl(cim[r - 1], 63);     // lane 32 <- lane 63
+            a_re = dd_readlane(cre[r - 1], 31); a_im = dd_readlane(cim[r - 1], 31);
+            c_re = dd_readlane(cre[r - 1], 63); c_im = dd_readlane(cim[r - 1], 63);
         } else {
-            if (r > 0) { a_re = __shfl(cre[r - 1], 63); a_im = __shfl(cim[r - 1], 63); }   // rows 8,16,24 <- 7,15,23
-            else { a_re = prev_strip.x; a_im = prev_strip.y; }                               // row 0 <- previous strip
-            c_re = __shfl(cre[r + 3], 31); c_im = __shfl(cim[r + 3], 31);                    // rows 4,12,.. <- 3,11,..
+            if (r > 0) { a_re = dd_readlane(cre[r - 1], 63); a_im = dd_readlane(cim[r - 1], 63); }
+            else { a_re = prev_strip.x; a_im = prev_strip.y; }
+            c_re = dd_readlane(cre[r + 3], 31); c_im = dd_readlane(cim[r + 3], 31);
         }
-        if (lane == 0) { pre = a_re; pim = a_im; }
-        if (lane == 32) { pre = c_re; pim = c_im; }
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int64_t p = pw + 32 * row + j;
-        const float2 cur = make_float2(cre[r], cim[r]);
-        if (p >= p_lo && p >= P.s && p < P.Ld) {
-            out[p - P.s] = dd_fm_angle(cur, make_float2(pre, pim));
+        pre = (lane == 0) ? a_re : pre;  pim = (lane == 0) ? a_im : pim;
+        pre = (lane == 32) ? c_re : pre; pim = (lane == 32) ? c_im : pim;
+        const int rowbase = (r & 3) + 8 * (r >> 2);        // row = rowbase + 4h
+        const float ang = dd_fm_angle_fast(cre[r], cim[r], pre, pim);
+        if (INTERIOR) {
+            if (wave > 0 || rowbase > 0 || h > 0) out[32 * rowbase] = ang;
+        } else {
+            const int64_t p = pw + 32 * (rowbase + 4 * h) + j;
+            if (p >= p_lo && p >= P.s && p < P.Ld) out[32 * rowbase] = ang;
+            if (p == P.Ld - 1) *P.lasty_out = make_float2(cre[r] * unscale, cim[r] * unscale);
         }
-        if (p == P.Ld - 1 && p >= p_lo - (b == 0 ? 0 : 0)) {
-            *P.lasty_out = make_float2(cur.x * unscale, cur.y * unscale);
+    }
+}
+
+// Edge tiles (stream start/end, unaligned or u8 input, partial tiles): one tile per
+// workgroup, fully predicated.  tile = first + blockIdx.x * stride.
+template <int NKS>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChainParams P, const DDMfmaTaps taps, int first, int stride) {
+    using G = MfmaGeom<NKS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = first + (int)blockIdx.x * stride;
+    float4 raw[G::NIT];
+    dd_tile_load<NKS>(P, b, false, raw);
+    float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+    if (P.flags & DD_CHAIN_NCO) {
+        w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
+        w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
+    }
+    const float scale = dd_tile_stage<NKS, false>(P, b, raw, smem, w1a, w1b, dd_tile_w2<NKS>(P, b));
+    v8h bh[NKS], bl[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        bh[ks] = taps.frag[ks * 64 + lane];
+        bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    const int sb = wave * MF_STRIP;
+    const char* abase = smem + (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
+    v16f cre, cim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int off = 32 * ks + 16 * (ks >> 1);
+        const v8h arh = *reinterpret_cast<const v8h*>(abase + off);
+        const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
+        const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
+        const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bh[ks], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bh[ks], cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, bh[ks], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, bh[ks], cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bl[ks], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bl[ks], cim, 0, 0, 0);
+    }
+    dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
+}
+
+// Interior tiles [t_first, t_last): persistent workgroups.  Each owns a contiguous
+// run of tiles (neighbouring halos stay in its XCD's L2), keeps the Toeplitz tap
+// fragments in registers for the whole launch and prefetches the next tile's
+// samples while the matrix cores work on the current one.
+template <int NKS>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+    using G = MfmaGeom<NKS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x;
+    const int wg = blockIdx.x;
+    const int nt = t_last - t_first;
+    const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
+    const int t_end = t_first + (int)(((int64_t)(wg + 1) * nt) / nwg);
+    if (t_begin >= t_end) return;
+
+    float4 raw[G::NIT];
+    dd_tile_load<NKS>(P, t_begin, true, raw);
+    float2 w2mine = dd_tile_w2<NKS>(P, t_begin);
+
+    // high tap limb in registers; the low limb (used once per k-step) lives in LDS
+    v8h bh[NKS];
+    v8h* bl_lds = reinterpret_cast<v8h*>(smem + MF_LDS_TILE_BYTES(NKS));
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) bh[ks] = taps.frag[ks * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < MF_BL_SLOTS(NKS) / MF_THREADS; ++q) {     // padded image: every lane stores
+        const int idx = tid + MF_THREADS * q;
+        bl_lds[idx] = taps.frag[NKS * 64 + (idx < NKS * 64 ? idx : NKS * 64 - 1)];
+    }
+    float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+    if (P.flags & DD_CHAIN_NCO) {
+        w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
+        w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
+    }
+    const int i = lane & 31, h = lane >> 5;
+    const int sb = wave * MF_STRIP;
+    const char* abase = smem + (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
+
+    for (int b = t_begin; b < t_end; ++b) {
+        const float scale = dd_tile_stage<NKS, true>(P, b, raw, smem, w1a, w1b, w2mine);
+        if (b + 1 < t_end) {
+            dd_tile_load<NKS>(P, b + 1, true, raw);
+            w2mine = dd_tile_w2<NKS>(P, b + 1);
         }
+        __syncthreads();
+
+        // ---- Toeplitz GEMM: 6 MFMAs per k-step (3 limb products x re/im)
+        v16f cre, cim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+        {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int off = 32 * ks + 16 * (ks >> 1);
+                const v8h arh = *reinterpret_cast<const v8h*>(abase + off);
+                const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
+                const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
+                const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
+                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bh[ks], cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bh[ks], cim, 0, 0, 0);
+                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, bh[ks], cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, bh[ks], cim, 0, 0, 0);
+                const v8h blk = bl_lds[ks * 64 + lane];
+                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, blk, cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, blk, cim, 0, 0, 0);
+            }
+        }
+        dd_tile_epilogue<NKS, true>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
     }
 }
 
@@ -319,21 +484,49 @@ void dd_mfma_destroy(void* st) {
 
 template <int NKS>
 static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s) {
-    constexpr int HALO = 16 * NKS - 32;
-    constexpr int SPAN = MF_T + HALO;
-    constexpr int PLANE = SPAN * 2 + (SPAN / 32) * 16;
-    const size_t lds = (size_t)4 * PLANE + sizeof(float2) * (SPAN / 64) + sizeof(float) * MF_WAVES +
-                       sizeof(float2) * MF_WAVES + 16;
+    using G = MfmaGeom<NKS>;
+    const size_t lds = (size_t)MF_LDS_TILE_BYTES(NKS) + (size_t)MF_BL_SLOTS(NKS) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     DDMfmaTaps t;
     t.frag = st->frag;
     t.inv_tapscale = st->inv_tapscale;
-    hipLaunchKernelGGL(k_chain_mfma<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t);
-    DD_LAUNCH_CHECK();
+    // interior tiles: whole span inside the chunk, all outputs emitted, aligned complex64
+    int t_first = 1, t_last = 1;
+    const bool aligned = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
+    if (aligned && P.nblocks > 2) {
+        // tile b: ns = b*ADV - 32 - HALO >= 0 ; ns + SPAN <= L ; b*ADV - 32 + T <= Ld
+        int64_t lo = (32 + G::HALO + MF_ADV - 1) / MF_ADV;
+        if (lo < 1) lo = 1;
+        int64_t hi1 = (P.L - G::SPAN + 32 + G::HALO) / MF_ADV;         // last b with ns + SPAN <= L
+        int64_t hi2 = (P.Ld - MF_T + 32) / MF_ADV;                     // last b with P0 + T <= Ld
+        int64_t hi = hi1 < hi2 ? hi1 : hi2;
+        if (hi > P.nblocks - 2) hi = P.nblocks - 2;
+        if (hi >= lo) { t_first = (int)lo; t_last = (int)hi + 1; }
+    }
+    const int n_int = t_last - t_first;
+    if (n_int > 0) {
+        int grid = n_int < 512 ? n_int : 512;       // 2 persistent workgroups per CU (256 CUs)
+        { const char* e = getenv("DD_GRID"); if (e && atoi(e) > 0) grid = atoi(e) < n_int ? atoi(e) : n_int; }
+        hipLaunchKernelGGL(k_chain_mfma<NKS>, dim3(grid), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
+        DD_LAUNCH_CHECK();
+        // edge tiles on both sides
+        if (t_first > 0) {
+            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(t_first), dim3(MF_THREADS), lds, s, P, t, 0, 1);
+            DD_LAUNCH_CHECK();
+        }
+        if (t_last < P.nblocks) {
+            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks - t_last), dim3(MF_THREADS), lds, s, P, t, t_last, 1);
+            DD_LAUNCH_CHECK();
+        }
+    } else {
+        hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t, 0, 1);
+        DD_LAUNCH_CHECK();
+    }
     return DD_OK;
 }
 
@@ -341,6 +534,7 @@ int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s) {
     const DDMfmaState* st = reinterpret_cast<const DDMfmaState*>(stv);
     DDChainParams P = Pin;
     P.T = MF_T;
+    { const char* e = getenv("DD_DBG"); P.dbg = e ? atoi(e) : 0; }
     P.nblocks = (int)((P.Ld + MF_ADV - 1) / MF_ADV);
     if (P.nblocks < 1) P.nblocks = 1;
     switch (st->nks) {
