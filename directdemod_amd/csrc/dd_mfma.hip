@@ -38,6 +38,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 struct DDMfmaTaps {
     const v8h* frag;     // [limb][ks][lane] B fragments
     float inv_tapscale;  // 1 / (power-of-two scale applied to the taps)
+    unsigned long long* stamps;   // diagnostic build only (env DD_STAMPS): per-wave segment cycle sums
 };
 
 __device__ __forceinline__ float dd_pow2_scale_for(float m) {
@@ -336,76 +337,380 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
     dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
 }
 
-// Interior tiles [t_first, t_last): persistent workgroups.  Each owns a contiguous
-// run of tiles (neighbouring halos stay in its XCD's L2), keeps the Toeplitz tap
-// fragments in registers for the whole launch and prefetches the next tile's
-// samples while the matrix cores work on the current one.
+// ---------------------------------------------------------------------------------
+// Interior tiles: wave-specialised persistent kernel (one 16-wave workgroup per CU).
+//
+//   waves 0..3   "matrix" waves, one per SIMD: the 108 MFMAs of one 1024-output strip
+//                per tile (A = signal limbs and B = tap limbs, both read from LDS),
+//                then the strip's FIR outputs go to an LDS y-buffer in output order;
+//   waves 4..15  "vector" waves, three per SIMD: NCO rotation + f16 limb split of the
+//                next tile into the other LDS plane buffer, and the discriminator
+//                epilogue of the previous tile read back from the y-buffer: 4
+//                consecutive outputs per lane, so y[n-1] is in the lane's own
+//                registers and every store is a 16-byte-per-lane contiguous line.
+//
+// Why: the vector side is latency/issue bound when only one or two waves per SIMD
+// run it (measured: ~10 cycles per VALU instruction, 2.6x the matrix time).  Three
+// vector waves per SIMD hide that latency by thread-level parallelism while the
+// matrix wave keeps the MFMA pipe busy; 128 VGPRs per wave make 4 waves/SIMD fit.
+//
+// Pipeline over the workgroup's tiles (two workgroup barriers per phase p):
+//   vector: [tile-max of tile p; epilogue of tile p-2]  B1  [convert tile p -> planes[p&1];
+//           issue loads of tile p+1]  B2
+//   matrix: [MFMA k-steps 0..KS1 of tile p-1 from planes[(p-1)&1]]  B1
+//           [remaining k-steps; write y-buffer]  B2
+// ---------------------------------------------------------------------------------
+#define WS_THREADS 1024
+#define WS_MWAVES 4
+#define WS_VTHREADS (WS_THREADS - 64 * WS_MWAVES)     // 768
+#define WS_VWAVES (WS_VTHREADS / 64)                   // 12
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v2f dd_cmul2(v2f a, v2f b) {          // complex product, (re, im) in one VGPR pair
+    const v2f bs = {-b.y, b.x};
+    return a.yy * bs + a.xx * b;
+}
+
 template <int NKS>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+struct WsGeom {
     using G = MfmaGeom<NKS>;
+    static constexpr int NQ = G::SPAN / 4;                        // 4-sample groups per tile
+    static constexpr int NIT = (NQ + WS_VTHREADS - 1) / WS_VTHREADS;
+    static constexpr int PLANES_BYTES = 4 * G::PLANE;             // one plane buffer
+    static constexpr int YBUF_OFF = 2 * PLANES_BYTES;
+    static constexpr int YBUF_BYTES = 16 + MF_T * 8;              // one float2 of slack in front (y[-1] of lane 0)
+    static constexpr int TAPS_OFF = YBUF_OFF + YBUF_BYTES;
+    static constexpr int TAPS_BYTES = 2 * NKS * 64 * 16;
+    static constexpr int W2_OFF = TAPS_OFF + TAPS_BYTES;          // [2][NGRP] float2
+    static constexpr int RED_OFF = W2_OFF + 2 * G::NGRP * 8;      // [2][WS_VWAVES] float
+    static constexpr int SCALE_OFF = RED_OFF + 2 * WS_VWAVES * 4; // [4] float
+    static constexpr int PTAB_OFF = (SCALE_OFF + 16 + 15) & ~15;  // [256] float2: exp(-j 2 pi k / 256)
+    static constexpr int LDS_BYTES = PTAB_OFF + 256 * 8;
+    static constexpr int KS1 = (2 * NKS) / 3;                     // k-steps before the mid-phase barrier
+};
+
+// two discriminator outputs per call (packed polynomial)
+__device__ __forceinline__ v2f dd_fm_angle2(v2f cx, v2f cy, v2f px, v2f py) {
+    const v2f re = cx * px + cy * py;
+    const v2f im = cy * px - cx * py;
+    const v2f ax = __builtin_elementwise_abs(re), ay = __builtin_elementwise_abs(im);
+    const v2f mx = __builtin_elementwise_max(ax, ay), mn = __builtin_elementwise_min(ax, ay);
+    const v2f rc = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    const v2f t = mn * rc;
+    const v2f z = t * t;
+    v2f p = z * -4.054567120e-03f + 2.186295773e-02f;
+    p = p * z + -5.591232695e-02f;
+    p = p * z + 9.642197381e-02f;
+    p = p * z + -1.390862959e-01f;
+    p = p * z + 1.994656567e-01f;
+    p = p * z + -3.332986079e-01f;
+    p = p * z + 9.999993356e-01f;
+    v2f r = p * t;
+    const v2f rq = 1.5707963267948966f - r;
+    r.x = (ay.x > ax.x) ? rq.x : r.x;
+    r.y = (ay.y > ax.y) ? rq.y : r.y;
+    const v2f rh = 3.141592653589793f - r;
+    r.x = (re.x < 0.f) ? rh.x : r.x;
+    r.y = (re.y < 0.f) ? rh.y : r.y;
+    r.x = (mx.x == 0.f) ? 0.f : r.x;                   // angle(0) = 0 like np.angle
+    r.y = (mx.y == 0.f) ? 0.f : r.y;
+    return (v2f){copysignf(r.x, im.x), copysignf(r.y, im.y)};
+}
+
+// ------------------------------------------------------------------ vector waves
+template <int NKS>
+__device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[2 * WsGeom<NKS>::NIT]) {
+    using G = MfmaGeom<NKS>;
+    using W = WsGeom<NKS>;
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + ns);
+#pragma unroll
+    for (int it = 0; it < W::NIT; ++it) {
+        int q = vt + WS_VTHREADS * it;
+        if (WS_VTHREADS * (it + 1) > W::NQ) q = q < W::NQ ? q : W::NQ - 1;   // partial last step: re-read, write masked
+        raw[2 * it] = src[2 * q];
+        raw[2 * it + 1] = src[2 * q + 1];
+    }
+}
+
+// exp(-j 2 pi phase) from a 256-entry LDS table + 4th-order residual (theta < 2 pi / 256).
+// LDS, not global: a global table fetch in the pipelined loop would make its vmcnt wait
+// drain the tile loads in flight behind it (vmcnt retires in order).
+__device__ __forceinline__ float2 dd_phasor_lds(uint64_t phase64, const float2* ptab) {
+    const uint32_t k = (uint32_t)(phase64 >> 56);
+    const uint32_t lo = (uint32_t)(phase64 >> 24);                 // next 32 bits
+    const float theta = (float)lo * (6.283185307179586f * 9.094947017729282e-13f);   // 2 pi 2^-40
+    const float t2 = theta * theta;
+    const float c = fmaf(t2, fmaf(t2, 4.1666668e-2f, -0.5f), 1.0f);
+    const float sn = theta * fmaf(t2, fmaf(t2, 8.3333338e-3f, -0.16666667f), 1.0f);
+    const float2 T = ptab[k];                                      // (cos, -sin)(2 pi k/256)
+    return make_float2(fmaf(T.x, c, T.y * sn), fmaf(T.y, c, -T.x * sn));
+}
+
+template <int NKS>
+__device__ __forceinline__ float2 dd_ws_w2(const DDChainParams& P, int b, int vt, const float2* ptab) {
+    using G = MfmaGeom<NKS>;
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    const int g = vt < G::NGRP ? vt : G::NGRP - 1;
+    if (!(P.flags & DD_CHAIN_NCO)) return make_float2(1.f, 0.f);
+    return dd_phasor_lds((uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc, ptab);
+}
+
+template <int NKS>
+__device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[2 * WsGeom<NKS>::NIT], char* planes, const float2* w2,
+                                              const v2f (&w1)[4], float scale, int vt) {
+    using G = MfmaGeom<NKS>;
+    using W = WsGeom<NKS>;
+#pragma unroll
+    for (int it = 0; it < W::NIT; ++it) {
+        const int q = vt + WS_VTHREADS * it;
+        if (WS_VTHREADS * (it + 1) > W::NQ && q >= W::NQ) continue;
+        const int e = 4 * q;
+        const float2 g = w2[e >> 6];
+        const v2f gs = {g.x * scale, g.y * scale};
+        v2f x[4];
+        x[0] = dd_cmul2((v2f){raw[2 * it].x, raw[2 * it].y}, dd_cmul2(gs, w1[0]));
+        x[1] = dd_cmul2((v2f){raw[2 * it].z, raw[2 * it].w}, dd_cmul2(gs, w1[1]));
+        x[2] = dd_cmul2((v2f){raw[2 * it + 1].x, raw[2 * it + 1].y}, dd_cmul2(gs, w1[2]));
+        x[3] = dd_cmul2((v2f){raw[2 * it + 1].z, raw[2 * it + 1].w}, dd_cmul2(gs, w1[3]));
+        v4h rh, rl, ih, il;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rh[k] = (_Float16)x[k].x;
+            ih[k] = (_Float16)x[k].y;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rl[k] = (_Float16)(x[k].x - (float)rh[k]);
+            il[k] = (_Float16)(x[k].y - (float)ih[k]);
+        }
+        const int off = 2 * e + 16 * (e >> 5);
+        *reinterpret_cast<v4h*>(planes + off) = rh;
+        *reinterpret_cast<v4h*>(planes + G::PLANE + off) = rl;
+        *reinterpret_cast<v4h*>(planes + 2 * G::PLANE + off) = ih;
+        *reinterpret_cast<v4h*>(planes + 3 * G::PLANE + off) = il;
+    }
+}
+
+// epilogue of one 256-output unit u of tile b: lane handles outputs o = 256u + 4 lane + {0..3}
+__device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int b, int u, int lane, const float2* yb, float unscale) {
+    const int o = 256 * u + 4 * lane;
+    if (o < 32) return;                                    // the tile's first column belongs to the previous tile
+    const float2 ym = yb[o - 1];
+    const float4 y01 = *reinterpret_cast<const float4*>(yb + o);
+    const float4 y23 = *reinterpret_cast<const float4*>(yb + o + 2);
+    const int64_t p = (int64_t)b * MF_ADV - 32 + o;
+    if (P.flags & DD_CHAIN_FM) {
+        const v2f a01 = dd_fm_angle2((v2f){y01.x, y01.z}, (v2f){y01.y, y01.w}, (v2f){ym.x, y01.x}, (v2f){ym.y, y01.y});
+        const v2f a23 = dd_fm_angle2((v2f){y23.x, y23.z}, (v2f){y23.y, y23.w}, (v2f){y01.z, y23.x}, (v2f){y01.w, y23.y});
+        float* out = reinterpret_cast<float*>(P.out) + (p - P.s);
+        if (P.s == 0) {
+            *reinterpret_cast<float4*>(out) = make_float4(a01.x, a01.y, a23.x, a23.y);
+        } else {                                           // first chunk of a stream: outputs shifted by one
+            out[0] = a01.x; out[1] = a01.y; out[2] = a23.x; out[3] = a23.y;
+        }
+    } else {
+        float4* out = reinterpret_cast<float4*>(reinterpret_cast<float2*>(P.out) + p);
+        out[0] = make_float4(y01.x * unscale, y01.y * unscale, y01.z * unscale, y01.w * unscale);
+        out[1] = make_float4(y23.x * unscale, y23.y * unscale, y23.z * unscale, y23.w * unscale);
+    }
+}
+
+// one vector-wave phase: loads of tile p+2 are issued first (two phases of prefetch
+// distance: HBM latency under load is several microseconds), then tile-max of tile p,
+// epilogue of tile p-2, B1, conversion of tile p, B2.
+template <int NKS>
+__device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
+                                             float4 (&rcur)[2 * WsGeom<NKS>::NIT], float2& w2cur,
+                                             float4 (&rld)[2 * WsGeom<NKS>::NIT], float2& w2ld,
+                                             const v2f (&w1)[4], int vt, int vw, int lane, int u2,
+                                             unsigned long long (&acc_t)[8]) {
+    using G = MfmaGeom<NKS>;
+    using W = WsGeom<NKS>;
+    const bool stamp = taps.stamps != nullptr;
+    unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
+#define DD_STAMP(i) if (stamp) { const unsigned long long tn = __builtin_readcyclecounter(); acc_t[i] += tn - tp; tp = tn; }
+    float2* w2 = reinterpret_cast<float2*>(smem + W::W2_OFF) + (p & 1) * G::NGRP;
+    float* red = reinterpret_cast<float*>(smem + W::RED_OFF) + (p & 1) * WS_VWAVES;
+    float* scales = reinterpret_cast<float*>(smem + W::SCALE_OFF);
+    const float2* yb = reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16);
+    const bool has_cvt = p < n;
+    {
+        const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
+        w2ld = dd_ws_w2<NKS>(P, bl, vt, reinterpret_cast<const float2*>(smem + W::PTAB_OFF));
+        dd_ws_load<NKS>(P, bl, vt, rld);
+    }
+    DD_STAMP(0)
+    if (has_cvt) {
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2 * W::NIT; ++it) {
+            m = fmaxf(fmaxf(m, fabsf(rcur[it].x)), fmaxf(fabsf(rcur[it].y), fmaxf(fabsf(rcur[it].z), fabsf(rcur[it].w))));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[vw] = m;
+        if (vt < G::NGRP) w2[vt] = w2cur;
+    }
+    DD_STAMP(1)
+    if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
+        const float unscale = taps.inv_tapscale / scales[(p - 2) & 3];
+        dd_ws_epilogue_unit(P, t_begin + p - 2, vw, lane, yb, unscale);
+        if (u2 >= 0) dd_ws_epilogue_unit(P, t_begin + p - 2, u2, lane, yb, unscale);
+    }
+    DD_STAMP(2)
+    __syncthreads();                                        // B1
+    DD_STAMP(3)
+    if (has_cvt) {
+        float m = red[0];
+#pragma unroll
+        for (int k = 1; k < WS_VWAVES; ++k) m = fmaxf(m, red[k]);
+        const float scale = dd_pow2_scale_for(m);
+        if (vt == 0) scales[p & 3] = scale;
+        if (!(P.dbg & 4)) dd_ws_convert<NKS>(rcur, smem + (p & 1) * W::PLANES_BYTES, w2, w1, scale, vt);
+    }
+    DD_STAMP(4)
+    __syncthreads();                                        // B2
+    DD_STAMP(5)
+}
+
+template <int NKS>
+__device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
+    using W = WsGeom<NKS>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int vt = tid - 64 * WS_MWAVES, vw = vt >> 6;
+    const int n = t_end - t_begin;
+
+    v2f w1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float2 w = make_float2(1.f, 0.f);
+        if (P.flags & DD_CHAIN_NCO) w = dd_phasor((uint64_t)(((4 * vt) & 63) + k) * P.cyc, P.nco_tbl);
+        w1[k] = (v2f){w.x, w.y};
+    }
+    float4 r0[2 * W::NIT], r1[2 * W::NIT], r2[2 * W::NIT];
+    const float2* ptab = reinterpret_cast<const float2*>(smem + W::PTAB_OFF);
+    float2 wa = dd_ws_w2<NKS>(P, t_begin, vt, ptab);
+    float2 wb = dd_ws_w2<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, ptab);
+    float2 wc = wa;
+    dd_ws_load<NKS>(P, t_begin, vt, r0);
+    dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
+
+    // second epilogue unit of the waves that have only one convert step (balance)
+    const int u2 = (vw >= 5 && vw <= 8) ? 12 + (vw - 5) : -1;
+
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, wa, r2, wc, w1, vt, vw, lane, u2, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, wb, r0, wa, w1, vt, vw, lane, u2, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, wc, r1, wb, w1, vt, vw, lane, u2, acc_t);
+    }
+    if (taps.stamps && lane == 0) {
+        for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
+        taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + 7] = nph;
+    }
+}
+
+// ------------------------------------------------------------------ matrix waves
+template <int NKS>
+__device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
+    using G = MfmaGeom<NKS>;
+    using W = WsGeom<NKS>;
+    const int tid = threadIdx.x, lane = tid & 63, mw = tid >> 6;
+    const int n = t_end - t_begin;
+    const int i = lane & 31, h = lane >> 5;
+    const int sb = mw * MF_STRIP;
+    const int aoff = (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
+    const v8h* tb = reinterpret_cast<const v8h*>(smem + W::TAPS_OFF) + lane;
+    float2* yw = reinterpret_cast<float2*>(smem + W::YBUF_OFF + 16) + sb + 128 * h + i;   // + 32*rowbase(r)
+
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamp = taps.stamps != nullptr;
+    for (int p = 0; p < nph; ++p) {
+        unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
+        const bool go = p >= 1 && p <= n && !(P.dbg & 1);
+        const char* abase = smem + ((p - 1) & 1) * W::PLANES_BYTES + aoff;
+        v16f cre, cim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+        // software pipeline: the six fragments of k-step ks+1 are in flight while the six
+        // MFMAs of k-step ks (192 cycles) run; sched_barrier pins that order
+        v8h f[2][6];
+#define DD_WS_LOADF(buf, ks)                                                                     \
+        {                                                                                        \
+            const int off_ = 32 * (ks) + 16 * ((ks) >> 1);                                       \
+            f[buf][0] = *reinterpret_cast<const v8h*>(abase + off_);                             \
+            f[buf][1] = *reinterpret_cast<const v8h*>(abase + G::PLANE + off_);                  \
+            f[buf][2] = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off_);              \
+            f[buf][3] = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off_);              \
+            f[buf][4] = tb[(ks) * 64];                                                           \
+            f[buf][5] = tb[(NKS + (ks)) * 64];                                                   \
+        }
+#define DD_WS_MFMA6(buf)                                                                         \
+        {                                                                                        \
+            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][0], f[buf][4], cre, 0, 0, 0);   \
+            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][2], f[buf][4], cim, 0, 0, 0);   \
+            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][1], f[buf][4], cre, 0, 0, 0);   \
+            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][3], f[buf][4], cim, 0, 0, 0);   \
+            cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][0], f[buf][5], cre, 0, 0, 0);   \
+            cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][2], f[buf][5], cim, 0, 0, 0);   \
+        }
+        if (go) {
+            DD_WS_LOADF(0, 0)
+#pragma unroll
+            for (int ks = 0; ks < W::KS1; ++ks) {
+                DD_WS_LOADF((ks + 1) & 1, ks + 1)           // KS1 < NKS: always a valid k-step
+                __builtin_amdgcn_sched_barrier(0);
+                DD_WS_MFMA6(ks & 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DD_STAMP(0)
+        __syncthreads();                                    // B1: the vector waves are done reading the y-buffer
+        DD_STAMP(1)
+        if (go) {
+#pragma unroll
+            for (int ks = W::KS1; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) DD_WS_LOADF((ks + 1) & 1, ks + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                DD_WS_MFMA6(ks & 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // register r of lane (i, h) is output 32 (rowbase(r) + 4h) + i of the strip
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yw[32 * ((r & 3) + 8 * (r >> 2))] = make_float2(cre[r], cim[r]);
+        }
+        DD_STAMP(2)
+        __syncthreads();                                    // B2
+        DD_STAMP(3)
+    }
+    if (stamp && lane == 0) {
+        for (int q = 0; q < 4; ++q) taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + q] = acc_t[q];
+        taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 7] = nph;
+    }
+}
+
+template <int NKS>
+__global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+    using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x;
     const int wg = blockIdx.x;
     const int nt = t_last - t_first;
     const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
     const int t_end = t_first + (int)(((int64_t)(wg + 1) * nt) / nwg);
     if (t_begin >= t_end) return;
-
-    float4 raw[G::NIT];
-    dd_tile_load<NKS>(P, t_begin, true, raw);
-    float2 w2mine = dd_tile_w2<NKS>(P, t_begin);
-
-    // high tap limb in registers; the low limb (used once per k-step) lives in LDS
-    v8h bh[NKS];
-    v8h* bl_lds = reinterpret_cast<v8h*>(smem + MF_LDS_TILE_BYTES(NKS));
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) bh[ks] = taps.frag[ks * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < MF_BL_SLOTS(NKS) / MF_THREADS; ++q) {     // padded image: every lane stores
-        const int idx = tid + MF_THREADS * q;
-        bl_lds[idx] = taps.frag[NKS * 64 + (idx < NKS * 64 ? idx : NKS * 64 - 1)];
+    // tap limb fragments -> LDS once per workgroup (all 1024 threads; 2*NKS*64 entries)
+    {
+        v8h* tl = reinterpret_cast<v8h*>(smem + W::TAPS_OFF);
+        for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
+        if (threadIdx.x < 256) reinterpret_cast<float2*>(smem + W::PTAB_OFF)[threadIdx.x] = P.nco_tbl[threadIdx.x * (DD_NCO_TSIZE / 256)];
     }
-    float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
-    if (P.flags & DD_CHAIN_NCO) {
-        w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
-        w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
-    }
-    const int i = lane & 31, h = lane >> 5;
-    const int sb = wave * MF_STRIP;
-    const char* abase = smem + (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
-
-    for (int b = t_begin; b < t_end; ++b) {
-        const float scale = dd_tile_stage<NKS, true>(P, b, raw, smem, w1a, w1b, w2mine);
-        if (b + 1 < t_end) {
-            dd_tile_load<NKS>(P, b + 1, true, raw);
-            w2mine = dd_tile_w2<NKS>(P, b + 1);
-        }
-        __syncthreads();
-
-        // ---- Toeplitz GEMM: 6 MFMAs per k-step (3 limb products x re/im)
-        v16f cre, cim;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-        {
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const int off = 32 * ks + 16 * (ks >> 1);
-                const v8h arh = *reinterpret_cast<const v8h*>(abase + off);
-                const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
-                const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
-                const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
-                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bh[ks], cre, 0, 0, 0);
-                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bh[ks], cim, 0, 0, 0);
-                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, bh[ks], cre, 0, 0, 0);
-                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, bh[ks], cim, 0, 0, 0);
-                const v8h blk = bl_lds[ks * 64 + lane];
-                cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, blk, cre, 0, 0, 0);
-                cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, blk, cim, 0, 0, 0);
-            }
-        }
-        dd_tile_epilogue<NKS, true>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
-    }
+    __syncthreads();
+    const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3
+    if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ws_vector<NKS>(P, taps, smem, t_begin, t_end, nph);
 }
 
 // ============================================================================
@@ -485,16 +790,25 @@ void dd_mfma_destroy(void* st) {
 template <int NKS>
 static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s) {
     using G = MfmaGeom<NKS>;
-    const size_t lds = (size_t)MF_LDS_TILE_BYTES(NKS) + (size_t)MF_BL_SLOTS(NKS) * 16;
+    const size_t lds = (size_t)MF_LDS_TILE_BYTES(NKS);
+    const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     DDMfmaTaps t;
     t.frag = st->frag;
     t.inv_tapscale = st->inv_tapscale;
+    t.stamps = nullptr;
+    static unsigned long long* stamp_buf = nullptr;
+    const bool want_stamps = getenv("DD_STAMPS") != nullptr;
+    if (want_stamps) {
+        if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, 256 * 16 * 8 * 8));
+        DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, 256 * 16 * 8 * 8, s));
+        t.stamps = stamp_buf;
+    }
     // interior tiles: whole span inside the chunk, all outputs emitted, aligned complex64
     int t_first = 1, t_last = 1;
     const bool aligned = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
@@ -510,10 +824,31 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     }
     const int n_int = t_last - t_first;
     if (n_int > 0) {
-        int grid = n_int < 512 ? n_int : 512;       // 2 persistent workgroups per CU (256 CUs)
+        int grid = (n_int + 3) / 4 < 256 ? (n_int + 3) / 4 : 256;       // one persistent 16-wave workgroup per CU
         { const char* e = getenv("DD_GRID"); if (e && atoi(e) > 0) grid = atoi(e) < n_int ? atoi(e) : n_int; }
-        hipLaunchKernelGGL(k_chain_mfma<NKS>, dim3(grid), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
+        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last);
         DD_LAUNCH_CHECK();
+        if (want_stamps) {
+            static int printed = 0;
+            std::vector<unsigned long long> hb(256 * 16 * 8);
+            DD_HIP_CHECK(hipMemcpyAsync(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost, s));
+            DD_HIP_CHECK(hipStreamSynchronize(s));
+            if (printed++ == 3) {
+                const char* vn[6] = {"V:issue loads", "V:tile max (waits raw)", "V:epilogue", "V:B1 wait", "V:convert", "V:B2 wait"};
+                const char* mn[4] = {"M:mfma part 1", "M:B1 wait", "M:mfma part 2 + y write", "M:B2 wait"};
+                const double nphd = (double)hb[7];
+                for (int q = 0; q < 4; ++q) {
+                    double sum = 0; int cnt = 0;
+                    for (int w = 0; w < grid; ++w) for (int mw = 0; mw < 4; ++mw) { sum += (double)hb[((size_t)w * 16 + mw) * 8 + q]; cnt++; }
+                    fprintf(stderr, "[stamps] %-28s %8.0f cycles/phase\n", mn[q], sum / cnt / nphd);
+                }
+                for (int q = 0; q < 6; ++q) {
+                    double sum = 0; int cnt = 0;
+                    for (int w = 0; w < grid; ++w) for (int vw = 4; vw < 16; ++vw) { sum += (double)hb[((size_t)w * 16 + vw) * 8 + q]; cnt++; }
+                    fprintf(stderr, "[stamps] %-28s %8.0f cycles/phase\n", vn[q], sum / cnt / nphd);
+                }
+            }
+        }
         // edge tiles on both sides
         if (t_first > 0) {
             hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(t_first), dim3(MF_THREADS), lds, s, P, t, 0, 1);

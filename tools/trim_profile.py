@@ -13,5 +13,5 @@ with open(src, newline="") as f, open(dst, "w", newline="") as g:
     w.writerow(hdr)
     col = hdr.index("Name") if "Name" in hdr else hdr.index("Kernel_Name")
     for row in r:
-        if row[col].startswith("k_"):
+        if row[col].startswith(("k_", "void k_")):
             w.writerow(row)
