@@ -127,25 +127,36 @@ __device__ __forceinline__ void dd_tile_load(const DDChainParams& P, int b, bool
             raw[it] = src[q < G::SPAN / 2 ? q : G::SPAN / 2 - 1];
         }
     } else {
-        const bool fast_ok = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
+        // stream edges, carried history (already NCO-rotated), u8 ingest.  Every load is
+        // unconditional on a clamped index and the value is selected afterwards: a
+        // predicated load makes hipcc branch and drain vmcnt per element (measured: one edge
+        // tile took 15 us that way).
+        const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+        const int K1 = P.K - 1;
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
             const int e = 2 * (tid + MF_THREADS * it);
-            const int64_t n = ns + e;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < G::SPAN) {
-                if (fast_ok && n >= 0 && n + 1 < P.L) {
-                    v = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + n);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t n = ns + e + k;
+                const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
+                float2 x;
+                if (u8) {
+                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[nc];
+                    x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
                 } else {
-                    // stream edges, carried history (already NCO-rotated), u8 ingest
-                    DDChainParams Q = P;
-                    Q.flags &= ~DD_CHAIN_NCO;
-                    const float2 a = dd_load_sample(Q, n, make_float2(1.f, 0.f));
-                    const float2 c = dd_load_sample(Q, n + 1, make_float2(1.f, 0.f));
-                    v = make_float4(a.x, a.y, c.x, c.y);
+                    x = reinterpret_cast<const float2*>(P.in)[nc];
                 }
+                const int64_t ti = n + K1;                       // index into the carried history
+                const int64_t tc = ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti);
+                const float2 t = P.tail_in[tc];
+                const bool in_chunk = n >= 0 && n < P.L;
+                const bool in_tail = n < 0 && ti >= 0;
+                v[2 * k] = in_chunk ? x.x : (in_tail ? t.x : 0.f);
+                v[2 * k + 1] = in_chunk ? x.y : (in_tail ? t.y : 0.f);
             }
-            raw[it] = v;
+            raw[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -294,11 +305,12 @@ __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, 
 // Edge tiles (stream start/end, unaligned or u8 input, partial tiles): one tile per
 // workgroup, fully predicated.  tile = first + blockIdx.x * stride.
 template <int NKS>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChainParams P, const DDMfmaTaps taps, int first, int stride) {
+__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
     using G = MfmaGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = first + (int)blockIdx.x * stride;
+    // edge tiles are [0, t_first) and [t_last, nblocks)
+    const int b = (int)blockIdx.x < t_first ? (int)blockIdx.x : t_last + ((int)blockIdx.x - t_first);
     float4 raw[G::NIT];
     dd_tile_load<NKS>(P, b, false, raw);
     float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
@@ -424,13 +436,14 @@ __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
-    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + ns);
+    const char* base = reinterpret_cast<const char*>(reinterpret_cast<const float2*>(P.in) + ns);   // wave-uniform
 #pragma unroll
     for (int it = 0; it < W::NIT; ++it) {
         int q = vt + WS_VTHREADS * it;
         if (WS_VTHREADS * (it + 1) > W::NQ) q = q < W::NQ ? q : W::NQ - 1;   // partial last step: re-read, write masked
-        raw[2 * it] = src[2 * q];
-        raw[2 * it + 1] = src[2 * q + 1];
+        const unsigned off = 32u * (unsigned)q;                              // 32-bit lane offset (saddr + voffset form)
+        raw[2 * it] = *reinterpret_cast<const float4*>(base + off);
+        raw[2 * it + 1] = *reinterpret_cast<const float4*>(base + off + 16);
     }
 }
 
@@ -538,7 +551,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     const bool has_cvt = p < n;
     {
         const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
-        w2ld = dd_ws_w2<NKS>(P, bl, vt, reinterpret_cast<const float2*>(smem + W::PTAB_OFF));
+        if (vw < (G::NGRP + 63) / 64) w2ld = dd_ws_w2<NKS>(P, bl, vt, reinterpret_cast<const float2*>(smem + W::PTAB_OFF));
         dd_ws_load<NKS>(P, bl, vt, rld);
     }
     DD_STAMP(0)
@@ -647,23 +660,35 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
             f[buf][4] = tb[(ks) * 64];                                                           \
             f[buf][5] = tb[(NKS + (ks)) * 64];                                                   \
         }
-#define DD_WS_MFMA6(buf)                                                                         \
+        // one k-step: the six MFMAs of buffer `buf`, with one fragment read of the next
+        // k-step (buffer nb) issued in each MFMA gap (no read burst between MFMA groups)
+#define DD_WS_STEP(buf, nb, ksn, pre)                                                            \
         {                                                                                        \
+            const int off_ = 32 * (ksn) + 16 * ((ksn) >> 1);                                     \
             cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][0], f[buf][4], cre, 0, 0, 0);   \
+            if (pre) f[nb][0] = *reinterpret_cast<const v8h*>(abase + off_);                     \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][2], f[buf][4], cim, 0, 0, 0);   \
+            if (pre) f[nb][4] = tb[(ksn) * 64];                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][1], f[buf][4], cre, 0, 0, 0);   \
+            if (pre) f[nb][2] = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off_);      \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][3], f[buf][4], cim, 0, 0, 0);   \
+            if (pre) f[nb][1] = *reinterpret_cast<const v8h*>(abase + G::PLANE + off_);          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][0], f[buf][5], cre, 0, 0, 0);   \
+            if (pre) f[nb][3] = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off_);      \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[buf][2], f[buf][5], cim, 0, 0, 0);   \
+            if (pre) f[nb][5] = tb[(NKS + (ksn)) * 64];                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
         }
         if (go) {
             DD_WS_LOADF(0, 0)
 #pragma unroll
             for (int ks = 0; ks < W::KS1; ++ks) {
-                DD_WS_LOADF((ks + 1) & 1, ks + 1)           // KS1 < NKS: always a valid k-step
-                __builtin_amdgcn_sched_barrier(0);
-                DD_WS_MFMA6(ks & 1)
-                __builtin_amdgcn_sched_barrier(0);
+                DD_WS_STEP(ks & 1, (ks + 1) & 1, ks + 1, true)     // KS1 < NKS: always a valid next k-step
             }
         }
         DD_STAMP(0)
@@ -672,10 +697,7 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         if (go) {
 #pragma unroll
             for (int ks = W::KS1; ks < NKS; ++ks) {
-                if (ks + 1 < NKS) DD_WS_LOADF((ks + 1) & 1, ks + 1)
-                __builtin_amdgcn_sched_barrier(0);
-                DD_WS_MFMA6(ks & 1)
-                __builtin_amdgcn_sched_barrier(0);
+                DD_WS_STEP(ks & 1, (ks + 1) & 1, (ks + 1 < NKS ? ks + 1 : ks), (ks + 1 < NKS))
             }
             // register r of lane (i, h) is output 32 (rowbase(r) + 4h) + i of the strip
 #pragma unroll
@@ -849,17 +871,14 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
                 }
             }
         }
-        // edge tiles on both sides
-        if (t_first > 0) {
-            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(t_first), dim3(MF_THREADS), lds, s, P, t, 0, 1);
-            DD_LAUNCH_CHECK();
-        }
-        if (t_last < P.nblocks) {
-            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks - t_last), dim3(MF_THREADS), lds, s, P, t, t_last, 1);
+        // edge tiles on both sides of the interior run, one launch
+        const int n_edge = t_first + (P.nblocks - t_last);
+        if (n_edge > 0) {
+            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
             DD_LAUNCH_CHECK();
         }
     } else {
-        hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t, 0, 1);
+        hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t, P.nblocks, P.nblocks);
         DD_LAUNCH_CHECK();
     }
     return DD_OK;
