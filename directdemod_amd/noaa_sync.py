@@ -1,0 +1,129 @@
+"""
+NOAA APT sync detection on the device -- the build's driver for BASELINE config 4
+(SURVEY.md 8a rows A1/X1/X2/P).  Stage order and constants follow the reference's
+callers (decode_noaa.__audio :600-629, __getAM :631-657, __correlate :659-675,
+__correlateAndFindPeaks :677-767, getCrudeSync :769-806, getAccurateSync :808-880);
+the arithmetic runs in the HIP kernels behind this package's drop-in classes.
+"""
+import numpy as np
+
+from . import _ops, chunker, comm, constants, demod_am, demod_fm, filters
+from ._hip import DevArray
+
+
+def sync_needle(sync_bits, samp_rate, positive=True):
+    """decode_noaa.py:689-694"""
+    rep = round(samp_rate * constants.NOAA_T)
+    if positive:
+        return ((np.repeat(sync_bits, rep) * 233) + 11) / 255
+    return np.repeat(sync_bits, rep) - 0.5
+
+
+class noaa_sync:
+    '''Sync detection of a NOAA APT recording (crude @ ~60 kS/s, accurate @ IQ rate)'''
+
+    def __init__(self, sigsrc, offset, bw=None):
+        self.__sigsrc = sigsrc
+        self.__offset = offset
+        self.__bw = constants.NOAA_FMBW if bw is None else bw
+        self.__syncA = None
+        self.__syncB = None
+        self.__rate = None
+        self.__useful = 0
+
+    # ---- FM audio in chunks: one fused kernel per chunk (decode_noaa.py:600-629)
+    def audio(self, audioFreq=constants.NOAA_CRUDESYNCSAMPRATE, strictness=False, chunkSize=constants.PROC_CHUNKSIZE):
+        src = self.__sigsrc
+        audioOut = comm.commSignal(audioFreq)
+        bhFilter = filters.blackmanHarris(151)
+        fmDemodulator = demod_fm.demod_fm()
+        chunkerObj = chunker.chunker(src, chunkSize)
+        read = src.read_device if hasattr(src, "read_device") else src.read
+        for a, b in chunkerObj.getChunks:
+            sig = comm.commSignal(src.sampFreq, read(a, b), chunkerObj).offsetFreq(self.__offset) \
+                .filter(bhFilter).bwLim(self.__bw, uniq="First").funcApply(fmDemodulator.demod) \
+                .bwLim(audioFreq, strictness)
+            audioOut.extend(sig)
+        return audioOut
+
+    # ---- envelope in 240 000-sample blocks (decode_noaa.py:631-657)
+    def envelope(self, sig):
+        am = demod_am.demod_am().demod_blocks(sig.device_signal, 60000 * 4)
+        return comm.commSignal(sig.sampRate, am)
+
+    # ---- normalised correlation + peak pick (decode_noaa.py:677-767)
+    def correlate_and_find_peaks(self, sig, sync, use_filter=False, extra=False):
+        needle = sync_needle(sync, sig.sampRate)
+        hay = sig.device_signal
+        if hay.dtype != np.dtype(np.float64):
+            hay = comm._convert(hay, np.float64)
+        if use_filter:      # zero-phase Hamming(492) pre-filter (default argument at decode_noaa.py:677)
+            hay = filters.hamming(492, zeroPhase=True).applyOn(hay)
+        cor = _ops.xcorr_norm(hay, needle)
+        peaks = _ops.find_peaks(cor, sig.sampRate, len(needle))
+        if not extra:
+            return peaks
+        n = len(needle)
+        s = np.asarray(sig.signal, dtype=np.float64)
+        corh = cor.to_host()
+        heights, tsync = [], []
+        for i in peaks:                                          # :754-762
+            tsync.append(float(np.average(s[i + n:i + 2 * n])) if i + 2 * n < len(s) else None)
+            heights.append(float(corh[i + int(n / 2)]))
+        return peaks, heights, tsync
+
+    def getCrudeSync(self):
+        if self.__syncA is None or self.__syncB is None:
+            sig = self.envelope(self.audio(constants.NOAA_CRUDESYNCSAMPRATE, False))
+            self.__rate = sig.sampRate
+            self.__syncA = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCA)
+            self.__syncB = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCB)
+
+            def _min_dev(s):                                      # :794-801
+                d = np.abs(np.diff(s) - (self.__rate * 0.5))
+                m = len(d) - constants.NOAA_DETECTCONSSYNCSNUM + 1
+                if m <= 0:
+                    return np.inf
+                return np.min([np.max(d[i:i + constants.NOAA_DETECTCONSSYNCSNUM]) for i in range(m)])
+            if _min_dev(self.__syncA) < constants.NOAA_DETECTMAXCHANGE or \
+                    _min_dev(self.__syncB) < constants.NOAA_DETECTMAXCHANGE:
+                self.__useful = 1
+        return [self.__syncA, self.__syncB]
+
+    @property
+    def useful(self):
+        if self.__syncA is None:
+            self.getCrudeSync()
+        return self.__useful
+
+    @property
+    def crudeRate(self):
+        return self.__rate
+
+    def accurate_window(self, startI, endI, sync):
+        """one search window of getAccurateSync (decode_noaa.py:852-853)"""
+        src = self.__sigsrc
+        read = src.read_device if hasattr(src, "read_device") else src.read
+        sig = comm.commSignal(src.sampFreq, read(startI, endI)).offsetFreq(self.__offset) \
+            .filter(filters.blackmanHarris(151, zeroPhase=True)) \
+            .funcApply(demod_fm.demod_fm().demod).funcApply(demod_am.demod_am().demod)
+        pk, ht, ts = self.correlate_and_find_peaks(sig, sync, use_filter=True, extra=True)
+        return int(pk[0]) + startI, ht[0], ts[0]
+
+    def getAccurateSync(self):
+        sa, sb = self.getCrudeSync()
+        src = self.__sigsrc
+        width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
+        out = []
+        for crude, sync in ((sa, constants.NOAA_SYNCA), (sb, constants.NOAA_SYNCB)):
+            idx, pks, tms = [], [], []
+            for c in crude / self.__rate * src.sampFreq:                                  # :828-835
+                startI, endI = int(c) - width, int(c) + width
+                if startI < 0 or endI > src.length:
+                    continue
+                i, h, t = self.accurate_window(startI, endI, sync)
+                idx.append(i)
+                pks.append(h)
+                tms.append(t)
+            out.append((np.array(idx, dtype=np.int64), pks, tms))
+        return out

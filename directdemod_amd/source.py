@@ -1,0 +1,116 @@
+"""
+IQ sources -- feeders of the hot path (reference:
+directdemod/source.py:53-324).  ``read(a, b)`` keeps the reference's contract
+(complex64, I + jQ - (127.5 + 127.5j), ValueError on bad indices, ``limitData``);
+``read_device(a, b)`` is the MI355X ingest: the raw interleaved uint8 pairs cross
+PCIe (2 B/sample instead of 8) through a pinned staging buffer and are widened on
+the device (dd_u8iq_to_c64), or consumed directly by the fused kernel
+(DD_CHAIN_U8_INPUT).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip, constants
+from ._hip import DevArray, check, lib
+
+
+class _u8source:
+    """Common logic over an interleaved uint8 [N, 2] array (memmap or in memory)."""
+
+    def __init__(self, data_u8_n2, sampFreq, sourceType):
+        self._data = data_u8_n2
+        self.__sampFreq = sampFreq
+        self.__sourceType = sourceType
+        self.__offset = 0
+        self.__actualLength = data_u8_n2.shape[0]
+        self.__length = data_u8_n2.shape[0]
+
+    @property
+    def sampFreq(self):
+        ''':obj:`int`: get sampling freq of source'''
+        return self.__sampFreq
+
+    @property
+    def sourceType(self):
+        ''':obj:`int`: get source type'''
+        return self.__sourceType
+
+    @property
+    def length(self):
+        ''':obj:`int`: get source length'''
+        return self.__length
+
+    def _range(self, fromIndex, toIndex):
+        if toIndex is None:
+            toIndex = fromIndex + 1
+        if fromIndex < 0 or toIndex < 0 or fromIndex >= self.length or toIndex > self.length:
+            raise ValueError("fromIndex and toIndex have invalid values")          # source.py:114-115
+        return fromIndex + self.__offset, toIndex + self.__offset
+
+    def read(self, fromIndex, toIndex=None):
+        '''Complex IQ samples in a numpy array (host), like the reference's read'''
+        a, b = self._range(fromIndex, toIndex)
+        d = np.asarray(self._data[a:b])
+        out = np.empty(b - a, dtype=np.complex64)
+        out.real = d[:, 0]
+        out.imag = d[:, 1]
+        out -= np.complex64(127.5 + 127.5j)
+        return out
+
+    def read_raw_u8(self, fromIndex, toIndex=None):
+        '''the raw interleaved uint8 pairs (no conversion): feed for the fused u8 ingest'''
+        a, b = self._range(fromIndex, toIndex)
+        return np.ascontiguousarray(self._data[a:b]).reshape(-1)
+
+    def read_device(self, fromIndex, toIndex=None):
+        '''Complex64 samples as a device array: 2 B/sample over PCIe, widened in HBM'''
+        raw = self.read_raw_u8(fromIndex, toIndex)
+        n = raw.size // 2
+        d_raw = DevArray.from_host(raw, dtype=np.uint8)
+        out = DevArray(n, np.complex64)
+        check(lib().dd_u8iq_to_c64(d_raw.ptr, out.ptr, n, None), "dd_u8iq_to_c64")
+        _hip.sync()
+        return out
+
+    def limitData(self, initOffset=None, finalLimit=None):
+        '''Limit source data (source.py:120-138)'''
+        self.__offset = initOffset if initOffset is not None else 0
+        if finalLimit is not None:
+            self.__length = finalLimit - self.__offset
+        else:
+            self.__length = self.__actualLength
+
+
+class IQarray(_u8source):
+    '''In-memory uint8 [N, 2] recording (synthetic inputs, tests, benchmarks)'''
+
+    def __init__(self, raw_u8_n2, sampFreq):
+        raw = np.asarray(raw_u8_n2, dtype=np.uint8)
+        if raw.ndim != 2 or raw.shape[1] != 2:
+            raise TypeError("expected a uint8 array of shape [N, 2]")
+        super().__init__(raw, sampFreq, constants.SOURCE_IQWAV)
+
+
+class IQwav(_u8source):
+    '''8-bit stereo IQ.wav (SDRSharp style): 44-byte header assumed, like the reference
+    (source.py:66); the sample rate comes from the header unless given.'''
+
+    def __init__(self, filename, givenSampFreq=None):
+        hdr = np.fromfile(filename, dtype=np.uint8, count=44)
+        rate = int(np.frombuffer(hdr[24:28].tobytes(), dtype="<u4")[0])
+        mm = np.memmap(filename, dtype=np.uint8, mode="r", offset=44)
+        n = mm.shape[0] // 2
+        super().__init__(mm[:2 * n].reshape(n, 2), givenSampFreq if givenSampFreq is not None else rate,
+                         constants.SOURCE_IQWAV)
+
+
+class IQdat(_u8source):
+    '''Raw interleaved uint8 I,Q file (rtl_sdr style)'''
+
+    def __init__(self, filename, givenSampFreq=None):
+        mm = np.memmap(filename, dtype=np.uint8, mode="r")
+        n = mm.shape[0] // 2
+        super().__init__(mm[:2 * n].reshape(n, 2),
+                         givenSampFreq if givenSampFreq is not None else constants.IQ_SDRSAMPRATE,
+                         constants.SOURCE_IQDAT)

@@ -1,0 +1,192 @@
+"""
+GPU parity of the audio-rate rows (R2 FFT resample, A1 Hilbert envelope, X1
+normalised correlation, X2 peak pick, F2 filtfilt) and of the end-to-end configs 3
+and 4, against the reference's golden vectors and the oracle.
+
+Tolerances: float64 stages 1e-9 relative (FFT/summation order differs from
+NumPy's); sync index picks and all lengths/rates are exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dd():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from directdemod_amd import _hip
+    _hip.require_gpu()
+    from directdemod_amd import comm, filters, demod_fm, demod_am, chunker, _ops, noaa_sync, source
+
+    class NS:
+        pass
+    ns = NS()
+    ns.hip, ns.comm, ns.filters, ns.demod_fm, ns.demod_am, ns.chunker, ns.ops, ns.noaa, ns.source = \
+        _hip, comm, filters, demod_fm, demod_am, chunker, _ops, noaa_sync, source
+    return ns
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(params=[0, 1, 2])
+def ops(request, golden_dir):
+    return _load(golden_dir, "ops_seed%d.npz" % request.param)
+
+
+def test_resample_strict_golden(dd, ops):
+    ang = ops["fm_nostate"]
+    s = dd.comm.commSignal(60235, ang).bwLim(40960, True)
+    assert s.sampRate == 40960 and s.length == len(ops["resample_60235_40960"])
+    assert rel_err(s.signal, ops["resample_60235_40960"]) < 1e-9
+    s = dd.comm.commSignal(200000, ang).bwLim(11025, True)
+    assert s.sampRate == 11025
+    assert rel_err(s.signal, ops["resample_200000_11025"]) < 1e-9
+
+
+@pytest.mark.parametrize("n,num", [(1000, 333), (1001, 500), (1000, 1000), (999, 1500), (1024, 2048), (7, 3)])
+def test_resample_vs_oracle_shapes(dd, n, num):
+    x = np.random.default_rng(n).standard_normal(n)
+    got = dd.ops.resample_fft(dd.hip.DevArray.from_host(x), num).to_host()
+    assert rel_err(got, O.resample_fft(x, num)) < 1e-9
+
+
+def test_am_envelope_golden(dd, ops):
+    ang = ops["fm_nostate"]
+    L = len(ang) + 1
+    am = dd.demod_am.demod_am()
+    a = am.demod(ang[:L - 1 if (L - 1) % 2 == 0 else L - 2])
+    assert rel_err(a, ops["am_env_full"]) < 1e-9
+    b = am.demod(np.resize(ang, 3000)) if L >= 3000 else am.demod(ang[:750])
+    assert rel_err(b, ops["am_env_3000"]) < 1e-9
+    with pytest.raises(TypeError):
+        am.demod(np.ones(8, dtype=np.complex64))
+
+
+def test_am_envelope_blocks_vs_oracle(dd):
+    x = np.random.default_rng(3).standard_normal(10007)
+    got = dd.demod_am.demod_am().demod_blocks(x, 3000)
+    assert rel_err(got, O.am_demod_blocks(x, 3000)) < 1e-9
+
+
+def test_filtfilt_complex128_vs_oracle(dd):
+    x = np.random.default_rng(5).standard_normal(2000) + 1j * np.random.default_rng(6).standard_normal(2000)
+    d = dd.hip.DevArray.from_host(x.astype(np.complex128))
+    got = dd.ops.filtfilt(O.win_blackmanharris(151), d).to_host()
+    assert rel_err(got, O.filtfilt(O.win_blackmanharris(151), [1.0], x)) < 1e-10
+
+
+@pytest.fixture(scope="module")
+def noaa_inputs(golden_dir):
+    g = _load(golden_dir, "noaa_c4.npz")
+    raw = O.synth_apt_iq(float(g["dur"]), 2048000, seed=1)
+    return g, raw
+
+
+def test_xcorr_and_peaks_3s_golden(dd, noaa_inputs):
+    g, raw = noaa_inputs
+    # oracle audio/envelope (pinned to the reference's in the CPU suite) as the stage input
+    audio, rate = O.audio_chain(lambda a, b: O.read_iq_u8(raw, a, b), len(raw), 2048000, 30000.0,
+                                O.win_blackmanharris(151), 60000, audio_rate=40960, strict=False)
+    am = O.am_demod_blocks(audio[:3 * rate])
+    d = dd.hip.DevArray.from_host(am)
+    needle = O.sync_needle(O.NOAA_SYNCA, rate)
+    xc = dd.ops.xcorr_norm(d, needle).to_host()
+    assert np.max(np.abs(xc[:20000] - g["xcorr_3s_syncA_head"])) < 1e-9
+    assert np.max(np.abs(xc[-2000:] - g["xcorr_3s_syncA_tail"])) < 1e-9
+    assert abs(np.sum(xc) - float(g["xcorr_3s_syncA_sum"])) < 1e-6
+    pk = dd.ops.find_peaks(dd.hip.DevArray.from_host(xc), rate, len(needle))
+    assert np.array_equal(pk, g["peaks_3s_syncA"])
+    sig = dd.comm.commSignal(rate, am)
+    ns = dd.noaa.noaa_sync(None, 0.0)
+    assert np.array_equal(ns.correlate_and_find_peaks(sig, O.NOAA_SYNCA), g["peaks_3s_syncA"])
+    assert np.array_equal(ns.correlate_and_find_peaks(sig, O.NOAA_SYNCB), g["peaks_3s_syncB"])
+
+
+def test_c4_crude_and_accurate_sync_indices_golden(dd, noaa_inputs):
+    """config 4 end to end on the device: index lists identical to the reference's"""
+    g, raw = noaa_inputs
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    sa, sb = ns.getCrudeSync()
+    assert ns.crudeRate == int(g["audio_rate"]) == 60235
+    assert np.array_equal(sa, g["crude_syncA"])
+    assert np.array_equal(sb, g["crude_syncB"])
+    assert ns.useful == int(g["useful"]) == 1
+    (ia, pa, ta), (ib, pb, tb) = ns.getAccurateSync()
+    assert np.array_equal(ia, g["acc_syncA"])
+    assert np.array_equal(ib, g["acc_syncB"])
+    assert np.max(np.abs(np.array(pa) - g["acc_syncA_pk"])) < 1e-4
+    assert np.max(np.abs(np.array(pb) - g["acc_syncB_pk"])) < 1e-4
+    assert np.max(np.abs(np.array(ta) - g["acc_syncA_time"])) < 1e-4
+
+
+def test_c4_audio_stage_vs_golden(dd, noaa_inputs):
+    g, raw = noaa_inputs
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    aud = ns.audio(40960, False, chunkSize=5000000)      # several chunks: state carried on the device
+    assert aud.sampRate == 60235
+    a = aud.signal
+    d = np.abs(np.angle(np.exp(1j * (a[:20000] - g["audio_3s_head"]))))
+    assert np.max(d) < 1e-4 and np.median(d) < 2e-6
+
+
+def test_c3_chain_golden(dd, golden_dir):
+    """config 3: chunked remez-127 / M=50 / FM / FFT-resample to 11 025 S/s"""
+    g = _load(golden_dir, "chain_c3.npz")
+    L = int(g["L"])
+    x = O.grid_c64(O.synth_iq_fm(L, 1e7, int(g["seed"]), f_carrier=250e3, f_mod=1e3, dev=5.0))
+
+    class _Src:
+        length = L
+    ck = dd.chunker.chunker(_Src(), 8192)
+    out = dd.comm.commSignal(11025)
+    rz = dd.filters.remez(10000000, [[0, 100e3], [150e3, 4999999]], [1, 0], ntaps=127)
+    assert np.max(np.abs(np.asarray(rz.getB) - g["taps_remez127"])) < 1e-12
+    fm = dd.demod_fm.demod_fm()
+    for a, b in ck.getChunks:
+        s = dd.comm.commSignal(10000000, x[a:b], ck).offsetFreq(250000.0).filter(rz) \
+            .bwLim(200000, uniq="First").funcApply(fm.demod).bwLim(11025, True)
+        out.extend(s)
+    assert out.sampRate == int(g["chain_c3_rate"]) == 11025
+    assert out.length == len(g["chain_c3"])
+    # the FFT resample spreads the float32 discriminator error over the chunk
+    assert np.max(np.abs(out.signal - g["chain_c3"])) < 2e-5
+
+
+def test_source_readers(dd, tmp_path):
+    raw = O.synth_iq_noise(5000, 8)
+    f = tmp_path / "x.dat"
+    raw.tofile(f)
+    s = dd.source.IQdat(str(f), 2048000)
+    assert s.length == 5000
+    assert np.array_equal(s.read(10, 500), O.read_iq_u8(raw, 10, 500))
+    assert np.array_equal(s.read_device(10, 500).to_host(), O.read_iq_u8(raw, 10, 500))
+    with pytest.raises(ValueError):
+        s.read(10, 6000)
+    s.limitData(100, 600)
+    assert s.length == 500 and np.array_equal(s.read(0, 5), O.read_iq_u8(raw, 100, 105))
+    w = tmp_path / "x.wav"
+    hdr = np.zeros(44, dtype=np.uint8)
+    hdr[24:28] = np.frombuffer(np.uint32(2400000).tobytes(), dtype=np.uint8)
+    with open(w, "wb") as fh:
+        fh.write(hdr.tobytes())
+        fh.write(raw.tobytes())
+    sw = dd.source.IQwav(str(w))
+    assert sw.sampFreq == 2400000 and sw.length == 5000
+    assert np.array_equal(sw.read(0, 5000), O.grid_c64(raw))
