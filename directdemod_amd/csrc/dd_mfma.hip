@@ -387,8 +387,8 @@ __device__ __forceinline__ v2f dd_cmul2(v2f a, v2f b) {          // complex prod
 template <int NKS>
 struct WsGeom {
     using G = MfmaGeom<NKS>;
-    static constexpr int NQ = G::SPAN / 4;                        // 4-sample groups per tile
-    static constexpr int NIT = (NQ + WS_VTHREADS - 1) / WS_VTHREADS;
+    static constexpr int NQ = G::SPAN / 2;                        // sample pairs per tile
+    static constexpr int NIT = (NQ + WS_VTHREADS - 1) / WS_VTHREADS;   // 3 steps for 12 vector waves: 94 % lane use
     static constexpr int PLANES_BYTES = 4 * G::PLANE;             // one plane buffer
     static constexpr int YBUF_OFF = 2 * PLANES_BYTES;
     static constexpr int YBUF_BYTES = 16 + MF_T * 8;              // one float2 of slack in front (y[-1] of lane 0)
@@ -399,7 +399,7 @@ struct WsGeom {
     static constexpr int SCALE_OFF = RED_OFF + 2 * WS_VWAVES * 4; // [4] float
     static constexpr int PTAB_OFF = (SCALE_OFF + 16 + 15) & ~15;  // [256] float2: exp(-j 2 pi k / 256)
     static constexpr int LDS_BYTES = PTAB_OFF + 256 * 8;
-    static constexpr int KS1 = (2 * NKS) / 3;                     // k-steps before the mid-phase barrier
+    static constexpr int KS1 = NKS / 2;                           // k-steps before the mid-phase barrier (balances both halves)
 };
 
 // two discriminator outputs per call (packed polynomial)
@@ -432,7 +432,7 @@ __device__ __forceinline__ v2f dd_fm_angle2(v2f cx, v2f cy, v2f px, v2f py) {
 
 // ------------------------------------------------------------------ vector waves
 template <int NKS>
-__device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[2 * WsGeom<NKS>::NIT]) {
+__device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[WsGeom<NKS>::NIT]) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
@@ -441,9 +441,7 @@ __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt
     for (int it = 0; it < W::NIT; ++it) {
         int q = vt + WS_VTHREADS * it;
         if (WS_VTHREADS * (it + 1) > W::NQ) q = q < W::NQ ? q : W::NQ - 1;   // partial last step: re-read, write masked
-        const unsigned off = 32u * (unsigned)q;                              // 32-bit lane offset (saddr + voffset form)
-        raw[2 * it] = *reinterpret_cast<const float4*>(base + off);
-        raw[2 * it + 1] = *reinterpret_cast<const float4*>(base + off + 16);
+        raw[it] = *reinterpret_cast<const float4*>(base + 16u * (unsigned)q);   // two consecutive samples
     }
 }
 
@@ -471,38 +469,32 @@ __device__ __forceinline__ float2 dd_ws_w2(const DDChainParams& P, int b, int vt
 }
 
 template <int NKS>
-__device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[2 * WsGeom<NKS>::NIT], char* planes, const float2* w2,
-                                              const v2f (&w1)[4], float scale, int vt) {
+__device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::NIT], char* planes, const float2* w2,
+                                              const v2f (&w1)[2], float scale, int vt) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
 #pragma unroll
     for (int it = 0; it < W::NIT; ++it) {
         const int q = vt + WS_VTHREADS * it;
         if (WS_VTHREADS * (it + 1) > W::NQ && q >= W::NQ) continue;
-        const int e = 4 * q;
+        const int e = 2 * q;
         const float2 g = w2[e >> 6];
-        const v2f gs = {g.x * scale, g.y * scale};
-        v2f x[4];
-        x[0] = dd_cmul2((v2f){raw[2 * it].x, raw[2 * it].y}, dd_cmul2(gs, w1[0]));
-        x[1] = dd_cmul2((v2f){raw[2 * it].z, raw[2 * it].w}, dd_cmul2(gs, w1[1]));
-        x[2] = dd_cmul2((v2f){raw[2 * it + 1].x, raw[2 * it + 1].y}, dd_cmul2(gs, w1[2]));
-        x[3] = dd_cmul2((v2f){raw[2 * it + 1].z, raw[2 * it + 1].w}, dd_cmul2(gs, w1[3]));
-        v4h rh, rl, ih, il;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rh[k] = (_Float16)x[k].x;
-            ih[k] = (_Float16)x[k].y;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rl[k] = (_Float16)(x[k].x - (float)rh[k]);
-            il[k] = (_Float16)(x[k].y - (float)ih[k]);
-        }
+        const float2 gs = make_float2(g.x * scale, g.y * scale);
+        // (2 vt + 1536 it) & 63 == (2 vt) & 63: the lane's in-group phasors are loop invariant.
+        // Plain v_fma/v_mul on purpose: packed f32 ops issued beside the matrix waves' MFMAs
+        // cost ~5x a plain op (measured: the vector phases ran 2.3x slower with v_pk_*).
+        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), dd_cmul(gs, make_float2(w1[0].x, w1[0].y)));
+        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), dd_cmul(gs, make_float2(w1[1].x, w1[1].y)));
+        v2h rh, rl, ih, il;
+        rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
+        ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
+        rl.x = (_Float16)(xa.x - (float)rh.x); rl.y = (_Float16)(xb.x - (float)rh.y);
+        il.x = (_Float16)(xa.y - (float)ih.x); il.y = (_Float16)(xb.y - (float)ih.y);
         const int off = 2 * e + 16 * (e >> 5);
-        *reinterpret_cast<v4h*>(planes + off) = rh;
-        *reinterpret_cast<v4h*>(planes + G::PLANE + off) = rl;
-        *reinterpret_cast<v4h*>(planes + 2 * G::PLANE + off) = ih;
-        *reinterpret_cast<v4h*>(planes + 3 * G::PLANE + off) = il;
+        *reinterpret_cast<v2h*>(planes + off) = rh;
+        *reinterpret_cast<v2h*>(planes + G::PLANE + off) = rl;
+        *reinterpret_cast<v2h*>(planes + 2 * G::PLANE + off) = ih;
+        *reinterpret_cast<v2h*>(planes + 3 * G::PLANE + off) = il;
     }
 }
 
@@ -515,8 +507,11 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
     const float4 y23 = *reinterpret_cast<const float4*>(yb + o + 2);
     const int64_t p = (int64_t)b * MF_ADV - 32 + o;
     if (P.flags & DD_CHAIN_FM) {
-        const v2f a01 = dd_fm_angle2((v2f){y01.x, y01.z}, (v2f){y01.y, y01.w}, (v2f){ym.x, y01.x}, (v2f){ym.y, y01.y});
-        const v2f a23 = dd_fm_angle2((v2f){y23.x, y23.z}, (v2f){y23.y, y23.w}, (v2f){y01.z, y23.x}, (v2f){y01.w, y23.y});
+        v2f a01, a23;
+        a01.x = dd_fm_angle_fast(y01.x, y01.y, ym.x, ym.y);
+        a01.y = dd_fm_angle_fast(y01.z, y01.w, y01.x, y01.y);
+        a23.x = dd_fm_angle_fast(y23.x, y23.y, y01.z, y01.w);
+        a23.y = dd_fm_angle_fast(y23.z, y23.w, y23.x, y23.y);
         float* out = reinterpret_cast<float*>(P.out) + (p - P.s);
         if (P.s == 0) {
             *reinterpret_cast<float4*>(out) = make_float4(a01.x, a01.y, a23.x, a23.y);
@@ -530,14 +525,28 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
     }
 }
 
+// max over the wave in 6 DPP steps (row_shr 1,2,4,8 then row_bcast 15/31); valid in lane 63
+__device__ __forceinline__ float dd_wave_max(float m) {
+#define DD_DPP_MAX(ctrl, rmask)                                                                              \
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, rmask, 0xf, false)));
+    DD_DPP_MAX(0x111, 0xf)      // row_shr:1   (values are >= 0, so the 0 filled into invalid lanes is neutral)
+    DD_DPP_MAX(0x112, 0xf)      // row_shr:2
+    DD_DPP_MAX(0x114, 0xf)      // row_shr:4
+    DD_DPP_MAX(0x118, 0xf)      // row_shr:8   -> lane 15 of each row holds the row max
+    DD_DPP_MAX(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    DD_DPP_MAX(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
+#undef DD_DPP_MAX
+    return m;
+}
+
 // one vector-wave phase: loads of tile p+2 are issued first (two phases of prefetch
 // distance: HBM latency under load is several microseconds), then tile-max of tile p,
 // epilogue of tile p-2, B1, conversion of tile p, B2.
 template <int NKS>
 __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
-                                             float4 (&rcur)[2 * WsGeom<NKS>::NIT], float2& w2cur,
-                                             float4 (&rld)[2 * WsGeom<NKS>::NIT], float2& w2ld,
-                                             const v2f (&w1)[4], int vt, int vw, int lane, int u2,
+                                             float4 (&rcur)[WsGeom<NKS>::NIT], float2& w2cur,
+                                             float4 (&rld)[WsGeom<NKS>::NIT], float2& w2ld,
+                                             const v2f (&w1)[2], int vt, int vw, int lane,
                                              unsigned long long (&acc_t)[8]) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -558,19 +567,17 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     if (has_cvt) {
         float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < 2 * W::NIT; ++it) {
+        for (int it = 0; it < W::NIT; ++it) {
             m = fmaxf(fmaxf(m, fabsf(rcur[it].x)), fmaxf(fabsf(rcur[it].y), fmaxf(fabsf(rcur[it].z), fabsf(rcur[it].w))));
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) red[vw] = m;
+        m = dd_wave_max(m);                                 // DPP reduction, result in lane 63
+        if (lane == 63) red[vw] = m;
         if (vt < G::NGRP) w2[vt] = w2cur;
     }
     DD_STAMP(1)
     if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
         const float unscale = taps.inv_tapscale / scales[(p - 2) & 3];
-        dd_ws_epilogue_unit(P, t_begin + p - 2, vw, lane, yb, unscale);
-        if (u2 >= 0) dd_ws_epilogue_unit(P, t_begin + p - 2, u2, lane, yb, unscale);
+        dd_ws_epilogue_unit(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
     }
     DD_STAMP(2)
     __syncthreads();                                        // B1
@@ -595,14 +602,14 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
     const int vt = tid - 64 * WS_MWAVES, vw = vt >> 6;
     const int n = t_end - t_begin;
 
-    v2f w1[4];
+    v2f w1[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2; ++k) {
         float2 w = make_float2(1.f, 0.f);
-        if (P.flags & DD_CHAIN_NCO) w = dd_phasor((uint64_t)(((4 * vt) & 63) + k) * P.cyc, P.nco_tbl);
+        if (P.flags & DD_CHAIN_NCO) w = dd_phasor((uint64_t)(((2 * vt) & 63) + k) * P.cyc, P.nco_tbl);
         w1[k] = (v2f){w.x, w.y};
     }
-    float4 r0[2 * W::NIT], r1[2 * W::NIT], r2[2 * W::NIT];
+    float4 r0[W::NIT], r1[W::NIT], r2[W::NIT];
     const float2* ptab = reinterpret_cast<const float2*>(smem + W::PTAB_OFF);
     float2 wa = dd_ws_w2<NKS>(P, t_begin, vt, ptab);
     float2 wb = dd_ws_w2<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, ptab);
@@ -610,14 +617,11 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
     dd_ws_load<NKS>(P, t_begin, vt, r0);
     dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
 
-    // second epilogue unit of the waves that have only one convert step (balance)
-    const int u2 = (vw >= 5 && vw <= 8) ? 12 + (vw - 5) : -1;
-
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, wa, r2, wc, w1, vt, vw, lane, u2, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, wb, r0, wa, w1, vt, vw, lane, u2, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, wc, r1, wb, w1, vt, vw, lane, u2, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, wa, r2, wc, w1, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, wb, r0, wa, w1, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, wc, r1, wb, w1, vt, vw, lane, acc_t);
     }
     if (taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -643,6 +647,11 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     for (int p = 0; p < nph; ++p) {
         unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
         const bool go = p >= 1 && p <= n && !(P.dbg & 1);
+        if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {          // the matrix waves take the last 4 epilogue units
+            const float unscale = taps.inv_tapscale / reinterpret_cast<const float*>(smem + W::SCALE_OFF)[(p - 2) & 3];
+            dd_ws_epilogue_unit(P, t_begin + p - 2, WS_VWAVES + mw, lane,
+                                reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale);
+        }
         const char* abase = smem + ((p - 1) & 1) * W::PLANES_BYTES + aoff;
         v16f cre, cim;
 #pragma unroll
