@@ -71,6 +71,21 @@ __device__ __forceinline__ float dd_fast_atan2(float y, float x) {
     return copysignf(r, y);
 }
 
+// atan(y/x) for x > 0, |y| <= tan(pi/8) x: same polynomial, no octant logic
+__device__ __forceinline__ float dd_atan_small(float y, float x) {
+    const float t = y * __builtin_amdgcn_rcpf(x);
+    const float z = t * t;
+    float p = -4.054567120e-03f;
+    p = fmaf(p, z, 2.186295773e-02f);
+    p = fmaf(p, z, -5.591232695e-02f);
+    p = fmaf(p, z, 9.642197381e-02f);
+    p = fmaf(p, z, -1.390862959e-01f);
+    p = fmaf(p, z, 1.994656567e-01f);
+    p = fmaf(p, z, -3.332986079e-01f);
+    p = fmaf(p, z, 9.999993356e-01f);
+    return p * t;
+}
+
 __device__ __forceinline__ float dd_fm_angle_fast(float cx, float cy, float px, float py) {
     const float re = fmaf(cx, px, cy * py);
     const float im = fmaf(cy, px, -cx * py);
@@ -394,11 +409,10 @@ struct WsGeom {
     static constexpr int YBUF_BYTES = 16 + MF_T * 8;              // one float2 of slack in front (y[-1] of lane 0)
     static constexpr int TAPS_OFF = YBUF_OFF + YBUF_BYTES;
     static constexpr int TAPS_BYTES = 2 * NKS * 64 * 16;
-    static constexpr int W2_OFF = TAPS_OFF + TAPS_BYTES;          // [2][NGRP] float2
-    static constexpr int RED_OFF = W2_OFF + 2 * G::NGRP * 8;      // [2][WS_VWAVES] float
+    static constexpr int RED_OFF = TAPS_OFF + TAPS_BYTES;         // [2][WS_VWAVES] float
     static constexpr int SCALE_OFF = RED_OFF + 2 * WS_VWAVES * 4; // [4] float
-    static constexpr int PTAB_OFF = (SCALE_OFF + 16 + 15) & ~15;  // [256] float2: exp(-j 2 pi k / 256)
-    static constexpr int LDS_BYTES = PTAB_OFF + 256 * 8;
+    static constexpr int YDONE_OFF = SCALE_OFF + 16;              // int: waves that finished reading the y-buffer
+    static constexpr int LDS_BYTES = (YDONE_OFF + 16 + 15) & ~15;
     static constexpr int KS1 = NKS / 2;                           // k-steps before the mid-phase barrier (balances both halves)
 };
 
@@ -445,32 +459,15 @@ __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt
     }
 }
 
-// exp(-j 2 pi phase) from a 256-entry LDS table + 4th-order residual (theta < 2 pi / 256).
-// LDS, not global: a global table fetch in the pipelined loop would make its vmcnt wait
-// drain the tile loads in flight behind it (vmcnt retires in order).
-__device__ __forceinline__ float2 dd_phasor_lds(uint64_t phase64, const float2* ptab) {
-    const uint32_t k = (uint32_t)(phase64 >> 56);
-    const uint32_t lo = (uint32_t)(phase64 >> 24);                 // next 32 bits
-    const float theta = (float)lo * (6.283185307179586f * 9.094947017729282e-13f);   // 2 pi 2^-40
-    const float t2 = theta * theta;
-    const float c = fmaf(t2, fmaf(t2, 4.1666668e-2f, -0.5f), 1.0f);
-    const float sn = theta * fmaf(t2, fmaf(t2, 8.3333338e-3f, -0.16666667f), 1.0f);
-    const float2 T = ptab[k];                                      // (cos, -sin)(2 pi k/256)
-    return make_float2(fmaf(T.x, c, T.y * sn), fmaf(T.y, c, -T.x * sn));
-}
-
+// NCO with TILE-RELATIVE phase: x[n] e^{-j w (n0+k)} = e^{-j w n0} (x[n] e^{-j w k}).  The
+// lane's phasors W[k] (k = its fixed positions inside a tile) are loop invariant registers;
+// the per-tile factor e^{-j w n0} is common to every output of the tile, so it cancels in
+// the discriminator's y[n] conj(y[n-1]) and is applied in the epilogue only for complex
+// output.  Plain v_fma/v_mul on purpose: packed f32 ops beside the matrix waves' MFMAs
+// cost ~5x a plain op (measured: the vector phases ran 2.3x slower with v_pk_*).
 template <int NKS>
-__device__ __forceinline__ float2 dd_ws_w2(const DDChainParams& P, int b, int vt, const float2* ptab) {
-    using G = MfmaGeom<NKS>;
-    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
-    const int g = vt < G::NGRP ? vt : G::NGRP - 1;
-    if (!(P.flags & DD_CHAIN_NCO)) return make_float2(1.f, 0.f);
-    return dd_phasor_lds((uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc, ptab);
-}
-
-template <int NKS>
-__device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::NIT], char* planes, const float2* w2,
-                                              const v2f (&w1)[2], float scale, int vt) {
+__device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::NIT], char* planes,
+                                              const float2 (&wk)[WsGeom<NKS>::NIT][2], float scale, int vt) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
 #pragma unroll
@@ -478,13 +475,8 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
         const int q = vt + WS_VTHREADS * it;
         if (WS_VTHREADS * (it + 1) > W::NQ && q >= W::NQ) continue;
         const int e = 2 * q;
-        const float2 g = w2[e >> 6];
-        const float2 gs = make_float2(g.x * scale, g.y * scale);
-        // (2 vt + 1536 it) & 63 == (2 vt) & 63: the lane's in-group phasors are loop invariant.
-        // Plain v_fma/v_mul on purpose: packed f32 ops issued beside the matrix waves' MFMAs
-        // cost ~5x a plain op (measured: the vector phases ran 2.3x slower with v_pk_*).
-        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), dd_cmul(gs, make_float2(w1[0].x, w1[0].y)));
-        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), dd_cmul(gs, make_float2(w1[1].x, w1[1].y)));
+        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), make_float2(wk[it][0].x * scale, wk[it][0].y * scale));
+        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), make_float2(wk[it][1].x * scale, wk[it][1].y * scale));
         v2h rh, rl, ih, il;
         rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
         ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
@@ -499,6 +491,7 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
 }
 
 // epilogue of one 256-output unit u of tile b: lane handles outputs o = 256u + 4 lane + {0..3}
+template <int NKS>
 __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int b, int u, int lane, const float2* yb, float unscale) {
     const int o = 256 * u + 4 * lane;
     if (o < 32) return;                                    // the tile's first column belongs to the previous tile
@@ -507,21 +500,42 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
     const float4 y23 = *reinterpret_cast<const float4*>(yb + o + 2);
     const int64_t p = (int64_t)b * MF_ADV - 32 + o;
     if (P.flags & DD_CHAIN_FM) {
-        v2f a01, a23;
-        a01.x = dd_fm_angle_fast(y01.x, y01.y, ym.x, ym.y);
-        a01.y = dd_fm_angle_fast(y01.z, y01.w, y01.x, y01.y);
-        a23.x = dd_fm_angle_fast(y23.x, y23.y, y01.z, y01.w);
-        a23.y = dd_fm_angle_fast(y23.z, y23.w, y23.x, y23.y);
+        // z_k = y_k conj(y_{k-1})
+        const float re0 = fmaf(y01.x, ym.x, y01.y * ym.y), im0 = fmaf(y01.y, ym.x, -y01.x * ym.y);
+        const float re1 = fmaf(y01.z, y01.x, y01.w * y01.y), im1 = fmaf(y01.w, y01.x, -y01.z * y01.y);
+        const float re2 = fmaf(y23.x, y01.z, y23.y * y01.w), im2 = fmaf(y23.y, y01.z, -y23.x * y01.w);
+        const float re3 = fmaf(y23.z, y23.x, y23.w * y23.y), im3 = fmaf(y23.w, y23.x, -y23.z * y23.y);
+        float a0, a1, a2, a3;
+        // wave-uniform fast path: every |angle| below 22.5 degrees (an oversampled FM signal
+        // always is): atan(t) needs no octant logic.  One ballot decides for the whole wave.
+        const bool small = (fabsf(im0) <= 0.41421354f * re0) && (fabsf(im1) <= 0.41421354f * re1) &&
+                           (fabsf(im2) <= 0.41421354f * re2) && (fabsf(im3) <= 0.41421354f * re3);
+        if (__builtin_amdgcn_ballot_w64(!small) == 0) {
+            a0 = dd_atan_small(im0, re0); a1 = dd_atan_small(im1, re1);
+            a2 = dd_atan_small(im2, re2); a3 = dd_atan_small(im3, re3);
+        } else {
+            a0 = dd_fast_atan2(im0, re0); a1 = dd_fast_atan2(im1, re1);
+            a2 = dd_fast_atan2(im2, re2); a3 = dd_fast_atan2(im3, re3);
+        }
         float* out = reinterpret_cast<float*>(P.out) + (p - P.s);
         if (P.s == 0) {
-            *reinterpret_cast<float4*>(out) = make_float4(a01.x, a01.y, a23.x, a23.y);
+            *reinterpret_cast<float4*>(out) = make_float4(a0, a1, a2, a3);
         } else {                                           // first chunk of a stream: outputs shifted by one
-            out[0] = a01.x; out[1] = a01.y; out[2] = a23.x; out[3] = a23.y;
+            out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
         }
     } else {
+        // complex output: undo the power-of-two scales and apply the tile's NCO factor
+        float2 t = make_float2(unscale, 0.f);
+        if (P.flags & DD_CHAIN_NCO) {
+            const int64_t ns = (int64_t)b * MF_ADV - 32 - MfmaGeom<NKS>::HALO;
+            const float2 ph = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
+            t = make_float2(ph.x * unscale, ph.y * unscale);
+        }
+        const float2 o0 = dd_cmul(make_float2(y01.x, y01.y), t), o1 = dd_cmul(make_float2(y01.z, y01.w), t);
+        const float2 o2 = dd_cmul(make_float2(y23.x, y23.y), t), o3 = dd_cmul(make_float2(y23.z, y23.w), t);
         float4* out = reinterpret_cast<float4*>(reinterpret_cast<float2*>(P.out) + p);
-        out[0] = make_float4(y01.x * unscale, y01.y * unscale, y01.z * unscale, y01.w * unscale);
-        out[1] = make_float4(y23.x * unscale, y23.y * unscale, y23.z * unscale, y23.w * unscale);
+        out[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
+        out[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
     }
 }
 
@@ -539,89 +553,99 @@ __device__ __forceinline__ float dd_wave_max(float m) {
     return m;
 }
 
-// one vector-wave phase: loads of tile p+2 are issued first (two phases of prefetch
-// distance: HBM latency under load is several microseconds), then tile-max of tile p,
-// epilogue of tile p-2, B1, conversion of tile p, B2.
+// One vector-wave phase p (ONE workgroup barrier per phase):
+//   loads of tile p+2 are issued first (two phases of prefetch distance: HBM latency under
+//   load is several microseconds); epilogue of tile p-2 out of the y-buffer, then the
+//   wave signals "y-buffer read" on an LDS counter (the matrix waves wait on it before
+//   they overwrite the buffer -- they get there thousands of cycles later, so the wait is
+//   free); conversion of tile p with the scale published during phase p-1; tile max and
+//   group phasors of tile p+1 for the next phase; barrier.
 template <int NKS>
 __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
-                                             float4 (&rcur)[WsGeom<NKS>::NIT], float2& w2cur,
-                                             float4 (&rld)[WsGeom<NKS>::NIT], float2& w2ld,
-                                             const v2f (&w1)[2], int vt, int vw, int lane,
+                                             float4 (&rcur)[WsGeom<NKS>::NIT], float4 (&rnext)[WsGeom<NKS>::NIT],
+                                             float4 (&rld)[WsGeom<NKS>::NIT],
+                                             const float2 (&wk)[WsGeom<NKS>::NIT][2], int vt, int vw, int lane,
                                              unsigned long long (&acc_t)[8]) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const bool stamp = taps.stamps != nullptr;
     unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
 #define DD_STAMP(i) if (stamp) { const unsigned long long tn = __builtin_readcyclecounter(); acc_t[i] += tn - tp; tp = tn; }
-    float2* w2 = reinterpret_cast<float2*>(smem + W::W2_OFF) + (p & 1) * G::NGRP;
-    float* red = reinterpret_cast<float*>(smem + W::RED_OFF) + (p & 1) * WS_VWAVES;
+    float* redall = reinterpret_cast<float*>(smem + W::RED_OFF);
     float* scales = reinterpret_cast<float*>(smem + W::SCALE_OFF);
     const float2* yb = reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16);
-    const bool has_cvt = p < n;
     {
         const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
-        if (vw < (G::NGRP + 63) / 64) w2ld = dd_ws_w2<NKS>(P, bl, vt, reinterpret_cast<const float2*>(smem + W::PTAB_OFF));
         dd_ws_load<NKS>(P, bl, vt, rld);
     }
     DD_STAMP(0)
-    if (has_cvt) {
-        float m = 0.f;
-#pragma unroll
-        for (int it = 0; it < W::NIT; ++it) {
-            m = fmaxf(fmaxf(m, fabsf(rcur[it].x)), fmaxf(fabsf(rcur[it].y), fmaxf(fabsf(rcur[it].z), fabsf(rcur[it].w))));
-        }
-        m = dd_wave_max(m);                                 // DPP reduction, result in lane 63
-        if (lane == 63) red[vw] = m;
-        if (vt < G::NGRP) w2[vt] = w2cur;
-    }
-    DD_STAMP(1)
     if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
         const float unscale = taps.inv_tapscale / scales[(p - 2) & 3];
-        dd_ws_epilogue_unit(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
+        dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
     }
-    DD_STAMP(2)
-    __syncthreads();                                        // B1
-    DD_STAMP(3)
-    if (has_cvt) {
+    if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + W::YDONE_OFF), 1);   // this wave is done with the y-buffer
+    DD_STAMP(1)
+    if (p < n) {                                            // convert tile p (max published in phase p-1)
+        const float* red = redall + (p & 1) * WS_VWAVES;
         float m = red[0];
 #pragma unroll
         for (int k = 1; k < WS_VWAVES; ++k) m = fmaxf(m, red[k]);
         const float scale = dd_pow2_scale_for(m);
         if (vt == 0) scales[p & 3] = scale;
-        if (!(P.dbg & 4)) dd_ws_convert<NKS>(rcur, smem + (p & 1) * W::PLANES_BYTES, w2, w1, scale, vt);
+        if (!(P.dbg & 4)) dd_ws_convert<NKS>(rcur, smem + (p & 1) * W::PLANES_BYTES, wk, scale, vt);
     }
+    DD_STAMP(2)
+    if (p + 1 < n) {                                        // tile max + group phasors of tile p+1
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < W::NIT; ++it) {
+            m = fmaxf(fmaxf(m, fabsf(rnext[it].x)), fmaxf(fabsf(rnext[it].y), fmaxf(fabsf(rnext[it].z), fabsf(rnext[it].w))));
+        }
+        m = dd_wave_max(m);                                 // DPP reduction, result in lane 63
+        if (lane == 63) redall[((p + 1) & 1) * WS_VWAVES + vw] = m;
+    }
+    DD_STAMP(3)
+    __syncthreads();
     DD_STAMP(4)
-    __syncthreads();                                        // B2
-    DD_STAMP(5)
 }
 
 template <int NKS>
 __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
+    using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int vt = tid - 64 * WS_MWAVES, vw = vt >> 6;
     const int n = t_end - t_begin;
 
-    v2f w1[2];
+    // tile-relative NCO phasors of this lane's sample positions (loop invariant)
+    float2 wk[W::NIT][2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        float2 w = make_float2(1.f, 0.f);
-        if (P.flags & DD_CHAIN_NCO) w = dd_phasor((uint64_t)(((2 * vt) & 63) + k) * P.cyc, P.nco_tbl);
-        w1[k] = (v2f){w.x, w.y};
+    for (int it = 0; it < W::NIT; ++it) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pos = 2 * (vt + WS_VTHREADS * it) + k;
+            wk[it][k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)pos * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        }
     }
     float4 r0[W::NIT], r1[W::NIT], r2[W::NIT];
-    const float2* ptab = reinterpret_cast<const float2*>(smem + W::PTAB_OFF);
-    float2 wa = dd_ws_w2<NKS>(P, t_begin, vt, ptab);
-    float2 wb = dd_ws_w2<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, ptab);
-    float2 wc = wa;
     dd_ws_load<NKS>(P, t_begin, vt, r0);
     dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
+    {   // tile max and group phasors of tile 0 (what phase p-1 does for tile p)
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < W::NIT; ++it) {
+            m = fmaxf(fmaxf(m, fabsf(r0[it].x)), fmaxf(fabsf(r0[it].y), fmaxf(fabsf(r0[it].z), fabsf(r0[it].w))));
+        }
+        m = dd_wave_max(m);
+        if (lane == 63) reinterpret_cast<float*>(smem + W::RED_OFF)[vw] = m;
+    }
+    __syncthreads();                                        // prologue barrier (matched in dd_ws_matrix)
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, wa, r2, wc, w1, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, wb, r0, wa, w1, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, wc, r1, wb, w1, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
     }
     if (taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -641,6 +665,9 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     const int aoff = (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
     const v8h* tb = reinterpret_cast<const v8h*>(smem + W::TAPS_OFF) + lane;
     float2* yw = reinterpret_cast<float2*>(smem + W::YBUF_OFF + 16) + sb + 128 * h + i;   // + 32*rowbase(r)
+    int* ydone = reinterpret_cast<int*>(smem + W::YDONE_OFF);
+    __builtin_amdgcn_s_setprio(3);                          // MFMAs issue as soon as the pipe frees up
+    __syncthreads();                                        // prologue barrier (tile 0's max is published)
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamp = taps.stamps != nullptr;
@@ -649,9 +676,10 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         const bool go = p >= 1 && p <= n && !(P.dbg & 1);
         if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {          // the matrix waves take the last 4 epilogue units
             const float unscale = taps.inv_tapscale / reinterpret_cast<const float*>(smem + W::SCALE_OFF)[(p - 2) & 3];
-            dd_ws_epilogue_unit(P, t_begin + p - 2, WS_VWAVES + mw, lane,
-                                reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale);
+            dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, WS_VWAVES + mw, lane,
+                                     reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale);
         }
+        if (lane == 0) atomicAdd(ydone, 1);                 // done reading the y-buffer (own epilogue unit)
         const char* abase = smem + ((p - 1) & 1) * W::PLANES_BYTES + aoff;
         v16f cre, cim;
 #pragma unroll
@@ -693,27 +721,25 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
             if (pre) f[nb][5] = tb[(NKS + (ksn)) * 64];                                          \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }
+        DD_STAMP(0)
         if (go) {
             DD_WS_LOADF(0, 0)
 #pragma unroll
-            for (int ks = 0; ks < W::KS1; ++ks) {
-                DD_WS_STEP(ks & 1, (ks + 1) & 1, ks + 1, true)     // KS1 < NKS: always a valid next k-step
-            }
-        }
-        DD_STAMP(0)
-        __syncthreads();                                    // B1: the vector waves are done reading the y-buffer
-        DD_STAMP(1)
-        if (go) {
-#pragma unroll
-            for (int ks = W::KS1; ks < NKS; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 DD_WS_STEP(ks & 1, (ks + 1) & 1, (ks + 1 < NKS ? ks + 1 : ks), (ks + 1 < NKS))
             }
+        }
+        DD_STAMP(1)
+        // all 16 waves have finished reading the y-buffer of tile p-2 (normally long ago)
+        while (__hip_atomic_load(ydone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * (p + 1)) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (go) {
             // register r of lane (i, h) is output 32 (rowbase(r) + 4h) + i of the strip
 #pragma unroll
             for (int r = 0; r < 16; ++r) yw[32 * ((r & 3) + 8 * (r >> 2))] = make_float2(cre[r], cim[r]);
         }
         DD_STAMP(2)
-        __syncthreads();                                    // B2
+        __syncthreads();
         DD_STAMP(3)
     }
     if (stamp && lane == 0) {
@@ -736,7 +762,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     {
         v8h* tl = reinterpret_cast<v8h*>(smem + W::TAPS_OFF);
         for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
-        if (threadIdx.x < 256) reinterpret_cast<float2*>(smem + W::PTAB_OFF)[threadIdx.x] = P.nco_tbl[threadIdx.x * (DD_NCO_TSIZE / 256)];
+        if (threadIdx.x == 0) *reinterpret_cast<int*>(smem + W::YDONE_OFF) = 0;
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3
@@ -865,18 +891,18 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
             DD_HIP_CHECK(hipMemcpyAsync(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
             if (printed++ == 3) {
-                const char* vn[6] = {"V:issue loads", "V:tile max (waits raw)", "V:epilogue", "V:B1 wait", "V:convert", "V:B2 wait"};
-                const char* mn[4] = {"M:mfma part 1", "M:B1 wait", "M:mfma part 2 + y write", "M:B2 wait"};
+                const char* vn[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
+                const char* mn[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
                 const double nphd = (double)hb[7];
-                for (int q = 0; q < 4; ++q) {
-                    double sum = 0; int cnt = 0;
-                    for (int w = 0; w < grid; ++w) for (int mw = 0; mw < 4; ++mw) { sum += (double)hb[((size_t)w * 16 + mw) * 8 + q]; cnt++; }
-                    fprintf(stderr, "[stamps] %-28s %8.0f cycles/phase\n", mn[q], sum / cnt / nphd);
-                }
-                for (int q = 0; q < 6; ++q) {
-                    double sum = 0; int cnt = 0;
-                    for (int w = 0; w < grid; ++w) for (int vw = 4; vw < 16; ++vw) { sum += (double)hb[((size_t)w * 16 + vw) * 8 + q]; cnt++; }
-                    fprintf(stderr, "[stamps] %-28s %8.0f cycles/phase\n", vn[q], sum / cnt / nphd);
+                for (int wv = 0; wv < 16; ++wv) {
+                    const int nq = wv < 4 ? 4 : 5;
+                    fprintf(stderr, "[stamps] wave %2d:", wv);
+                    for (int q = 0; q < nq; ++q) {
+                        double sum = 0;
+                        for (int w = 0; w < grid; ++w) sum += (double)hb[((size_t)w * 16 + wv) * 8 + q];
+                        fprintf(stderr, " %s=%.0f", wv < 4 ? mn[q] : vn[q], sum / grid / nphd);
+                    }
+                    fprintf(stderr, "\n");
                 }
             }
         }
