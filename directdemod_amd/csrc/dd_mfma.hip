@@ -71,19 +71,15 @@ __device__ __forceinline__ float dd_fast_atan2(float y, float x) {
     return copysignf(r, y);
 }
 
-// atan(y/x) for x > 0, |y| <= tan(pi/8) x: same polynomial, no octant logic
+// atan(y/x) for x > 0, |y| <= tan(pi/8) x: t + t z (c0 + c1 z + c2 z^2 + c3 z^3), z = t^2
+// (minimax fit on [0, tan(pi/8)]; 2.3e-8 rad evaluated in f32), no octant logic
 __device__ __forceinline__ float dd_atan_small(float y, float x) {
     const float t = y * __builtin_amdgcn_rcpf(x);
     const float z = t * t;
-    float p = -4.054567120e-03f;
-    p = fmaf(p, z, 2.186295773e-02f);
-    p = fmaf(p, z, -5.591232695e-02f);
-    p = fmaf(p, z, 9.642197381e-02f);
-    p = fmaf(p, z, -1.390862959e-01f);
-    p = fmaf(p, z, 1.994656567e-01f);
-    p = fmaf(p, z, -3.332986079e-01f);
-    p = fmaf(p, z, 9.999993356e-01f);
-    return p * t;
+    float p = fmaf(7.902598251e-02f, z, -1.382445378e-01f);
+    p = fmaf(p, z, 1.997187931e-01f);
+    p = fmaf(p, z, -3.333275667e-01f);
+    return fmaf(t, z * p, t);
 }
 
 __device__ __forceinline__ float dd_fm_angle_fast(float cx, float cy, float px, float py) {
@@ -465,7 +461,7 @@ __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt
 // the discriminator's y[n] conj(y[n-1]) and is applied in the epilogue only for complex
 // output.  Plain v_fma/v_mul on purpose: packed f32 ops beside the matrix waves' MFMAs
 // cost ~5x a plain op (measured: the vector phases ran 2.3x slower with v_pk_*).
-template <int NKS>
+template <int NKS, bool UNIT_SCALE>
 __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::NIT], char* planes,
                                               const float2 (&wk)[WsGeom<NKS>::NIT][2], float scale, int vt) {
     using G = MfmaGeom<NKS>;
@@ -475,13 +471,19 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
         const int q = vt + WS_VTHREADS * it;
         if (WS_VTHREADS * (it + 1) > W::NQ && q >= W::NQ) continue;
         const int e = 2 * q;
-        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), make_float2(wk[it][0].x * scale, wk[it][0].y * scale));
-        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), make_float2(wk[it][1].x * scale, wk[it][1].y * scale));
+        float2 pa = wk[it][0], pb = wk[it][1];
+        if (!UNIT_SCALE) {
+            pa = make_float2(pa.x * scale, pa.y * scale);
+            pb = make_float2(pb.x * scale, pb.y * scale);
+        }
+        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
+        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
         v2h rh, rl, ih, il;
         rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
         ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
-        rl.x = (_Float16)(xa.x - (float)rh.x); rl.y = (_Float16)(xb.x - (float)rh.y);
-        il.x = (_Float16)(xa.y - (float)ih.x); il.y = (_Float16)(xb.y - (float)ih.y);
+        // low limb = x - (float)hi as one mixed-precision fma (v_fma_mix_f32) per value
+        rl.x = (_Float16)fmaf((float)rh.x, -1.0f, xa.x); rl.y = (_Float16)fmaf((float)rh.y, -1.0f, xb.x);
+        il.x = (_Float16)fmaf((float)ih.x, -1.0f, xa.y); il.y = (_Float16)fmaf((float)ih.y, -1.0f, xb.y);
         const int off = 2 * e + 16 * (e >> 5);
         *reinterpret_cast<v2h*>(planes + off) = rh;
         *reinterpret_cast<v2h*>(planes + G::PLANE + off) = rl;
@@ -508,9 +510,11 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
         float a0, a1, a2, a3;
         // wave-uniform fast path: every |angle| below 22.5 degrees (an oversampled FM signal
         // always is): atan(t) needs no octant logic.  One ballot decides for the whole wave.
-        const bool small = (fabsf(im0) <= 0.41421354f * re0) && (fabsf(im1) <= 0.41421354f * re1) &&
-                           (fabsf(im2) <= 0.41421354f * re2) && (fabsf(im3) <= 0.41421354f * re3);
-        if (__builtin_amdgcn_ballot_w64(!small) == 0) {
+        const unsigned long long big = __builtin_amdgcn_ballot_w64(!(fabsf(im0) <= 0.41421354f * re0)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im1) <= 0.41421354f * re1)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im2) <= 0.41421354f * re2)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im3) <= 0.41421354f * re3));
+        if (big == 0) {
             a0 = dd_atan_small(im0, re0); a1 = dd_atan_small(im1, re1);
             a2 = dd_atan_small(im2, re2); a3 = dd_atan_small(im3, re3);
         } else {
@@ -590,9 +594,14 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
         float m = red[0];
 #pragma unroll
         for (int k = 1; k < WS_VWAVES; ++k) m = fmaxf(m, red[k]);
-        const float scale = dd_pow2_scale_for(m);
+        // f16 limbs hold the tile as it is when its peak lies in [0.25, 32768) (hi limb cannot
+        // overflow after the rotation, the lo limb's subnormal floor stays below 2^-22 of the peak):
+        // the common case (8-bit SDR samples peak at 181) skips the scaling multiplies
+        const bool unit = (m >= 0.25f) && (m < 32768.0f);
+        const float scale = unit ? 1.0f : dd_pow2_scale_for(m);
         if (vt == 0) scales[p & 3] = scale;
-        if (!(P.dbg & 4)) dd_ws_convert<NKS>(rcur, smem + (p & 1) * W::PLANES_BYTES, wk, scale, vt);
+        if (unit) dd_ws_convert<NKS, true>(rcur, smem + (p & 1) * W::PLANES_BYTES, wk, scale, vt);
+        else dd_ws_convert<NKS, false>(rcur, smem + (p & 1) * W::PLANES_BYTES, wk, scale, vt);
     }
     DD_STAMP(2)
     if (p + 1 < n) {                                        // tile max + group phasors of tile p+1
@@ -732,7 +741,6 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         DD_STAMP(1)
         // all 16 waves have finished reading the y-buffer of tile p-2 (normally long ago)
         while (__hip_atomic_load(ydone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * (p + 1)) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (go) {
             // register r of lane (i, h) is output 32 (rowbase(r) + 4h) + i of the strip
 #pragma unroll
