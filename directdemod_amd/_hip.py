@@ -60,6 +60,8 @@ SIGNATURES = {
     "dd_event_destroy": (_int, [_p]),
     "dd_event_record": (_int, [_p, _p]),
     "dd_event_elapsed_ms": (_int, [_p, _p, C.POINTER(C.c_float)]),
+    "dd_event_sync": (_int, [_p]),
+    "dd_stream_wait_event": (_int, [_p, _p]),
     "dd_u8iq_to_c64": (_int, [_p, _p, _i64, _p]),
     "dd_nco_c64": (_int, [_p, _p, _i64, _u64, _i64, _p]),
     "dd_fir_create": (_int, [_pp, C.POINTER(C.c_double), _int]),

@@ -107,7 +107,7 @@ struct MfmaGeom {
     static constexpr int SPAN = MF_T + HALO;                     // staged samples (multiple of 32)
     static constexpr int PLANE = SPAN * 2 + (SPAN / 32) * 16;    // bytes per f16 plane incl. padding
     static constexpr int NIT = (SPAN / 2 + MF_THREADS - 1) / MF_THREADS;
-    static constexpr int NGRP = SPAN / 64;
+    static constexpr int NGRP = (SPAN + 63) / 64;                // 64-sample NCO phasor groups (SPAN need not be a multiple of 64)
 };
 
 // A tile is INTERIOR when its whole staged span lies inside the chunk, the input is

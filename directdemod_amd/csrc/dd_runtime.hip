@@ -121,6 +121,15 @@ extern "C" int dd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
     return DD_OK;
 }
 
+extern "C" int dd_event_sync(void* ev) {
+    DD_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev));
+    return DD_OK;
+}
+extern "C" int dd_stream_wait_event(void* stream, void* ev) {
+    DD_HIP_CHECK(hipStreamWaitEvent(dd_stream(stream), (hipEvent_t)ev, 0));
+    return DD_OK;
+}
+
 // ---------------------------------------------------------------- NCO table
 __global__ void k_fill_nco_table(float2* t) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,92 @@
+"""
+Streaming ingest: a source feeding pinned-host ring buffers whose host-to-device
+copies run on a side stream, overlapped with the fused kernel of the previous chunk
+(BASELINE north_star).  The raw interleaved uint8 I,Q pairs cross
+PCIe (2 B/sample instead of 8 for complex64) and the fused kernel widens them itself
+(DD_CHAIN_U8_INPUT), so nothing but the decoded output is ever written back.
+
+    ring slot k:  [pinned host u8]  --hipMemcpyAsync (copy stream)-->  [device u8]
+                   event "copied[k]"  ->  compute stream waits  ->  dd_chain_process
+                   event "consumed[k]" -> copy stream waits before reusing the slot
+
+The chunk loop itself is the reference's (decode_noaa.py:619-624): chunks in order,
+state carried inside the chain handle on the device; the host never synchronises
+inside the loop (only when the ring wraps onto a slot still being copied from).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip, chunker, constants
+from ._hip import DevArray, check, lib
+
+
+class PinnedRing:
+    """depth pinned host buffers + matching device buffers, with copy/consume events"""
+
+    def __init__(self, slot_bytes, depth=3):
+        _hip.require_gpu()
+        self.depth = depth
+        self.slot_bytes = int(slot_bytes)
+        self.host, self.dev, self.copied, self.consumed = [], [], [], []
+        for _ in range(depth):
+            h = C.c_void_p()
+            check(lib().dd_host_alloc_pinned(C.byref(h), self.slot_bytes), "dd_host_alloc_pinned")
+            self.host.append(h)
+            self.dev.append(DevArray(self.slot_bytes, np.uint8))
+            for lst in (self.copied, self.consumed):
+                e = C.c_void_p()
+                check(lib().dd_event_create(C.byref(e)), "dd_event_create")
+                lst.append(e)
+        s = C.c_void_p()
+        check(lib().dd_stream_create(C.byref(s)), "dd_stream_create")
+        self.copy_stream = s
+        self._used = [False] * depth
+
+    def host_view(self, k, nbytes):
+        return np.ctypeslib.as_array(C.cast(self.host[k], C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def close(self):
+        for h in self.host:
+            lib().dd_host_free_pinned(h)
+        for e in self.copied + self.consumed:
+            lib().dd_event_destroy(e)
+        lib().dd_stream_destroy(self.copy_stream)
+        for d in self.dev:
+            d.free()
+        self.host, self.dev = [], []
+
+
+def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSIZE, depth=3, compute_stream=None):
+    """offsetFreq -> FIR -> decimate -> FM over a u8 source, chunk by chunk, with the
+    ingest overlapped.  Returns (device float32 array of all outputs, output rate)."""
+    from .shard import HipChainEngine
+    fs = int(src.sampFreq)
+    eng = HipChainEngine(taps, freq_hz, fs, decim, fm=True, nco=True, u8=True, stream=compute_stream)
+    ck = chunker.chunker(src, chunk_size)
+    chunks = ck.getChunks
+    maxlen = max(b - a for a, b in chunks)
+    ring = PinnedRing(2 * maxlen, depth)
+    total_out = max(1, len(range(0, src.length, decim)))
+    out = DevArray(total_out, np.float32)
+    n_done = 0
+    L = lib()
+    try:
+        for i, (a, b) in enumerate(chunks):
+            k = i % depth
+            n = b - a
+            if ring._used[k]:
+                check(L.dd_event_sync(ring.consumed[k]), "dd_event_sync")       # slot free again?
+            ring.host_view(k, 2 * n)[:] = src.read_raw_u8(a, b)                  # file/memmap -> pinned
+            check(L.dd_memcpy_h2d(ring.dev[k].ptr, ring.host[k], 2 * n, ring.copy_stream), "h2d")
+            check(L.dd_event_record(ring.copied[k], ring.copy_stream), "record")
+            check(L.dd_stream_wait_event(compute_stream, ring.copied[k]), "wait")
+            got = eng.process(ring.dev[k].ptr, out.ptr + 4 * n_done, n)
+            check(L.dd_event_record(ring.consumed[k], compute_stream), "record")
+            ring._used[k] = True
+            n_done += got
+        check(L.dd_stream_sync(compute_stream), "sync")
+    finally:
+        eng.close()
+        ring.close()
+    return out.view(0, n_done), int(fs / decim)

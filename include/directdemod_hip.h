@@ -70,6 +70,8 @@ int  dd_event_create(void** ev);
 int  dd_event_destroy(void* ev);
 int  dd_event_record(void* ev, void* stream);
 int  dd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* syncs on ev_stop */
+int  dd_event_sync(void* ev);
+int  dd_stream_wait_event(void* stream, void* ev);   /* later work on `stream` waits for `ev` (no host sync) */
 
 /* ---- S1: source.IQwav/IQdat/IQwavAlt.read (source.py:117-118,209-210,303-304) -- */
 /* interleaved uint8 I,Q  ->  complex64 minus (127.5+127.5j) */

@@ -190,3 +190,19 @@ def test_source_readers(dd, tmp_path):
     sw = dd.source.IQwav(str(w))
     assert sw.sampFreq == 2400000 and sw.length == 5000
     assert np.array_equal(sw.read(0, 5000), O.grid_c64(raw))
+
+
+def test_streaming_ring_feeder_equals_one_shot(dd):
+    """u8 source -> pinned ring -> side-stream H2D -> fused u8 chain, chunked == one shot"""
+    from directdemod_amd import stream
+    raw = O.synth_iq_fm(300000, 2048000, 12, f_carrier=30e3)
+    src = dd.source.IQarray(raw, 2048000)
+    taps = O.win_blackmanharris(151)
+    for M in (34, 1):
+        out, rate = stream.stream_fm_chain(src, taps, 30000.0, M, chunk_size=70001, depth=3)
+        got = out.to_host().astype(np.float64)
+        ref, r2 = O.audio_chain(lambda a, b: O.read_iq_u8(raw, a, b), len(raw), 2048000, 30000.0, taps,
+                                2048000 // M if M > 1 else 2048000)
+        assert rate == r2 and got.shape == ref.shape
+        d = np.abs(np.angle(np.exp(1j * (got - ref))))
+        assert np.max(d) < 1e-4 and np.median(d) < 2e-6

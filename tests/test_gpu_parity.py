@@ -275,7 +275,8 @@ def test_fused_equals_unfused_stages(dd):
     assert np.max(np.abs(np.angle(np.exp(1j * (fused - a.signal))))) < 2e-5
 
 
-@pytest.mark.parametrize("M,K,chunk", [(1, 255, 5000), (1, 31, 777), (2, 64, 1000), (34, 151, 4096),
+@pytest.mark.parametrize("M,K,chunk", [(1, 255, 5000), (1, 31, 777), (1, 151, 9000), (1, 127, 20000), (1, 100, 6001),
+                                       (1, 257, 20000), (1, 300, 7000), (2, 64, 1000), (34, 151, 4096),
                                        (50, 127, 8192), (7, 255, 300), (200, 33, 5000), (32, 100, 3000)])
 def test_fused_chain_vs_oracle_shapes(dd, M, K, chunk):
     L = 20000
