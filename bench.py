@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--force-direct", action="store_true", help="f32 direct-form kernel instead of the MFMA path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=24)
+    ap.add_argument("--simulate-rank", type=int, default=None,
+                    help="debug: run this rank's shard (halo priming path) on one GPU without torch.distributed")
     args = ap.parse_args()
 
     import torch
@@ -92,6 +94,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.simulate_rank is not None:
+        rank = args.simulate_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -111,7 +115,7 @@ def main():
     _hip.check(lib.dd_set_device(local_rank), "dd_set_device")
 
     n = 1 << args.log2n
-    halo = NTAPS - 1 + 1
+    halo = 256                             # >= ntaps-1+decim (255) and a multiple of 2 samples: keeps the shard 16-byte aligned
     start = rank * n                       # absolute index of this rank's first sample
     pre = halo if rank > 0 else 0
     xin = make_input(torch, n + pre, start - pre, device, 1235 + rank)
@@ -182,7 +186,7 @@ def main():
     chk = out[1000:1000 + 4096].double().cpu().numpy()
     extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
 
-    if rank == 0:
+    if rank == 0 or args.simulate_rank is not None:
         total = world * n * args.steps
         value = total / dt_max / 1e6
         achieved = BYTES_PER_SAMPLE * n / (kern_ms_max * 1e-3) / 1e9
