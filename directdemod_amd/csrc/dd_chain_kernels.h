@@ -64,7 +64,6 @@ struct DDChainParams {
     int flags;                 // DD_CHAIN_NCO | DD_CHAIN_FM | DD_CHAIN_U8_INPUT
     int T;                     // FIR outputs computed per block
     int nblocks;
-    int dbg;                   // ablation bits (env DD_DBG; 0 in production): 1 no MFMA, 2 no epilogue math, 4 no convert, 8 no loads
 };
 
 // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the

@@ -13,15 +13,20 @@
 // GEMM shape per wave (one "strip" of 1024 consecutive outputs):
 //     D[i][j] = y[32 i + j] = sum_m A[i][m] * B[m][j],   i, j in [0, 32)
 //     A[i][m] = s[32 i + m]          signal window of segment i   (LDS, f16 limbs)
-//     B[m][j] = g2[m - j]            Toeplitz band of the reversed taps (registers)
+//     B[m][j] = g2[m - j]            Toeplitz band of the reversed taps (constant fragments)
 // K-dimension = 31 + (HALO+1) padded to 16*NKS.  With A = signal, the 32 lanes of
-// one accumulator register hold 32 CONSECUTIVE outputs, so the FM discriminator's
-// y[n-1] is one lane to the left and the result stores are full 128-byte lines.
+// one accumulator register hold 32 CONSECUTIVE outputs.
 //
 // LDS image: four f16 planes (re_hi, re_lo, im_hi, im_lo) of the NCO-rotated,
 // power-of-two-scaled tile; every 32 samples are followed by 16 B of padding so the
 // 64-byte-strided ds_read_b128 of the A fragments is bank-conflict free
 // (dword index 20 i + 4 h, distinct for the 16 lanes of every b128 lane group).
+//
+// Two kernels:
+//   k_chain_mfma_ws    interior tiles: persistent, wave-specialised (4 matrix + 12 vector
+//                      waves per CU), see the block comment above it;
+//   k_chain_mfma_edge  stream start/end, unaligned or u8 input, partial tiles: one tile
+//                      per 4-wave workgroup, fully predicated, same MFMA core.
 #include "dd_chain_kernels.h"
 #include <stdlib.h>
 
@@ -99,8 +104,6 @@ __device__ __forceinline__ float dd_readlane(float v, int l) {
 // bytes of LDS used by one tile's staging (planes + phasors + reduction + strip hand-over)
 #define MF_LDS_TILE_BYTES(NKS) ((4 * MfmaGeom<NKS>::PLANE + 8 * MfmaGeom<NKS>::NGRP + 4 * MF_WAVES + 8 * MF_WAVES + 15) & ~15)
 
-#define MF_BL_SLOTS(NKS) ((((NKS) * 64 + MF_THREADS - 1) / MF_THREADS) * MF_THREADS)
-
 template <int NKS>
 struct MfmaGeom {
     static constexpr int HALO = 16 * NKS - 32;
@@ -110,34 +113,13 @@ struct MfmaGeom {
     static constexpr int NGRP = (SPAN + 63) / 64;                // 64-sample NCO phasor groups (SPAN need not be a multiple of 64)
 };
 
-// A tile is INTERIOR when its whole staged span lies inside the chunk, the input is
-// 16-byte aligned complex64, every output of the tile is emitted and no carried
-// state is touched: no per-element predicates anywhere.
+// edge tiles: issue the tile's global loads (two consecutive samples per lane per step)
 template <int NKS>
-__device__ __forceinline__ bool dd_tile_interior(const DDChainParams& P, int b) {
-    using G = MfmaGeom<NKS>;
-    const int64_t P0 = (int64_t)b * MF_ADV - 32;
-    const int64_t ns = P0 - G::HALO;
-    return b > 0 && b < P.nblocks - 1 && ns >= 0 && ns + G::SPAN <= P.L && P0 + MF_T <= P.Ld &&
-           !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
-}
-
-// issue the tile's global loads (two consecutive samples per lane per step)
-template <int NKS>
-__device__ __forceinline__ void dd_tile_load(const DDChainParams& P, int b, bool interior, float4 (&raw)[MfmaGeom<NKS>::NIT]) {
+__device__ __forceinline__ void dd_tile_load(const DDChainParams& P, int b, float4 (&raw)[MfmaGeom<NKS>::NIT]) {
     using G = MfmaGeom<NKS>;
     const int tid = threadIdx.x;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
-    if (interior) {
-        // unconditional loads (a predicated load makes hipcc branch and drain vmcnt per
-        // element): the partial last step re-reads the final pair, its LDS write is masked
-        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(P.in) + ns);
-#pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            const int q = tid + MF_THREADS * it;
-            raw[it] = src[q < G::SPAN / 2 ? q : G::SPAN / 2 - 1];
-        }
-    } else {
+    {
         // stream edges, carried history (already NCO-rotated), u8 ingest.  Every load is
         // unconditional on a clamped index and the value is selected afterwards: a
         // predicated load makes hipcc branch and drain vmcnt per element (measured: one edge
@@ -323,7 +305,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
     // edge tiles are [0, t_first) and [t_last, nblocks)
     const int b = (int)blockIdx.x < t_first ? (int)blockIdx.x : t_last + ((int)blockIdx.x - t_first);
     float4 raw[G::NIT];
-    dd_tile_load<NKS>(P, b, false, raw);
+    dd_tile_load<NKS>(P, b, raw);
     float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
     if (P.flags & DD_CHAIN_NCO) {
         w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
@@ -583,7 +565,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
         dd_ws_load<NKS>(P, bl, vt, rld);
     }
     DD_STAMP(0)
-    if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
+    if (p >= 2 && p - 2 < n) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
         const float unscale = taps.inv_tapscale / scales[(p - 2) & 3];
         dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
     }
@@ -682,8 +664,8 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     const bool stamp = taps.stamps != nullptr;
     for (int p = 0; p < nph; ++p) {
         unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
-        const bool go = p >= 1 && p <= n && !(P.dbg & 1);
-        if (p >= 2 && p - 2 < n && !(P.dbg & 2)) {          // the matrix waves take the last 4 epilogue units
+        const bool go = p >= 1 && p <= n;
+        if (p >= 2 && p - 2 < n) {          // the matrix waves take the last 4 epilogue units
             const float unscale = taps.inv_tapscale / reinterpret_cast<const float*>(smem + W::SCALE_OFF)[(p - 2) & 3];
             dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, WS_VWAVES + mw, lane,
                                      reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale);
@@ -890,7 +872,6 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     const int n_int = t_last - t_first;
     if (n_int > 0) {
         int grid = (n_int + 3) / 4 < 256 ? (n_int + 3) / 4 : 256;       // one persistent 16-wave workgroup per CU
-        { const char* e = getenv("DD_GRID"); if (e && atoi(e) > 0) grid = atoi(e) < n_int ? atoi(e) : n_int; }
         hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last);
         DD_LAUNCH_CHECK();
         if (want_stamps) {
@@ -931,7 +912,6 @@ int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s) {
     const DDMfmaState* st = reinterpret_cast<const DDMfmaState*>(stv);
     DDChainParams P = Pin;
     P.T = MF_T;
-    { const char* e = getenv("DD_DBG"); P.dbg = e ? atoi(e) : 0; }
     P.nblocks = (int)((P.Ld + MF_ADV - 1) / MF_ADV);
     if (P.nblocks < 1) P.nblocks = 1;
     switch (st->nks) {
