@@ -53,13 +53,39 @@ __global__ void __launch_bounds__(DD_DENSE_THREADS) k_chain_dense(const DDChainP
     // ---- stage the tile (coalesced), NCO applied on the way in
     {
         const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
-        for (int e = t; e < S; e += DD_DENSE_THREADS) {
-            float2 ph = make_float2(1.f, 0.f);
-            if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
-            const float2 v = dd_load_sample(P, ns + e, ph);
-            const int p = e + (e >> 3);
-            sre[p] = v.x;
-            sim[p] = v.y;
+        // interior tile: batches of 8 unconditional loads in flight per lane (a predicated
+        // load makes hipcc branch and wait for every element separately)
+        const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L;
+        if (interior) {
+            const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;
+            for (int e0 = t; e0 < S; e0 += 8 * DD_DENSE_THREADS) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * DD_DENSE_THREADS;
+                    v[u] = src[e < S ? e : S - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * DD_DENSE_THREADS;
+                    if (e < S) {
+                        float2 x = v[u];
+                        if (P.flags & DD_CHAIN_NCO) x = dd_cmul(x, dd_cmul(w2[e >> 6], w1));
+                        const int p = e + (e >> 3);
+                        sre[p] = x.x;
+                        sim[p] = x.y;
+                    }
+                }
+            }
+        } else {
+            for (int e = t; e < S; e += DD_DENSE_THREADS) {
+                float2 ph = make_float2(1.f, 0.f);
+                if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
+                const float2 v = dd_load_sample(P, ns + e, ph);
+                const int p = e + (e >> 3);
+                sre[p] = v.x;
+                sim[p] = v.y;
+            }
         }
     }
     __syncthreads();
@@ -167,10 +193,35 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     __syncthreads();
     {
         const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
-        for (int e = t; e < S; e += DD_DECIM_THREADS) {
-            float2 ph = make_float2(1.f, 0.f);
-            if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
-            sx[e + (e >> 5)] = dd_load_sample(P, ns + e, ph);
+        // interior tile (whole span inside the chunk, complex64 input): batches of 8
+        // unconditional loads in flight per lane.  A predicated load (edges, history, u8)
+        // makes hipcc branch and wait for every element separately.
+        const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L;
+        if (interior) {
+            const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;
+            for (int e0 = t; e0 < S; e0 += 8 * DD_DECIM_THREADS) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * DD_DECIM_THREADS;
+                    v[u] = src[e < S ? e : S - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * DD_DECIM_THREADS;
+                    if (e < S) {
+                        float2 x = v[u];
+                        if (P.flags & DD_CHAIN_NCO) x = dd_cmul(x, dd_cmul(w2[e >> 6], w1));
+                        sx[e + (e >> 5)] = x;
+                    }
+                }
+            }
+        } else {
+            for (int e = t; e < S; e += DD_DECIM_THREADS) {
+                float2 ph = make_float2(1.f, 0.f);
+                if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
+                sx[e + (e >> 5)] = dd_load_sample(P, ns + e, ph);
+            }
         }
     }
     __syncthreads();
