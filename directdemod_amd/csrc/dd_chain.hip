@@ -313,6 +313,8 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->taps.assign(taps, taps + ntaps);
     f->taps_rev = nullptr;
     f->tail[0] = f->tail[1] = nullptr;
+    f->tail_const[0] = f->tail_const[1] = nullptr;
+    f->tail_override = nullptr;
     f->parity = 0;
     f->mfma = nullptr;
     f->mfma_tried = 0;
@@ -332,6 +334,14 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     if (e == hipSuccess) e = hipMemcpy(f->taps_rev, g.data(), len * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&f->tail[0], tb);
     if (e == hipSuccess) e = hipMalloc((void**)&f->tail[1], tb);
+    if (e == hipSuccess) e = hipMalloc((void**)&f->tail_const[0], tb);
+    if (e == hipSuccess) e = hipMalloc((void**)&f->tail_const[1], tb);
+    if (e == hipSuccess) {
+        const int nc = K > 1 ? K - 1 : 1;
+        hipLaunchKernelGGL(k_fill_c64, dim3((nc + 255) / 256), dim3(256), 0, 0, f->tail_const[0], nc, 0.f, 0.f);
+        hipLaunchKernelGGL(k_fill_c64, dim3((nc + 255) / 256), dim3(256), 0, 0, f->tail_const[1], nc, 1.f, 0.f);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         dd_fir_destroy(f);
         dd_set_error("dd_fir_create: %s", hipGetErrorString(e));
@@ -353,6 +363,8 @@ extern "C" int dd_fir_destroy(dd_fir* f) {
     hipFree(f->taps_rev);
     hipFree(f->tail[0]);
     hipFree(f->tail[1]);
+    hipFree(f->tail_const[0]);
+    hipFree(f->tail_const[1]);
     hipFree(f->taps_dev);
     hipFree(f->hist[0]);
     hipFree(f->hist[1]);
@@ -372,11 +384,11 @@ extern "C" int dd_fir_reset(dd_fir* f, int mode, const float* hist_host, void* s
             DD_REQUIRE(hist_host, "hist_host");
             DD_HIP_CHECK(hipMemcpyAsync(f->tail[f->parity], hist_host, sizeof(float2) * n, hipMemcpyHostToDevice, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
+            f->tail_override = nullptr;
         } else {
-            // DD_HIST_ONES: lfilter_zi(b,[1]) unscaled == history of 1.0+0j (filters.py:45, quirk Q1)
-            hipLaunchKernelGGL(k_fill_c64, dim3((n + 255) / 256), dim3(256), 0, s, f->tail[f->parity], n,
-                               mode == DD_HIST_ONES ? 1.f : 0.f, 0.f);
-            DD_LAUNCH_CHECK();
+            // DD_HIST_ONES: lfilter_zi(b,[1]) unscaled == history of 1.0+0j (filters.py:45, quirk Q1).
+            // No launch: the next kernel simply reads the constant history buffer.
+            f->tail_override = f->tail_const[mode == DD_HIST_ONES ? 1 : 0];
         }
     }
     f->hist_mode = mode;
@@ -431,7 +443,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
     memset(&P, 0, sizeof(P));
     P.in = a.in;
     P.out = a.out;
-    P.tail_in = fir->tail[fir->parity];
+    P.tail_in = fir->tail_override ? fir->tail_override : fir->tail[fir->parity];
     P.tail_out = a.commit ? fir->tail[fir->parity ^ 1] : nullptr;
     P.taps_rev = fir->taps_rev;
     P.nco_tbl = dd_nco_table();
@@ -461,6 +473,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
             hipLaunchKernelGGL(k_tail_update, dim3(1), dim3(256), 0, s, P);
             DD_LAUNCH_CHECK();
             fir->parity ^= 1;
+            fir->tail_override = nullptr;
         }
         return DD_OK;
     }
@@ -507,7 +520,10 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), lds, s, P);
         DD_LAUNCH_CHECK();
     }
-    if (a.commit) fir->parity ^= 1;
+    if (a.commit) {
+        fir->parity ^= 1;
+        fir->tail_override = nullptr;
+    }
     if (isfm) {
         fm->parity ^= 1;
         fm->has_last = 1;

@@ -11,6 +11,8 @@ struct dd_fir {
     std::vector<double> taps;
     float* taps_rev;        // device: reversed taps, zero padded (direct-form kernels)
     float2* tail[2];        // device: K-1 past inputs (complex64), ping-pong
+    float2* tail_const[2];  // device: constant histories (all zeros / all ones) for launch-free resets
+    const float2* tail_override;   // non-null: the next launch reads this history instead of tail[parity]
     int parity;
     void* mfma;             // f16-limb Toeplitz operand for the MFMA path (lazy)
     int mfma_tried;

@@ -662,6 +662,8 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamp = taps.stamps != nullptr;
+    const unsigned long long t_clk0 = stamp ? __builtin_readcyclecounter() : 0;
+    const unsigned long long t_rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int p = 0; p < nph; ++p) {
         unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
         const bool go = p >= 1 && p <= n;
@@ -733,6 +735,12 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         DD_STAMP(3)
     }
     if (stamp && lane == 0) {
+        if (mw == 0) {   // in-kernel clock: shader ticks per 100 MHz reference tick over the whole loop
+            taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 5] = __builtin_readcyclecounter() - t_clk0;
+            taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 6] = __builtin_amdgcn_s_memrealtime() - t_rt0;
+            taps.stamps[((size_t)blockIdx.x * 16 + 1) * 8 + 4] = t_rt0;                              // loop start (abs)
+            taps.stamps[((size_t)blockIdx.x * 16 + 2) * 8 + 4] = __builtin_amdgcn_s_memrealtime();   // loop end (abs)
+        }
         for (int q = 0; q < 4; ++q) taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + q] = acc_t[q];
         taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 7] = nph;
     }
@@ -744,6 +752,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = gridDim.x;
     const int wg = blockIdx.x;
+    if (taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int nt = t_last - t_first;
     const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
     const int t_end = t_first + (int)(((int64_t)(wg + 1) * nt) / nwg);
@@ -883,6 +892,19 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
                 const char* vn[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
                 const char* mn[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
                 const double nphd = (double)hb[7];
+                fprintf(stderr, "[stamps] in-kernel clock: %.3f GHz (%llu shader ticks / %llu ref ticks @100 MHz), %d phases\n",
+                        (double)hb[5] / (double)hb[6] * 0.1, hb[5], hb[6], (int)nphd);
+                {
+                    unsigned long long e_min = ~0ull, e_max = 0, ls_min = ~0ull, ls_max = 0, le_min = ~0ull, le_max = 0;
+                    for (int w = 0; w < grid; ++w) {
+                        const unsigned long long e = hb[((size_t)w * 16) * 8 + 4], a = hb[((size_t)w * 16 + 1) * 8 + 4], b2 = hb[((size_t)w * 16 + 2) * 8 + 4];
+                        e_min = e < e_min ? e : e_min; e_max = e > e_max ? e : e_max;
+                        ls_min = a < ls_min ? a : ls_min; ls_max = a > ls_max ? a : ls_max;
+                        le_min = b2 < le_min ? b2 : le_min; le_max = b2 > le_max ? b2 : le_max;
+                    }
+                    fprintf(stderr, "[stamps] workgroup timeline (us, relative to the first kernel entry): entry %.1f..%.1f, loop start %.1f..%.1f, loop end %.1f..%.1f\n",
+                            0.0, (e_max - e_min) * 0.01, (ls_min - e_min) * 0.01, (ls_max - e_min) * 0.01, (le_min - e_min) * 0.01, (le_max - e_min) * 0.01);
+                }
                 for (int wv = 0; wv < 16; ++wv) {
                     const int nq = wv < 4 ? 4 : 5;
                     fprintf(stderr, "[stamps] wave %2d:", wv);
