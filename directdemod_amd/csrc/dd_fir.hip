@@ -189,3 +189,170 @@ extern "C" int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* 
     DD_REQUIRE(taps_host && ntaps >= 1 && in_c64 && out_c64 && n >= 0, "arguments");
     return filtfilt_impl<float2>(taps_host, ntaps, (const float2*)in_c64, (float2*)out_c64, n, dd_stream(stream));
 }
+
+// ---------------------------------------------------------------- F4: IIR (butter), float64
+// scipy.signal.lfilter's transposed direct form II:
+//   y = b0 x + z0 ; z_k = z_{k+1} + b_{k+1} x - a_{k+1} y ; z_{n-2} = b_{n-1} x - a_{n-1} y
+// One lane per real component (lane 1 = imaginary part of complex data); the state
+// lives in registers for the whole run.  `mode`: 0 state as given, 1 state scaled by the
+// pass's first input sample (filtfilt), `rev`: walk the arrays backwards.
+#define DD_IIR_MAXN 16
+struct dd_iir {
+    int n;
+    double b[DD_IIR_MAXN], a[DD_IIR_MAXN];
+    double zi[DD_IIR_MAXN];
+    double* state;          // device: 2 * (n-1) doubles (re, im)
+};
+struct DDIirCoef {
+    int n;
+    double b[DD_IIR_MAXN], a[DD_IIR_MAXN], zi[DD_IIR_MAXN];
+};
+
+__global__ void k_iir_df2t(const double* __restrict__ in, double* __restrict__ out, int64_t n, int ncomp, DDIirCoef C,
+                           double* __restrict__ state, int mode, int rev, int save) {
+    const int c = threadIdx.x;
+    if (c >= ncomp) return;
+    const int N = C.n;
+    double z[DD_IIR_MAXN];
+#pragma unroll
+    for (int k = 0; k < DD_IIR_MAXN; ++k) z[k] = 0.0;
+    const int64_t first = rev ? n - 1 : 0;
+    if (mode == 1) {
+        const double x0 = in[first * ncomp + c];
+#pragma unroll
+        for (int k = 0; k < DD_IIR_MAXN - 1; ++k) if (k < N - 1) z[k] = C.zi[k] * x0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < DD_IIR_MAXN - 1; ++k) if (k < N - 1) z[k] = state[c * (DD_IIR_MAXN - 1) + k];
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t idx = (rev ? n - 1 - i : i) * ncomp + c;
+        const double x = in[idx];
+        const double y = fma(C.b[0], x, z[0]);
+#pragma unroll
+        for (int k = 0; k < DD_IIR_MAXN - 1; ++k) {
+            if (k < N - 1) {
+                const double zn = (k + 1 < N - 1) ? z[k + 1] : 0.0;
+                z[k] = zn + C.b[k + 1] * x - C.a[k + 1] * y;
+            }
+        }
+        out[idx] = y;
+    }
+    if (save) {
+#pragma unroll
+        for (int k = 0; k < DD_IIR_MAXN - 1; ++k) if (k < N - 1) state[c * (DD_IIR_MAXN - 1) + k] = z[k];
+    }
+}
+
+static void iir_coef(const dd_iir* h, DDIirCoef* C) {
+    C->n = h->n;
+    for (int k = 0; k < DD_IIR_MAXN; ++k) {
+        C->b[k] = h->b[k];
+        C->a[k] = h->a[k];
+        C->zi[k] = h->zi[k];
+    }
+}
+
+static int iir_set_state(dd_iir* h, hipStream_t s) {
+    double st[2 * (DD_IIR_MAXN - 1)];
+    for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < DD_IIR_MAXN - 1; ++k) st[c * (DD_IIR_MAXN - 1) + k] = (c == 0 && k < h->n - 1) ? h->zi[k] : 0.0;
+    // a real zi applied to complex data seeds the real part only (SciPy casts zi to complex)
+    DD_HIP_CHECK(hipMemcpyAsync(h->state, st, sizeof(st), hipMemcpyHostToDevice, s));
+    DD_HIP_CHECK(hipStreamSynchronize(s));
+    return DD_OK;
+}
+
+extern "C" int dd_iir_create(dd_iir** h, const double* b, const double* a, int n, const double* zi_host) {
+    DD_REQUIRE(h && b && a, "null argument");
+    DD_REQUIRE(n >= 1 && n <= DD_IIR_MAXN, "filter order too high (n <= 16 coefficients)");
+    DD_REQUIRE(a[0] != 0.0, "a[0] must be non-zero");
+    dd_iir* f = new dd_iir();
+    f->n = n;
+    for (int k = 0; k < DD_IIR_MAXN; ++k) {
+        f->b[k] = k < n ? b[k] / a[0] : 0.0;
+        f->a[k] = k < n ? a[k] / a[0] : 0.0;
+        f->zi[k] = (zi_host && k < n - 1) ? zi_host[k] : 0.0;
+    }
+    f->state = nullptr;
+    hipError_t e = hipMalloc((void**)&f->state, sizeof(double) * 2 * (DD_IIR_MAXN - 1));
+    if (e != hipSuccess) {
+        delete f;
+        dd_set_error("dd_iir_create: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? DD_ERR_NODEVICE : DD_ERR_HIP;
+    }
+    int rc = iir_set_state(f, nullptr);
+    if (rc != DD_OK) {
+        hipFree(f->state);
+        delete f;
+        return rc;
+    }
+    *h = f;
+    return DD_OK;
+}
+
+extern "C" int dd_iir_destroy(dd_iir* h) {
+    if (h) {
+        hipFree(h->state);
+        delete h;
+    }
+    return DD_OK;
+}
+
+extern "C" int dd_iir_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, int carry, void* stream) {
+    DD_REQUIRE(h && n >= 0, "h/n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in && out, "null buffer");
+    DDIirCoef C;
+    iir_coef(h, &C);
+    if (!carry) {        // plain lfilter: zero state, nothing kept (filters.py:75)
+        for (int k = 0; k < DD_IIR_MAXN; ++k) C.zi[k] = 0.0;
+        hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, dd_stream(stream), in, out, n, is_complex ? 2 : 1, C, h->state, 1, 0, 0);
+    } else {
+        hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, dd_stream(stream), in, out, n, is_complex ? 2 : 1, C, h->state, 0, 0, 1);
+    }
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_odd_ext(const T* __restrict__ x, T* __restrict__ ext, int64_t n, int edge) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n + 2 * (int64_t)edge) ext[i] = dd_ext_at(x, n, edge, i);
+}
+
+extern "C" int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, void* stream) {
+    DD_REQUIRE(h && in && out && n >= 0, "arguments");
+    const int edge = 3 * h->n;
+    if (n <= edge) {
+        dd_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
+        return DD_ERR_INVALID;
+    }
+    hipStream_t s = dd_stream(stream);
+    const int nc = is_complex ? 2 : 1;
+    const int64_t N = n + 2 * (int64_t)edge;
+    double *ext = nullptr, *y1 = nullptr;
+    DD_HIP_CHECK(hipMalloc((void**)&ext, sizeof(double) * N * nc));
+    hipError_t e = hipMalloc((void**)&y1, sizeof(double) * N * nc);
+    if (e != hipSuccess) {
+        hipFree(ext);
+        dd_set_error("hipMalloc: %s", hipGetErrorString(e));
+        return DD_ERR_NOMEM;
+    }
+    DDIirCoef C;
+    iir_coef(h, &C);
+    if (is_complex) hipLaunchKernelGGL(k_odd_ext<double2>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const double2*)in, (double2*)ext, n, edge);
+    else hipLaunchKernelGGL(k_odd_ext<double>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, ext, n, edge);
+    // forward pass with zi * ext[0]; backward pass over y1 with zi * y1[N-1], written in place order
+    hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, s, ext, y1, N, nc, C, h->state, 1, 0, 0);
+    hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, s, y1, ext, N, nc, C, h->state, 1, 1, 0);
+    hipError_t le = hipGetLastError();
+    hipError_t ce = hipMemcpyAsync(out, ext + (int64_t)edge * nc, sizeof(double) * n * nc, hipMemcpyDeviceToDevice, s);
+    hipError_t se = hipStreamSynchronize(s);
+    hipFree(ext);
+    hipFree(y1);
+    DD_HIP_CHECK(le);
+    DD_HIP_CHECK(ce);
+    DD_HIP_CHECK(se);
+    return DD_OK;
+}

@@ -48,6 +48,7 @@ class filter:
         self.__b = b
         self.__a = a
         self.__h = None
+        self.__iir = None
         self.__seeded = self.__initOut is None      # initOut history still to be loaded?
         av = np.atleast_1d(np.asarray(a, dtype=np.float64))
         self.__isFIR = av.size == 1
@@ -70,6 +71,8 @@ class filter:
         try:
             if self.__h is not None:
                 lib().dd_fir_destroy(self.__h)
+            if self.__iir is not None:
+                lib().dd_iir_destroy(self.__iir)
         except Exception:
             pass
 
@@ -113,7 +116,8 @@ class filter:
         else:
             d = x
         if not self.__isFIR:
-            raise NotImplementedError("IIR (butter) application is not on the GPU hot path yet (SURVEY.md 8f-3)")
+            out = self._apply_iir(d)
+            return out.to_host() if host else out
         if self.__zeroPhase:
             out = _ops.filtfilt(self.__taps, d)
         elif d.dtype == _C64:
@@ -126,6 +130,50 @@ class filter:
             out = DevArray(d.n, _F64)
             check(lib().dd_fir_f64(self._handle(), d.ptr, out.ptr, d.n, 1 if carry else 0, None), "dd_fir_f64")
         return out.to_host() if host else out
+
+    # -- IIR (butter): transposed direct form II recurrence on the device, float64 -------
+    def _iir_handle(self):
+        if self.__iir is None:
+            _hip.require_gpu()
+            b = np.atleast_1d(np.asarray(self.__b, dtype=np.float64))
+            a = np.atleast_1d(np.asarray(self.__a, dtype=np.float64))
+            n = max(len(a), len(b))
+            b = np.r_[b, np.zeros(n - len(b))] / a[0]
+            a = np.r_[a, np.zeros(n - len(a))] / a[0]
+            # scipy.signal.lfilter_zi(b, a): steady-state state of the step response, used
+            # unscaled by the reference (filters.py:45)
+            comp = np.zeros((n - 1, n - 1))
+            comp[0, :] = -a[1:]
+            if n > 2:
+                comp[1:, :-1] = np.eye(n - 2)
+            zi = np.linalg.solve(np.eye(n - 1) - comp.T, b[1:] - a[1:] * b[0]) if n > 1 else np.zeros(0)
+            self.__iir_zi = np.ascontiguousarray(zi)
+            p = C.c_void_p()
+            dp = C.POINTER(C.c_double)
+            bb, aa = np.ascontiguousarray(b), np.ascontiguousarray(a)
+            zarg = self.__iir_zi.ctypes.data_as(dp)
+            check(lib().dd_iir_create(C.byref(p), bb.ctypes.data_as(dp), aa.ctypes.data_as(dp), n, zarg), "dd_iir_create")
+            self.__iir = p
+        return self.__iir
+
+    def _apply_iir(self, d):
+        if d.dtype == _C64:
+            d = DevArray.from_host(d.to_host().astype(np.complex128))
+        elif d.dtype == _F32:
+            from .comm import _convert
+            d = _convert(d, _F64)
+        cplx = d.dtype == np.dtype(np.complex128)
+        if not cplx and d.dtype != _F64:
+            raise TypeError("unsupported dtype %s" % d.dtype)
+        if self.__initOut is not None and not self.__zeroPhase:
+            raise NotImplementedError("initOut with an IIR filter (lfiltic) is not supported on the device")
+        h = self._iir_handle()
+        out = DevArray(d.n, d.dtype)
+        if self.__zeroPhase:
+            check(lib().dd_iir_filtfilt_f64(h, d.ptr, out.ptr, d.n, 1 if cplx else 0, None), "dd_iir_filtfilt_f64")
+        else:
+            check(lib().dd_iir_f64(h, d.ptr, out.ptr, d.n, 1 if cplx else 0, 1 if self.__storeState else 0, None), "dd_iir_f64")
+        return out
 
     @property
     def getA(self):
@@ -187,9 +235,9 @@ class gaussian(filter):
 
 
 class butter(filter):
-    '''Butterworth filter design (filters.py:232-273).  IIR: the recurrence itself is
-    the next item on the hot-path list; design and error behaviour
-    are in place.'''
+    '''Butterworth filter (filters.py:232-273).  IIR: applied by a float64 transposed
+    direct form II recurrence on the device (sequential -- audio-rate use; the block-parallel
+    scan for full-rate IQ is the next step).'''
 
     def __init__(self, Fs, cutoffA, cutoffB=None, n=6, typeFlt=constants.FLT_LP, storeState=True,
                  zeroPhase=False, initOut=None):

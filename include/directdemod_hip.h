@@ -107,6 +107,20 @@ int dd_filtfilt_f64(const double* taps_host, int ntaps, const double* in, double
 int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* in_c64, float* out_c64,
                     int64_t n, void* stream);
 
+/* ---- F4: filters.butter -> scipy.signal.lfilter with a != [1] (filters.py:232-273) ---
+ * Transposed direct form II recurrence, float64, state carried on the device.
+ * Sequential by nature: one lane per real component (a block-parallel scan is the
+ * next step); meant for audio-rate data.  b, a: `n` coefficients each
+ * (pad the shorter with zeros), a[0] != 0.  zi_host: n-1 initial state values
+ * (scipy.signal.lfilter_zi(b, a), unscaled like filters.py:45) or NULL for zeros. */
+typedef struct dd_iir dd_iir;
+int dd_iir_create(dd_iir** h, const double* b, const double* a, int n, const double* zi_host);
+int dd_iir_destroy(dd_iir* h);
+/* is_complex: 0 = float64, 1 = complex128 (interleaved); carry: keep the final state */
+int dd_iir_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, int carry, void* stream);
+/* scipy.signal.filtfilt(b, a, x): odd extension 3*n, zi scaled by the first sample of each pass */
+int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, void* stream);
+
 /* ---- R1: commSignal.bwLim non-strict (comm.py:118-130) ---------------------- */
 /* out[i] = in[offset + i*m]; elem_bytes in {4,8,16}; n_out = ceil((n-offset)/m) */
 int dd_decimate(const void* in, void* out, int64_t n, int m, int offset, int elem_bytes,

@@ -88,6 +88,19 @@ def test_filtfilt(ops):
         O.filtfilt(O.win_hamming(492), [1.0], np.zeros(1476))
 
 
+def test_iir_butter(ops):
+    """F4: filters.butter through the base class (lfilter DF2T with unscaled lfilter_zi,
+    plain lfilter, filtfilt) -- filters.py:232-273"""
+    g, x = ops
+    cuts = g["fir_cuts"]
+    b, a = g["iir_b"], g["iir_a"]
+    xr = x.real.astype(np.float64)
+    f = O.FilterState(b, a)
+    y = np.concatenate([f.applyOn(xr[cuts[i]:cuts[i + 1]]) for i in range(3)])
+    assert _relerr(y, g["iir_lp_real_chunks"]) < 1e-9
+    assert _relerr(O.FilterState(b, a, zeroPhase=True).applyOn(xr), g["iir_lp_filtfilt"]) < 1e-9
+
+
 @pytest.mark.parametrize("fs,t,tag", [(2048000, 60000, "m34"), (10000000, 200000, "m50")])
 def test_decimation_carry(ops, fs, t, tag):
     g, x = ops

@@ -119,6 +119,16 @@ def main():
             g["filtfilt_hamming492_real"] = filters.hamming(492, zeroPhase=True).applyOn(x.real.astype(np.float64))
         g["filtfilt_hamming101_real"] = filters.hamming(101, zeroPhase=True).applyOn(x.real.astype(np.float64))
 
+        # F4 butter (IIR): state carried over chunks (real + complex), plain, zero-phase
+        bt = filters.butter(60235, 4160.0)
+        g["iir_b"], g["iir_a"] = np.asarray(bt.getB), np.asarray(bt.getA)
+        xr = x.real.astype(np.float64)
+        g["iir_lp_real_chunks"] = np.concatenate([bt.applyOn(xr[cuts[i]:cuts[i + 1]]) for i in range(3)])
+        btc = filters.butter(2048000, 20000.0)
+        g["iir_lp_cplx_chunks"] = np.concatenate([btc.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(3)])
+        g["iir_bp_plain"] = filters.butter(60235, 1000.0, 3000.0, n=4, typeFlt=constants.FLT_BP, storeState=False).applyOn(xr)
+        g["iir_lp_filtfilt"] = filters.butter(60235, 4160.0, zeroPhase=True).applyOn(xr)
+
         # R1 decimation with carry over uneven chunks, M=34 and 50
         for fs, t, tag in ((2048000, 60000, "m34"), (10000000, 200000, "m50")):
             ck = chunker.chunker(_Src())
