@@ -113,45 +113,44 @@ struct MfmaGeom {
     static constexpr int NGRP = (SPAN + 63) / 64;                // 64-sample NCO phasor groups (SPAN need not be a multiple of 64)
 };
 
+// samples n0, n0+1 of the chunk as the FIR sees them: stream edges, carried history (already
+// NCO-rotated), u8 ingest.  Every load is unconditional on a clamped index and the value is
+// selected afterwards: a predicated load makes hipcc branch and drain vmcnt per element
+// (measured: one edge tile took 15 us that way).
+__device__ __forceinline__ float4 dd_edge_fetch2(const DDChainParams& P, int64_t n0) {
+    const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+    const int K1 = P.K - 1;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t n = n0 + k;
+        const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
+        float2 x;
+        if (u8) {
+            const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[nc];
+            x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+        } else {
+            x = reinterpret_cast<const float2*>(P.in)[nc];
+        }
+        const int64_t ti = n + K1;                       // index into the carried history
+        const int64_t tc = ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti);
+        const float2 t = P.tail_in[tc];
+        const bool in_chunk = n >= 0 && n < P.L;
+        const bool in_tail = n < 0 && ti >= 0;
+        v[2 * k] = in_chunk ? x.x : (in_tail ? t.x : 0.f);
+        v[2 * k + 1] = in_chunk ? x.y : (in_tail ? t.y : 0.f);
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // edge tiles: issue the tile's global loads (two consecutive samples per lane per step)
 template <int NKS>
 __device__ __forceinline__ void dd_tile_load(const DDChainParams& P, int b, float4 (&raw)[MfmaGeom<NKS>::NIT]) {
     using G = MfmaGeom<NKS>;
     const int tid = threadIdx.x;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
-    {
-        // stream edges, carried history (already NCO-rotated), u8 ingest.  Every load is
-        // unconditional on a clamped index and the value is selected afterwards: a
-        // predicated load makes hipcc branch and drain vmcnt per element (measured: one edge
-        // tile took 15 us that way).
-        const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
-        const int K1 = P.K - 1;
 #pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            const int e = 2 * (tid + MF_THREADS * it);
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int64_t n = ns + e + k;
-                const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
-                float2 x;
-                if (u8) {
-                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[nc];
-                    x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
-                } else {
-                    x = reinterpret_cast<const float2*>(P.in)[nc];
-                }
-                const int64_t ti = n + K1;                       // index into the carried history
-                const int64_t tc = ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti);
-                const float2 t = P.tail_in[tc];
-                const bool in_chunk = n >= 0 && n < P.L;
-                const bool in_tail = n < 0 && ti >= 0;
-                v[2 * k] = in_chunk ? x.x : (in_tail ? t.x : 0.f);
-                v[2 * k + 1] = in_chunk ? x.y : (in_tail ? t.y : 0.f);
-            }
-            raw[it] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
+    for (int it = 0; it < G::NIT; ++it) raw[it] = dd_edge_fetch2(P, ns + 2 * (tid + MF_THREADS * it));
 }
 
 // phasor of the first sample of this thread's 64-sample group of tile b (threads
@@ -297,13 +296,14 @@ __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, 
 
 // Edge tiles (stream start/end, unaligned or u8 input, partial tiles): one tile per
 // workgroup, fully predicated.  tile = first + blockIdx.x * stride.
-template <int NKS>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+// One edge tile by the first 4 waves of the workgroup.  lds_taps == nullptr: tap fragments
+// are fetched from global memory into registers (stand-alone edge kernel); otherwise they are
+// read per k-step from the LDS copy the caller made (edge tiles riding along in the ws launch,
+// where the register budget is that of a 16-wave workgroup).
+template <int NKS, bool TAPS_LDS>
+__device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfmaTaps& taps, int b, char* smem, const v8h* lds_taps) {
     using G = MfmaGeom<NKS>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // edge tiles are [0, t_first) and [t_last, nblocks)
-    const int b = (int)blockIdx.x < t_first ? (int)blockIdx.x : t_last + ((int)blockIdx.x - t_first);
     float4 raw[G::NIT];
     dd_tile_load<NKS>(P, b, raw);
     float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
@@ -312,11 +312,13 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
         w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
     }
     const float scale = dd_tile_stage<NKS, false>(P, b, raw, smem, w1a, w1b, dd_tile_w2<NKS>(P, b));
-    v8h bh[NKS], bl[NKS];
+    v8h bh[TAPS_LDS ? 1 : NKS], bl[TAPS_LDS ? 1 : NKS];
+    if (!TAPS_LDS) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        bh[ks] = taps.frag[ks * 64 + lane];
-        bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
+        for (int ks = 0; ks < NKS; ++ks) {
+            bh[ks] = taps.frag[ks * 64 + lane];
+            bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
+        }
     }
     __syncthreads();
     const int i = lane & 31, h = lane >> 5;
@@ -332,14 +334,105 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
         const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
         const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
         const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bh[ks], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bh[ks], cim, 0, 0, 0);
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, bh[ks], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, bh[ks], cim, 0, 0, 0);
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, bl[ks], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, bl[ks], cim, 0, 0, 0);
+        const v8h th = TAPS_LDS ? lds_taps[ks * 64 + lane] : bh[TAPS_LDS ? 0 : ks];
+        const v8h tl = TAPS_LDS ? lds_taps[(NKS + ks) * 64 + lane] : bl[TAPS_LDS ? 0 : ks];
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, th, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, th, cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, th, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, th, cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, tl, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, tl, cim, 0, 0, 0);
     }
     dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
+}
+
+// The same edge tile inside the register budget of the 16-wave ws kernel (a kernel that
+// spills there runs its persistent loop ~12 % slower -- measured -- even though the spills
+// sit in this path only): the tile is fetched twice, once for its peak and once to stage
+// it, three fetches in flight, instead of being held in 36 registers.
+template <int NKS>
+__device__ __forceinline__ void dd_edge_tile_lean(const DDChainParams& P, const DDMfmaTaps& taps, int b, char* smem, const v8h* lds_taps) {
+    using G = MfmaGeom<NKS>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    char* planes = smem;
+    float* red = reinterpret_cast<float*>(smem + 4 * G::PLANE + 8 * G::NGRP);   // same LDS layout as dd_tile_stage
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    float m = 0.f;
+#pragma unroll 3
+    for (int it = 0; it < G::NIT; ++it) {
+        const float4 v = dd_edge_fetch2(P, ns + 2 * (tid + MF_THREADS * it));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = dd_pow2_scale_for(m);
+    const float inv_scale = 1.0f / scale;
+    const int64_t tail_first = P.L - (P.K - 1);     // first sample of the new history
+    const bool tail_writer = (b == P.nblocks - 1) && P.tail_out != nullptr;
+#pragma unroll 3
+    for (int it = 0; it < G::NIT; ++it) {
+        const int e = 2 * (tid + MF_THREADS * it);
+        if (e >= G::SPAN) continue;
+        const int64_t n = ns + e;
+        const float4 v = dd_edge_fetch2(P, n);
+        float2 pa = make_float2(scale, 0.f), pb = make_float2(scale, 0.f);
+        if (nco) {                                  // history samples (n < 0) are already rotated
+            if (n >= 0) { const float2 w = dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl); pa = make_float2(w.x * scale, w.y * scale); }
+            if (n + 1 >= 0) { const float2 w = dd_phasor((uint64_t)(P.abs0 + n + 1) * P.cyc, P.nco_tbl); pb = make_float2(w.x * scale, w.y * scale); }
+        }
+        const float2 xa = dd_cmul(make_float2(v.x, v.y), pa);
+        const float2 xb = dd_cmul(make_float2(v.z, v.w), pb);
+        if (tail_writer) {
+            if (n >= tail_first && n < P.L) P.tail_out[n - tail_first] = make_float2(xa.x * inv_scale, xa.y * inv_scale);
+            if (n + 1 >= tail_first && n + 1 < P.L) P.tail_out[n + 1 - tail_first] = make_float2(xb.x * inv_scale, xb.y * inv_scale);
+        }
+        v2h rh, rl, ih, il;
+        rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
+        ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
+        rl.x = (_Float16)(xa.x - (float)rh.x); rl.y = (_Float16)(xb.x - (float)rh.y);
+        il.x = (_Float16)(xa.y - (float)ih.x); il.y = (_Float16)(xb.y - (float)ih.y);
+        const int off = 2 * e + 16 * (e >> 5);
+        *reinterpret_cast<v2h*>(planes + off) = rh;
+        *reinterpret_cast<v2h*>(planes + G::PLANE + off) = rl;
+        *reinterpret_cast<v2h*>(planes + 2 * G::PLANE + off) = ih;
+        *reinterpret_cast<v2h*>(planes + 3 * G::PLANE + off) = il;
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    const int sb = wave * MF_STRIP;
+    const char* abase = smem + (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
+    v16f cre, cim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+#pragma unroll 2
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int off = 32 * ks + 16 * (ks >> 1);
+        const v8h arh = *reinterpret_cast<const v8h*>(abase + off);
+        const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
+        const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
+        const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
+        const v8h th = lds_taps[ks * 64 + lane];
+        const v8h tl = lds_taps[(NKS + ks) * 64 + lane];
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, th, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, th, cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, th, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, th, cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, tl, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, tl, cim, 0, 0, 0);
+    }
+    dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
+}
+
+template <int NKS>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // edge tiles are [0, t_first) and [t_last, nblocks)
+    const int b = (int)blockIdx.x < t_first ? (int)blockIdx.x : t_last + ((int)blockIdx.x - t_first);
+    dd_edge_tile<NKS, false>(P, taps, b, smem, nullptr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -460,17 +553,25 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
         }
         const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
         const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
-        v2h rh, rl, ih, il;
-        rh.x = (_Float16)xa.x; rh.y = (_Float16)xb.x;
-        ih.x = (_Float16)xa.y; ih.y = (_Float16)xb.y;
-        // low limb = x - (float)hi as one mixed-precision fma (v_fma_mix_f32) per value
-        rl.x = (_Float16)fmaf((float)rh.x, -1.0f, xa.x); rl.y = (_Float16)fmaf((float)rh.y, -1.0f, xb.x);
-        il.x = (_Float16)fmaf((float)ih.x, -1.0f, xa.y); il.y = (_Float16)fmaf((float)ih.y, -1.0f, xb.y);
+        uint32_t rh, rl, ih, il;
+        // (hi = RNE(x), lo = RNE(x - hi); left to the compiler's selection on purpose: a
+        // hand-written 3.5-instruction form built on v_fma_mix with an f16 SOURCE operand made
+        // the matrix waves' MFMAs on the same SIMD run at 50 cycles each instead of 35 -- like
+        // packed f32 ops, that form does not coexist with the matrix pipe)
+        {
+            v2h rh_, rl_, ih_, il_;
+            rh_.x = (_Float16)xa.x; rh_.y = (_Float16)xb.x;
+            ih_.x = (_Float16)xa.y; ih_.y = (_Float16)xb.y;
+            rl_.x = (_Float16)fmaf((float)rh_.x, -1.0f, xa.x); rl_.y = (_Float16)fmaf((float)rh_.y, -1.0f, xb.x);
+            il_.x = (_Float16)fmaf((float)ih_.x, -1.0f, xa.y); il_.y = (_Float16)fmaf((float)ih_.y, -1.0f, xb.y);
+            rh = __builtin_bit_cast(uint32_t, rh_); rl = __builtin_bit_cast(uint32_t, rl_);
+            ih = __builtin_bit_cast(uint32_t, ih_); il = __builtin_bit_cast(uint32_t, il_);
+        }
         const int off = 2 * e + 16 * (e >> 5);
-        *reinterpret_cast<v2h*>(planes + off) = rh;
-        *reinterpret_cast<v2h*>(planes + G::PLANE + off) = rl;
-        *reinterpret_cast<v2h*>(planes + 2 * G::PLANE + off) = ih;
-        *reinterpret_cast<v2h*>(planes + 3 * G::PLANE + off) = il;
+        *reinterpret_cast<uint32_t*>(planes + off) = rh;
+        *reinterpret_cast<uint32_t*>(planes + G::PLANE + off) = rl;
+        *reinterpret_cast<uint32_t*>(planes + 2 * G::PLANE + off) = ih;
+        *reinterpret_cast<uint32_t*>(planes + 3 * G::PLANE + off) = il;
     }
 }
 
@@ -592,7 +693,15 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
         for (int it = 0; it < W::NIT; ++it) {
             m = fmaxf(fmaxf(m, fabsf(rnext[it].x)), fmaxf(fabsf(rnext[it].y), fmaxf(fabsf(rnext[it].z), fabsf(rnext[it].w))));
         }
-        m = dd_wave_max(m);                                 // DPP reduction, result in lane 63
+        // Only the question "does the tile fit the f16 limbs unscaled" needs answering in the
+        // common case: two ballots.  A wave whose lanes all sit inside [.., 32768) with at least
+        // one >= 0.25 publishes 1.0 (any value of the unit range does); otherwise its true max
+        // (DPP reduction, result in lane 63) -- the tile max over the waves' entries then still
+        // selects the same scale as the exact max would.
+        const bool hi_any = __builtin_amdgcn_ballot_w64(!(m < 32768.0f)) != 0;
+        const bool lo_any = __builtin_amdgcn_ballot_w64(m >= 0.25f) != 0;
+        if (hi_any || !lo_any) m = dd_wave_max(m);
+        else m = 1.0f;
         if (lane == 63) redall[((p + 1) & 1) * WS_VWAVES + vw] = m;
     }
     DD_STAMP(3)
@@ -640,7 +749,7 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
     }
     if (taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
-        taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + 7] = nph;
+        taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + 7] = (unsigned long long)nph | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
     }
 }
 
@@ -677,9 +786,13 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         v16f cre, cim;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-        // software pipeline: the six fragments of k-step ks+1 are in flight while the six
-        // MFMAs of k-step ks (192 cycles) run; sched_barrier pins that order
-        v8h f[2][6];
+        // software pipeline, distance TWO k-steps: the six fragments of k-step ks+2 are issued
+        // during the six MFMAs of k-step ks (one read per MFMA gap), so a fragment has ~250-380
+        // cycles to arrive.  With distance one (~160 cycles) the kernel was bistable: whenever
+        // the vector waves' LDS bursts pushed the read latency past that, the MFMAs waited, the
+        // vector waves won more issue slots, bunched their LDS traffic further, and the matrix
+        // segment settled at 50 cycles per MFMA instead of 35.  sched_barrier pins the order.
+        v8h f[3][6];
 #define DD_WS_LOADF(buf, ks)                                                                     \
         {                                                                                        \
             const int off_ = 32 * (ks) + 16 * ((ks) >> 1);                                       \
@@ -717,9 +830,10 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         DD_STAMP(0)
         if (go) {
             DD_WS_LOADF(0, 0)
+            DD_WS_LOADF(1, 1)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                DD_WS_STEP(ks & 1, (ks + 1) & 1, (ks + 1 < NKS ? ks + 1 : ks), (ks + 1 < NKS))
+                DD_WS_STEP(ks % 3, (ks + 2) % 3, (ks + 2 < NKS ? ks + 2 : ks), (ks + 2 < NKS))
             }
         }
         DD_STAMP(1)
@@ -742,16 +856,30 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
             taps.stamps[((size_t)blockIdx.x * 16 + 2) * 8 + 4] = __builtin_amdgcn_s_memrealtime();   // loop end (abs)
         }
         for (int q = 0; q < 4; ++q) taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + q] = acc_t[q];
-        taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 7] = nph;
+        taps.stamps[((size_t)blockIdx.x * 16 + mw) * 8 + 7] = (unsigned long long)nph | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
     }
 }
 
 template <int NKS>
-__global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last) {
+__global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nwg = gridDim.x;
+#ifdef DD_WS_VGPR_PAD
+    asm volatile("" ::: DD_WS_VGPR_PAD);                    // raises the kernel's VGPR allocation
+#endif
     const int wg = blockIdx.x;
+    if (wg >= nwg) {
+        // edge tiles ([0, t_first) and [t_last, nblocks)) ride along as trailing workgroups:
+        // they are dispatched when the first persistent workgroups retire, i.e. inside the
+        // spread of the persistent workgroups' finish times, and cost no launch of their own
+        if (threadIdx.x >= MF_THREADS) return;              // 4 waves do the tile (exited waves leave the barrier)
+        const int e = wg - nwg;
+        const int b = e < t_first ? e : t_last + (e - t_first);
+        v8h* tl = reinterpret_cast<v8h*>(smem + W::TAPS_OFF);
+        for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += MF_THREADS) tl[idx] = taps.frag[idx];
+        dd_edge_tile_lean<NKS>(P, taps, b, smem, tl);        // (its staging barriers order the tap copy)
+        return;
+    }
     if (taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int nt = t_last - t_first;
     const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
@@ -880,9 +1008,19 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     }
     const int n_int = t_last - t_first;
     if (n_int > 0) {
-        int grid = (n_int + 3) / 4 < 256 ? (n_int + 3) / 4 : 256;       // one persistent 16-wave workgroup per CU
-        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last);
+        // one 16-wave workgroup per CU (LDS bound): persistent workgroups for the interior run plus
+        // one workgroup per edge tile (both sides of the run), all resident at once -- the edge
+        // tiles cost neither a launch of their own nor a tail after the persistent loop
+        const int n_edge = t_first + (P.nblocks - t_last);
+        const int cus = n_edge < 128 ? 256 - n_edge : 128;
+        int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
+        static const bool edge_sep = getenv("DD_EDGE_SEPARATE") != nullptr;
+        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid + (edge_sep ? 0 : n_edge)), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
+        if (edge_sep && n_edge > 0) {
+            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
+            DD_LAUNCH_CHECK();
+        }
         if (want_stamps) {
             static int printed = 0;
             std::vector<unsigned long long> hb(256 * 16 * 8);
@@ -891,7 +1029,18 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
             if (printed++ == 3) {
                 const char* vn[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
                 const char* mn[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
-                const double nphd = (double)hb[7];
+                const double nphd = (double)(hb[7] & 0xffffffffull);
+                {   // wave placement: SIMD id (HW_ID bits 5:4) of each of the 16 waves, histogram over workgroups
+                    int bad = 0;
+                    for (int w = 0; w < grid; ++w) {
+                        int cnt[4] = {0, 0, 0, 0};
+                        for (int wv = 0; wv < 4; ++wv) cnt[(hb[((size_t)w * 16 + wv) * 8 + 7] >> 36) & 3]++;
+                        if (cnt[0] != 1 || cnt[1] != 1 || cnt[2] != 1 || cnt[3] != 1) ++bad;
+                    }
+                    fprintf(stderr, "[stamps] workgroups whose 4 matrix waves do NOT sit on 4 different SIMDs: %d of %d; wg0 simd ids:", bad, grid);
+                    for (int wv = 0; wv < 16; ++wv) fprintf(stderr, " %d", (int)((hb[((size_t)wv) * 8 + 7] >> 36) & 3));
+                    fprintf(stderr, "\n");
+                }
                 fprintf(stderr, "[stamps] in-kernel clock: %.3f GHz (%llu shader ticks / %llu ref ticks @100 MHz), %d phases\n",
                         (double)hb[5] / (double)hb[6] * 0.1, hb[5], hb[6], (int)nphd);
                 {
@@ -916,12 +1065,6 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
                     fprintf(stderr, "\n");
                 }
             }
-        }
-        // edge tiles on both sides of the interior run, one launch
-        const int n_edge = t_first + (P.nblocks - t_last);
-        if (n_edge > 0) {
-            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
-            DD_LAUNCH_CHECK();
         }
     } else {
         hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t, P.nblocks, P.nblocks);
