@@ -77,8 +77,11 @@ def cpu_baseline(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-ms", type=float, default=250.0,
+                    help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
+                         "chip holds under sustained load (a cold MI355X runs its first ~10 ms of kernels 15-20 %% slower)")
     ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the decoded output")
     ap.add_argument("--force-direct", action="store_true", help="f32 direct-form kernel instead of the MFMA path")
@@ -131,34 +134,42 @@ def main():
     in_ptr = xin.data_ptr() + pre * 8
     n_out = C.c_int64(0)
 
-    def step(ev0=None, ev1=None):
+    def step():
         # new stream position: state derived from the absolute index (rank 0: stream start,
         # history of ones; rank r: primed from the halo that precedes its shard)
         if rank == 0:
             _hip.check(lib.dd_chain_reset(h, stream), "dd_chain_reset")
         else:
             _hip.check(lib.dd_chain_prime(h, xin.data_ptr(), pre, start, stream), "dd_chain_prime")
-        if ev0 is not None:
-            ev0.record()
         _hip.check(lib.dd_chain_process(h, in_ptr, out.data_ptr(), n, C.byref(n_out), stream), "dd_chain_process")
-        if ev1 is not None:
-            ev1.record()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp_steps = 0
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:          # untimed clock pre-roll
+        for _ in range(25):
+            step()
+        torch.cuda.synchronize()
+        ramp_steps += 25
     for _ in range(args.warmup):
         step()
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the hot kernel's launch duration: HIP events on the launch stream around the K timed launches
+    # (the chain is ONE kernel launch per step -- edge tiles ride along in it -- so elapsed / K is the
+    # average launch duration, launch gaps included)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        step(*evs[i])
+        step()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
     path = lib.dd_chain_path(h)
 
     tmax = torch.tensor([dt, kern_ms], dtype=torch.float64, device=device)
@@ -185,6 +196,7 @@ def main():
     # sanity: the output is a demodulated 1 kHz tone of deviation 5 rad * 2 pi * 1 kHz / fs
     chk = out[1000:1000 + 4096].double().cpu().numpy()
     extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
+    extra["clock_preroll"] = {"ms": args.ramp_ms, "steps": ramp_steps}
 
     if rank == 0 or args.simulate_rank is not None:
         total = world * n * args.steps
