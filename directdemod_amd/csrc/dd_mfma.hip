@@ -483,7 +483,8 @@ struct WsGeom {
     static constexpr int RED_OFF = TAPS_OFF + TAPS_BYTES;         // [2][WS_VWAVES] float
     static constexpr int SCALE_OFF = RED_OFF + 2 * WS_VWAVES * 4; // [4] float
     static constexpr int YDONE_OFF = SCALE_OFF + 16;              // int: waves that finished reading the y-buffer
-    static constexpr int LDS_BYTES = (YDONE_OFF + 16 + 15) & ~15;
+    static constexpr int NONUNIT_OFF = YDONE_OFF + 16;            // [4] int: "some wave saw a tile part outside the unit range", per tile slot
+    static constexpr int LDS_BYTES = (NONUNIT_OFF + 16 + 15) & ~15;
     static constexpr int KS1 = NKS / 2;                           // k-steps before the mid-phase barrier (balances both halves)
 };
 
@@ -515,7 +516,6 @@ __device__ __forceinline__ v2f dd_fm_angle2(v2f cx, v2f cy, v2f px, v2f py) {
     return (v2f){copysignf(r.x, im.x), copysignf(r.y, im.y)};
 }
 
-// ------------------------------------------------------------------ vector waves
 template <int NKS>
 __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[WsGeom<NKS>::NIT]) {
     using G = MfmaGeom<NKS>;
@@ -674,9 +674,15 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     DD_STAMP(1)
     if (p < n) {                                            // convert tile p (max published in phase p-1)
         const float* red = redall + (p & 1) * WS_VWAVES;
-        float m = red[0];
+        // common case: no wave raised the tile's non-unit flag -> unit scale, no reduction to read
+        int* nonunit = reinterpret_cast<int*>(smem + W::NONUNIT_OFF);
+        float m = 1.0f;
+        if (__builtin_amdgcn_readfirstlane(nonunit[p & 3]) != 0) {
+            m = red[0];
 #pragma unroll
-        for (int k = 1; k < WS_VWAVES; ++k) m = fmaxf(m, red[k]);
+            for (int k = 1; k < WS_VWAVES; ++k) m = fmaxf(m, red[k]);
+        }
+        if (vt == 0) nonunit[(p + 2) & 3] = 0;              // re-arm the slot tile p+2's producers raise in phase p+1
         // f16 limbs hold the tile as it is when its peak lies in [0.25, 32768) (hi limb cannot
         // overflow after the rotation, the lo limb's subnormal floor stays below 2^-22 of the peak):
         // the common case (8-bit SDR samples peak at 181) skips the scaling multiplies
@@ -700,8 +706,10 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
         // selects the same scale as the exact max would.
         const bool hi_any = __builtin_amdgcn_ballot_w64(!(m < 32768.0f)) != 0;
         const bool lo_any = __builtin_amdgcn_ballot_w64(m >= 0.25f) != 0;
-        if (hi_any || !lo_any) m = dd_wave_max(m);
-        else m = 1.0f;
+        if (hi_any || !lo_any) {
+            m = dd_wave_max(m);
+            if (lane == 63) atomicOr(reinterpret_cast<int*>(smem + W::NONUNIT_OFF) + ((p + 1) & 3), 1);
+        } else m = 1.0f;
         if (lane == 63) redall[((p + 1) & 1) * WS_VWAVES + vw] = m;
     }
     DD_STAMP(3)
@@ -890,6 +898,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
         v8h* tl = reinterpret_cast<v8h*>(smem + W::TAPS_OFF);
         for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
         if (threadIdx.x == 0) *reinterpret_cast<int*>(smem + W::YDONE_OFF) = 0;
+        if (threadIdx.x < 4) reinterpret_cast<int*>(smem + W::NONUNIT_OFF)[threadIdx.x] = threadIdx.x == 0 ? 1 : 0;   // tile 0: read the true max
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3

@@ -454,3 +454,50 @@ def test_k_shards_on_one_gpu_equal_one_shot(dd):
             got = np.concatenate(parts)
             assert got.shape == ref.shape
             assert np.max(np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - ref))))) < 2e-5
+
+
+# ----------------------------------------------------------------------------- dynamic range of the MFMA path
+@pytest.mark.parametrize("profile", ["tiny", "huge", "mixed_tiles", "one_spike", "zeros_then_signal"])
+def test_mfma_tile_scaling_paths(dd, profile):
+    """The f16-limb tiles are used unscaled while their peak lies in [0.25, 32768) and with a
+    per-tile power-of-two scale otherwise; the decision is taken per wave with two ballots and
+    published through an LDS flag.  Drive interior (persistent-kernel) tiles through every
+    branch: all waves below the range, all above, a few waves out of range inside a tile,
+    neighbouring tiles on different branches."""
+    L = 90000                                   # ~22 tiles of 4064 outputs: interior tiles on both branches
+    fs = 2400000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 77, f_carrier=25e3)).astype(np.complex128)
+    env = np.ones(L)
+    if profile == "tiny":
+        env[:] = 1e-4
+    elif profile == "huge":
+        env[:] = 3e5
+    elif profile == "mixed_tiles":
+        env[20000:33000] = 1e-5                 # whole tiles below the unit range
+        env[50000:58000] = 5e4                  # whole tiles above it
+    elif profile == "one_spike":
+        env[41234] = 1e4                        # one sample (one wave of one tile) leaves the range
+    elif profile == "zeros_then_signal":
+        env[:30000] = 0.0
+    x = (x * env).astype(np.complex64)
+    taps = O.win_hamming(255)
+    # FIR + NCO, complex output
+    y = dd.comm.commSignal(fs, x).offsetFreq(25000.0).filter(dd.filters.hamming(255)).signal
+    y_ref = O.FilterState(taps).applyOn(O.nco(x, 25000.0, fs, 0))
+    # tolerance relative to the local (tile-sized) peak: a tile's error scales with its own peak
+    blk = 4064
+    for s0 in range(0, L, blk):
+        ref = y_ref[s0:s0 + blk]
+        peak = max(np.max(np.abs(y_ref[max(0, s0 - blk):s0 + 2 * blk])), 1e-30)
+        assert np.max(np.abs(y[s0:s0 + blk] - ref)) <= 4 * FIR_TOL * peak, (profile, s0)
+    # FM on top (angles only where the reference product is not vanishing)
+    a = dd.comm.commSignal(fs, x).offsetFreq(25000.0).filter(dd.filters.hamming(255)) \
+        .funcApply(dd.demod_fm.demod_fm().demod).signal
+    a_ref, _ = O.fm_demod(y_ref, None)
+    prod = np.abs(y_ref[1:] * np.conj(y_ref[:-1]))
+    loc = np.array([np.max(prod[max(0, i - blk):i + blk]) for i in range(0, len(prod), blk)]).repeat(blk)[:len(prod)]
+    mask = prod >= 1e-3 * loc
+    mask &= prod > 0
+    d = np.abs(np.angle(np.exp(1j * (np.asarray(a, dtype=np.float64) - a_ref))))
+    assert len(a) == L - 1
+    assert np.max(d[mask]) <= 2e-4, (profile, float(np.max(d[mask])))
