@@ -191,6 +191,15 @@ int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needle_host, int
 int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate, int needle_len,
                       int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream);
 
+/* ---- AFSK1200 correlators (decode_afsk1200.py:99-158) ------------ */
+/* binary_filter[s] = mi^2 + mq^2 - si^2 - sq^2, the four sums over buffer_size samples
+ * from s against tables_host[4][bs] = mark cos/sin, space cos/sin (:110-123); entries
+ * s >= n - bs are 0 (:126).  Same operation order as the reference: float64 bit-exact. */
+int dd_afsk_binary_filter_f64(const double* sig, int64_t n, const double* tables_host, int bs,
+                              double* out, void* stream);
+/* out = np.correlate(np.sign(binary_filter), [-1]*(spb/2) + [1]*(spb - spb/2), 'same') / spb (:147-156) */
+int dd_afsk_edges_f64(const double* binary_filter, int64_t n, int spb, double* out, void* stream);
+
 /* float32 -> float64 / complex64 -> complex128 widening (audio-rate hand-over) */
 int dd_f32_to_f64(const float* in, double* out, int64_t n, void* stream);
 int dd_f64_to_f32(const double* in, float* out, int64_t n, void* stream);

@@ -610,3 +610,62 @@ def synth_apt_iq(duration_s, fs=2048000, seed=1, f_offset=30000.0, dev=17000.0,
 def grid_c64(raw_u8):
     """u8[N,2] -> complex64 on the source.read grid."""
     return read_iq_u8(raw_u8, 0, len(raw_u8))
+
+
+# ------------------------------------------------------------------ AFSK1200 correlators
+# decode_afsk1200.py:99-158 restated: the quadrature correlators for the mark (1200 Hz) and
+# space (2200 Hz) tones over one baud, their power difference, and the bit-edge detector.
+def afsk_tables(bw, baud=1200, mark=1200, space=2200):
+    """decode_afsk1200.py:99-123: buffer_size = round(bw/baud) samples of cos/sin at both tones;
+    returns (tables[4, buffer_size] = mark_i, mark_q, space_i, space_q, samples_per_baud)."""
+    bs = int(np.round(bw / baud))
+    spb = bw // baud
+    tb = np.zeros((4, bs))
+    for i in range(bs):
+        ma = (i * 1.0 / bw) / (1 / mark) * 2 * np.pi
+        sa = (i * 1.0 / bw) / (1 / space) * 2 * np.pi
+        tb[0, i], tb[1, i], tb[2, i], tb[3, i] = np.cos(ma), np.sin(ma), np.cos(sa), np.sin(sa)
+    return tb, int(spb)
+
+
+def afsk_binary_filter(sig, tables):
+    """decode_afsk1200.py:126-141.  out[s] = mi^2 + mq^2 - si^2 - sq^2 with the four sums taken
+    in the reference's order (sub = 0 .. buffer_size-1, product then add, float64); the last
+    buffer_size entries stay 0 (the loop stops at len - buffer_size)."""
+    sig = np.asarray(sig, dtype=np.float64)
+    bs = tables.shape[1]
+    n = len(sig) - bs
+    out = np.zeros(len(sig))
+    if n <= 0:
+        return out
+    acc = np.zeros((4, n))
+    for sub in range(bs):
+        seg = sig[sub:sub + n]
+        for c in range(4):
+            acc[c] = acc[c] + seg * tables[c, sub]
+    out[:n] = acc[0] ** 2 + acc[1] ** 2 - acc[2] ** 2 - acc[3] ** 2
+    return out
+
+
+def afsk_edges(binary_filter, spb):
+    """decode_afsk1200.py:147-156: correlate(sign(bf), [-1]*(spb//2) + [1]*(spb - spb//2), 'same') / spb"""
+    kernel = np.where(np.arange(spb) < spb // 2, -1.0, 1.0)
+    return np.correlate(np.sign(binary_filter), kernel, mode="same") / spb
+
+
+def synth_afsk_iq(n_bits, fs, seed, bw=22050, baud=1200, mark=1200, space=2200, dev=3000.0, amp=60.0, sigma=2.0):
+    """FM-modulated AFSK1200 (random NRZI bits) as u8 IQ at `fs` (a multiple of bw)."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, n_bits)
+    spb_fs = fs / baud
+    n = int(n_bits * spb_fs)
+    t = np.arange(n)
+    tone = np.where(bits[np.minimum((t / spb_fs).astype(np.int64), n_bits - 1)] == 1, mark, space).astype(np.float64)
+    audio_phase = 2 * np.pi * np.cumsum(tone) / fs
+    audio = np.cos(audio_phase)
+    rf_phase = 2 * np.pi * dev * np.cumsum(audio) / fs
+    s = amp * np.exp(1j * rf_phase) + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    raw = np.empty((n, 2), dtype=np.uint8)
+    raw[:, 0] = np.clip(np.round(s.real + 127.5), 0, 255).astype(np.uint8)
+    raw[:, 1] = np.clip(np.round(s.imag + 127.5), 0, 255).astype(np.uint8)
+    return raw

@@ -228,3 +228,61 @@ def test_iir_butter_golden(dd, ops):
     assert rel_err(yp, ops["iir_bp_plain"]) < 1e-7      # 8th-order band-pass recurrence: same remark
     yz = dd.filters.butter(60235, 4160.0, zeroPhase=True).applyOn(xr)
     assert rel_err(yz, ops["iir_lp_filtfilt"]) < 1e-7
+
+
+# ----------------------------------------------------------------------------- AFSK1200 correlators (8f-4)
+def test_afsk_correlators_golden(dd, golden_dir):
+    """sign(binary_filter) and the bit-edge signal of the reference's own getMsg run, bit-exact"""
+    from directdemod_amd import afsk
+    g = _load(golden_dir, "afsk.npz")
+    tb, spb = afsk.correlator_tables(int(g["bw"]))
+    tb_o, spb_o = O.afsk_tables(int(g["bw"]))
+    assert spb == spb_o == 18 and np.array_equal(tb, tb_o)
+    bf = afsk.binary_filter(g["audio"], int(g["bw"]))
+    assert bf.dtype == np.float64 and len(bf) == len(g["audio"])
+    assert np.array_equal(np.sign(bf).astype(np.int8), g["sign"])
+    assert np.array_equal(bf, O.afsk_binary_filter(g["audio"], tb_o))           # same operation order: same bits
+    ch = afsk.bit_edges(bf, spb)
+    assert np.array_equal(ch, g["edge_sums"].astype(np.float64) / spb)
+
+
+@pytest.mark.parametrize("n,bw", [(18, 22050), (19, 22050), (5000, 22050), (100000, 44100), (4097, 48000)])
+def test_afsk_correlators_vs_oracle(dd, n, bw):
+    from directdemod_amd import afsk
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) * 0.3 + np.sin(2 * np.pi * 1700 * np.arange(n) / bw)
+    tb, spb = O.afsk_tables(bw)
+    bf = afsk.binary_filter(x, bw)
+    assert np.array_equal(bf, O.afsk_binary_filter(x, tb))
+    if n >= spb:
+        assert np.array_equal(afsk.bit_edges(bf, spb), O.afsk_edges(bf, spb))
+    else:
+        with pytest.raises(ValueError):
+            afsk.bit_edges(bf, spb)
+
+
+def test_afsk_front_end_on_device(dd):
+    """decode_afsk1200.getMsg's stage order (:67-158) end to end on the device, device arrays
+    handed from stage to stage: fused NCO/BH151/decimate chain, FM, butter band-pass, correlators."""
+    from directdemod_amd import afsk, constants
+    fs, bw = 22050 * 40, 22050
+    raw = O.synth_afsk_iq(96, fs, 11)
+    x = O.grid_c64(raw)
+    sig = dd.comm.commSignal(fs, x).offsetFreq(0).filter(dd.filters.blackmanHarris(151)).bwLim(bw) \
+        .funcApply(dd.demod_fm.demod_fm().demod)
+    sig.filter(dd.filters.butter(sig.sampRate, 1200 - 500, 2200 + 500, typeFlt=constants.FLT_BP))
+    audio = np.asarray(sig.signal, dtype=np.float64)
+    # oracle: same stages in float64
+    y = O.FilterState(O.win_blackmanharris(151)).applyOn(O.nco(x, 0.0, fs, 0))
+    y, rate, _, _ = O.decimate_carry(y, fs, bw, 0)
+    a, _ = O.fm_demod(y, None)
+    import scipy.signal as ss
+    b_, a_ = ss.butter(6, [700 / (0.5 * rate), 2700 / (0.5 * rate)], btype="bandpass")
+    ref_audio = ss.lfilter(b_, a_, a, zi=ss.lfilter_zi(b_, a_))[0]
+    assert sig.sampRate == rate and len(audio) == len(ref_audio)
+    assert np.max(np.abs(audio - ref_audio)) < 5e-4 * np.max(np.abs(ref_audio))   # f32 chain in front of a resonant band-pass
+    tb, spb = O.afsk_tables(bw)
+    bf = afsk.binary_filter(audio, bw)
+    bf_ref = O.afsk_binary_filter(ref_audio, tb)
+    strong = np.abs(bf_ref) > 0.05 * np.max(np.abs(bf_ref))
+    assert np.array_equal(np.sign(bf[strong]), np.sign(bf_ref[strong]))           # bit decisions agree wherever they are decisions

@@ -234,3 +234,21 @@ def test_noaa_accurate_sync_indices(noaa):
         assert abs(tsync - ts) < 1e-9
         done += 1
     assert done == 3
+
+
+# ----------------------------------------------------------------------------- AFSK1200 correlators
+def test_afsk_correlators_match_reference_run(golden_dir):
+    """sign(binary_filter) and the bit-edge signal captured from the reference's own
+    decode_afsk1200.getMsg run (tools/gen_golden.py) on the audio it fed its correlator loop."""
+    g = np.load(os.path.join(golden_dir, "afsk.npz"))
+    tb, spb = O.afsk_tables(int(g["bw"]))
+    assert tb.shape == (4, 18) and spb == 18
+    bf = O.afsk_binary_filter(g["audio"], tb)
+    assert np.array_equal(np.sign(bf).astype(np.int8), g["sign"])
+    assert np.all(bf[-tb.shape[1]:] == 0)
+    assert np.array_equal(np.where(np.arange(spb) < spb // 2, -1, 1).astype(np.int8), g["kernel"])
+    ch = O.afsk_edges(bf, spb)
+    assert np.array_equal(ch, g["edge_sums"].astype(np.float64) / spb)
+    # the generator in the oracle reproduces the recording the golden run used
+    raw = O.synth_afsk_iq(int(g["n_bits"]), int(g["fs_iq"]), int(g["seed"]))
+    assert raw.shape == (int(g["n_bits"]) * int(g["fs_iq"]) // 1200, 2)

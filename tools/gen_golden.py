@@ -65,7 +65,52 @@ class ArraySource:
         return np.array(s).astype("complex64") - (127.5 + 1j * 127.5)
 
 
+def gen_afsk(O, filters):
+    # ------------------------------------------------------------------ AFSK1200 correlators (decode_afsk1200.py:58-158)
+    # The correlators live inline in decode_afsk1200.getMsg.  Run the reference's getMsg on a small
+    # synthetic AFSK recording and capture (a) the audio it hands to the correlator loop -- the output of
+    # its butter band-pass -- and (b) the arguments/result of its single np.correlate call, i.e.
+    # sign(binary_filter) and the bit-edge signal; then stop it (the frame decoder behind is host logic).
+    from directdemod import decode_afsk1200 as dafsk
+    fs_iq = 22050 * 40
+    raw = O.synth_afsk_iq(64, fs_iq, 5)
+    cap = {}
+
+    class _Stop(Exception):
+        pass
+    _apply = filters.filter.applyOn
+
+    def _butter_tap(self, x):          # butter inherits applyOn: shadow it on the subclass only
+        y = _apply(self, x)
+        cap["audio"] = np.array(y, dtype=np.float64)
+        return y
+    _corr = np.correlate
+
+    def _correlate_tap(a, v, mode="valid"):
+        r = _corr(a, v, mode=mode)
+        cap["sign"], cap["kernel"], cap["changes"] = np.array(a), np.array(v), np.array(r)
+        raise _Stop()
+    filters.butter.applyOn = _butter_tap
+    dafsk.np.correlate = _correlate_tap
+    try:
+        dafsk.decode_afsk1200(ArraySource(raw, fs_iq), 0, 22050).getMsg
+    except _Stop:
+        pass
+    finally:
+        del filters.butter.applyOn
+        dafsk.np.correlate = _corr
+    spb = 22050 // 1200
+    g = {"fs_iq": np.int64(fs_iq), "n_bits": np.int64(64), "seed": np.int64(5), "bw": np.int64(22050),
+         "audio": cap["audio"], "sign": cap["sign"].astype(np.int8), "kernel": cap["kernel"].astype(np.int8),
+         "edge_sums": np.round(cap["changes"]).astype(np.int16)}     # np.correlate output; the reference divides it by spb (:156)
+    assert np.array_equal(g["edge_sums"].astype(np.float64), cap["changes"])
+    np.savez_compressed(os.path.join(OUT, "afsk.npz"), **g)
+    print("afsk: audio", cap["audio"].shape, "sign +/0/-", int(np.sum(cap["sign"] > 0)), int(np.sum(cap["sign"] == 0)),
+          int(np.sum(cap["sign"] < 0)))
+
+
 def main():
+    only_afsk = "--afsk-only" in sys.argv
     install_shim()
     sys.path.insert(0, REF)
     sys.path.insert(0, ROOT)
@@ -75,6 +120,9 @@ def main():
     from oracle import dd_oracle as O
 
     os.makedirs(OUT, exist_ok=True)
+    if only_afsk:
+        gen_afsk(O, filters)
+        return
 
     # ------------------------------------------------------------------ per-op vectors
     for seed, L in ((0, 2048), (1, 1024), (2, 1024)):
@@ -246,6 +294,8 @@ def main():
     g["peaks_3s_syncB"] = np.asarray(nobj._decode_noaa__correlateAndFindPeaks(amsig, constants.NOAA_SYNCB), dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "noaa_c4.npz"), **g)
     print("noaa_c4: crude A", g["crude_syncA"][:4], "acc A", g["acc_syncA"][:4], "useful", g["useful"])
+
+    gen_afsk(O, filters)
 
 
 if __name__ == "__main__":
