@@ -300,6 +300,10 @@ def _convert(d, want):
         _hip.check(lib.dd_f32_to_f64(d.ptr, out.ptr, d.n, None), "f32->f64")
     elif d.dtype == _F64 and want == _F32:
         _hip.check(lib.dd_f64_to_f32(d.ptr, out.ptr, d.n, None), "f64->f32")
+    elif d.dtype == np.dtype(np.complex64) and want == np.dtype(np.complex128):
+        _hip.check(lib.dd_f32_to_f64(d.ptr, out.ptr, 2 * d.n, None), "c64->c128")      # interleaved re, im
+    elif d.dtype == np.dtype(np.complex128) and want == np.dtype(np.complex64):
+        _hip.check(lib.dd_f64_to_f32(d.ptr, out.ptr, 2 * d.n, None), "c128->c64")
     else:
         out = DevArray.from_host(d.to_host().astype(want))
     return out

@@ -112,7 +112,8 @@ class filter:
         host = not isinstance(x, DevArray)
         if host:
             a = np.asarray(x)
-            d = DevArray.from_host(a, dtype=_C64 if np.iscomplexobj(a) else _F64)
+            # complex data: complex64 for the FIR kernels, complex128 kept for the float64 IIR recurrence
+            d = DevArray.from_host(a, dtype=(_C64 if self.__isFIR else np.complex128) if np.iscomplexobj(a) else _F64)
         else:
             d = x
         if not self.__isFIR:
@@ -158,7 +159,8 @@ class filter:
 
     def _apply_iir(self, d):
         if d.dtype == _C64:
-            d = DevArray.from_host(d.to_host().astype(np.complex128))
+            from .comm import _convert
+            d = _convert(d, np.complex128)
         elif d.dtype == _F32:
             from .comm import _convert
             d = _convert(d, _F64)
@@ -235,9 +237,11 @@ class gaussian(filter):
 
 
 class butter(filter):
-    '''Butterworth filter (filters.py:232-273).  IIR: applied by a float64 transposed
-    direct form II recurrence on the device (sequential -- audio-rate use; the block-parallel
-    scan for full-rate IQ is the next step).'''
+    '''Butterworth filter (filters.py:232-273).  IIR: a float64 transposed direct form II
+    recurrence on the device -- one lane per component for short (audio-rate) inputs, the
+    block-parallel form (dd_fir.hip: block end states, two-level scan of the start states,
+    re-run) from 4096 samples up, which is what full-rate IQ through a butter takes
+    (decode_funcube.py:160,230).'''
 
     def __init__(self, Fs, cutoffA, cutoffB=None, n=6, typeFlt=constants.FLT_LP, storeState=True,
                  zeroPhase=False, initOut=None):

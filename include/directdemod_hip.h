@@ -109,8 +109,11 @@ int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* in_c64, flo
 
 /* ---- F4: filters.butter -> scipy.signal.lfilter with a != [1] (filters.py:232-273) ---
  * Transposed direct form II recurrence, float64, state carried on the device.
- * Sequential by nature: one lane per real component (a block-parallel scan is the
- * next step); meant for audio-rate data.  b, a: `n` coefficients each
+ * Short inputs: one lane per real component.  From 4096 samples up: block-parallel
+ * (block end states from zero, two-level scan of the block start states with the block
+ * map A^256 held in double-double, blocks re-run from their true start states), which
+ * is what full-rate IQ through a butter takes (decode_funcube.py:160,230; SURVEY.md
+ * 8f-3).  b, a: `n` coefficients each
  * (pad the shorter with zeros), a[0] != 0.  zi_host: n-1 initial state values
  * (scipy.signal.lfilter_zi(b, a), unscaled like filters.py:45) or NULL for zeros. */
 typedef struct dd_iir dd_iir;

@@ -286,3 +286,43 @@ def test_afsk_front_end_on_device(dd):
     bf_ref = O.afsk_binary_filter(ref_audio, tb)
     strong = np.abs(bf_ref) > 0.05 * np.max(np.abs(bf_ref))
     assert np.array_equal(np.sign(bf[strong]), np.sign(bf_ref[strong]))           # bit decisions agree wherever they are decisions
+
+
+# ----------------------------------------------------------------------------- F4 at IQ rate: block-parallel IIR (8f-3)
+@pytest.mark.parametrize("cplx", [False, True])
+def test_iir_block_parallel_long_inputs(dd, cplx):
+    """Inputs above 4096 samples take the block-parallel recurrence (block end states, two-level
+    scan, re-run); the carried state must hand over between it and the one-lane kernel in
+    either direction.  Checker: scipy.signal.lfilter, the routine the reference calls."""
+    import scipy.signal as ss
+    from directdemod_amd import constants
+    rng = np.random.default_rng(5)
+    n = 300000
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    x = x.astype(np.complex128 if cplx else np.float64)
+    for args, kw, tol in (((60235, 4160.0), {}, 1e-9),
+                          ((2048000, 20000.0), {}, 1e-7),
+                          ((22050, 700.0, 2700.0), {"typeFlt": constants.FLT_BP}, 1e-8)):
+        f = dd.filters.butter(*args, **kw)
+        b, a = np.asarray(f.getB), np.asarray(f.getA)
+        zi = ss.lfilter_zi(b, a)
+        cuts = [0, 70001, 70001 + 3000, 70001 + 3000 + 131072, n]      # parallel, one-lane, parallel (whole blocks), parallel (ragged)
+        got = np.concatenate([f.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+        ref = ss.lfilter(b, a, x, zi=zi.astype(x.dtype))[0]
+        assert got.dtype == x.dtype
+        assert rel_err(got, ref) < tol, (args, rel_err(got, ref))
+        # stateless form
+        f0 = dd.filters.butter(*args, storeState=False, **kw)
+        assert rel_err(f0.applyOn(x[:100000]), ss.lfilter(b, a, x[:100000])) < tol
+
+
+def test_iir_block_parallel_complex64_iq(dd):
+    """decode_funcube.py:160 shape: complex64 IQ through a butter low-pass, device array in and out"""
+    import scipy.signal as ss
+    x = O.grid_c64(O.synth_iq_fm(1 << 20, 2400000, 3))
+    f = dd.filters.butter(2400000, 100000.0, storeState=False)
+    d = dd.hip.DevArray.from_host(x)
+    y = f.applyOn(d)
+    assert isinstance(y, dd.hip.DevArray) and y.dtype == np.complex128 and y.n == len(x)
+    ref = ss.lfilter(np.asarray(f.getB), np.asarray(f.getA), x.astype(np.complex128))
+    assert rel_err(y.to_host(), ref) < 1e-9
