@@ -1,0 +1,145 @@
+"""
+Parity at BASELINE.json's full size (C2: 2^26 samples, NCO 25 kHz + Hamming(255) + FM), where the
+float64 oracle cannot run the whole array in seconds: size-independent properties through the C-ABI,
+plus oracle spot checks on windows of the same run.
+
+  * two independent kernels agree: the MFMA f16-limb path against the f32 direct-form path
+    (DD_CHAIN_FORCE_DIRECT) on the same device-resident input, every output;
+  * chunked == one-shot: 16 chunks of 2^22 with the FIR history / last FM sample / NCO index carried
+    on the device, against the single-chunk run;
+  * k shards primed from their halos == one-shot (config 5's rule, 8 shards);
+  * oracle windows: 8192-sample windows at the start, an interior tile seam, and the very end.
+
+Angles are compared wrapped; the bench input (FM tone, SNR ~20 dB) keeps |y[n] conj y[n-1]| far from
+zero, so no conditioning mask is needed.  Tolerance 1e-4 rad (the FM bound of the small-size tests).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FS, F_OFF, NTAPS, LOG2N = 2400000, 25000.0, 255, 26
+TOL = 1e-4
+
+
+def _wrapped_max(torch, a, b, blk=1 << 24):
+    m = 0.0
+    for s in range(0, a.numel(), blk):
+        d = (a[s:s + blk].double() - b[s:s + blk].double())
+        d = torch.remainder(d + np.pi, 2 * np.pi) - np.pi
+        m = max(m, float(d.abs().max()))
+    return m
+
+
+@pytest.fixture(scope="module")
+def run():
+    torch = pytest.importorskip("torch")
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from directdemod_amd import _hip
+    _hip.require_gpu()
+    import bench
+    n = 1 << LOG2N
+    dev = torch.device("cuda", 0)
+    x = bench.make_input(torch, n, 0, dev, 1235)               # [n, 2] float32 == complex64 interleaved
+    taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
+    lib = _hip.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def chain(flags_extra=0):
+        h = C.c_void_p()
+        _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), NTAPS,
+                                       _hip.cycles_q64(F_OFF, FS), 1, _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | flags_extra),
+                   "dd_chain_create")
+        return h
+
+    def process(h, in_ptr, out_ptr, cnt):
+        got = C.c_int64(0)
+        _hip.check(lib.dd_chain_process(h, in_ptr, out_ptr, cnt, C.byref(got), stream), "dd_chain_process")
+        return got.value
+
+    h = chain()
+    one = torch.empty(n, dtype=torch.float32, device=dev)
+    assert process(h, x.data_ptr(), one.data_ptr(), n) == n - 1          # quirk Q3: first chunk is one short
+    assert lib.dd_chain_path(h) == 1                                     # the MFMA path ran
+    lib.dd_chain_destroy(h)
+    torch.cuda.synchronize()
+
+    class R:
+        pass
+    r = R()
+    r.torch, r.hip, r.lib, r.x, r.one, r.n, r.taps, r.chain, r.process, r.stream, r.dev = \
+        torch, _hip, lib, x, one, n, taps, chain, process, stream, dev
+    return r
+
+
+def test_mfma_path_equals_direct_f32_path_everywhere(run):
+    t = run.torch
+    h = run.chain(run.hip.DD_CHAIN_FORCE_DIRECT)
+    out = t.empty(run.n, dtype=t.float32, device=run.dev)
+    assert run.process(h, run.x.data_ptr(), out.data_ptr(), run.n) == run.n - 1
+    assert run.lib.dd_chain_path(h) == 0
+    run.lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert _wrapped_max(t, out[:run.n - 1], run.one[:run.n - 1]) < TOL
+    assert bool(t.isfinite(run.one[:run.n - 1]).all())
+
+
+def test_sixteen_chunks_with_carried_state_equal_one_shot(run):
+    t = run.torch
+    h = run.chain()
+    out = t.empty(run.n, dtype=t.float32, device=run.dev)
+    c = run.n // 16
+    pos = 0
+    for k in range(16):
+        got = run.process(h, run.x.data_ptr() + 8 * k * c, out.data_ptr() + 4 * pos, c)
+        assert got == (c - 1 if k == 0 else c)
+        pos += got
+    run.lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert pos == run.n - 1
+    assert _wrapped_max(t, out[:pos], run.one[:pos]) < TOL
+
+
+def test_eight_primed_shards_equal_one_shot(run):
+    from directdemod_amd import shard
+    t = run.torch
+    out = t.empty(run.n, dtype=t.float32, device=run.dev)
+    pos = 0
+    for a, b in shard.shard_ranges(run.n, 8, 1):
+        eng = shard.HipChainEngine(run.taps, F_OFF, FS, 1, stream=run.stream)
+        got = shard.run_shard(eng, lambda g: run.x.data_ptr() + 8 * g, a, b, NTAPS, 1, out.data_ptr() + 4 * pos)
+        assert got == shard.output_count(a, b, 1, True)
+        pos += got
+        eng.close()
+    t.cuda.synchronize()
+    assert pos == run.n - 1
+    assert _wrapped_max(t, out[:pos], run.one[:pos]) < TOL
+
+
+@pytest.mark.parametrize("where", ["start", "seam", "middle", "end"])
+def test_oracle_windows_of_the_full_run(run, where):
+    W = 8192
+    n = run.n
+    w0 = {"start": 0, "seam": 4064 * 8000 - 4096, "middle": n // 2 + 12345, "end": n - W}[where]
+    h0 = max(0, w0 - (NTAPS - 1) - 1)                                    # FIR history + one sample for the FM lag
+    xs = run.x[h0:w0 + W].cpu().numpy().astype(np.float32)
+    xc = (xs[:, 0] + 1j * xs[:, 1]).astype(np.complex64)
+    y = O.nco(xc, F_OFF, FS, h0)
+    if h0 == 0:
+        y = O.FilterState(run.taps).applyOn(y)                           # stream start: history of ones (Q1)
+    else:
+        y = O.lfilter_fir(run.taps, y, None)[NTAPS - 1:]                 # steady state: drop the warm-up outputs
+        h0 += NTAPS - 1
+    a_ref, _ = O.fm_demod(y, None)                                       # a_ref[i] pairs global samples h0+i+1, h0+i
+    first = h0 + 1                                                       # global index of the first pair's newer sample
+    got = run.one[first - 1:first - 1 + len(a_ref)].cpu().numpy().astype(np.float64)   # output k-1 holds pair (k, k-1)
+    d = np.abs(np.angle(np.exp(1j * (got - a_ref))))
+    assert len(got) == len(a_ref) and len(a_ref) >= W - 1
+    assert np.max(d) < TOL and np.median(d) < 2e-6
