@@ -104,6 +104,28 @@ _gpu_checked = False
 _last_path = None
 
 
+def _bind_to_pytorch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, requested by libtorch_hip as plain "libamdhip64.so"): if this library has
+    already pulled in the system runtime when torch initialises, the process ends up with two
+    runtimes and torch reports "no ROCm-capable device".  Loading torch's copy first -- without
+    importing torch -- makes our DT_NEEDED resolve to it, whatever the import order (bench.py,
+    the torch.distributed sharding path and the tests use both in one process).
+    DD_HIP_SYSTEM_RUNTIME=1 keeps the system runtime."""
+    if os.environ.get("DD_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """dlopen the C-ABI library and bind every declared symbol (no GPU needed)."""
     global _lib
@@ -114,6 +136,7 @@ def load():
             raise ImportError(
                 "directdemod_amd: %s is missing -- run `python __graft_entry__.py` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        _bind_to_pytorch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported

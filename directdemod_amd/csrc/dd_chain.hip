@@ -193,28 +193,49 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     __syncthreads();
     {
         const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
-        // interior tile (whole span inside the chunk, complex64 input): batches of 8
-        // unconditional loads in flight per lane.  A predicated load (edges, history, u8)
-        // makes hipcc branch and wait for every element separately.
-        const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L;
+        // interior tile (whole span inside the chunk, complex64 input): the WHOLE tile is requested
+        // at once -- up to 12 unconditional 16-byte loads (two samples each) in flight per lane --
+        // so a tile costs one HBM latency, not one per batch: with three batches of eight 8-byte
+        // loads the kernel sat at 2.9 TB/s (Little: ~45 KB in flight per CU only while loading).
+        // A predicated load (edges, history, u8) makes hipcc branch and wait for every element.
+        const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L && S <= DD_DECIM_SPAN_MAX;
         if (interior) {
+            typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));     // 16-byte load on an 8-byte boundary
             const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;
-            for (int e0 = t; e0 < S; e0 += 8 * DD_DECIM_THREADS) {
-                float2 v[8];
+            constexpr int NV = (DD_DECIM_SPAN_MAX / 2 + DD_DECIM_THREADS - 1) / DD_DECIM_THREADS;
+            const int nq = S / 2;                             // whole sample pairs in the span
+            float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+            if (P.flags & DD_CHAIN_NCO) {
+                w1a = dd_phasor((uint64_t)((2 * t) & 63) * P.cyc, P.nco_tbl);
+                w1b = dd_phasor((uint64_t)(((2 * t) & 63) + 1) * P.cyc, P.nco_tbl);
+            }
+            v4f_a8 v[NV];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * DD_DECIM_THREADS;
-                    v[u] = src[e < S ? e : S - 1];
-                }
+            for (int u = 0; u < NV; ++u) {
+                int q = t + u * DD_DECIM_THREADS;
+                q = q < nq ? q : nq - 1;                      // past the span: harmless re-read, never used
+                v[u] = *reinterpret_cast<const v4f_a8*>(src + 2 * q);
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * DD_DECIM_THREADS;
-                    if (e < S) {
-                        float2 x = v[u];
-                        if (P.flags & DD_CHAIN_NCO) x = dd_cmul(x, dd_cmul(w2[e >> 6], w1));
-                        sx[e + (e >> 5)] = x;
+            for (int u = 0; u < NV; ++u) {
+                const int q = t + u * DD_DECIM_THREADS;
+                const int e = 2 * q;
+                if (q < nq) {
+                    float2 xa = make_float2(v[u].x, v[u].y), xb = make_float2(v[u].z, v[u].w);
+                    if (P.flags & DD_CHAIN_NCO) {
+                        const float2 g = w2[e >> 6];
+                        xa = dd_cmul(xa, dd_cmul(g, w1a));
+                        xb = dd_cmul(xb, dd_cmul(g, w1b));
                     }
+                    sx[e + (e >> 5)] = xa;
+                    sx[e + 1 + (e >> 5)] = xb;
                 }
+            }
+            if ((S & 1) && t == 0) {                          // odd span: its last sample on its own
+                const int e = S - 1;
+                float2 x = src[e];
+                if (P.flags & DD_CHAIN_NCO) x = dd_cmul(x, dd_cmul(w2[e >> 6], dd_phasor((uint64_t)(e & 63) * P.cyc, P.nco_tbl)));
+                sx[e + (e >> 5)] = x;
             }
         } else {
             for (int e = t; e < S; e += DD_DECIM_THREADS) {

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Side measurement: config 4 (NOAA APT sync detection) end to end on the device -- crude sync over the
+whole recording and the accurate-sync windows -- on a synthetic recording (not the headline metric)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from directdemod_amd import _hip, noaa_sync, source
+from oracle import dd_oracle as O      # synthetic generator only
+_hip.require_gpu()
+dur = float(sys.argv[1]) if len(sys.argv) > 1 else 16.0
+raw = O.synth_apt_iq(dur, seed=1)
+src = source.IQarray(raw, 2048000)
+for rep in range(2):
+    obj = noaa_sync.noaa_sync(src, 30000.0)
+    t0 = time.perf_counter()
+    sa, sb = obj.getCrudeSync()
+    _hip.sync()
+    t1 = time.perf_counter()
+    acc = obj.getAccurateSync()
+    _hip.sync()
+    t2 = time.perf_counter()
+    nwin = len(acc[0][0]) + len(acc[1][0])
+    print("run %d: %.0f s recording (%d IQ samples): crude sync %.1f ms (%d + %d syncs), accurate sync %.1f ms for %d windows = %.2f ms/window"
+          % (rep, dur, src.length, (t1 - t0) * 1e3, len(sa), len(sb), (t2 - t1) * 1e3, nwin, (t2 - t1) * 1e3 / max(1, nwin)))
