@@ -294,14 +294,10 @@ __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, 
     }
 }
 
-// Edge tiles (stream start/end, unaligned or u8 input, partial tiles): one tile per
-// workgroup, fully predicated.  tile = first + blockIdx.x * stride.
-// One edge tile by the first 4 waves of the workgroup.  lds_taps == nullptr: tap fragments
-// are fetched from global memory into registers (stand-alone edge kernel); otherwise they are
-// read per k-step from the LDS copy the caller made (edge tiles riding along in the ws launch,
-// where the register budget is that of a 16-wave workgroup).
-template <int NKS, bool TAPS_LDS>
-__device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfmaTaps& taps, int b, char* smem, const v8h* lds_taps) {
+// Edge tiles (stream start/end, unaligned or u8 input, partial tiles): one tile per 4-wave
+// workgroup, fully predicated, tap fragments held in registers (stand-alone edge kernel).
+template <int NKS>
+__device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfmaTaps& taps, int b, char* smem) {
     using G = MfmaGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float4 raw[G::NIT];
@@ -312,13 +308,11 @@ __device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfm
         w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
     }
     const float scale = dd_tile_stage<NKS, false>(P, b, raw, smem, w1a, w1b, dd_tile_w2<NKS>(P, b));
-    v8h bh[TAPS_LDS ? 1 : NKS], bl[TAPS_LDS ? 1 : NKS];
-    if (!TAPS_LDS) {
+    v8h bh[NKS], bl[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            bh[ks] = taps.frag[ks * 64 + lane];
-            bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
-        }
+    for (int ks = 0; ks < NKS; ++ks) {
+        bh[ks] = taps.frag[ks * 64 + lane];
+        bl[ks] = taps.frag[(NKS + ks) * 64 + lane];
     }
     __syncthreads();
     const int i = lane & 31, h = lane >> 5;
@@ -334,8 +328,7 @@ __device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfm
         const v8h arl = *reinterpret_cast<const v8h*>(abase + G::PLANE + off);
         const v8h aih = *reinterpret_cast<const v8h*>(abase + 2 * G::PLANE + off);
         const v8h ail = *reinterpret_cast<const v8h*>(abase + 3 * G::PLANE + off);
-        const v8h th = TAPS_LDS ? lds_taps[ks * 64 + lane] : bh[TAPS_LDS ? 0 : ks];
-        const v8h tl = TAPS_LDS ? lds_taps[(NKS + ks) * 64 + lane] : bl[TAPS_LDS ? 0 : ks];
+        const v8h th = bh[ks], tl = bl[ks];
         cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, th, cre, 0, 0, 0);
         cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, th, cim, 0, 0, 0);
         cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, th, cre, 0, 0, 0);
@@ -432,7 +425,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // edge tiles are [0, t_first) and [t_last, nblocks)
     const int b = (int)blockIdx.x < t_first ? (int)blockIdx.x : t_last + ((int)blockIdx.x - t_first);
-    dd_edge_tile<NKS, false>(P, taps, b, smem, nullptr);
+    dd_edge_tile<NKS>(P, taps, b, smem);
 }
 
 // ---------------------------------------------------------------------------------
@@ -980,6 +973,19 @@ void dd_mfma_destroy(void* st) {
     delete s;
 }
 
+#define DD_STAMP_WGS 1024      // workgroups the DD_STAMPS diagnostic buffer holds
+
+// compute units of the current device (256 on MI355X); queried once
+static int dd_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 template <int NKS>
 static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s) {
     using G = MfmaGeom<NKS>;
@@ -998,8 +1004,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     static unsigned long long* stamp_buf = nullptr;
     const bool want_stamps = getenv("DD_STAMPS") != nullptr;
     if (want_stamps) {
-        if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, 256 * 16 * 8 * 8));
-        DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, 256 * 16 * 8 * 8, s));
+        if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, DD_STAMP_WGS * 16 * 8 * 8));
+        DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, DD_STAMP_WGS * 16 * 8 * 8, s));
         t.stamps = stamp_buf;
     }
     // interior tiles: whole span inside the chunk, all outputs emitted, aligned complex64
@@ -1021,18 +1027,14 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
         // one workgroup per edge tile (both sides of the run), all resident at once -- the edge
         // tiles cost neither a launch of their own nor a tail after the persistent loop
         const int n_edge = t_first + (P.nblocks - t_last);
-        const int cus = n_edge < 128 ? 256 - n_edge : 128;
+        const int ncu = dd_cu_count() < DD_STAMP_WGS ? dd_cu_count() : DD_STAMP_WGS;
+        const int cus = n_edge < ncu / 2 ? ncu - n_edge : ncu / 2;
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
-        static const bool edge_sep = getenv("DD_EDGE_SEPARATE") != nullptr;
-        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid + (edge_sep ? 0 : n_edge)), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
+        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
-        if (edge_sep && n_edge > 0) {
-            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
-            DD_LAUNCH_CHECK();
-        }
         if (want_stamps) {
             static int printed = 0;
-            std::vector<unsigned long long> hb(256 * 16 * 8);
+            std::vector<unsigned long long> hb(DD_STAMP_WGS * 16 * 8);
             DD_HIP_CHECK(hipMemcpyAsync(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
             if (printed++ == 3) {
