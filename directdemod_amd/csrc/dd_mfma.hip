@@ -1002,7 +1002,12 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     t.inv_tapscale = st->inv_tapscale;
     t.stamps = nullptr;
     static unsigned long long* stamp_buf = nullptr;
-    const bool want_stamps = getenv("DD_STAMPS") != nullptr;
+    // DD_STAMPS=<k>: per-wave stage stamps, printed for the k-th launch (k <= 3 -> the 4th: a cold GPU;
+    // a few hundred -> the clock the chip holds under sustained load)
+    static const char* stamps_env = getenv("DD_STAMPS");
+    static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
+    static int launches = 0;
+    const bool want_stamps = stamps_env != nullptr && launches++ == stamps_at;
     if (want_stamps) {
         if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, DD_STAMP_WGS * 16 * 8 * 8));
         DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, DD_STAMP_WGS * 16 * 8 * 8, s));
@@ -1037,7 +1042,7 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
             std::vector<unsigned long long> hb(DD_STAMP_WGS * 16 * 8);
             DD_HIP_CHECK(hipMemcpyAsync(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
-            if (printed++ == 3) {
+            if (printed++ == 0) {
                 const char* vn[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
                 const char* mn[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
                 const double nphd = (double)(hb[7] & 0xffffffffull);

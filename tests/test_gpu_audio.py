@@ -326,3 +326,40 @@ def test_iir_block_parallel_complex64_iq(dd):
     assert isinstance(y, dd.hip.DevArray) and y.dtype == np.complex128 and y.n == len(x)
     ref = ss.lfilter(np.asarray(f.getB), np.asarray(f.getA), x.astype(np.complex128))
     assert rel_err(y.to_host(), ref) < 1e-9
+
+
+# ----------------------------------------------------------------------------- X1: both forms of the correlation
+@pytest.mark.parametrize("kind", ["runs_even", "runs_odd", "dense", "many_runs"])
+def test_xcorr_norm_forms_vs_oracle(dd, kind):
+    """piecewise-constant needles take the prefix-sum form, anything else the direct sum; both
+    against the oracle's definition (np 'same' centring for even and odd needle lengths)"""
+    rng = np.random.default_rng(17)
+    n = 50000
+    h = np.abs(rng.standard_normal(n)) + 0.2
+    if kind == "runs_even":
+        needle = O.sync_needle(O.NOAA_SYNCA, 60235) if hasattr(O, "NOAA_SYNCA") else ((np.repeat(rng.integers(0, 2, 40), 14) * 233) + 11) / 255
+    elif kind == "runs_odd":
+        needle = ((np.repeat(rng.integers(0, 2, 39), 17) * 233) + 11) / 255
+    elif kind == "dense":
+        needle = rng.standard_normal(301)
+    else:
+        needle = np.repeat(rng.standard_normal(200), 2)        # 200 runs of 2: more runs than the fast path takes
+    d = dd.hip.DevArray.from_host(h)
+    got = dd.ops.xcorr_norm(d, needle).to_host()
+    ref = O.xcorr_norm(h, needle)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+def test_xcorr_norm_silent_stretch(dd):
+    """windows of exact zeros: the reference's formula (decode_noaa.py:673) divides rounding noise of its
+    FFT correlation by zero there (inf or NaN); the device forms give NaN.  Non-finite in the same places,
+    equal everywhere else."""
+    h = np.abs(np.random.default_rng(3).standard_normal(20000)) + 0.1
+    h[5000:9000] = 0.0
+    needle = ((np.repeat(np.array([0, 0, 1, 1, 0, 0, 1, 1, 0, 0]), 30) * 233) + 11) / 255
+    got = dd.ops.xcorr_norm(dd.hip.DevArray.from_host(h), needle).to_host()
+    ref = O.xcorr_norm(h, needle, exact_energy=True)
+    bad_ref = ~np.isfinite(ref)
+    assert bad_ref.sum() > 3000 and np.array_equal(~np.isfinite(got), bad_ref)
+    assert np.max(np.abs(got[~bad_ref] - ref[~bad_ref])) < 1e-9
