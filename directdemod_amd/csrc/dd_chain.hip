@@ -172,10 +172,11 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = P.K, M = P.M, T = P.T;
     const int S = (T - 1) * M + K + (M - 1);
-    const int SP = S + (S >> 5) + 4;
+    const int SP = S + 4;                                 // linear image: see the tap loop
     float2* sx = reinterpret_cast<float2*>(smem);
     float2* w2 = sx + SP;
     float2* yblk = w2 + ((S + 63) / 64 + 1);
+    float* gl = reinterpret_cast<float*>(yblk + DD_DECIM_THREADS);     // taps, K floats (+ pad to 8)
 
     const int t = threadIdx.x;
     const int b = dd_xcd_tile(blockIdx.x, P.nblocks);
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     const bool fm = (P.flags & DD_CHAIN_FM) != 0;
 
     const int ngroups = (S + 63) / 64;
+    for (int j = t; j < ((K + 7) & ~7); j += DD_DECIM_THREADS) gl[j] = j < K ? P.taps_rev[(DD_DENSE_R - 1) + j] : 0.f;
     if (P.flags & DD_CHAIN_NCO) {
         for (int g = t; g < ngroups; g += DD_DECIM_THREADS) {
             const uint64_t ph = (uint64_t)(P.abs0 + ns + (int64_t)g * 64) * P.cyc;
@@ -227,21 +229,21 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
                         xa = dd_cmul(xa, dd_cmul(g, w1a));
                         xb = dd_cmul(xb, dd_cmul(g, w1b));
                     }
-                    sx[e + (e >> 5)] = xa;
-                    sx[e + 1 + (e >> 5)] = xb;
+                    sx[e] = xa;
+                    sx[e + 1] = xb;
                 }
             }
             if ((S & 1) && t == 0) {                          // odd span: its last sample on its own
                 const int e = S - 1;
                 float2 x = src[e];
                 if (P.flags & DD_CHAIN_NCO) x = dd_cmul(x, dd_cmul(w2[e >> 6], dd_phasor((uint64_t)(e & 63) * P.cyc, P.nco_tbl)));
-                sx[e + (e >> 5)] = x;
+                sx[e] = x;
             }
         } else {
             for (int e = t; e < S; e += DD_DECIM_THREADS) {
                 float2 ph = make_float2(1.f, 0.f);
                 if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
-                sx[e + (e >> 5)] = dd_load_sample(P, ns + e, ph);
+                sx[e] = dd_load_sample(P, ns + e, ph);
             }
         }
     }
@@ -250,28 +252,31 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     if (b == P.nblocks - 1 && P.tail_out) {
         for (int i = t; i < K - 1; i += DD_DECIM_THREADS) {
             const int64_t e = (P.L - (K - 1) + i) - ns;
-            P.tail_out[i] = sx[(int)e + ((int)e >> 5)];
+            P.tail_out[i] = sx[(int)e];
         }
     }
 
+    // Tap loop.  The LDS image is linear (no skew) on purpose: thread t's window starts at sample
+    // t*M, so every read is base + immediate offset (ds_read2_b64) and a tap costs one packed FMA.
+    // A skewed image avoided the 2-way bank conflict of the stride-M reads but cost ~4 vector
+    // instructions of index arithmetic per tap.  Taps are read from their LDS copy: fetched from
+    // global memory here they came as per-lane vector loads with a wait every 16 taps.
     float2 acc = make_float2(0.f, 0.f);
-    const float* __restrict__ G = P.taps_rev + (DD_DENSE_R - 1);   // g[j] = h[K-1-j]
+    const float* __restrict__ G = gl;                              // g[j] = h[K-1-j]
     if (t < T) {
-        const int e0 = t * M;
+        const float2* __restrict__ win = sx + t * M;
         int j = 0;
-        for (; j + 4 <= K; j += 4) {
+        for (; j + 8 <= K; j += 8) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + j + u;
-                const float2 v = sx[e + (e >> 5)];
+            for (int u = 0; u < 8; ++u) {
+                const float2 v = win[j + u];
                 const float g = G[j + u];
                 acc.x = fmaf(g, v.x, acc.x);
                 acc.y = fmaf(g, v.y, acc.y);
             }
         }
         for (; j < K; ++j) {
-            const int e = e0 + j;
-            const float2 v = sx[e + (e >> 5)];
+            const float2 v = win[j];
             const float g = G[j];
             acc.x = fmaf(g, v.x, acc.x);
             acc.y = fmaf(g, v.y, acc.y);
@@ -533,8 +538,8 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         P.nblocks = isfm ? (int)((P.Ld - P.s + (P.T - 2)) / (P.T - 1)) : (int)((P.Ld + P.T - 1) / P.T);
         if (P.nblocks < 1) P.nblocks = 1;
         const int S = (T - 1) * P.M + P.K + (P.M - 1);
-        const int SP = S + (S >> 5) + 4;
-        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS);
+        const int SP = S + 4;
+        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7);
         DD_REQUIRE(lds <= 160 * 1024, "filter/decimation too large for the decimating kernel's LDS tile");
         if (lds > 64 * 1024)
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
