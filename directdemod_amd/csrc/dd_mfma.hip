@@ -718,6 +718,11 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
     const int vt = tid - 64 * WS_MWAVES, vw = vt >> 6;
     const int n = t_end - t_begin;
 
+    // the first two tiles are requested before anything else: their (cold) HBM latency covers the
+    // phasor table fetches below and the tap copy of the kernel prologue
+    float4 r0[W::NIT], r1[W::NIT], r2[W::NIT];
+    dd_ws_load<NKS>(P, t_begin, vt, r0);
+    dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
     // tile-relative NCO phasors of this lane's sample positions (loop invariant)
     float2 wk[W::NIT][2];
 #pragma unroll
@@ -728,9 +733,6 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
             wk[it][k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)pos * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
         }
     }
-    float4 r0[W::NIT], r1[W::NIT], r2[W::NIT];
-    dd_ws_load<NKS>(P, t_begin, vt, r0);
-    dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
     {   // tile max and group phasors of tile 0 (what phase p-1 does for tile p)
         float m = 0.f;
 #pragma unroll
