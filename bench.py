@@ -9,9 +9,9 @@ roofline.  Workload = BASELINE.json configs[1] ("C2"):
   + demod_fm.demod, one chunk per step, output float32 radians (N-1 values).
 A "step" = one pass of the fused hot path over the GPU's shard.  With --gpus N>1
 (launched by torch.distributed.run, one rank per GPU) the stream is N shards of
-2^26 samples; rank r primes its filter/NCO/FM state from the 255 samples before
-its shard (absolute-index state, no halo exchange) and no collective sits on the
-data path (weak scaling).  `--gather` additionally times an RCCL all_gather of the
+2^26 samples; rank r re-filters the 256 samples before its shard as a lead-in of
+the same launch (absolute-index state, no halo exchange) and no collective sits on
+the data path (weak scaling).  `--gather` additionally times an RCCL all_gather of the
 decoded output and reports it in "extra" (never in `value`).
 
 Prints ONE JSON line on rank 0.
@@ -122,7 +122,8 @@ def main():
     start = rank * n                       # absolute index of this rank's first sample
     pre = halo if rank > 0 else 0
     xin = make_input(torch, n + pre, start - pre, device, 1235 + rank)
-    out = torch.empty(n, dtype=torch.float32, device=device)
+    out = torch.empty(n + pre, dtype=torch.float32, device=device)
+    first = max(0, pre - 1)                    # index of the shard's first output in `out` (ranks > 0: after the lead-in's)
     torch.cuda.synchronize()
 
     taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
@@ -131,17 +132,16 @@ def main():
     _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), NTAPS,
                                    _hip.cycles_q64(F_OFFSET, FS), 1, flags), "dd_chain_create")
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    in_ptr = xin.data_ptr() + pre * 8
     n_out = C.c_int64(0)
 
     def step():
-        # new stream position: state derived from the absolute index (rank 0: stream start,
-        # history of ones; rank r: primed from the halo that precedes its shard)
-        if rank == 0:
-            _hip.check(lib.dd_chain_reset(h, stream), "dd_chain_reset")
-        else:
-            _hip.check(lib.dd_chain_prime(h, xin.data_ptr(), pre, start, stream), "dd_chain_prime")
-        _hip.check(lib.dd_chain_process(h, in_ptr, out.data_ptr(), n, C.byref(n_out), stream), "dd_chain_process")
+        # new stream position, state derived from the absolute index alone.  Rank 0: the stream start
+        # (history of ones).  Rank r: its shard plus the 256-sample lead-in in front of it as one chunk
+        # from a zero history -- the lead-in's outputs (the first pre-1, with the filter still filling)
+        # are not part of the shard; out[pre-1 : pre-1+n] is what rank r contributes (SURVEY.md 8e:
+        # the halo is re-filtered locally, no exchange, no collective).  One launch per step on every rank.
+        _hip.check(lib.dd_chain_seek(h, start - pre, stream), "dd_chain_seek")
+        _hip.check(lib.dd_chain_process(h, xin.data_ptr(), out.data_ptr(), n + pre, C.byref(n_out), stream), "dd_chain_process")
 
     def barrier():
         if world > 1:
@@ -179,14 +179,15 @@ def main():
 
     extra = {}
     if args.gather and world > 1:
-        bufs = [torch.empty_like(out) for _ in range(world)]
+        shard_out = out[first:first + n]                    # this rank's n outputs (a view)
+        bufs = [torch.empty_like(shard_out) for _ in range(world)]
         for _ in range(2):
-            dist.all_gather(bufs, out)
+            dist.all_gather(bufs, shard_out)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-            dist.all_gather(bufs, out)
+            dist.all_gather(bufs, shard_out)
         barrier()
         dtg = time.perf_counter() - t0
         tg = torch.tensor([dtg], dtype=torch.float64, device=device)
@@ -194,7 +195,7 @@ def main():
         extra["with_all_gather_MSamples_per_s"] = round(world * n * args.steps / float(tg[0]) / 1e6, 1)
 
     # sanity: the output is a demodulated 1 kHz tone of deviation 5 rad * 2 pi * 1 kHz / fs
-    chk = out[1000:1000 + 4096].double().cpu().numpy()
+    chk = out[first + 1000:first + 1000 + 4096].double().cpu().numpy()
     extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
     extra["clock_preroll"] = {"ms": args.ramp_ms, "steps": ramp_steps}
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     "dd_chain_create": (_int, [_pp, C.POINTER(C.c_double), _int, _u64, _int, _int]),
     "dd_chain_destroy": (_int, [_p]),
     "dd_chain_reset": (_int, [_p, _p]),
+    "dd_chain_seek": (_int, [_p, _i64, _p]),
     "dd_chain_prime": (_int, [_p, _p, _i64, _i64, _p]),
     "dd_chain_out_count": (_i64, [_p, _i64]),
     "dd_chain_process": (_int, [_p, _p, _p, _i64, _pi64, _p]),

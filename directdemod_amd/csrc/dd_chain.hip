@@ -716,6 +716,13 @@ extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t 
     return rc;
 }
 
+extern "C" int dd_chain_seek(dd_chain* c, int64_t abs_index, void* stream) {
+    DD_REQUIRE(c && abs_index >= 0, "arguments");
+    c->abs_index = abs_index;
+    if (c->fm) dd_fm_reset(c->fm);
+    return dd_fir_reset(c->fir, abs_index == 0 ? DD_HIST_ONES : DD_HIST_ZEROS, nullptr, stream);   // launch-free
+}
+
 extern "C" int dd_chain_prime(dd_chain* c, const void* halo_in, int64_t n_halo, int64_t abs_index, void* stream) {
     DD_REQUIRE(c && n_halo >= 0 && abs_index >= 0, "arguments");
     DD_REQUIRE(n_halo <= abs_index, "halo longer than the samples that precede abs_index");

@@ -162,6 +162,14 @@ int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles
 int dd_chain_destroy(dd_chain* h);
 /* start a new stream (new chunker object): abs index 0, history ones, no FM state */
 int dd_chain_reset(dd_chain* h, void* stream);
+/* Start a stream position without touching the device: the next chunk is taken to begin at
+ * absolute sample `abs_index` with an all-zero FIR history and no previous FM sample (index 0:
+ * the stream start, history of ones like dd_chain_reset).  A shard can then be run in ONE call
+ * over [start - lead, stop) with lead >= ntaps-1+decim and the lead-in's outputs discarded --
+ * the same outputs as dd_chain_prime + dd_chain_process (the halo is re-filtered
+ * locally, no exchange), one launch instead of two. */
+int dd_chain_seek(dd_chain* h, int64_t abs_index, void* stream);
+
 /* multi-GPU / shard start: establish state as if samples [0, abs_index) had been
  * processed, from the `n_halo` raw input samples that precede abs_index
  * (n_halo >= ntaps-1+decim; fewer only if abs_index == n_halo i.e. stream start). */

@@ -501,3 +501,31 @@ def test_mfma_tile_scaling_paths(dd, profile):
     d = np.abs(np.angle(np.exp(1j * (np.asarray(a, dtype=np.float64) - a_ref))))
     assert len(a) == L - 1
     assert np.max(d[mask]) <= 2e-4, (profile, float(np.max(d[mask])))
+
+
+def test_seek_with_lead_in_equals_primed_shard(dd):
+    """dd_chain_seek + one call over [start - lead, stop) with the lead-in's outputs dropped gives the
+    outputs of dd_chain_prime + dd_chain_process (the rule bench.py's ranks > 0 use: one launch)."""
+    import ctypes as C
+    from directdemod_amd import shard
+    hip = dd.hip
+    total, fs = 260000, 2400000
+    x = O.grid_c64(O.synth_iq_fm(total, fs, 33))
+    dx = hip.DevArray.from_host(x)
+    for M, taps, lead in ((1, O.win_hamming(255), 256), (34, O.win_blackmanharris(151), 34 * 6)):
+        for start in (M * 2000, M * 3571):
+            stop = total
+            eng = shard.HipChainEngine(taps, 25000.0, fs, M)
+            o1 = hip.DevArray(stop - start, np.float32)
+            n1 = shard.run_shard(eng, lambda g: dx.ptr + 8 * g, start, stop, len(taps), M, o1.ptr)
+            ref = o1.to_host()[:n1]
+            eng.close()
+            eng = shard.HipChainEngine(taps, 25000.0, fs, M)
+            hip.check(eng.lib.dd_chain_seek(eng.h, start - lead, None), "dd_chain_seek")
+            o2 = hip.DevArray(stop - start + lead, np.float32)
+            n2 = eng.process(dx.ptr + 8 * (start - lead), o2.ptr, stop - start + lead)
+            eng.close()
+            skip = lead // M - 1                       # lead-in pairs: the first chunk of a stream is one output short (Q3)
+            got = o2.to_host()[skip:n2]
+            assert n2 - skip == n1 and got.shape == ref.shape
+            assert np.max(np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - ref))))) < 2e-5
