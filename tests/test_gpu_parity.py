@@ -529,3 +529,33 @@ def test_seek_with_lead_in_equals_primed_shard(dd):
             got = o2.to_host()[skip:n2]
             assert n2 - skip == n1 and got.shape == ref.shape
             assert np.max(np.abs(np.angle(np.exp(1j * (got.astype(np.float64) - ref))))) < 2e-5
+
+
+@pytest.mark.parametrize("L", [300, 4063, 4064, 4065, 4096 + 254, 8128, 8129, 12191, 12192, 12193, 16257, 40000])
+@pytest.mark.parametrize("shift", [0, 1])
+def test_mfma_tile_boundaries_and_alignment(dd, L, shift):
+    """chunk lengths around the 4064-output tile advance (no interior tile, exactly one, ragged last
+    tile) and an input that starts on an 8-byte but not 16-byte boundary (every tile then takes the
+    predicated edge kernel); FM and complex output, two chunks so the carried state crosses too"""
+    fs = 2400000
+    x = O.grid_c64(O.synth_iq_fm(L + shift + 5000, fs, 100 + L % 97))
+    d = dd.hip.DevArray.from_host(x)
+    taps = O.win_hamming(255)
+    for fm in (True, False):
+        f = dd.filters.hamming(255)
+        dem = dd.demod_fm.demod_fm()
+        ck = dd.chunker.chunker(_Src(L + 5000))
+        outs = []
+        for a, b in ((0, L), (L, L + 5000)):
+            s = dd.comm.commSignal(fs, d.view(shift + a, b - a), ck).offsetFreq(25000.0).filter(f)
+            if fm:
+                s = s.funcApply(dem.demod)
+            outs.append(np.asarray(s.signal))
+        got = np.concatenate(outs)
+        xs = x[shift:shift + L + 5000]
+        y_ref = O.FilterState(taps).applyOn(O.nco(xs, 25000.0, fs, 0))
+        if fm:
+            a_ref, _ = O.fm_demod(y_ref, None)
+            fm_check(got, a_ref, np.abs(y_ref[1:] * np.conj(y_ref[:-1])))
+        else:
+            assert rel_err(got, y_ref) < FIR_TOL
