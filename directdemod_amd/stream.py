@@ -14,6 +14,7 @@ state carried inside the chain handle on the device; the host never synchronises
 inside the loop (only when the ring wraps onto a slot still being copied from).
 """
 import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -57,7 +58,20 @@ class PinnedRing:
         self.host, self.dev = [], []
 
 
-def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSIZE, depth=3, compute_stream=None):
+def _stage(dst, srcarr, pool, nthreads):
+    """source array -> pinned slot.  One memcpy thread moves ~10 GB/s, a fifth of what PCIe gen5 x16
+    takes; NumPy releases the GIL while copying, so the slot is filled in `nthreads` slices."""
+    flat = np.asarray(srcarr).reshape(-1)
+    n = flat.size
+    if nthreads <= 1 or n < (1 << 22):
+        dst[:n] = flat
+        return
+    step = -(-n // nthreads)
+    list(pool.map(lambda i: dst.__setitem__(slice(i, min(n, i + step)), flat[i:min(n, i + step)]), range(0, n, step)))
+
+
+def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSIZE, depth=3, compute_stream=None,
+                    copy_threads=4):
     """offsetFreq -> FIR -> decimate -> FM over a u8 source, chunk by chunk, with the
     ingest overlapped.  Returns (device float32 array of all outputs, output rate)."""
     from .shard import HipChainEngine
@@ -71,13 +85,14 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
     out = DevArray(total_out, np.float32)
     n_done = 0
     L = lib()
+    pool = ThreadPoolExecutor(max(1, copy_threads))
     try:
         for i, (a, b) in enumerate(chunks):
             k = i % depth
             n = b - a
             if ring._used[k]:
                 check(L.dd_event_sync(ring.consumed[k]), "dd_event_sync")       # slot free again?
-            ring.host_view(k, 2 * n)[:] = src.read_raw_u8(a, b)                  # file/memmap -> pinned
+            _stage(ring.host_view(k, 2 * n), src.read_raw_u8(a, b), pool, copy_threads)      # file/memmap -> pinned
             check(L.dd_memcpy_h2d(ring.dev[k].ptr, ring.host[k], 2 * n, ring.copy_stream), "h2d")
             check(L.dd_event_record(ring.copied[k], ring.copy_stream), "record")
             check(L.dd_stream_wait_event(compute_stream, ring.copied[k]), "wait")
@@ -87,6 +102,7 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
             n_done += got
         check(L.dd_stream_sync(compute_stream), "sync")
     finally:
+        pool.shutdown(wait=True)
         eng.close()
         ring.close()
     return out.view(0, n_done), int(fs / decim)
