@@ -212,20 +212,75 @@ _DT = {
 }
 
 
+# ------------------------------------------------------------------ device buffer pool
+# hipMalloc / hipFree cost tens of microseconds each and hipFree synchronises the device; a chunk
+# loop allocates the same few sizes over and over (decode_noaa.py:619-624: one set of intermediates
+# per chunk).  Freed buffers are kept by size (rounded up to 4 KiB) and handed out again; work is
+# stream-ordered, so a buffer reused by a later call on the same stream is safe.  At most
+# DD_POOL_BYTES (default 1 GiB) are held; DD_POOL_BYTES=0 disables the pool.
+_POOL_LIMIT = int(os.environ.get("DD_POOL_BYTES", str(1 << 30)))
+_pool = {}
+_pool_bytes = 0
+_pool_lock = threading.Lock()
+
+
+def _pool_round(nbytes):
+    return (max(16, int(nbytes)) + 4095) & ~4095
+
+
+def _pool_alloc(nbytes):
+    global _pool_bytes
+    size = _pool_round(nbytes)
+    with _pool_lock:
+        lst = _pool.get(size)
+        if lst:
+            _pool_bytes -= size
+            return lst.pop(), size
+    p = C.c_void_p()
+    rc = lib().dd_malloc(C.byref(p), size)
+    if rc == DD_ERR_NOMEM and _pool:
+        pool_trim(0)
+        rc = lib().dd_malloc(C.byref(p), size)
+    check(rc, "dd_malloc")
+    return p.value, size
+
+
+def _pool_free(ptr, size):
+    global _pool_bytes
+    with _pool_lock:
+        if _pool_bytes + size <= _POOL_LIMIT:
+            _pool.setdefault(size, []).append(ptr)
+            _pool_bytes += size
+            return
+    lib().dd_free(ptr)
+
+
+def pool_trim(keep_bytes=0):
+    """give pooled device memory back to the driver until at most keep_bytes are held"""
+    global _pool_bytes
+    with _pool_lock:
+        for size in sorted(_pool, reverse=True):
+            lst = _pool[size]
+            while lst and _pool_bytes > keep_bytes:
+                lib().dd_free(lst.pop())
+                _pool_bytes -= size
+        for size in [k for k, v in _pool.items() if not v]:
+            del _pool[size]
+
+
 class DevArray:
     """1-D array resident in HBM (owned hipMalloc buffer or a view of one)."""
 
-    __slots__ = ("ptr", "n", "dtype", "_owner", "_base")
+    __slots__ = ("ptr", "n", "dtype", "_owner", "_base", "_size")
 
     def __init__(self, n, dtype, ptr=None, base=None):
         self.n = int(n)
         self.dtype = np.dtype(dtype)
         self._base = base
+        self._size = 0
         if ptr is None:
             require_gpu()
-            p = C.c_void_p()
-            check(lib().dd_malloc(C.byref(p), max(16, self.n * self.dtype.itemsize)), "dd_malloc")
-            self.ptr = p.value
+            self.ptr, self._size = _pool_alloc(self.n * self.dtype.itemsize)
             self._owner = True
         else:
             self.ptr = int(ptr)
@@ -261,7 +316,7 @@ class DevArray:
     def free(self):
         if getattr(self, "_owner", False) and self.ptr:
             try:
-                lib().dd_free(self.ptr)
+                _pool_free(self.ptr, self._size)
             except Exception:
                 pass
             self.ptr = 0
