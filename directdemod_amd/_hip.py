@@ -95,6 +95,7 @@ SIGNATURES = {
     "dd_find_peaks_f64": (_int, [_p, _i64, C.c_double, _int, _pi64, _int, C.POINTER(_int), _p]),
     "dd_afsk_binary_filter_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
     "dd_afsk_edges_f64": (_int, [_p, _i64, _int, _p, _p]),
+    "dd_abs_f64": (_int, [_p, _int, _p, _i64, _p]),
     "dd_f32_to_f64": (_int, [_p, _p, _i64, _p]),
     "dd_f64_to_f32": (_int, [_p, _p, _i64, _p]),
 }

@@ -282,3 +282,26 @@ extern "C" int dd_f64_to_f32(const double* in, float* out, int64_t n, void* stre
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
+
+// ---------------------------------------------------------------- np.abs (demod_am.demod_amFLT, demod_am.py:62)
+// kind 0: float64 -> |x| ; 1: complex128 ; 2: complex64 (both -> float64 magnitude, hypot like NumPy)
+template <int KIND>
+__global__ void __launch_bounds__(256) k_abs_f64(const void* __restrict__ in, double* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (KIND == 0) out[i] = fabs(reinterpret_cast<const double*>(in)[i]);
+        else if (KIND == 1) { const double2 v = reinterpret_cast<const double2*>(in)[i]; out[i] = hypot(v.x, v.y); }
+        else { const float2 v = reinterpret_cast<const float2*>(in)[i]; out[i] = hypot((double)v.x, (double)v.y); }
+    }
+}
+extern "C" int dd_abs_f64(const void* in, int kind, double* out, int64_t n, void* stream) {
+    DD_REQUIRE(kind >= 0 && kind <= 2 && n >= 0, "dd_abs_f64: kind / n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in && out, "dd_abs_f64: null buffer");
+    const dim3 g(dd_grid_for(n, 256)), b(256);
+    if (kind == 0) hipLaunchKernelGGL(k_abs_f64<0>, g, b, 0, dd_stream(stream), in, out, n);
+    else if (kind == 1) hipLaunchKernelGGL(k_abs_f64<1>, g, b, 0, dd_stream(stream), in, out, n);
+    else hipLaunchKernelGGL(k_abs_f64<2>, g, b, 0, dd_stream(stream), in, out, n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}

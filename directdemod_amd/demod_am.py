@@ -40,3 +40,44 @@ class demod_am():
         if isinstance(sig, DevArray):
             return _ops.am_envelope(sig, block)
         return _ops.am_envelope(DevArray.from_host(np.asarray(sig), dtype=np.float64), block).to_host()
+
+
+class demod_amFLT():
+    '''
+    AM demodulation by low pass filter (demod_am.py:35-62): butter(Fs, cutoff) applied to |sig|,
+    the filter state carried from call to call like the reference's.  Runs on the device
+    (magnitude kernel + the float64 IIR recurrence, block-parallel for long inputs).
+    '''
+
+    def __init__(self, Fs, cutoff):
+        from . import filters
+        self.__filter = filters.butter(Fs, cutoff)
+
+    def demod(self, sig):
+        '''Args:
+            sig: numpy array or device array (real or complex)
+
+        Returns:
+            demodulated signal, float64; numpy for numpy input, device array for device input
+        '''
+        import ctypes as C
+        from . import _hip
+        from .comm import flush_all
+        flush_all()
+        host = not isinstance(sig, DevArray)
+        if host:
+            a = np.asarray(sig)
+            d = DevArray.from_host(a, dtype=np.complex128 if np.iscomplexobj(a) else np.float64)
+        else:
+            d = sig
+        kind = {np.dtype(np.float64): 0, np.dtype(np.complex128): 1, np.dtype(np.complex64): 2}.get(d.dtype)
+        if kind is None:
+            if d.dtype == np.dtype(np.float32):
+                from .comm import _convert
+                d, kind = _convert(d, np.float64), 0
+            else:
+                raise TypeError("unsupported dtype %s" % d.dtype)
+        mag = DevArray(d.n, np.float64)
+        _hip.check(_hip.lib().dd_abs_f64(d.ptr, kind, mag.ptr, d.n, None), "dd_abs_f64")
+        out = self.__filter.applyOn(mag)
+        return out.to_host() if host else out

@@ -114,3 +114,15 @@ class IQdat(_u8source):
         super().__init__(mm[:2 * n].reshape(n, 2),
                          givenSampFreq if givenSampFreq is not None else constants.IQ_SDRSAMPRATE,
                          constants.SOURCE_IQDAT)
+
+
+class IQwavAlt(_u8source):
+    '''The reference's alternative IQ.wav reader (source.py:237-324): memmap behind a 44-byte
+    header, the sample rate NOT taken from the header (IQ_SDRSAMPRATE unless given).'''
+
+    def __init__(self, filename, givenSampFreq=None):
+        mm = np.memmap(filename, dtype=np.uint8, mode="r", offset=44)
+        n = mm.shape[0] // 2
+        super().__init__(mm[:2 * n].reshape(n, 2),
+                         givenSampFreq if givenSampFreq is not None else constants.IQ_SDRSAMPRATE,
+                         constants.SOURCE_IQWAV)

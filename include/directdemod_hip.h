@@ -211,6 +211,10 @@ int dd_afsk_binary_filter_f64(const double* sig, int64_t n, const double* tables
 /* out = np.correlate(np.sign(binary_filter), [-1]*(spb/2) + [1]*(spb - spb/2), 'same') / spb (:147-156) */
 int dd_afsk_edges_f64(const double* binary_filter, int64_t n, int spb, double* out, void* stream);
 
+/* np.abs for demod_am.demod_amFLT (demod_am.py:35-62: butter low-pass of |sig|).
+ * kind 0: float64, 1: complex128, 2: complex64 input; float64 output (hypot). */
+int dd_abs_f64(const void* in, int kind, double* out, int64_t n, void* stream);
+
 /* float32 -> float64 / complex64 -> complex128 widening (audio-rate hand-over) */
 int dd_f32_to_f64(const float* in, double* out, int64_t n, void* stream);
 int dd_f64_to_f32(const double* in, float* out, int64_t n, void* stream);

@@ -30,6 +30,8 @@ def dd():
     ns = NS()
     ns.hip, ns.comm, ns.filters, ns.demod_fm, ns.demod_am, ns.chunker, ns.ops, ns.noaa, ns.source = \
         _hip, comm, filters, demod_fm, demod_am, chunker, _ops, noaa_sync, source
+    from directdemod_amd import constants
+    ns.constants = constants
     return ns
 
 
@@ -190,6 +192,10 @@ def test_source_readers(dd, tmp_path):
     sw = dd.source.IQwav(str(w))
     assert sw.sampFreq == 2400000 and sw.length == 5000
     assert np.array_equal(sw.read(0, 5000), O.grid_c64(raw))
+    sa = dd.source.IQwavAlt(str(w))                                   # source.py:237-324: rate not read from the header
+    assert sa.sampFreq == dd.constants.IQ_SDRSAMPRATE and sa.length == 5000
+    assert np.array_equal(sa.read(7, 4000), O.read_iq_u8(raw, 7, 4000))
+    assert dd.source.IQwavAlt(str(w), 1234567).sampFreq == 1234567
 
 
 def test_streaming_ring_feeder_equals_one_shot(dd):
@@ -363,3 +369,27 @@ def test_xcorr_norm_silent_stretch(dd):
     bad_ref = ~np.isfinite(ref)
     assert bad_ref.sum() > 3000 and np.array_equal(~np.isfinite(got), bad_ref)
     assert np.max(np.abs(got[~bad_ref] - ref[~bad_ref])) < 1e-9
+
+
+# ----------------------------------------------------------------------------- demod_amFLT (demod_am.py:35-62)
+@pytest.mark.parametrize("cplx", [False, True])
+def test_demod_amflt_vs_scipy(dd, cplx):
+    """butter low-pass of |sig| with the state carried over chunks; short (one-lane) and long
+    (block-parallel) chunks; real and complex input"""
+    import scipy.signal as ss
+    rng = np.random.default_rng(9)
+    n = 60000
+    car = np.exp(2j * np.pi * 0.11 * np.arange(n)) * (1 + 0.5 * np.sin(2 * np.pi * 0.001 * np.arange(n)))
+    sig = car + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    sig = sig if cplx else sig.real
+    dem = dd.demod_am.demod_amFLT(60235, 4160.0)
+    cuts = [0, 3000, 50000, n]
+    got = np.concatenate([dem.demod(sig[cuts[i]:cuts[i + 1]]) for i in range(3)])
+    b, a = ss.butter(6, 4160.0 / (0.5 * 60235))
+    ref = ss.lfilter(b, a, np.abs(sig), zi=ss.lfilter_zi(b, a))[0]
+    assert got.dtype == np.float64 and rel_err(got, ref) < 1e-9
+    d = dd.hip.DevArray.from_host(sig.astype(np.complex64) if cplx else sig)
+    out = dd.demod_am.demod_amFLT(60235, 4160.0).demod(d)
+    assert isinstance(out, dd.hip.DevArray)
+    ref32 = ss.lfilter(b, a, np.abs(sig.astype(np.complex64)) if cplx else np.abs(sig), zi=ss.lfilter_zi(b, a))[0]
+    assert rel_err(out.to_host(), ref32) < (1e-6 if cplx else 1e-9)
