@@ -64,6 +64,7 @@ SIGNATURES = {
     "dd_stream_wait_event": (_int, [_p, _p]),
     "dd_u8iq_to_c64": (_int, [_p, _p, _i64, _p]),
     "dd_nco_c64": (_int, [_p, _p, _i64, _u64, _i64, _p]),
+    "dd_nco_c64_freqs": (_int, [_p, _p, _i64, _p, C.c_double, _i64, _p]),
     "dd_fir_create": (_int, [_pp, C.POINTER(C.c_double), _int]),
     "dd_fir_destroy": (_int, [_p]),
     "dd_fir_reset": (_int, [_p, _int, _p, _p]),

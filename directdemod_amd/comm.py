@@ -133,12 +133,23 @@ class commSignal:
 
     def offsetFreq(self, freqOffset):
         '''Offset signal by a frequency by multiplying a complex envelope (comm.py:63-78)'''
-        if np.ndim(freqOffset) != 0:
-            raise TypeError("per-sample frequency arrays are outside the GPU hot path (decode_funcube only)")
         offset = 0
         if self.__chunker is not None:
             offset = self.__chunker.get(constants.CHUNK_FREQOFFSET, 0)
             self.__chunker.set(constants.CHUNK_FREQOFFSET, offset + self.length)
+        if np.ndim(freqOffset) != 0:
+            # per-sample frequency (Doppler correction, decode_funcube.py:228): its own kernel, run now
+            f = np.ascontiguousarray(freqOffset, dtype=np.float64).ravel()
+            if len(f) != self.length:
+                raise ValueError("operands could not be broadcast together with shapes (%d,) (%d,)" % (self.length, len(f)))
+            self._materialise()
+            d = self._device(_C64)
+            out = DevArray(d.n, _C64)
+            df = DevArray.from_host(f)
+            _hip.check(_hip.lib().dd_nco_c64_freqs(d.ptr, out.ptr, d.n, df.ptr, float(self.sampRate), int(offset), None),
+                       "dd_nco_c64_freqs")
+            self._store(out, copy=False)
+            return self
         self._record(("nco", _hip.cycles_q64(freqOffset, self.sampRate), int(offset)))
         return self
 

@@ -233,6 +233,36 @@ extern "C" int dd_nco_c64(const float* in_c64, float* out_c64, int64_t n, uint64
     return DD_OK;
 }
 
+// ---------------------------------------------------------------- N1 with a per-sample frequency (comm.py:77 with an
+// array freqOffset: the Doppler correction of decode_funcube.py:228).  phase = f[n] (n0+n) / fs is
+// formed and reduced in float64, like the reference's np.exp argument; 1e-9-grade phase, the product
+// is rounded once to complex64.
+__global__ void __launch_bounds__(256) k_nco_c64_freqs(const float2* __restrict__ in, float2* __restrict__ out, int64_t n,
+                                                       const double* __restrict__ f, double fs, int64_t start) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double cyc = f[i] * (double)(start + i) / fs;
+        const double fr = cyc - floor(cyc);
+        double sn, cs;
+        sincospi(2.0 * fr, &sn, &cs);
+        const float2 x = in[i];
+        const double re = (double)x.x * cs + (double)x.y * sn;      // x * (cos - j sin)
+        const double im = (double)x.y * cs - (double)x.x * sn;
+        out[i] = make_float2((float)re, (float)im);
+    }
+}
+
+extern "C" int dd_nco_c64_freqs(const float* in_c64, float* out_c64, int64_t n, const double* freqs_hz, double samp_rate,
+                                int64_t start_index, void* stream) {
+    DD_REQUIRE(n >= 0 && samp_rate > 0, "n / samp_rate");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in_c64 && out_c64 && freqs_hz, "null buffer");
+    hipLaunchKernelGGL(k_nco_c64_freqs, dim3(dd_grid_for(n, 256)), dim3(256), 0, dd_stream(stream),
+                       (const float2*)in_c64, (float2*)out_c64, n, freqs_hz, samp_rate, start_index);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 // ---------------------------------------------------------------- R1: decimation gather
 template <typename T>
 __global__ void __launch_bounds__(256) k_decimate(const T* __restrict__ in, T* __restrict__ out, int64_t n_out, int m, int off) {

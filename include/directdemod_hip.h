@@ -84,6 +84,10 @@ int dd_u8iq_to_c64(const uint8_t* in_iq, float* out_c64, int64_t n, void* stream
  * In place allowed (in == out). */
 int dd_nco_c64(const float* in_c64, float* out_c64, int64_t n, uint64_t cycles_q64,
                int64_t start_index, void* stream);
+/* the same with a per-sample frequency array (device, float64 Hz): comm.py:77 with an array
+ * freqOffset (Doppler correction, decode_funcube.py:228); phase formed and reduced in float64 */
+int dd_nco_c64_freqs(const float* in_c64, float* out_c64, int64_t n, const double* freqs_hz, double samp_rate,
+                     int64_t start_index, void* stream);
 
 /* ---- F1/F3: filters.filter.applyOn, FIR (a=[1]) (filters.py:21-75) ------------ */
 typedef struct dd_fir dd_fir;

@@ -559,3 +559,20 @@ def test_mfma_tile_boundaries_and_alignment(dd, L, shift):
             fm_check(got, a_ref, np.abs(y_ref[1:] * np.conj(y_ref[:-1])))
         else:
             assert rel_err(got, y_ref) < FIR_TOL
+
+
+def test_nco_per_sample_frequency_array(dd):
+    """offsetFreq with an array (Doppler correction, decode_funcube.py:228), with and without a chunker offset"""
+    fs, L = 2400000, 30000
+    x = O.grid_c64(O.synth_iq_noise(L, 4))
+    f = 25000.0 + 300.0 * np.sin(2 * np.pi * np.arange(L) / 7000.0)
+    got = dd.comm.commSignal(fs, x).offsetFreq(f).signal
+    assert got.dtype == np.complex64 and rel_err(got, O.nco(x, f, fs, 0)) < NCO_TOL
+    ck = dd.chunker.chunker(_Src(L))
+    ck.set("freqoffset", 4000000)
+    got = dd.comm.commSignal(fs, x, ck).offsetFreq(f).filter(dd.filters.hamming(255)).signal
+    ref = O.FilterState(O.win_hamming(255)).applyOn(O.nco(x, f, fs, 4000000))
+    assert ck.get("freqoffset") == 4000000 + L
+    assert rel_err(got, ref) < FIR_TOL
+    with pytest.raises(ValueError):
+        dd.comm.commSignal(fs, x).offsetFreq(f[:-1])
