@@ -169,7 +169,7 @@ __device__ __forceinline__ float2 dd_tile_w2(const DDChainParams& P, int b) {
 // rotate, scale, split into f16 limbs, write the LDS planes.  Returns the tile's
 // power-of-two scale.  Contains one barrier (max reduction; it also fences the
 // previous tile's LDS reads).
-template <int NKS, bool INTERIOR>
+template <int NKS>
 __device__ __forceinline__ float dd_tile_stage(const DDChainParams& P, int b, const float4 (&raw)[MfmaGeom<NKS>::NIT],
                                                char* smem, float2 w1a, float2 w1b, float2 w2mine) {
     using G = MfmaGeom<NKS>;
@@ -197,7 +197,7 @@ __device__ __forceinline__ float dd_tile_stage(const DDChainParams& P, int b, co
     const float inv_scale = 1.0f / scale;
 
     const int64_t tail_first = P.L - (K - 1);       // first sample of the new history
-    const bool tail_writer = !INTERIOR && (b == P.nblocks - 1) && P.tail_out != nullptr;
+    const bool tail_writer = (b == P.nblocks - 1) && P.tail_out != nullptr;
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
         const int e = 2 * (tid + MF_THREADS * it);
@@ -207,8 +207,8 @@ __device__ __forceinline__ float dd_tile_stage(const DDChainParams& P, int b, co
         if (nco) {
             const float2 g = w2[e >> 6];
             const float2 gs = make_float2(g.x * scale, g.y * scale);
-            if (INTERIOR || n >= 0) pa = dd_cmul(gs, w1a);
-            if (INTERIOR || n + 1 >= 0) pb = dd_cmul(gs, w1b);
+            if (n >= 0) pa = dd_cmul(gs, w1a);                 // history samples (n < 0) are already rotated
+            if (n + 1 >= 0) pb = dd_cmul(gs, w1b);
         }
         const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
         const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
@@ -232,7 +232,7 @@ __device__ __forceinline__ float dd_tile_stage(const DDChainParams& P, int b, co
 
 // epilogue.  lane (j = lane & 31, h = lane >> 5), register r holds output
 //   p = P0 + 1024*wave + 32*row + j,  row = (r & 3) + 8 (r >> 2) + 4 h
-template <int NKS, bool INTERIOR>
+template <int NKS>
 __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, v16f& cre, v16f& cim, float unscale, char* smem) {
     using G = MfmaGeom<NKS>;
     float2* wlast = reinterpret_cast<float2*>(smem + 4 * G::PLANE + sizeof(float2) * G::NGRP + sizeof(float) * MF_WAVES);
@@ -249,13 +249,13 @@ __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, 
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int64_t p = pw + 32 * row + j;
-            if (INTERIOR ? (wave > 0 || row > 0) : (p >= p_lo && p < P.Ld))
+            if (p >= p_lo && p < P.Ld)
                 out[p] = make_float2(cre[r] * unscale, cim[r] * unscale);
         }
         return;
     }
 
-    if (!INTERIOR && P.s == 0 && b == 0 && wave == 0 && lane == 31) {   // p == -1: sample carried from the previous chunk
+    if (P.s == 0 && b == 0 && wave == 0 && lane == 31) {   // p == -1: sample carried from the previous chunk
         const float2 ly = *P.lasty_in;                     // (any positive scale: only its angle matters)
         cre[0] = ly.x;
         cim[0] = ly.y;
@@ -284,13 +284,9 @@ __device__ __forceinline__ void dd_tile_epilogue(const DDChainParams& P, int b, 
         pre = (lane == 32) ? c_re : pre; pim = (lane == 32) ? c_im : pim;
         const int rowbase = (r & 3) + 8 * (r >> 2);        // row = rowbase + 4h
         const float ang = dd_fm_angle_fast(cre[r], cim[r], pre, pim);
-        if (INTERIOR) {
-            if (wave > 0 || rowbase > 0 || h > 0) out[32 * rowbase] = ang;
-        } else {
-            const int64_t p = pw + 32 * (rowbase + 4 * h) + j;
-            if (p >= p_lo && p >= P.s && p < P.Ld) out[32 * rowbase] = ang;
-            if (p == P.Ld - 1) *P.lasty_out = make_float2(cre[r] * unscale, cim[r] * unscale);
-        }
+        const int64_t p = pw + 32 * (rowbase + 4 * h) + j;
+        if (p >= p_lo && p >= P.s && p < P.Ld) out[32 * rowbase] = ang;
+        if (p == P.Ld - 1) *P.lasty_out = make_float2(cre[r] * unscale, cim[r] * unscale);
     }
 }
 
@@ -307,7 +303,7 @@ __device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfm
         w1a = dd_phasor((uint64_t)((2 * tid) & 63) * P.cyc, P.nco_tbl);
         w1b = dd_phasor((uint64_t)(((2 * tid) & 63) + 1) * P.cyc, P.nco_tbl);
     }
-    const float scale = dd_tile_stage<NKS, false>(P, b, raw, smem, w1a, w1b, dd_tile_w2<NKS>(P, b));
+    const float scale = dd_tile_stage<NKS>(P, b, raw, smem, w1a, w1b, dd_tile_w2<NKS>(P, b));
     v8h bh[NKS], bl[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -336,7 +332,7 @@ __device__ __forceinline__ void dd_edge_tile(const DDChainParams& P, const DDMfm
         cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, tl, cre, 0, 0, 0);
         cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, tl, cim, 0, 0, 0);
     }
-    dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
+    dd_tile_epilogue<NKS>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
 }
 
 // The same edge tile inside the register budget of the 16-wave ws kernel (a kernel that
@@ -417,7 +413,7 @@ __device__ __forceinline__ void dd_edge_tile_lean(const DDChainParams& P, const 
         cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, tl, cre, 0, 0, 0);
         cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, tl, cim, 0, 0, 0);
     }
-    dd_tile_epilogue<NKS, false>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
+    dd_tile_epilogue<NKS>(P, b, cre, cim, taps.inv_tapscale / scale, smem);
 }
 
 template <int NKS>
