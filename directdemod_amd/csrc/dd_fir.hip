@@ -355,10 +355,25 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
     }
     const int64_t i0 = b * IIR_LB;
     const int64_t i1 = i0 + IIR_LB < n ? i0 + IIR_LB : n;
-    for (int64_t i = i0; i < i1; ++i) {
-        double y;
-        dd_iir_step(C, N, z, in[i * ncomp + c], y);
-        if (write_out) out[i * ncomp + c] = y;
+    // the recurrence is serial, its input is not: 16 samples are requested at once (a lane's reads are a
+    // 4 KiB stride apart from its neighbours', so each costs a full memory latency when taken one by one)
+    for (int64_t i = i0; i < i1; i += 16) {
+        double xs[16], ys[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t q = i + u < i1 ? i + u : i1 - 1;
+            xs[u] = in[q * ncomp + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (i + u < i1) dd_iir_step(C, N, z, xs[u], ys[u]);
+        }
+        if (write_out) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (i + u < i1) out[(i + u) * ncomp + c] = ys[u];
+            }
+        }
     }
     if (!write_out) {
 #pragma unroll
@@ -370,7 +385,8 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
 }
 
 // u <- M u + e with M = hi + lo (double-double), products and sum carried in double-double
-__device__ __forceinline__ void dd_iir_affine(const double* __restrict__ mh, const double* __restrict__ ml, int S,
+template <int S>
+__device__ __forceinline__ void dd_iir_affine(const double* __restrict__ mh, const double* __restrict__ ml,
                                               double (&u)[IIR_S], const double* e) {
 #pragma clang fp contract(off)      // error-free transformations below: no fusing of their multiplies and adds
     double v[IIR_S];
@@ -397,8 +413,9 @@ __device__ __forceinline__ void dd_iir_affine(const double* __restrict__ mh, con
 }
 
 // phase 0: group end vectors from zero (grp[]); phase 2: block start states written over blk[]
+template <int S>
 __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, double* __restrict__ grp, int64_t nb, int ncomp,
-                                                   int S, const double* __restrict__ mats, int phase) {
+                                                   const double* __restrict__ mats, int phase) {
     const int64_t ng = (nb + IIR_G - 1) / IIR_G;
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= ng * ncomp) return;
@@ -408,16 +425,22 @@ __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, dou
 #pragma unroll
     for (int k = 0; k < IIR_S; ++k) u[k] = (phase == 2 && k < S) ? grp[t * IIR_S + k] : 0.0;
     const int64_t b0 = g * IIR_G, b1 = b0 + IIR_G < nb ? b0 + IIR_G : nb;
+    // the chain u <- M u + e is serial; the e vectors are not: the next one is fetched while this step runs
+    double e[IIR_S], en[IIR_S];
+#pragma unroll
+    for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? blk[(b0 * ncomp + c) * IIR_S + k] : 0.0;
     for (int64_t b = b0; b < b1; ++b) {
         double* slot = blk + (b * ncomp + c) * IIR_S;
-        double e[IIR_S];
+        const double* nslot = blk + ((b + 1 < b1 ? b + 1 : b) * ncomp + c) * IIR_S;
 #pragma unroll
-        for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? slot[k] : 0.0;
+        for (int k = 0; k < IIR_S; ++k) en[k] = (k < S) ? nslot[k] : 0.0;
         if (phase == 2) {
 #pragma unroll
             for (int k = 0; k < IIR_S; ++k) if (k < S) slot[k] = u[k];       // this block's start state
         }
-        dd_iir_affine(mats, mats + IIR_MAT, S, u, e);
+        dd_iir_affine<S>(mats, mats + IIR_MAT, u, e);
+#pragma unroll
+        for (int k = 0; k < IIR_S; ++k) e[k] = en[k];
     }
     if (phase == 0) {
 #pragma unroll
@@ -426,21 +449,27 @@ __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, dou
 }
 
 // phase 1: sequential sweep over the groups (one lane per component): grp[g] <- start state of group g
-__global__ void k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, int S, const double* __restrict__ mats,
+template <int S>
+__global__ void k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, const double* __restrict__ mats,
                                   const double* __restrict__ state, int zero_state) {
     const int c = threadIdx.x;
     if (c >= ncomp) return;
     double u[IIR_S];
 #pragma unroll
     for (int k = 0; k < IIR_S; ++k) u[k] = (!zero_state && k < S) ? state[c * IIR_S + k] : 0.0;
+    double e[IIR_S], en[IIR_S];
+#pragma unroll
+    for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? grp[c * IIR_S + k] : 0.0;
     for (int64_t g = 0; g < ng; ++g) {
         double* slot = grp + (g * ncomp + c) * IIR_S;
-        double e[IIR_S];
+        const double* nslot = grp + ((g + 1 < ng ? g + 1 : g) * ncomp + c) * IIR_S;
 #pragma unroll
-        for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? slot[k] : 0.0;
+        for (int k = 0; k < IIR_S; ++k) en[k] = (k < S) ? nslot[k] : 0.0;
 #pragma unroll
         for (int k = 0; k < IIR_S; ++k) if (k < S) slot[k] = u[k];
-        dd_iir_affine(mats + 2 * IIR_MAT, mats + 3 * IIR_MAT, S, u, e);
+        dd_iir_affine<S>(mats + 2 * IIR_MAT, mats + 3 * IIR_MAT, u, e);
+#pragma unroll
+        for (int k = 0; k < IIR_S; ++k) e[k] = en[k];
     }
 }
 
@@ -505,9 +534,20 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     iir_coef(h, &C);
     const unsigned gb = (unsigned)((nb * ncomp + 255) / 256), gg = (unsigned)((ng * ncomp + 63) / 64);
     hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0);
-    hipLaunchKernelGGL(k_iir_groups, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, S, h->mats, 0);
-    hipLaunchKernelGGL(k_iir_group_sweep, dim3(1), dim3(64), 0, s, grp, ng, ncomp, S, h->mats, h->state, carry ? 0 : 1);
-    hipLaunchKernelGGL(k_iir_groups, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, S, h->mats, 2);
+    // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
+    // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
+#define DD_IIR_SCAN(SS)                                                                                              \
+    case SS:                                                                                                         \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, h->mats, 0);             \
+        hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, h->mats, h->state, carry ? 0 : 1); \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, h->mats, 2);             \
+        break;
+    switch (S) {
+        DD_IIR_SCAN(1) DD_IIR_SCAN(2) DD_IIR_SCAN(3) DD_IIR_SCAN(4) DD_IIR_SCAN(5) DD_IIR_SCAN(6) DD_IIR_SCAN(7) DD_IIR_SCAN(8)
+        DD_IIR_SCAN(9) DD_IIR_SCAN(10) DD_IIR_SCAN(11) DD_IIR_SCAN(12) DD_IIR_SCAN(13) DD_IIR_SCAN(14) DD_IIR_SCAN(15)
+        default: break;
+    }
+#undef DD_IIR_SCAN
     hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0);
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
