@@ -15,8 +15,12 @@
 #define DD_DENSE_R 8
 #define DD_DENSE_THREADS 256
 #define DD_DENSE_T (DD_DENSE_R * DD_DENSE_THREADS)
+#ifndef DD_DECIM_THREADS
 #define DD_DECIM_THREADS 256
+#endif
+#ifndef DD_DECIM_SPAN_MAX
 #define DD_DECIM_SPAN_MAX 6144
+#endif
 
 // ============================================================================
 // dense kernel
@@ -176,15 +180,38 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     float2* sx = reinterpret_cast<float2*>(smem);
     float2* w2 = sx + SP;
     float2* yblk = w2 + ((S + 63) / 64 + 1);
-    float* gl = reinterpret_cast<float*>(yblk + DD_DECIM_THREADS);     // taps, K floats (+ pad to 8)
+    // taps, K floats (+ pad to 8), 16-byte aligned.  Offset arithmetic on the LDS base, not on a uintptr_t:
+    // a pointer that went through an integer is a generic pointer to the compiler, its reads become
+    // flat loads, and a flat load's vmcnt wait in the tap loop drains every tile load in flight
+    float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)SP + ((S + 63) / 64 + 1) + DD_DECIM_THREADS) + 15) & ~(size_t)15));
 
     const int t = threadIdx.x;
-    const int b = dd_xcd_tile(blockIdx.x, P.nblocks);
+    int b = dd_xcd_tile(blockIdx.x, P.nblocks - (P.skip_hi - P.skip_lo));
+    if (b >= P.skip_lo) b += P.skip_hi - P.skip_lo;        // those tiles run in k_chain_decim_p
     const int64_t pfirst = dd_tile_pfirst(P, b);
     const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
     const bool fm = (P.flags & DD_CHAIN_FM) != 0;
 
     const int ngroups = (S + 63) / 64;
+    // interior tile (whole span inside the chunk, complex64 input): the WHOLE tile is requested at
+    // once, before anything else -- up to 12 unconditional 16-byte loads (two samples each) in flight
+    // per lane -- so a tile costs one HBM latency and that latency also covers the tap copy and the
+    // phasor table fetches below.  (A predicated load -- edges, history, u8 -- makes hipcc branch and
+    // wait for every element: those tiles take the loop further down.)
+    typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));     // 16-byte load on an 8-byte boundary
+    constexpr int NV = (DD_DECIM_SPAN_MAX / 2 + DD_DECIM_THREADS - 1) / DD_DECIM_THREADS;
+    const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L && S <= DD_DECIM_SPAN_MAX;
+    const int nq = S / 2;                                     // whole sample pairs in the span
+    v4f_a8 v[NV];
+    if (interior) {
+        const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            int q = t + u * DD_DECIM_THREADS;
+            q = q < nq ? q : nq - 1;                          // past the span: harmless re-read, never used
+            v[u] = *reinterpret_cast<const v4f_a8*>(src + 2 * q);
+        }
+    }
     for (int j = t; j < ((K + 7) & ~7); j += DD_DECIM_THREADS) gl[j] = j < K ? P.taps_rev[(DD_DENSE_R - 1) + j] : 0.f;
     if (P.flags & DD_CHAIN_NCO) {
         for (int g = t; g < ngroups; g += DD_DECIM_THREADS) {
@@ -195,28 +222,12 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     __syncthreads();
     {
         const float2 w1 = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(t & 63) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
-        // interior tile (whole span inside the chunk, complex64 input): the WHOLE tile is requested
-        // at once -- up to 12 unconditional 16-byte loads (two samples each) in flight per lane --
-        // so a tile costs one HBM latency, not one per batch: with three batches of eight 8-byte
-        // loads the kernel sat at 2.9 TB/s (Little: ~45 KB in flight per CU only while loading).
-        // A predicated load (edges, history, u8) makes hipcc branch and wait for every element.
-        const bool interior = !(P.flags & DD_CHAIN_U8_INPUT) && ns >= 0 && ns + S <= P.L && S <= DD_DECIM_SPAN_MAX;
         if (interior) {
-            typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));     // 16-byte load on an 8-byte boundary
             const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;
-            constexpr int NV = (DD_DECIM_SPAN_MAX / 2 + DD_DECIM_THREADS - 1) / DD_DECIM_THREADS;
-            const int nq = S / 2;                             // whole sample pairs in the span
             float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
             if (P.flags & DD_CHAIN_NCO) {
                 w1a = dd_phasor((uint64_t)((2 * t) & 63) * P.cyc, P.nco_tbl);
                 w1b = dd_phasor((uint64_t)(((2 * t) & 63) + 1) * P.cyc, P.nco_tbl);
-            }
-            v4f_a8 v[NV];
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                int q = t + u * DD_DECIM_THREADS;
-                q = q < nq ? q : nq - 1;                      // past the span: harmless re-read, never used
-                v[u] = *reinterpret_cast<const v4f_a8*>(src + 2 * q);
             }
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
@@ -266,13 +277,34 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     if (t < T) {
         const float2* __restrict__ win = sx + t * M;
         int j = 0;
-        for (; j + 8 <= K; j += 8) {
+        if ((M & 1) == 0) {
+            // even M: every window starts on a 16-byte boundary -> ds_read_b128 (two samples), whose
+            // 16-lane groups make the stride-M reads bank-conflict free at 256 B/clk; as ds_read2_b64
+            // (128 B/clk, 2-way conflicts) these reads kept the LDS array busy 70 % of the kernel
+            // (PMC: SQ_LDS_IDX_ACTIVE, a third of it SQ_LDS_BANK_CONFLICT).
+            const float4* __restrict__ win4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(win, 16));
+            const float4* __restrict__ G4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(G, 16));
+            for (; j + 8 <= K; j += 8) {
+                const float4 x0 = win4[j / 2], x1 = win4[j / 2 + 1], x2 = win4[j / 2 + 2], x3 = win4[j / 2 + 3];
+                const float4 c0 = G4[j / 4], c1 = G4[j / 4 + 1];
+                acc.x = fmaf(c0.x, x0.x, acc.x); acc.y = fmaf(c0.x, x0.y, acc.y);
+                acc.x = fmaf(c0.y, x0.z, acc.x); acc.y = fmaf(c0.y, x0.w, acc.y);
+                acc.x = fmaf(c0.z, x1.x, acc.x); acc.y = fmaf(c0.z, x1.y, acc.y);
+                acc.x = fmaf(c0.w, x1.z, acc.x); acc.y = fmaf(c0.w, x1.w, acc.y);
+                acc.x = fmaf(c1.x, x2.x, acc.x); acc.y = fmaf(c1.x, x2.y, acc.y);
+                acc.x = fmaf(c1.y, x2.z, acc.x); acc.y = fmaf(c1.y, x2.w, acc.y);
+                acc.x = fmaf(c1.z, x3.x, acc.x); acc.y = fmaf(c1.z, x3.y, acc.y);
+                acc.x = fmaf(c1.w, x3.z, acc.x); acc.y = fmaf(c1.w, x3.w, acc.y);
+            }
+        } else {
+            for (; j + 8 <= K; j += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float2 v = win[j + u];
-                const float g = G[j + u];
-                acc.x = fmaf(g, v.x, acc.x);
-                acc.y = fmaf(g, v.y, acc.y);
+                for (int u = 0; u < 8; ++u) {
+                    const float2 v = win[j + u];
+                    const float g = G[j + u];
+                    acc.x = fmaf(g, v.x, acc.x);
+                    acc.y = fmaf(g, v.y, acc.y);
+                }
             }
         }
         for (; j < K; ++j) {
@@ -299,6 +331,140 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
         }
         if (p == P.Ld - 1) *P.lasty_out = acc;
     }
+}
+
+// ============================================================================
+// decimating kernel, interior tiles, persistent
+// ============================================================================
+// One launch-long workgroup per third of a CU (LDS bound, 3 per CU) walks a contiguous run of
+// interior tiles: whole span inside the chunk, every output valid, complex64 input.  The next
+// tile's samples are requested (12 x 16 B per lane) the moment the current tile has been staged
+// into LDS -- into the same registers, which staging has just freed -- so they are in flight
+// during the tap loop, the discriminator and both barriers, and the per-workgroup constants
+// (taps in LDS, group and lane phasors) are built once per launch instead of once per tile.  NCO phase is TILE-RELATIVE: the factor exp(-j w (abs0 + ns)) is
+// common to a tile, so it cancels in the discriminator (a tile recomputes the output before
+// its first one, pairs never straddle tiles) and is applied to the FIR output only for
+// complex output.
+#define DD_DECIM_NV ((DD_DECIM_SPAN_MAX / 2 + DD_DECIM_THREADS - 1) / DD_DECIM_THREADS)
+typedef float dd_v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));     // 16-byte load on an 8-byte boundary
+
+__device__ __forceinline__ void dd_decim_issue(const DDChainParams& P, int b, int nq, int t, dd_v4f_a8 (&v)[DD_DECIM_NV]) {
+    const int64_t ns = (int64_t)P.off + dd_tile_pfirst(P, b) * P.M - (P.K - 1);
+    const float2* __restrict__ src = reinterpret_cast<const float2*>(P.in) + ns;      // wave uniform
+#pragma unroll
+    for (int u = 0; u < DD_DECIM_NV; ++u) {
+        int q = t + u * DD_DECIM_THREADS;
+        q = q < nq ? q : nq - 1;                          // past the span: harmless re-read, never used
+        v[u] = *reinterpret_cast<const dd_v4f_a8*>(src + 2 * q);
+    }
+}
+
+__device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int b_next, int nq, int t, dd_v4f_a8 (&v)[DD_DECIM_NV],
+                                              float2* sx, const float2* w2, float2* yblk, const float* gl, float2 w1a, float2 w1b) {
+    const int K = P.K, M = P.M, T = P.T;
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
+    const int64_t pfirst = dd_tile_pfirst(P, b);
+    float2 tilew = make_float2(1.f, 0.f);
+    if (nco && !fm) {                                      // absolute phase of the tile start (table fetch issued early)
+        const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
+        tilew = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
+    }
+    float2 g[DD_DECIM_NV];
+    if (nco) {
+#pragma unroll
+        for (int u = 0; u < DD_DECIM_NV; ++u) {
+            const int q = t + u * DD_DECIM_THREADS;
+            g[u] = w2[(q < nq ? 2 * q : 0) >> 6];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < DD_DECIM_NV; ++u) {
+        const int q = t + u * DD_DECIM_THREADS;
+        if (q < nq) {
+            float2 xa = make_float2(v[u].x, v[u].y), xb = make_float2(v[u].z, v[u].w);
+            if (nco) {
+                xa = dd_cmul(xa, dd_cmul(g[u], w1a));
+                xb = dd_cmul(xb, dd_cmul(g[u], w1b));
+            }
+            *reinterpret_cast<float4*>(sx + 2 * q) = make_float4(xa.x, xa.y, xb.x, xb.y);
+        }
+    }
+    if (b_next >= 0) dd_decim_issue(P, b_next, nq, t, v);  // next tile: in flight from here to the next staging
+    __syncthreads();
+    float2 acc = make_float2(0.f, 0.f);
+    if (t < T) {
+        const float2* __restrict__ win = sx + t * M;
+        int j = 0;
+        if ((M & 1) == 0) {                                // 16-byte aligned windows: conflict-free ds_read_b128 (see k_chain_decim)
+            const float4* __restrict__ win4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(win, 16));
+            const float4* __restrict__ G4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(gl, 16));
+            for (; j + 8 <= K; j += 8) {
+                const float4 x0 = win4[j / 2], x1 = win4[j / 2 + 1], x2 = win4[j / 2 + 2], x3 = win4[j / 2 + 3];
+                const float4 c0 = G4[j / 4], c1 = G4[j / 4 + 1];
+                acc.x = fmaf(c0.x, x0.x, acc.x); acc.y = fmaf(c0.x, x0.y, acc.y);
+                acc.x = fmaf(c0.y, x0.z, acc.x); acc.y = fmaf(c0.y, x0.w, acc.y);
+                acc.x = fmaf(c0.z, x1.x, acc.x); acc.y = fmaf(c0.z, x1.y, acc.y);
+                acc.x = fmaf(c0.w, x1.z, acc.x); acc.y = fmaf(c0.w, x1.w, acc.y);
+                acc.x = fmaf(c1.x, x2.x, acc.x); acc.y = fmaf(c1.x, x2.y, acc.y);
+                acc.x = fmaf(c1.y, x2.z, acc.x); acc.y = fmaf(c1.y, x2.w, acc.y);
+                acc.x = fmaf(c1.z, x3.x, acc.x); acc.y = fmaf(c1.z, x3.y, acc.y);
+                acc.x = fmaf(c1.w, x3.z, acc.x); acc.y = fmaf(c1.w, x3.w, acc.y);
+            }
+        }
+        for (; j + 8 <= K; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float2 x = win[j + u];
+                const float c = gl[j + u];
+                acc.x = fmaf(c, x.x, acc.x);
+                acc.y = fmaf(c, x.y, acc.y);
+            }
+        }
+        for (; j < K; ++j) {
+            const float2 x = win[j];
+            const float c = gl[j];
+            acc.x = fmaf(c, x.x, acc.x);
+            acc.y = fmaf(c, x.y, acc.y);
+        }
+    }
+    const int64_t p = pfirst + t;
+    if (!fm) {
+        if (t < T) reinterpret_cast<float2*>(P.out)[p] = dd_cmul(acc, tilew);
+        __syncthreads();                                   // tap loop done everywhere before the image is overwritten
+        return;
+    }
+    if (t < T) yblk[t] = acc;
+    __syncthreads();                                       // (also: tap loop done everywhere)
+    if (t > 0 && t < T) reinterpret_cast<float*>(P.out)[p - P.s] = dd_fm_angle(acc, yblk[t - 1]);
+}
+
+__global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDChainParams P, int b_lo, int b_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = P.K, M = P.M, T = P.T;
+    const int S = ((T - 1) * M + K + (M - 1) + 1) & ~1;    // span, rounded up to whole sample pairs
+    const int nq = S / 2;
+    float2* sx = reinterpret_cast<float2*>(smem);
+    float2* w2 = sx + S + 4;
+    float2* yblk = w2 + (S / 64 + 2);
+    float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)S + 4 + (S / 64 + 2) + DD_DECIM_THREADS) + 15) & ~(size_t)15));   // (LDS offset arithmetic: see k_chain_decim)
+    const int t = threadIdx.x;
+    // contiguous run of tiles per workgroup, and per XCD (workgroups are dealt round-robin to the 8 XCDs)
+    const int nwg = gridDim.x, n = b_hi - b_lo;
+    const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int begin = b_lo + (int)(((int64_t)wg * n) / nwg), end = b_lo + (int)(((int64_t)(wg + 1) * n) / nwg);
+    if (begin >= end) return;
+
+    dd_v4f_a8 v[DD_DECIM_NV];
+    dd_decim_issue(P, begin, nq, t, v);                    // in flight while the constants are built
+    for (int j = t; j < ((K + 7) & ~7); j += DD_DECIM_THREADS) gl[j] = j < K ? P.taps_rev[(DD_DENSE_R - 1) + j] : 0.f;
+    float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+    if (P.flags & DD_CHAIN_NCO) {
+        for (int g = t; g < S / 64 + 1; g += DD_DECIM_THREADS) w2[g] = dd_phasor((uint64_t)g * 64 * P.cyc, P.nco_tbl);
+        w1a = dd_phasor((uint64_t)((2 * t) & 63) * P.cyc, P.nco_tbl);
+        w1b = dd_phasor((uint64_t)(((2 * t) & 63) + 1) * P.cyc, P.nco_tbl);
+    }
+    __syncthreads();
+    for (int b = begin; b < end; ++b) dd_decim_tile(P, b, b + 1 < end ? b + 1 : -1, nq, t, v, sx, w2, yblk, gl, w1a, w1b);
 }
 
 // rare path (chunk without a kept sample) and shard priming: new tail only
@@ -539,12 +705,50 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         if (P.nblocks < 1) P.nblocks = 1;
         const int S = (T - 1) * P.M + P.K + (P.M - 1);
         const int SP = S + 4;
-        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7);
+        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
         DD_REQUIRE(lds <= 160 * 1024, "filter/decimation too large for the decimating kernel's LDS tile");
         if (lds > 64 * 1024)
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), lds, s, P);
-        DD_LAUNCH_CHECK();
+        // interior tiles [b_lo, b_hi): span (rounded up to a sample pair) inside the chunk, all T outputs valid,
+        // complex64 input, not the chunk's last tile (that one writes the carried state)
+        P.skip_lo = P.skip_hi = P.nblocks;
+        const int S2 = (S + 1) & ~1;
+        if (!(P.flags & DD_CHAIN_U8_INPUT) && S2 <= DD_DECIM_SPAN_MAX && (reinterpret_cast<uintptr_t>(P.in) & 7) == 0) {
+            const int64_t adv = isfm ? (P.T - 1) : P.T;                  // outputs a tile advances by
+            const int64_t pf0 = isfm ? (int64_t)P.s - 1 : 0;             // pfirst of tile 0
+            // ns(b) = off + (pf0 + b adv) M - (K-1) >= 0 ;  ns(b) + S2 <= L ;  pf0 + b adv >= 0 ;  pf0 + b adv + T <= Ld
+            int64_t lo = 0;
+            while (lo < P.nblocks && ((int64_t)P.off + (pf0 + lo * adv) * P.M - (P.K - 1) < 0 || pf0 + lo * adv < 0)) ++lo;
+            int64_t hi = P.nblocks - 1;                                  // exclusive bound candidates, walk down
+            while (hi > lo && ((int64_t)P.off + (pf0 + (hi - 1) * adv) * P.M - (P.K - 1) + S2 > P.L || pf0 + (hi - 1) * adv + P.T > P.Ld)) --hi;
+            if (hi - lo >= 64) {
+                P.skip_lo = (int)lo;
+                P.skip_hi = (int)hi;
+                const size_t lds_p = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
+                static bool attr_p = false;
+                if (!attr_p) {
+                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr_p = true;
+                }
+                int ncu = 256, dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                // every workgroup must be resident from the start (a persistent grid with queued workgroups
+                // runs in rounds): ask the runtime how many fit (LDS and registers)
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p, DD_DECIM_THREADS, lds_p) != hipSuccess || per_cu < 1) per_cu = 1;
+                int grid = ncu * per_cu;
+                if (grid > hi - lo) grid = (int)(hi - lo);
+                if (grid >= 8) grid &= ~7;
+                hipLaunchKernelGGL(k_chain_decim_p, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
+                DD_LAUNCH_CHECK();
+            }
+        }
+        const int n_rest = P.nblocks - (P.skip_hi - P.skip_lo);
+        if (n_rest > 0) {
+            hipLaunchKernelGGL(k_chain_decim, dim3(n_rest), dim3(DD_DECIM_THREADS), lds, s, P);
+            DD_LAUNCH_CHECK();
+        }
+
     }
     if (a.commit) {
         fir->parity ^= 1;

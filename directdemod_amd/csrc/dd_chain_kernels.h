@@ -66,6 +66,7 @@ struct DDChainParams {
     int flags;                 // DD_CHAIN_NCO | DD_CHAIN_FM | DD_CHAIN_U8_INPUT
     int T;                     // FIR outputs computed per block
     int nblocks;
+    int skip_lo, skip_hi;      // tiles [skip_lo, skip_hi) belong to another launch (persistent interior kernel); equal = none
 };
 
 // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the
