@@ -785,12 +785,9 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         v16f cre, cim;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-        // software pipeline, distance TWO k-steps: the six fragments of k-step ks+2 are issued
-        // during the six MFMAs of k-step ks (one read per MFMA gap), so a fragment has ~250-380
-        // cycles to arrive.  With distance one (~160 cycles) the kernel was bistable: whenever
-        // the vector waves' LDS bursts pushed the read latency past that, the MFMAs waited, the
-        // vector waves won more issue slots, bunched their LDS traffic further, and the matrix
-        // segment settled at 50 cycles per MFMA instead of 35.  sched_barrier pins the order.
+        // software pipeline, distance two k-steps: the six fragments of k-step ks+2 are issued during the
+        // six MFMAs of k-step ks, one read per MFMA gap (no read burst between MFMA groups), so a
+        // fragment has ~250-380 cycles to arrive; sched_barrier pins the order.
         v8h f[3][6];
 #define DD_WS_LOADF(buf, ks)                                                                     \
         {                                                                                        \

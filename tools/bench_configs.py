@@ -50,6 +50,27 @@ def main():
         print(json.dumps({"config": name, "ms": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
                           "bytes_per_sample": round(bps, 3), "hbm_frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)}))
         eng.close()
+    # FIR only, complex64 output (16 B/sample), MFMA path
+    outc = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    ham = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(255) / 254)
+    eng = shard.HipChainEngine(ham, 25000.0, 2400000, 1, fm=False, stream=stream)
+    lib = _hip.lib()
+    for _ in range(20):
+        lib.dd_chain_reset(eng.h, stream)
+        eng.process(x.data_ptr(), outc.data_ptr(), n)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        lib.dd_chain_reset(eng.h, stream)
+        eng.process(x.data_ptr(), outc.data_ptr(), n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 50
+    print(json.dumps({"config": "NCO + hamming255, /1, complex64 out (MFMA path)", "ms": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
+                      "bytes_per_sample": 16.0, "hbm_frac_of_8TBs": round(n * 16.0 / (ms * 1e-3) / 8e12, 4)}))
+    eng.close()
+    del outc
     # streaming ring feeder: host-resident u8 -> decoded audio (PCIe inclusive)
     from directdemod_amd import source, stream as st
     nraw = 1 << 27
