@@ -466,7 +466,11 @@ struct WsGeom {
     static constexpr int NIT = (NQ + WS_VTHREADS - 1) / WS_VTHREADS;   // 3 steps for 12 vector waves: 94 % lane use
     static constexpr int PLANES_BYTES = 4 * G::PLANE;             // one plane buffer
     static constexpr int YBUF_OFF = 2 * PLANES_BYTES;
-    static constexpr int YBUF_BYTES = 16 + MF_T * 8;              // one float2 of slack in front (y[-1] of lane 0)
+    // y-buffer: planar (real plane, imaginary plane), each with 16 B of slack in front (y[-1] of lane 0).
+    // Planar so that a matrix wave stores its accumulators as they sit in registers (ds_write2_b32 pairs):
+    // the interleaved float2 form needed 24 v_mov per strip to pair re with im first.
+    static constexpr int YPLANE_F = 4 + MF_T;
+    static constexpr int YBUF_BYTES = 2 * YPLANE_F * 4;
     static constexpr int TAPS_OFF = YBUF_OFF + YBUF_BYTES;
     static constexpr int TAPS_BYTES = 2 * NKS * 64 * 16;
     static constexpr int RED_OFF = TAPS_OFF + TAPS_BYTES;         // [2][WS_VWAVES] float
@@ -569,9 +573,13 @@ template <int NKS>
 __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int b, int u, int lane, const float2* yb, float unscale) {
     const int o = 256 * u + 4 * lane;
     if (o < 32) return;                                    // the tile's first column belongs to the previous tile
-    const float2 ym = yb[o - 1];
-    const float4 y01 = *reinterpret_cast<const float4*>(yb + o);
-    const float4 y23 = *reinterpret_cast<const float4*>(yb + o + 2);
+    // planar y-buffer: yb points at real[0]; imaginary plane YPLANE_F floats further
+    const float* yre = reinterpret_cast<const float*>(yb);
+    const float* yim = yre + WsGeom<NKS>::YPLANE_F;
+    const float4 r4 = *reinterpret_cast<const float4*>(yre + o), i4 = *reinterpret_cast<const float4*>(yim + o);
+    const float2 ym = make_float2(yre[o - 1], yim[o - 1]);
+    const float4 y01 = make_float4(r4.x, i4.x, r4.y, i4.y);
+    const float4 y23 = make_float4(r4.z, i4.z, r4.w, i4.w);
     const int64_t p = (int64_t)b * MF_ADV - 32 + o;
     if (P.flags & DD_CHAIN_FM) {
         // z_k = y_k conj(y_{k-1})
@@ -763,7 +771,7 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     const int sb = mw * MF_STRIP;
     const int aoff = (2 * sb + (sb >> 1)) + 80 * i + 16 * h;
     const v8h* tb = reinterpret_cast<const v8h*>(smem + W::TAPS_OFF) + lane;
-    float2* yw = reinterpret_cast<float2*>(smem + W::YBUF_OFF + 16) + sb + 128 * h + i;   // + 32*rowbase(r)
+    float* ywr = reinterpret_cast<float*>(smem + W::YBUF_OFF + 16) + sb + 128 * h + i;    // + 32*rowbase(r); imaginary plane YPLANE_F further
     int* ydone = reinterpret_cast<int*>(smem + W::YDONE_OFF);
     __builtin_amdgcn_s_setprio(3);                          // MFMAs issue as soon as the pipe frees up
     __syncthreads();                                        // prologue barrier (tile 0's max is published)
@@ -824,21 +832,28 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }
         DD_STAMP(0)
+        int yd_early = 0;
         if (go) {
             DD_WS_LOADF(0, 0)
             DD_WS_LOADF(1, 1)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
+            for (int ks = 0; ks < NKS - 1; ++ks) {
                 DD_WS_STEP(ks % 3, (ks + 2) % 3, (ks + 2 < NKS ? ks + 2 : ks), (ks + 2 < NKS))
             }
+            yd_early = __hip_atomic_load(ydone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // in flight under the last k-step
+            DD_WS_STEP((NKS - 1) % 3, (NKS + 1) % 3, NKS - 1, false)
         }
         DD_STAMP(1)
         // all 16 waves have finished reading the y-buffer of tile p-2 (normally long ago)
+        if (yd_early < 16 * (p + 1))
         while (__hip_atomic_load(ydone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 16 * (p + 1)) __builtin_amdgcn_s_sleep(2);
         if (go) {
             // register r of lane (i, h) is output 32 (rowbase(r) + 4h) + i of the strip
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yw[32 * ((r & 3) + 8 * (r >> 2))] = make_float2(cre[r], cim[r]);
+            for (int r = 0; r < 16; ++r) {
+                ywr[32 * ((r & 3) + 8 * (r >> 2))] = cre[r];
+                ywr[W::YPLANE_F + 32 * ((r & 3) + 8 * (r >> 2))] = cim[r];
+            }
         }
         DD_STAMP(2)
         __syncthreads();
@@ -860,9 +875,6 @@ template <int NKS>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef DD_WS_VGPR_PAD
-    asm volatile("" ::: DD_WS_VGPR_PAD);                    // raises the kernel's VGPR allocation
-#endif
     const int wg = blockIdx.x;
     if (wg >= nwg) {
         // edge tiles ([0, t_first) and [t_last, nblocks)) ride along as trailing workgroups:
