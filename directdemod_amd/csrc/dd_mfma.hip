@@ -441,23 +441,16 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_chain_mfma_edge(const DDChain
 // vector waves per SIMD hide that latency by thread-level parallelism while the
 // matrix wave keeps the MFMA pipe busy; 128 VGPRs per wave make 4 waves/SIMD fit.
 //
-// Pipeline over the workgroup's tiles (two workgroup barriers per phase p):
-//   vector: [tile-max of tile p; epilogue of tile p-2]  B1  [convert tile p -> planes[p&1];
-//           issue loads of tile p+1]  B2
-//   matrix: [MFMA k-steps 0..KS1 of tile p-1 from planes[(p-1)&1]]  B1
-//           [remaining k-steps; write y-buffer]  B2
+// Pipeline over the workgroup's tiles, ONE workgroup barrier per phase p:
+//   vector: issue loads of tile p+2 | epilogue of tile p-2 from the y-buffer, signal "y read" |
+//           convert tile p -> planes[p&1] | peak of tile p+1 |  barrier
+//   matrix: own epilogue unit of tile p-2, signal "y read" | 108 MFMAs of tile p-1 from
+//           planes[(p-1)&1] | wait until all 16 waves have read y, write y of tile p-1 |  barrier
 // ---------------------------------------------------------------------------------
 #define WS_THREADS 1024
 #define WS_MWAVES 4
 #define WS_VTHREADS (WS_THREADS - 64 * WS_MWAVES)     // 768
 #define WS_VWAVES (WS_VTHREADS / 64)                   // 12
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef _Float16 v4h __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ v2f dd_cmul2(v2f a, v2f b) {          // complex product, (re, im) in one VGPR pair
-    const v2f bs = {-b.y, b.x};
-    return a.yy * bs + a.xx * b;
-}
 
 template <int NKS>
 struct WsGeom {
@@ -478,36 +471,7 @@ struct WsGeom {
     static constexpr int YDONE_OFF = SCALE_OFF + 16;              // int: waves that finished reading the y-buffer
     static constexpr int NONUNIT_OFF = YDONE_OFF + 16;            // [4] int: "some wave saw a tile part outside the unit range", per tile slot
     static constexpr int LDS_BYTES = (NONUNIT_OFF + 16 + 15) & ~15;
-    static constexpr int KS1 = NKS / 2;                           // k-steps before the mid-phase barrier (balances both halves)
 };
-
-// two discriminator outputs per call (packed polynomial)
-__device__ __forceinline__ v2f dd_fm_angle2(v2f cx, v2f cy, v2f px, v2f py) {
-    const v2f re = cx * px + cy * py;
-    const v2f im = cy * px - cx * py;
-    const v2f ax = __builtin_elementwise_abs(re), ay = __builtin_elementwise_abs(im);
-    const v2f mx = __builtin_elementwise_max(ax, ay), mn = __builtin_elementwise_min(ax, ay);
-    const v2f rc = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
-    const v2f t = mn * rc;
-    const v2f z = t * t;
-    v2f p = z * -4.054567120e-03f + 2.186295773e-02f;
-    p = p * z + -5.591232695e-02f;
-    p = p * z + 9.642197381e-02f;
-    p = p * z + -1.390862959e-01f;
-    p = p * z + 1.994656567e-01f;
-    p = p * z + -3.332986079e-01f;
-    p = p * z + 9.999993356e-01f;
-    v2f r = p * t;
-    const v2f rq = 1.5707963267948966f - r;
-    r.x = (ay.x > ax.x) ? rq.x : r.x;
-    r.y = (ay.y > ax.y) ? rq.y : r.y;
-    const v2f rh = 3.141592653589793f - r;
-    r.x = (re.x < 0.f) ? rh.x : r.x;
-    r.y = (re.y < 0.f) ? rh.y : r.y;
-    r.x = (mx.x == 0.f) ? 0.f : r.x;                   // angle(0) = 0 like np.angle
-    r.y = (mx.y == 0.f) ? 0.f : r.y;
-    return (v2f){copysignf(r.x, im.x), copysignf(r.y, im.y)};
-}
 
 template <int NKS>
 __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[WsGeom<NKS>::NIT]) {
