@@ -359,7 +359,48 @@ __device__ __forceinline__ void dd_decim_issue(const DDChainParams& P, int b, in
     }
 }
 
+// raw u8 input (DD_CHAIN_U8_INPUT, 2 B/sample): a 16-byte load carries eight samples (I0 Q0 I1 Q1 ...)
+#define DD_DECIM_NV8 ((DD_DECIM_SPAN_MAX / 8 + DD_DECIM_THREADS - 1) / DD_DECIM_THREADS)
+typedef uint32_t dd_v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load on a 4-byte boundary
+
+__device__ __forceinline__ void dd_decim_issue_u8(const DDChainParams& P, int b, int nq8, int t, dd_v4u_a4 (&v)[DD_DECIM_NV8]) {
+    const int64_t ns = (int64_t)P.off + dd_tile_pfirst(P, b) * P.M - (P.K - 1);
+    const unsigned char* __restrict__ src = reinterpret_cast<const unsigned char*>(P.in) + 2 * ns;   // wave uniform
+#pragma unroll
+    for (int u = 0; u < DD_DECIM_NV8; ++u) {
+        int q = t + u * DD_DECIM_THREADS;
+        q = q < nq8 ? q : nq8 - 1;
+        v[u] = *reinterpret_cast<const dd_v4u_a4*>(src + 16 * q);
+    }
+}
+
+// stage one tile of raw u8 samples: widen (source.py:117-118: value - 127.5), rotate, write the LDS image
+__device__ __forceinline__ void dd_decim_stage_u8(const DDChainParams& P, int nq8, int t, const dd_v4u_a4 (&v)[DD_DECIM_NV8],
+                                                  float2* sx, const float2* w2, const float2 (&w1)[8]) {
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+#pragma unroll
+    for (int u = 0; u < DD_DECIM_NV8; ++u) {
+        const int q = t + u * DD_DECIM_THREADS;
+        if (q < nq8) {
+            const float2 g = nco ? w2[(8 * q) >> 6] : make_float2(1.f, 0.f);
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float2 xa = make_float2((float)(d[k] & 0xff) - 127.5f, (float)((d[k] >> 8) & 0xff) - 127.5f);
+                float2 xb = make_float2((float)((d[k] >> 16) & 0xff) - 127.5f, (float)(d[k] >> 24) - 127.5f);
+                if (nco) {
+                    xa = dd_cmul(xa, dd_cmul(g, w1[2 * k]));
+                    xb = dd_cmul(xb, dd_cmul(g, w1[2 * k + 1]));
+                }
+                *reinterpret_cast<float4*>(sx + 8 * q + 2 * k) = make_float4(xa.x, xa.y, xb.x, xb.y);
+            }
+        }
+    }
+}
+
+template <bool U8>
 __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int b_next, int nq, int t, dd_v4f_a8 (&v)[DD_DECIM_NV],
+                                              dd_v4u_a4 (&v8)[DD_DECIM_NV8], const float2 (&w18)[8],
                                               float2* sx, const float2* w2, float2* yblk, const float* gl, float2 w1a, float2 w1b) {
     const int K = P.K, M = P.M, T = P.T;
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
@@ -369,27 +410,32 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int
         const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
         tilew = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
     }
-    float2 g[DD_DECIM_NV];
-    if (nco) {
+    if (U8) {
+        dd_decim_stage_u8(P, nq, t, v8, sx, w2, w18);      // (nq counts octets here)
+        if (b_next >= 0) dd_decim_issue_u8(P, b_next, nq, t, v8);
+    } else {
+        float2 g[DD_DECIM_NV];
+        if (nco) {
+#pragma unroll
+            for (int u = 0; u < DD_DECIM_NV; ++u) {
+                const int q = t + u * DD_DECIM_THREADS;
+                g[u] = w2[(q < nq ? 2 * q : 0) >> 6];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < DD_DECIM_NV; ++u) {
             const int q = t + u * DD_DECIM_THREADS;
-            g[u] = w2[(q < nq ? 2 * q : 0) >> 6];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < DD_DECIM_NV; ++u) {
-        const int q = t + u * DD_DECIM_THREADS;
-        if (q < nq) {
-            float2 xa = make_float2(v[u].x, v[u].y), xb = make_float2(v[u].z, v[u].w);
-            if (nco) {
-                xa = dd_cmul(xa, dd_cmul(g[u], w1a));
-                xb = dd_cmul(xb, dd_cmul(g[u], w1b));
+            if (q < nq) {
+                float2 xa = make_float2(v[u].x, v[u].y), xb = make_float2(v[u].z, v[u].w);
+                if (nco) {
+                    xa = dd_cmul(xa, dd_cmul(g[u], w1a));
+                    xb = dd_cmul(xb, dd_cmul(g[u], w1b));
+                }
+                *reinterpret_cast<float4*>(sx + 2 * q) = make_float4(xa.x, xa.y, xb.x, xb.y);
             }
-            *reinterpret_cast<float4*>(sx + 2 * q) = make_float4(xa.x, xa.y, xb.x, xb.y);
         }
+        if (b_next >= 0) dd_decim_issue(P, b_next, nq, t, v);  // next tile: in flight from here to the next staging
     }
-    if (b_next >= 0) dd_decim_issue(P, b_next, nq, t, v);  // next tile: in flight from here to the next staging
     __syncthreads();
     float2 acc = make_float2(0.f, 0.f);
     if (t < T) {
@@ -438,11 +484,13 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int
     if (t > 0 && t < T) reinterpret_cast<float*>(P.out)[p - P.s] = dd_fm_angle(acc, yblk[t - 1]);
 }
 
+template <bool U8>
 __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDChainParams P, int b_lo, int b_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = P.K, M = P.M, T = P.T;
-    const int S = ((T - 1) * M + K + (M - 1) + 1) & ~1;    // span, rounded up to whole sample pairs
-    const int nq = S / 2;
+    // span, rounded up to whole load granules: sample pairs (complex64) or octets (u8)
+    const int S = U8 ? (((T - 1) * M + K + (M - 1) + 7) & ~7) : (((T - 1) * M + K + (M - 1) + 1) & ~1);
+    const int nq = U8 ? S / 8 : S / 2;
     float2* sx = reinterpret_cast<float2*>(smem);
     float2* w2 = sx + S + 4;
     float2* yblk = w2 + (S / 64 + 2);
@@ -455,7 +503,9 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
     if (begin >= end) return;
 
     dd_v4f_a8 v[DD_DECIM_NV];
-    dd_decim_issue(P, begin, nq, t, v);                    // in flight while the constants are built
+    dd_v4u_a4 v8[DD_DECIM_NV8];
+    if (U8) dd_decim_issue_u8(P, begin, nq, t, v8);        // in flight while the constants are built
+    else dd_decim_issue(P, begin, nq, t, v);
     for (int j = t; j < ((K + 7) & ~7); j += DD_DECIM_THREADS) gl[j] = j < K ? P.taps_rev[(DD_DENSE_R - 1) + j] : 0.f;
     float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
     if (P.flags & DD_CHAIN_NCO) {
@@ -463,8 +513,12 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
         w1a = dd_phasor((uint64_t)((2 * t) & 63) * P.cyc, P.nco_tbl);
         w1b = dd_phasor((uint64_t)(((2 * t) & 63) + 1) * P.cyc, P.nco_tbl);
     }
+    float2 w18[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        w18[k] = (U8 && (P.flags & DD_CHAIN_NCO)) ? dd_phasor((uint64_t)(((8 * t) & 63) + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
     __syncthreads();
-    for (int b = begin; b < end; ++b) dd_decim_tile(P, b, b + 1 < end ? b + 1 : -1, nq, t, v, sx, w2, yblk, gl, w1a, w1b);
+    for (int b = begin; b < end; ++b) dd_decim_tile<U8>(P, b, b + 1 < end ? b + 1 : -1, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
 }
 
 // rare path (chunk without a kept sample) and shard priming: new tail only
@@ -712,8 +766,9 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         // interior tiles [b_lo, b_hi): span (rounded up to a sample pair) inside the chunk, all T outputs valid,
         // complex64 input, not the chunk's last tile (that one writes the carried state)
         P.skip_lo = P.skip_hi = P.nblocks;
-        const int S2 = (S + 1) & ~1;
-        if (!(P.flags & DD_CHAIN_U8_INPUT) && S2 <= DD_DECIM_SPAN_MAX && (reinterpret_cast<uintptr_t>(P.in) & 7) == 0) {
+        const bool u8in = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+        const int S2 = u8in ? ((S + 7) & ~7) : ((S + 1) & ~1);
+        if (S2 <= DD_DECIM_SPAN_MAX && (reinterpret_cast<uintptr_t>(P.in) & (u8in ? 3 : 7)) == 0) {
             const int64_t adv = isfm ? (P.T - 1) : P.T;                  // outputs a tile advances by
             const int64_t pf0 = isfm ? (int64_t)P.s - 1 : 0;             // pfirst of tile 0
             // ns(b) = off + (pf0 + b adv) M - (K-1) >= 0 ;  ns(b) + S2 <= L ;  pf0 + b adv >= 0 ;  pf0 + b adv + T <= Ld
@@ -727,7 +782,8 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
                 const size_t lds_p = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
                 static bool attr_p = false;
                 if (!attr_p) {
-                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     attr_p = true;
                 }
                 int ncu = 256, dev = 0;
@@ -735,11 +791,13 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
                 // every workgroup must be resident from the start (a persistent grid with queued workgroups
                 // runs in rounds): ask the runtime how many fit (LDS and registers)
                 int per_cu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p, DD_DECIM_THREADS, lds_p) != hipSuccess || per_cu < 1) per_cu = 1;
+                if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
                 int grid = ncu * per_cu;
                 if (grid > hi - lo) grid = (int)(hi - lo);
                 if (grid >= 8) grid &= ~7;
-                hipLaunchKernelGGL(k_chain_decim_p, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
+                if (u8in) hipLaunchKernelGGL(k_chain_decim_p<true>, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
+                else hipLaunchKernelGGL(k_chain_decim_p<false>, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
                 DD_LAUNCH_CHECK();
             }
         }

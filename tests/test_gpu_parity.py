@@ -576,3 +576,39 @@ def test_nco_per_sample_frequency_array(dd):
     assert rel_err(got, ref) < FIR_TOL
     with pytest.raises(ValueError):
         dd.comm.commSignal(fs, x).offsetFreq(f[:-1])
+
+
+@pytest.mark.parametrize("M,fm", [(34, True), (50, True), (34, False), (3, True)])
+def test_u8_ingest_long_chunks_persistent_path(dd, M, fm):
+    """raw u8 input long enough for the persistent decimating kernel's u8 flavour (>= 64 interior tiles),
+    two chunks with carried state, against the oracle on the widened samples"""
+    import ctypes as C
+    hip = dd.hip
+    lib = hip.lib()
+    fs = 2048000
+    L1, L2 = 64 * 6144 * 2 + 12345, 300001
+    raw = O.synth_iq_fm(L1 + L2, fs, 41, f_carrier=30e3)
+    d = hip.DevArray.from_host(raw.reshape(-1))
+    taps = np.ascontiguousarray(O.win_blackmanharris(151))
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 151, hip.cycles_q64(30000.0, fs), M,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_U8_INPUT | (hip.DD_CHAIN_FM if fm else 0)))
+    outs = []
+    pos = 0
+    for n in (L1, L2):
+        no = lib.dd_chain_out_count(h, n)
+        o = hip.DevArray(max(1, no), np.float32 if fm else np.complex64)
+        got = C.c_int64(0)
+        hip.check(lib.dd_chain_process(h, d.ptr + 2 * pos, o.ptr, n, C.byref(got), None))
+        assert got.value == no
+        outs.append(o.to_host()[:no])
+        pos += n
+    lib.dd_chain_destroy(h)
+    got = np.concatenate(outs)
+    x = O.grid_c64(raw)
+    y = O.FilterState(taps).applyOn(O.nco(x, 30000.0, fs, 0))[::M]
+    if fm:
+        a_ref, _ = O.fm_demod(y, None)
+        fm_check(got, a_ref, np.abs(y[1:] * np.conj(y[:-1])))
+    else:
+        assert rel_err(got, y) < FIR_TOL
