@@ -473,11 +473,24 @@ struct WsGeom {
     static constexpr int LDS_BYTES = (NONUNIT_OFF + 16 + 15) & ~15;
 };
 
-template <int NKS>
+template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ws_load(const DDChainParams& P, int b, int vt, float4 (&raw)[WsGeom<NKS>::NIT]) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    if (U8) {
+        // raw u8 I,Q pairs (source.py:117-118): two samples = one dword per lane, widened here
+        const char* base = reinterpret_cast<const char*>(P.in) + 2 * ns;                            // wave-uniform
+#pragma unroll
+        for (int it = 0; it < W::NIT; ++it) {
+            int q = vt + WS_VTHREADS * it;
+            if (WS_VTHREADS * (it + 1) > W::NQ) q = q < W::NQ ? q : W::NQ - 1;
+            const uint32_t d = *reinterpret_cast<const uint32_t*>(base + 4u * (unsigned)q);
+            raw[it] = make_float4((float)(d & 0xff) - 127.5f, (float)((d >> 8) & 0xff) - 127.5f,
+                                  (float)((d >> 16) & 0xff) - 127.5f, (float)(d >> 24) - 127.5f);
+        }
+        return;
+    }
     const char* base = reinterpret_cast<const char*>(reinterpret_cast<const float2*>(P.in) + ns);   // wave-uniform
 #pragma unroll
     for (int it = 0; it < W::NIT; ++it) {
@@ -608,7 +621,7 @@ __device__ __forceinline__ float dd_wave_max(float m) {
 //   they overwrite the buffer -- they get there thousands of cycles later, so the wait is
 //   free); conversion of tile p with the scale published during phase p-1; tile max and
 //   group phasors of tile p+1 for the next phase; barrier.
-template <int NKS>
+template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
                                              float4 (&rcur)[WsGeom<NKS>::NIT], float4 (&rnext)[WsGeom<NKS>::NIT],
                                              float4 (&rld)[WsGeom<NKS>::NIT],
@@ -624,7 +637,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     const float2* yb = reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16);
     {
         const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
-        dd_ws_load<NKS>(P, bl, vt, rld);
+        dd_ws_load<NKS, U8>(P, bl, vt, rld);
     }
     DD_STAMP(0)
     if (p >= 2 && p - 2 < n) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
@@ -678,7 +691,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     DD_STAMP(4)
 }
 
-template <int NKS>
+template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -689,8 +702,8 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
     // the first two tiles are requested before anything else: their (cold) HBM latency covers the
     // phasor table fetches below and the tap copy of the kernel prologue
     float4 r0[W::NIT], r1[W::NIT], r2[W::NIT];
-    dd_ws_load<NKS>(P, t_begin, vt, r0);
-    dd_ws_load<NKS>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
+    dd_ws_load<NKS, U8>(P, t_begin, vt, r0);
+    dd_ws_load<NKS, U8>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
     // tile-relative NCO phasors of this lane's sample positions (loop invariant)
     float2 wk[W::NIT][2];
 #pragma unroll
@@ -714,9 +727,9 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
     }
     if (taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -835,7 +848,8 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     }
 }
 
-template <int NKS>
+// U8: the input is raw interleaved uint8 I,Q (2 B/sample) instead of complex64; only the vector waves' loads differ
+template <int NKS, bool U8>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -867,7 +881,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3
     if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS>(P, taps, smem, t_begin, t_end, nph);
-    else dd_ws_vector<NKS>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ws_vector<NKS, U8>(P, taps, smem, t_begin, t_end, nph);
 }
 
 // ============================================================================
@@ -964,7 +978,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -986,7 +1001,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     }
     // interior tiles: whole span inside the chunk, all outputs emitted, aligned complex64
     int t_first = 1, t_last = 1;
-    const bool aligned = !(P.flags & DD_CHAIN_U8_INPUT) && ((reinterpret_cast<uintptr_t>(P.in) & 15) == 0);
+    const bool u8in = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(P.in) & (u8in ? 3 : 15)) == 0;
     if (aligned && P.nblocks > 2) {
         // tile b: ns = b*ADV - 32 - HALO >= 0 ; ns + SPAN <= L ; b*ADV - 32 + T <= Ld
         int64_t lo = (32 + G::HALO + MF_ADV - 1) / MF_ADV;
@@ -1006,7 +1022,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
         const int ncu = dd_cu_count() < DD_STAMP_WGS ? dd_cu_count() : DD_STAMP_WGS;
         const int cus = n_edge < ncu / 2 ? ncu - n_edge : ncu / 2;
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
-        hipLaunchKernelGGL(k_chain_mfma_ws<NKS>, dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
+        if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true>), dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
+        else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false>), dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
         if (want_stamps) {
             static int printed = 0;

@@ -612,3 +612,36 @@ def test_u8_ingest_long_chunks_persistent_path(dd, M, fm):
         fm_check(got, a_ref, np.abs(y[1:] * np.conj(y[:-1])))
     else:
         assert rel_err(got, y) < FIR_TOL
+
+
+@pytest.mark.parametrize("fm", [True, False])
+def test_u8_ingest_mfma_interior_tiles(dd, fm):
+    """raw u8 input through the MFMA path's persistent kernel (M = 1, interior tiles read and widen the bytes
+    themselves), two chunks, against the oracle"""
+    import ctypes as C
+    hip = dd.hip
+    lib = hip.lib()
+    fs = 2400000
+    L1, L2 = 70001, 50000
+    raw = O.synth_iq_fm(L1 + L2, fs, 43)
+    d = hip.DevArray.from_host(raw.reshape(-1))
+    taps = np.ascontiguousarray(O.win_hamming(255))
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, hip.cycles_q64(25000.0, fs), 1,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_U8_INPUT | (hip.DD_CHAIN_FM if fm else 0)))
+    outs, pos = [], 0
+    for n in (L1, L2):
+        no = lib.dd_chain_out_count(h, n)
+        o = hip.DevArray(no, np.float32 if fm else np.complex64)
+        hip.check(lib.dd_chain_process(h, d.ptr + 2 * pos, o.ptr, n, None, None))
+        outs.append(o.to_host())
+        pos += n
+    assert lib.dd_chain_path(h) == 1
+    lib.dd_chain_destroy(h)
+    got = np.concatenate(outs)
+    y = O.FilterState(taps).applyOn(O.nco(O.grid_c64(raw), 25000.0, fs, 0))
+    if fm:
+        a_ref, _ = O.fm_demod(y, None)
+        fm_check(got, a_ref, np.abs(y[1:] * np.conj(y[:-1])))
+    else:
+        assert rel_err(got, y) < FIR_TOL
