@@ -470,7 +470,8 @@ struct WsGeom {
     static constexpr int SCALE_OFF = RED_OFF + 2 * WS_VWAVES * 4; // [4] float
     static constexpr int YDONE_OFF = SCALE_OFF + 16;              // int: waves that finished reading the y-buffer
     static constexpr int NONUNIT_OFF = YDONE_OFF + 16;            // [4] int: "some wave saw a tile part outside the unit range", per tile slot
-    static constexpr int LDS_BYTES = (NONUNIT_OFF + 16 + 15) & ~15;
+    static constexpr int TILEW_OFF = NONUNIT_OFF + 16;            // [4] float2: NCO phasor of a tile's first sample (complex-output flavour)
+    static constexpr int LDS_BYTES = (TILEW_OFF + 32 + 15) & ~15;
 };
 
 template <int NKS, bool U8>
@@ -546,8 +547,9 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
 }
 
 // epilogue of one 256-output unit u of tile b: lane handles outputs o = 256u + 4 lane + {0..3}
-template <int NKS>
-__device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int b, int u, int lane, const float2* yb, float unscale) {
+template <int NKS, bool CX = false>
+__device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int b, int u, int lane, const float2* yb, float unscale,
+                                                    const float2* tilew = nullptr) {
     const int o = 256 * u + 4 * lane;
     if (o < 32) return;                                    // the tile's first column belongs to the previous tile
     // planar y-buffer: yb points at real[0]; imaginary plane YPLANE_F floats further
@@ -588,8 +590,16 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
         // complex output: undo the power-of-two scales and apply the tile's NCO factor
         float2 t = make_float2(unscale, 0.f);
         if (P.flags & DD_CHAIN_NCO) {
-            const int64_t ns = (int64_t)b * MF_ADV - 32 - MfmaGeom<NKS>::HALO;
-            const float2 ph = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
+            float2 ph;
+            if (CX) {
+                // complex-output flavour: the tile's phasor was fetched two phases ago by one lane and left in
+                // LDS -- fetched from the table here, its vmcnt wait would drain the vector waves' in-flight tile
+                // loads (vmcnt retires in order) and stall a matrix wave for a memory latency per phase
+                ph = *tilew;
+            } else {
+                const int64_t ns = (int64_t)b * MF_ADV - 32 - MfmaGeom<NKS>::HALO;
+                ph = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
+            }
             t = make_float2(ph.x * unscale, ph.y * unscale);
         }
         const float2 o0 = dd_cmul(make_float2(y01.x, y01.y), t), o1 = dd_cmul(make_float2(y01.z, y01.w), t);
@@ -621,7 +631,7 @@ __device__ __forceinline__ float dd_wave_max(float m) {
 //   they overwrite the buffer -- they get there thousands of cycles later, so the wait is
 //   free); conversion of tile p with the scale published during phase p-1; tile max and
 //   group phasors of tile p+1 for the next phase; barrier.
-template <int NKS, bool U8>
+template <int NKS, bool U8, bool CX>
 __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
                                              float4 (&rcur)[WsGeom<NKS>::NIT], float4 (&rnext)[WsGeom<NKS>::NIT],
                                              float4 (&rld)[WsGeom<NKS>::NIT],
@@ -635,6 +645,12 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     float* redall = reinterpret_cast<float*>(smem + W::RED_OFF);
     float* scales = reinterpret_cast<float*>(smem + W::SCALE_OFF);
     const float2* yb = reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16);
+    // complex-output flavour: one lane fetches tile p's start phasor BEFORE this phase's tile loads (so that
+    // waiting for it does not wait for them) and publishes it in LDS for the epilogues of phase p+2
+    float2* tilew = reinterpret_cast<float2*>(smem + W::TILEW_OFF);
+    const bool mk_tilew = CX && vt == 0 && p < n && (P.flags & DD_CHAIN_NCO);
+    float2 tw = make_float2(1.f, 0.f);
+    if (CX && mk_tilew) tw = dd_phasor((uint64_t)(P.abs0 + (int64_t)(t_begin + p) * MF_ADV - 32 - G::HALO) * P.cyc, P.nco_tbl);
     {
         const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
         dd_ws_load<NKS, U8>(P, bl, vt, rld);
@@ -642,8 +658,10 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     DD_STAMP(0)
     if (p >= 2 && p - 2 < n) {              // epilogue of tile p-2 (y-buffer written in phase p-1)
         const float unscale = taps.inv_tapscale / scales[(p - 2) & 3];
-        dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
+        if (CX) dd_ws_epilogue_unit<NKS, true>(P, t_begin + p - 2, vw, lane, yb, unscale, tilew + ((p - 2) & 3));
+        else dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, vw, lane, yb, unscale);      // units 12..15: matrix waves
     }
+    if (CX && mk_tilew) tilew[p & 3] = tw;
     if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + W::YDONE_OFF), 1);   // this wave is done with the y-buffer
     DD_STAMP(1)
     if (p < n) {                                            // convert tile p (max published in phase p-1)
@@ -691,7 +709,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     DD_STAMP(4)
 }
 
-template <int NKS, bool U8>
+template <int NKS, bool U8, bool CX>
 __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -727,9 +745,9 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
-        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS, U8>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
     }
     if (taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -738,7 +756,7 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
 }
 
 // ------------------------------------------------------------------ matrix waves
-template <int NKS>
+template <int NKS, bool CX>
 __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -762,6 +780,10 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
         const bool go = p >= 1 && p <= n;
         if (p >= 2 && p - 2 < n) {          // the matrix waves take the last 4 epilogue units
             const float unscale = taps.inv_tapscale / reinterpret_cast<const float*>(smem + W::SCALE_OFF)[(p - 2) & 3];
+            if (CX) dd_ws_epilogue_unit<NKS, true>(P, t_begin + p - 2, WS_VWAVES + mw, lane,
+                                                   reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale,
+                                                   reinterpret_cast<const float2*>(smem + W::TILEW_OFF) + ((p - 2) & 3));
+            else
             dd_ws_epilogue_unit<NKS>(P, t_begin + p - 2, WS_VWAVES + mw, lane,
                                      reinterpret_cast<const float2*>(smem + W::YBUF_OFF + 16), unscale);
         }
@@ -848,8 +870,11 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     }
 }
 
-// U8: the input is raw interleaved uint8 I,Q (2 B/sample) instead of complex64; only the vector waves' loads differ
-template <int NKS, bool U8>
+// U8: the input is raw interleaved uint8 I,Q (2 B/sample) instead of complex64; only the vector waves' loads differ.
+// CX: complex-output flavour (launched only without DD_CHAIN_FM): tile phasors handed over through LDS.  CX = false is
+// the code as it was before the flavour existed, token for token -- this kernel's speed depends on code generation in
+// ways its instruction mix does not explain, so the headline instantiation is kept byte-identical (assembly diff).
+template <int NKS, bool U8, bool CX>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -880,8 +905,8 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3
-    if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS>(P, taps, smem, t_begin, t_end, nph);
-    else dd_ws_vector<NKS, U8>(P, taps, smem, t_begin, t_end, nph);
+    if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS, CX>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ws_vector<NKS, U8, CX>(P, taps, smem, t_begin, t_end, nph);
 }
 
 // ============================================================================
@@ -978,8 +1003,10 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -1022,8 +1049,12 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
         const int ncu = dd_cu_count() < DD_STAMP_WGS ? dd_cu_count() : DD_STAMP_WGS;
         const int cus = n_edge < ncu / 2 ? ncu - n_edge : ncu / 2;
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
-        if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true>), dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
-        else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false>), dim3(grid + n_edge), dim3(WS_THREADS), lds_ws, s, P, t, t_first, t_last, grid);
+        const bool cx = !(P.flags & DD_CHAIN_FM);
+        const dim3 g(grid + n_edge), b(WS_THREADS);
+        if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
+        else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
+        else if (cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
+        else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
         if (want_stamps) {
             static int printed = 0;
