@@ -202,7 +202,8 @@ struct dd_iir {
     double b[DD_IIR_MAXN], a[DD_IIR_MAXN];
     double zi[DD_IIR_MAXN];
     double* state;          // device: 2 * (n-1) doubles (re, im)
-    double* mats;           // device: block-parallel path, [M_hi, M_lo, MG_hi, MG_lo] each IIR_S x IIR_S (see below)
+    double* mats;           // device: block-parallel path, [M_hi, M_lo, MG_hi, MG_lo] each IIR_S x IIR_S (see below), short blocks
+    double* mats_long;      //         the same for the long block length
 };
 struct DDIirCoef {
     int n;
@@ -277,6 +278,7 @@ extern "C" int dd_iir_create(dd_iir** h, const double* b, const double* a, int n
     }
     f->state = nullptr;
     f->mats = nullptr;
+    f->mats_long = nullptr;
     hipError_t e = hipMalloc((void**)&f->state, sizeof(double) * 2 * (DD_IIR_MAXN - 1));
     if (e != hipSuccess) {
         delete f;
@@ -297,6 +299,7 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
     if (h) {
         hipFree(h->state);
         if (h->mats) hipFree(h->mats);
+        if (h->mats_long) hipFree(h->mats_long);
         delete h;
     }
     return DD_OK;
@@ -319,7 +322,11 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 // STEPPING the homogeneous recurrence LB times from each unit vector (repeated squaring loses
 // the digits again), stored as double-double, and applied in double-double arithmetic; the
 // state handed from block to block is a plain double, exactly as in the sequential form.
-#define IIR_LB 256
+// block length: 256 samples, or 1024 from 2^25 samples up (measured on 2^24 / 2^26 complex128 samples: 256 ->
+// 1.45 / 3.69 ms, 1024 -> 1.82 / 2.72 ms: long blocks shorten the scan, short blocks keep the block kernels wide)
+#define IIR_LB_SHORT 256
+#define IIR_LB_LONG 1024
+#define IIR_LONG_FROM ((int64_t)1 << 25)
 #define IIR_G 256
 #define IIR_S (DD_IIR_MAXN - 1)
 #define IIR_MAT (IIR_S * IIR_S)
@@ -339,7 +346,7 @@ __device__ __forceinline__ void dd_iir_step(const DDIirCoef& C, int N, double (&
 // run each block from its start state in blk[], write y, last block saves the carried state
 __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ in, double* __restrict__ out, int64_t n, int ncomp,
                                                     DDIirCoef C, double* __restrict__ blk, int64_t nb, int write_out,
-                                                    double* __restrict__ state, int save) {
+                                                    double* __restrict__ state, int save, int lb) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= nb * ncomp) return;
     const int64_t b = t / ncomp;
@@ -353,8 +360,8 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
 #pragma unroll
         for (int k = 0; k < IIR_S; ++k) if (k < N - 1) z[k] = slot[k];
     }
-    const int64_t i0 = b * IIR_LB;
-    const int64_t i1 = i0 + IIR_LB < n ? i0 + IIR_LB : n;
+    const int64_t i0 = b * lb;
+    const int64_t i1 = i0 + lb < n ? i0 + lb : n;
     // the recurrence is serial, its input is not: 16 samples are requested at once (a lane's reads are a
     // 4 KiB stride apart from its neighbours', so each costs a full memory latency when taken one by one)
     for (int64_t i = i0; i < i1; i += 16) {
@@ -475,7 +482,7 @@ __global__ void k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncom
 
 // M = A^LB by stepping the homogeneous DF2T recurrence (z0' = z1 - a1 z0, ...) from each unit
 // vector, MG = M^G by stepping the block map; both in __float128, split into double-double.
-static void iir_block_matrices(const dd_iir* h, double* out /* 4 * IIR_MAT */) {
+static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 4 * IIR_MAT */) {
     const int S = h->n - 1;
     typedef __float128 q_t;
     q_t M[IIR_S][IIR_S], MG[IIR_S][IIR_S];
@@ -483,7 +490,7 @@ static void iir_block_matrices(const dd_iir* h, double* out /* 4 * IIR_MAT */) {
         q_t z[IIR_S + 1];
         for (int k = 0; k <= IIR_S; ++k) z[k] = 0;
         z[j] = 1;
-        for (int t = 0; t < IIR_LB; ++t) {
+        for (int t = 0; t < lb; ++t) {
             const q_t y = z[0];
             for (int k = 0; k < S; ++k) z[k] = (k + 1 < S ? z[k + 1] : (q_t)0) - (q_t)h->a[k + 1] * y;
         }
@@ -515,12 +522,14 @@ static void iir_block_matrices(const dd_iir* h, double* out /* 4 * IIR_MAT */) {
 
 static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int ncomp, int carry, hipStream_t s) {
     const int S = h->n - 1;
-    const int64_t nb = (n + IIR_LB - 1) / IIR_LB, ng = (nb + IIR_G - 1) / IIR_G;
-    if (!h->mats) {                                         // first long input on this handle
+    const int lb = n >= IIR_LONG_FROM ? IIR_LB_LONG : IIR_LB_SHORT;
+    const int64_t nb = (n + lb - 1) / lb, ng = (nb + IIR_G - 1) / IIR_G;
+    double*& mats = (lb == IIR_LB_LONG) ? h->mats_long : h->mats;
+    if (!mats) {                                            // first input of this length class on this handle
         double hm[4 * IIR_MAT];
-        iir_block_matrices(h, hm);
-        DD_HIP_CHECK(hipMalloc((void**)&h->mats, sizeof(hm)));
-        DD_HIP_CHECK(hipMemcpy(h->mats, hm, sizeof(hm), hipMemcpyHostToDevice));
+        iir_block_matrices(h, lb, hm);
+        DD_HIP_CHECK(hipMalloc((void**)&mats, sizeof(hm)));
+        DD_HIP_CHECK(hipMemcpy(mats, hm, sizeof(hm), hipMemcpyHostToDevice));
     }
     double *blk = nullptr, *grp = nullptr;
     DD_HIP_CHECK(hipMalloc((void**)&blk, sizeof(double) * IIR_S * nb * ncomp));
@@ -533,14 +542,14 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     DDIirCoef C;
     iir_coef(h, &C);
     const unsigned gb = (unsigned)((nb * ncomp + 255) / 256), gg = (unsigned)((ng * ncomp + 63) / 64);
-    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0);
+    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
     // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
     // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
 #define DD_IIR_SCAN(SS)                                                                                              \
     case SS:                                                                                                         \
-        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, h->mats, 0);             \
-        hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, h->mats, h->state, carry ? 0 : 1); \
-        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, h->mats, 2);             \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 0);             \
+        hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, mats, h->state, carry ? 0 : 1); \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 2);             \
         break;
     switch (S) {
         DD_IIR_SCAN(1) DD_IIR_SCAN(2) DD_IIR_SCAN(3) DD_IIR_SCAN(4) DD_IIR_SCAN(5) DD_IIR_SCAN(6) DD_IIR_SCAN(7) DD_IIR_SCAN(8)
@@ -548,7 +557,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         default: break;
     }
 #undef DD_IIR_SCAN
-    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0);
+    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
     hipFree(blk);
@@ -562,7 +571,7 @@ extern "C" int dd_iir_f64(dd_iir* h, const double* in, double* out, int64_t n, i
     DD_REQUIRE(h && n >= 0, "h/n");
     if (n == 0) return DD_OK;
     DD_REQUIRE(in && out, "null buffer");
-    if (n >= 16 * IIR_LB && h->n >= 2 && in != out) return iir_parallel(h, in, out, n, is_complex ? 2 : 1, carry, dd_stream(stream));
+    if (n >= 16 * IIR_LB_SHORT && h->n >= 2 && in != out) return iir_parallel(h, in, out, n, is_complex ? 2 : 1, carry, dd_stream(stream));
     DDIirCoef C;
     iir_coef(h, &C);
     if (!carry) {        // plain lfilter: zero state, nothing kept (filters.py:75)

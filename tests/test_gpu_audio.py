@@ -393,3 +393,17 @@ def test_demod_amflt_vs_scipy(dd, cplx):
     assert isinstance(out, dd.hip.DevArray)
     ref32 = ss.lfilter(b, a, np.abs(sig.astype(np.complex64)) if cplx else np.abs(sig), zi=ss.lfilter_zi(b, a))[0]
     assert rel_err(out.to_host(), ref32) < (1e-6 if cplx else 1e-9)
+
+
+def test_iir_block_parallel_long_block_length(dd):
+    """from 2^25 samples the block-parallel IIR switches to 1024-sample blocks (its own double-double block map);
+    state carried into a following short chunk"""
+    import scipy.signal as ss
+    rng = np.random.default_rng(12)
+    n = (1 << 25) + 12345
+    x = rng.standard_normal(n + 50000)
+    f = dd.filters.butter(2048000, 20000.0)
+    b, a = np.asarray(f.getB), np.asarray(f.getA)
+    got = np.concatenate([f.applyOn(x[:n]), f.applyOn(x[n:])])
+    ref = ss.lfilter(b, a, x, zi=ss.lfilter_zi(b, a))[0]
+    assert rel_err(got, ref) < 1e-7
