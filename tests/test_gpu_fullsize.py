@@ -143,3 +143,57 @@ def test_oracle_windows_of_the_full_run(run, where):
     d = np.abs(np.angle(np.exp(1j * (got - a_ref))))
     assert len(got) == len(a_ref) and len(a_ref) >= W - 1
     assert np.max(d) < TOL and np.median(d) < 2e-6
+
+
+def test_decimating_kernels_agree_with_the_dense_path_at_full_size(run):
+    """C4-shaped front end at 2^26 samples: the persistent decimating kernel (BH151, /34, complex output) against the
+    M = 1 MFMA path's output taken every 34th sample -- two unrelated kernels; then its raw-u8 flavour against the
+    complex64 flavour on the same samples; then FM on top against the angles of the complex outputs."""
+    t, hip, lib = run.torch, run.hip, run.lib
+    n, M, K = run.n, 34, 151
+    k = np.arange(K)
+    bh = np.ascontiguousarray(0.35875 - 0.48829 * np.cos(2 * np.pi * k / (K - 1)) + 0.14128 * np.cos(4 * np.pi * k / (K - 1))
+                              - 0.01168 * np.cos(6 * np.pi * k / (K - 1)))
+
+    def chain(decim, flags):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), bh.ctypes.data_as(C.POINTER(C.c_double)), K, hip.cycles_q64(30000.0, 2048000),
+                                      decim, flags), "dd_chain_create")
+        return h
+
+    nd = len(range(0, n, M))
+    # dense reference: complex64 output of the M = 1 path (512 MiB), every 34th sample
+    h = chain(1, hip.DD_CHAIN_NCO)
+    full = t.empty((n, 2), dtype=t.float32, device=run.dev)
+    assert run.process(h, run.x.data_ptr(), full.data_ptr(), n) == n
+    assert lib.dd_chain_path(h) == 1
+    lib.dd_chain_destroy(h)
+    ref = full[::M].contiguous()
+    del full
+    scale = float(ref.abs().max())
+    # decimating kernel, complex64 input
+    h = chain(M, hip.DD_CHAIN_NCO)
+    dec = t.empty((nd, 2), dtype=t.float32, device=run.dev)
+    assert run.process(h, run.x.data_ptr(), dec.data_ptr(), n) == nd
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert float((dec - ref).abs().max()) < 4e-6 * scale            # two f32 paths, each within 2e-6 of the float64 result
+    # raw-u8 flavour on the same samples (the bench input sits on the u8 grid)
+    raw = (run.x + 127.5).round().clamp(0, 255).to(t.uint8).contiguous()
+    h = chain(M, hip.DD_CHAIN_NCO | hip.DD_CHAIN_U8_INPUT)
+    dec8 = t.empty((nd, 2), dtype=t.float32, device=run.dev)
+    assert run.process(h, raw.data_ptr(), dec8.data_ptr(), n) == nd
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert float((dec8 - dec).abs().max()) < 2e-6 * scale
+    # FM flavour: angles of consecutive decimated outputs
+    h = chain(M, hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM)
+    ang = t.empty(nd, dtype=t.float32, device=run.dev)
+    assert run.process(h, run.x.data_ptr(), ang.data_ptr(), n) == nd - 1
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    zc = t.view_as_complex(dec.double().contiguous())
+    ref_ang = t.angle(zc[1:] * zc[:-1].conj())
+    d = t.remainder(ang[:nd - 1].double() - ref_ang + np.pi, 2 * np.pi) - np.pi
+    strong = (zc[1:] * zc[:-1].conj()).abs() >= 1e-3 * float((zc[1:] * zc[:-1].conj()).abs().median())
+    assert float(d[strong].abs().max()) < TOL
