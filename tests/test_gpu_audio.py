@@ -407,3 +407,33 @@ def test_iir_block_parallel_long_block_length(dd):
     got = np.concatenate([f.applyOn(x[:n]), f.applyOn(x[n:])])
     ref = ss.lfilter(b, a, x, zi=ss.lfilter_zi(b, a))[0]
     assert rel_err(got, ref) < 1e-7
+
+
+def test_afsk_front_end_matches_the_reference_run(dd, golden_dir):
+    """config 1's route (decode_afsk1200.py:67-98: offsetFreq -> blackmanHarris(151) -> bwLim(22050) -> demod_fm ->
+    butter band-pass) on the device against the audio the reference itself produced for the same synthetic
+    recording (tests/golden/afsk.npz, captured from its getMsg run), and the bit decisions behind it"""
+    from directdemod_amd import afsk, constants
+    g = _load(golden_dir, "afsk.npz")
+    fs, bw = int(g["fs_iq"]), int(g["bw"])
+    raw = O.synth_afsk_iq(int(g["n_bits"]), fs, int(g["seed"]))
+    src = dd.source.IQarray(raw, fs)
+    ck = dd.chunker.chunker(src)
+    sig = dd.comm.commSignal(fs)
+    bhf, fm = dd.filters.blackmanHarris(151), dd.demod_fm.demod_fm()
+    for a, b in ck.getChunks:
+        c = dd.comm.commSignal(fs, src.read(a, b), ck)
+        c.offsetFreq(0)
+        c.filter(bhf)
+        c.bwLim(bw)
+        sig.extend(c)
+    sig.funcApply(fm.demod)
+    sig.filter(dd.filters.butter(sig.sampRate, 1200 - 500, 2200 + 500, typeFlt=constants.FLT_BP))
+    audio = np.asarray(sig.signal, dtype=np.float64)
+    ref = g["audio"]
+    assert sig.sampRate == bw and audio.shape == ref.shape
+    assert np.max(np.abs(audio - ref)) < 5e-4 * np.max(np.abs(ref))          # float32 chain in front of a resonant band-pass
+    bf = afsk.binary_filter(audio, bw)
+    bf_ref = O.afsk_binary_filter(ref, O.afsk_tables(bw)[0])
+    strong = np.abs(bf_ref) > 0.05 * np.max(np.abs(bf_ref))
+    assert np.array_equal(np.sign(bf[strong]).astype(np.int8), g["sign"][strong])

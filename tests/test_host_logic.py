@@ -151,3 +151,12 @@ def test_filter_ctor_rules_and_errors():
     r = filters.remez(10000000, [[0, 100e3], [150e3, 4999999]], [1, 0], ntaps=127)
     assert len(r.getB) == 127
     assert not filters.butter(2048000, 20000)._fusable()
+
+
+def test_afsk_correlator_tables_match_the_oracle():
+    from directdemod_amd import afsk
+    from oracle import dd_oracle as O
+    for bw in (22050, 44100, 48000):
+        tb, spb = afsk.correlator_tables(bw)
+        tb_o, spb_o = O.afsk_tables(bw)
+        assert spb == spb_o and np.array_equal(tb, tb_o)
