@@ -790,9 +790,15 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
                 if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
                 // every workgroup must be resident from the start (a persistent grid with queued workgroups
                 // runs in rounds): ask the runtime how many fit (LDS and registers)
-                int per_cu = 0;
-                if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
+                static size_t occ_lds[2] = {0, 0};          // the answer depends on (flavour, LDS size) only: asked once per change
+                static int occ_val[2] = {0, 0};
+                int per_cu = occ_val[u8in];
+                if (occ_lds[u8in] != lds_p || per_cu < 1) {
+                    if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
+                    occ_lds[u8in] = lds_p;
+                    occ_val[u8in] = per_cu;
+                }
                 int grid = ncu * per_cu;
                 if (grid > hi - lo) grid = (int)(hi - lo);
                 if (grid >= 8) grid &= ~7;
