@@ -394,3 +394,329 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
     *n_peaks = (int)peaks.size();
     return DD_OK;
 }
+
+// ---------------------------------------------------------------- 8f-2: accurate-sync windows, batched
+// getAccurateSync (decode_noaa.py:808-880) cuts one +-width window of IQ samples around every crude sync
+// and runs, per window:  offsetFreq -> filter(blackmanHarris(151, zeroPhase)) -> demod_fm -> demod_am
+// (:852) and then __correlateAndFindPeaks with the zero-phase hamming(492) pre-filter (:677-767, :853).
+// The windows are independent and equally long, so the whole chain runs once over [windows][samples]
+// arrays: a dozen launches per batch instead of ~40 launches, ~25 allocations and 8 host round trips per
+// window.  Each stage is the arithmetic of the per-window entry points (same kernels or the same
+// device functions); only the prefix sums (own scan instead of hipcub) and the batched FFT plan may
+// round differently, at the 1e-13 level of the correlation.
+#include "dd_chain_kernels.h"
+#include "dd_filtfilt_kernels.h"
+
+template <bool U8>
+__global__ void __launch_bounds__(256) k_sync_front(const void* __restrict__ iq, const int64_t* __restrict__ starts, int64_t L,
+                                                    uint64_t cyc, const float2* __restrict__ tbl, float2* __restrict__ X) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    const int64_t g = starts[blockIdx.y] + i;
+    float2 v;
+    if (U8) {
+        const uchar2 u = reinterpret_cast<const uchar2*>(iq)[g];
+        v = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+    } else {
+        v = reinterpret_cast<const float2*>(iq)[g];
+    }
+    X[(int64_t)blockIdx.y * L + i] = dd_cmul(v, dd_phasor((uint64_t)i * cyc, tbl));      // sample index restarts per window (Q5)
+}
+
+// demod_fm (stateless) straight into the FFT buffer: W[b][j] = (angle(Y[j+1] conj Y[j]), 0)
+__global__ void __launch_bounds__(256) k_sync_fm(const float2* __restrict__ Y, int64_t L, double2* __restrict__ W) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= L - 1) return;
+    const float2* y = Y + (int64_t)blockIdx.y * L;
+    W[(int64_t)blockIdx.y * (L - 1) + j] = make_double2((double)dd_fm_angle(y[j + 1], y[j]), 0.0);
+}
+
+__global__ void __launch_bounds__(256) k_hilbert_mask_b(double2* __restrict__ X, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double h;
+    if ((n & 1) == 0) h = (i == 0 || i == n / 2) ? 1.0 : (i < n / 2 ? 2.0 : 0.0);
+    else h = (i == 0) ? 1.0 : (i < (n + 1) / 2 ? 2.0 : 0.0);
+    double2* p = X + (int64_t)blockIdx.y * n + i;
+    *p = make_double2(p->x * h, p->y * h);
+}
+__global__ void __launch_bounds__(256) k_cplx_abs_b(const double2* __restrict__ in, double* __restrict__ out, int64_t n, double inv_n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double2 v = in[(int64_t)blockIdx.y * n + i];
+    out[(int64_t)blockIdx.y * n + i] = hypot(v.x * inv_n, v.y * inv_n);
+}
+
+// P[b][i] = sum h[b][0..i), Q likewise of h^2; one workgroup walks one window in tiles of 4096
+__global__ void __launch_bounds__(1024) k_scan_pq(const double* __restrict__ h, double* __restrict__ P, double* __restrict__ Q, int64_t n) {
+    __shared__ double sp[16], sq[16];
+    h += (int64_t)blockIdx.x * n;
+    P += (int64_t)blockIdx.x * (n + 1);
+    Q += (int64_t)blockIdx.x * (n + 1);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double cp = 0.0, cq = 0.0;
+    if (t == 0) { P[0] = 0.0; Q[0] = 0.0; }
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i0 = base + 4 * t;
+        double p[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double v = (i0 + j < n) ? h[i0 + j] : 0.0;
+            p[j] = j ? p[j - 1] + v : v;
+            q[j] = j ? q[j - 1] + v * v : v * v;
+        }
+        double tp = p[3], tq = q[3];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double a = __shfl_up(tp, d), c = __shfl_up(tq, d);
+            if (lane >= d) { tp += a; tq += c; }
+        }
+        if (lane == 63) { sp[wv] = tp; sq[wv] = tq; }
+        double ep = __shfl_up(tp, 1), eq = __shfl_up(tq, 1);
+        if (lane == 0) { ep = 0.0; eq = 0.0; }
+        __syncthreads();
+        double totp = 0.0, totq = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            if (w == wv) { ep += cp + totp; eq += cq + totq; }
+            totp += sp[w];
+            totq += sq[w];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) { P[i0 + j + 1] = ep + p[j]; Q[i0 + j + 1] = eq + q[j]; }
+        cp += totp;
+        cq += totq;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_xcorr_runs_b(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
+                                                      const DDRuns R, double vv, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    P += (int64_t)blockIdx.y * (n + 1);
+    Q += (int64_t)blockIdx.y * (n + 1);
+    const int64_t a0 = i + (m - 1) / 2 - (m - 1);
+    auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
+    double c = 0.0;
+    double lo = at(P, a0);
+    for (int r = 0; r < R.nr; ++r) {
+        const double hi = at(P, a0 + R.start[r + 1]);
+        c = fma(R.val[r], hi - lo, c);
+        lo = hi;
+    }
+    double e = at(Q, a0 + m) - at(Q, a0);
+    if (!(e > 1e-13 * Q[n])) { c = 0.0; e = 0.0; }
+    out[(int64_t)blockIdx.y * n + i] = c / sqrt(e * vv);
+}
+
+// Peak pick of one window (decode_noaa.py:713-762) when the window is shorter than the 0.45 s group
+// distance: expectedPeaks K = 2, every candidate falls in one group, and the pick is the first index of
+// the maximum provided it exceeds the threshold.  Also the two "extras": peak height and the mean of the
+// next needle-length of the envelope.
+struct DDPk {
+    double m1, m2, l1, l2;
+    int64_t i1;
+    int nan;
+};
+__device__ __forceinline__ DDPk dd_pk_merge(const DDPk& a, const DDPk& b) {
+    DDPk r;
+    if (b.m1 > a.m1 || (b.m1 == a.m1 && b.i1 < a.i1)) {
+        r.m1 = b.m1; r.i1 = b.i1; r.m2 = fmax(a.m1, b.m2);
+    } else {
+        r.m1 = a.m1; r.i1 = a.i1; r.m2 = fmax(a.m2, b.m1);
+    }
+    if (b.l1 < a.l1) { r.l1 = b.l1; r.l2 = fmin(a.l1, b.l2); }
+    else { r.l1 = a.l1; r.l2 = fmin(a.l2, b.l1); }
+    r.nan = a.nan | b.nan;
+    return r;
+}
+__device__ __forceinline__ DDPk dd_pk_shfl(const DDPk& a, int d) {
+    DDPk r;
+    r.m1 = __shfl_down(a.m1, d); r.m2 = __shfl_down(a.m2, d);
+    r.l1 = __shfl_down(a.l1, d); r.l2 = __shfl_down(a.l2, d);
+    r.i1 = __shfl_down(a.i1, d); r.nan = __shfl_down(a.nan, d);
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) k_sync_peak(const double* __restrict__ cor, const double* __restrict__ env, int64_t n, int m,
+                                                    int64_t* __restrict__ peak, double* __restrict__ height, double* __restrict__ tsync) {
+    __shared__ DDPk sw[16];
+    __shared__ double ssum[16];
+    const double* c = cor + (int64_t)blockIdx.x * n;
+    const double* ev = env + (int64_t)blockIdx.x * n;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    DDPk a = {-inf, -inf, inf, inf, INT64_MAX, 0};
+    for (int64_t i = t; i < n; i += 1024) {
+        const double x = c[i];
+        DDPk b = {x, -inf, x, inf, i, (x != x) ? 1 : 0};
+        a = dd_pk_merge(a, b);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a = dd_pk_merge(a, dd_pk_shfl(a, d));
+    if (lane == 0) sw[wv] = a;
+    __syncthreads();
+    a = sw[0];
+    for (int w = 1; w < 16; ++w) a = dd_pk_merge(a, sw[w]);
+    double avgpk = (0.0 + a.m2 + a.m1) / 2.0;                       // mean of the K = 2 largest (:717-721)
+    avgpk -= 0.25 * (avgpk - (0.0 + a.l1 + a.l2) / 2.0);            // NOAA_PEAKHEIGHTWIGGLE (:723)
+    const bool found = !a.nan && a.m1 > avgpk;
+    const int64_t i = a.i1 - m / 2;                                 // :749
+    double s = 0.0;
+    const bool tail = found && i + 2 * (int64_t)m < n;              // :755
+    if (tail)
+        for (int64_t j = i + m + t; j < i + 2 * (int64_t)m; j += 1024) s += ev[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) ssum[wv] = s;
+    __syncthreads();
+    if (t == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += ssum[w];
+        peak[blockIdx.x] = found ? i : INT64_MIN;
+        height[blockIdx.x] = found ? a.m1 : __longlong_as_double(0x7ff8000000000000ll);
+        tsync[blockIdx.x] = tail ? tot / (double)m : __longlong_as_double(0x7ff8000000000000ll);
+    }
+}
+
+// grow-only scratch per device: the chain's intermediates (no allocation in the steady state)
+static std::mutex g_sync_mu;
+static void* g_sync_scratch[64] = {nullptr};
+static size_t g_sync_scratch_bytes[64] = {0};
+
+static int sync_scratch(size_t bytes, char** out) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (g_sync_scratch_bytes[dev] < bytes) {
+        if (g_sync_scratch[dev]) DD_HIP_CHECK(hipFree(g_sync_scratch[dev]));
+        g_sync_scratch[dev] = nullptr;
+        g_sync_scratch_bytes[dev] = 0;
+        DD_HIP_CHECK(hipMalloc(&g_sync_scratch[dev], bytes));
+        g_sync_scratch_bytes[dev] = bytes;
+    }
+    *out = (char*)g_sync_scratch[dev];
+    return DD_OK;
+}
+
+extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host, int n_windows, int64_t win_len,
+                                    uint64_t cycles_q64, const double* fir_taps_host, int fir_ntaps,
+                                    const double* pre_taps_host, int pre_ntaps, const double* needle_host, int needle_len,
+                                    double samp_rate, int64_t* peak_host, double* height_host, double* tsync_host,
+                                    void* stream) {
+    DD_REQUIRE(n_windows >= 0, "n_windows");
+    if (n_windows == 0) return DD_OK;
+    DD_REQUIRE(iq && starts_host && peak_host && height_host && tsync_host, "null buffer");
+    DD_REQUIRE(iq_kind == 0 || iq_kind == 1, "iq_kind (0 complex64, 1 uint8 pairs)");
+    DD_REQUIRE(fir_taps_host && fir_ntaps >= 1 && pre_ntaps >= 0 && (pre_taps_host || pre_ntaps == 0), "taps");
+    DD_REQUIRE(needle_host && needle_len >= 1 && samp_rate > 0, "needle/samp_rate");
+    const int64_t L = win_len, L2 = win_len - 1;
+    DD_REQUIRE(L2 >= 2 && needle_len <= L2 && L < ((int64_t)1 << 30), "window length");
+    if (!((double)L2 < 0.45 * samp_rate)) {
+        dd_set_error("dd_noaa_sync_windows: windows of %lld samples are not shorter than the 0.45 s peak distance; "
+                     "use the per-window entry points", (long long)L);
+        return DD_ERR_INVALID;
+    }
+    if (L <= 3 * fir_ntaps || (pre_ntaps && L2 <= 3 * pre_ntaps)) {
+        dd_set_error("The length of the input vector x must be greater than padlen, which is %d.",
+                     L <= 3 * fir_ntaps ? 3 * fir_ntaps : 3 * pre_ntaps);
+        return DD_ERR_INVALID;
+    }
+    if (!dd_ff_tiled_ok(fir_ntaps, 8) || (pre_ntaps && !dd_ff_tiled_ok(pre_ntaps, 8))) {
+        dd_set_error("dd_noaa_sync_windows: filter too long for the tiled zero-phase kernel");
+        return DD_ERR_INVALID;
+    }
+    // piecewise-constant needle -> runs
+    DDRuns R;
+    R.nr = 0;
+    for (int t = 0; t < needle_len; ++t) {
+        if (t == 0 || needle_host[t] != needle_host[t - 1]) {
+            if (R.nr == DD_XCORR_MAX_RUNS) {
+                dd_set_error("dd_noaa_sync_windows: the needle has more than %d constant runs", DD_XCORR_MAX_RUNS);
+                return DD_ERR_INVALID;
+            }
+            R.start[R.nr] = t;
+            R.val[R.nr] = needle_host[t];
+            ++R.nr;
+        }
+    }
+    R.start[R.nr] = needle_len;
+    double vv = 0.0;
+    for (int t = 0; t < needle_len; ++t) vv += needle_host[t] * needle_host[t];
+
+    hipStream_t s = dd_stream(stream);
+    const float2* tbl = dd_nco_table();
+    if (!tbl) {
+        dd_set_error("NCO table initialisation failed (no GPU?)");
+        return DD_ERR_NODEVICE;
+    }
+    int bmax = 64;
+    if (const char* e = getenv("DD_SYNC_BATCH")) bmax = atoi(e) > 0 ? atoi(e) : bmax;
+    const int B = n_windows < bmax ? n_windows : bmax;
+    const int64_t N1 = L + 6 * (int64_t)fir_ntaps, N2 = L2 + 6 * (int64_t)pre_ntaps;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // layout (per batch of B windows)
+    const size_t o_starts = 0;
+    const size_t o_taps1 = o_starts + al(sizeof(int64_t) * n_windows);
+    const size_t o_taps2 = o_taps1 + al(sizeof(double) * fir_ntaps);
+    const size_t o_res = o_taps2 + al(sizeof(double) * (pre_ntaps ? pre_ntaps : 1));
+    const size_t o_X = o_res + al(24 * (size_t)n_windows);
+    const size_t o_Y1 = o_X + al(sizeof(float2) * B * L);                 // X: c64 [B][L]; later the filtered IQ again
+    const size_t o_W = o_Y1 + al(sizeof(float2) * B * N1);                // Y1: c64 [B][N1]
+    const size_t o_ENV = o_W + al(sizeof(double2) * B * (L2 + 1));        // W: c128 [B][L2]; later P, Q: f64 [B][L2+1] each
+    const size_t o_F1 = o_ENV + al(sizeof(double) * B * L2);              // ENV f64 [B][L2]
+    const size_t o_H = o_F1 + al(sizeof(double) * B * N2);                // F1: f64 [B][N2]; later COR [B][L2]
+    const size_t total = o_H + al(sizeof(double) * B * L2);               // H: f64 [B][L2]
+    char* base = nullptr;
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    int rc = sync_scratch(total + 4096, &base);
+    if (rc != DD_OK) return rc;
+    int64_t* d_starts = (int64_t*)(base + o_starts);
+    double* d_taps1 = (double*)(base + o_taps1);
+    double* d_taps2 = (double*)(base + o_taps2);
+    int64_t* d_peak = (int64_t*)(base + o_res);
+    double* d_height = (double*)(base + o_res + 8 * (size_t)n_windows);
+    double* d_tsync = (double*)(base + o_res + 16 * (size_t)n_windows);
+    float2* X = (float2*)(base + o_X);
+    float2* Y1 = (float2*)(base + o_Y1);
+    double2* W = (double2*)(base + o_W);
+    double* ENV = (double*)(base + o_ENV);
+    double* F1 = (double*)(base + o_F1);
+    double* H = (double*)(base + o_H);
+    DD_HIP_CHECK(hipMemcpyAsync(d_starts, starts_host, sizeof(int64_t) * n_windows, hipMemcpyHostToDevice, s));
+    DD_HIP_CHECK(hipMemcpyAsync(d_taps1, fir_taps_host, sizeof(double) * fir_ntaps, hipMemcpyHostToDevice, s));
+    if (pre_ntaps) DD_HIP_CHECK(hipMemcpyAsync(d_taps2, pre_taps_host, sizeof(double) * pre_ntaps, hipMemcpyHostToDevice, s));
+    for (int w0 = 0; w0 < n_windows; w0 += B) {
+        const int b = n_windows - w0 < B ? n_windows - w0 : B;
+        const dim3 gL(grid1(L), b), gL2(grid1(L2), b);
+        if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+        else hipLaunchKernelGGL(k_sync_front<false>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+        dd_filtfilt_launch<float2>(X, L, Y1, X, L, L, fir_ntaps, d_taps1, b, s);            // X <- filtfilt(X): pass 2 reads only Y1
+        hipLaunchKernelGGL(k_sync_fm, gL2, dim3(256), 0, s, X, L, W);
+        hipfftHandle plan;
+        rc = get_plan(&plan, HIPFFT_Z2Z, L2, b, s);
+        if (rc != DD_OK) return rc;
+        DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(k_hilbert_mask_b, gL2, dim3(256), 0, s, W, L2);
+        DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_BACKWARD));
+        hipLaunchKernelGGL(k_cplx_abs_b, gL2, dim3(256), 0, s, W, ENV, L2, 1.0 / (double)L2);
+        const double* hay = ENV;
+        if (pre_ntaps) {
+            dd_filtfilt_launch<double>(ENV, L2, F1, H, L2, L2, pre_ntaps, d_taps2, b, s);
+            hay = H;
+        }
+        double* P = (double*)W;                                            // prefix sums into the (now free) FFT buffer
+        double* Q = P + (size_t)b * (L2 + 1);
+        hipLaunchKernelGGL(k_scan_pq, dim3(b), dim3(1024), 0, s, hay, P, Q, L2);
+        double* COR = F1;
+        hipLaunchKernelGGL(k_xcorr_runs_b, gL2, dim3(256), 0, s, P, Q, L2, needle_len, R, vv, COR);
+        hipLaunchKernelGGL(k_sync_peak, dim3(b), dim3(1024), 0, s, COR, ENV, L2, needle_len, d_peak + w0, d_height + w0, d_tsync + w0);
+        DD_LAUNCH_CHECK();
+    }
+    DD_HIP_CHECK(hipMemcpyAsync(peak_host, d_peak, sizeof(int64_t) * n_windows, hipMemcpyDeviceToHost, s));
+    DD_HIP_CHECK(hipMemcpyAsync(height_host, d_height, sizeof(double) * n_windows, hipMemcpyDeviceToHost, s));
+    DD_HIP_CHECK(hipMemcpyAsync(tsync_host, d_tsync, sizeof(double) * n_windows, hipMemcpyDeviceToHost, s));
+    DD_HIP_CHECK(hipStreamSynchronize(s));
+    return DD_OK;
+}

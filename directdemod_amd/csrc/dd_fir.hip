@@ -91,62 +91,7 @@ extern "C" int dd_fir_f64(dd_fir* f, const double* in, double* out, int64_t n, i
 // history = ext[0] (zi * x0), reverse, filter again with history = first sample,
 // reverse, crop.  Each pass is a direct FIR whose out-of-range taps read the
 // pass's first input sample.
-template <typename T> struct dd_acc;
-template <> struct dd_acc<double> {
-    __device__ static double zero() { return 0.0; }
-    __device__ static double mad(double t, double v, double a) { return fma(t, v, a); }
-    __device__ static double oddext(double e, double v) { return 2.0 * e - v; }
-};
-template <> struct dd_acc<double2> {
-    __device__ static double2 zero() { return make_double2(0.0, 0.0); }
-    __device__ static double2 mad(double t, double2 v, double2 a) { return make_double2(fma(t, v.x, a.x), fma(t, v.y, a.y)); }
-    __device__ static double2 oddext(double2 e, double2 v) { return make_double2(2.0 * e.x - v.x, 2.0 * e.y - v.y); }
-};
-template <> struct dd_acc<float2> {
-    __device__ static float2 zero() { return make_float2(0.f, 0.f); }
-    __device__ static float2 mad(double t, float2 v, float2 a) { return make_float2(fmaf((float)t, v.x, a.x), fmaf((float)t, v.y, a.y)); }
-    __device__ static float2 oddext(float2 e, float2 v) { return make_float2(2.f * e.x - v.x, 2.f * e.y - v.y); }
-};
-
-// ext[i], i in [0, n + 2*edge): odd extension of x about both ends
-template <typename T>
-__device__ __forceinline__ T dd_ext_at(const T* __restrict__ x, int64_t n, int edge, int64_t i) {
-    if (i < edge) return dd_acc<T>::oddext(x[0], x[edge - i]);
-    if (i < edge + n) return x[i - edge];
-    return dd_acc<T>::oddext(x[n - 1], x[n - 2 - (i - edge - n)]);
-}
-
-// pass 1: y1[i] = sum_k b[k] ext[max(i-k,0)]  for i in [0, N)
-template <typename T>
-__global__ void __launch_bounds__(256) k_filtfilt_fwd(const T* __restrict__ x, T* __restrict__ y1, int64_t n, int edge,
-                                                      const double* __restrict__ taps, int K) {
-    const int64_t N = n + 2 * (int64_t)edge;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    T acc = dd_acc<T>::zero();
-    for (int k = 0; k < K; ++k) {
-        const int64_t j = i - k;
-        acc = dd_acc<T>::mad(taps[k], dd_ext_at(x, n, edge, j > 0 ? j : 0), acc);
-    }
-    y1[i] = acc;
-}
-// pass 2 on the reversed sequence z[i] = y1[N-1-i]; w[i] = sum_k b[k] z[max(i-k,0)];
-// result[m] = w[N-1-(m+edge)] for m in [0, n)
-template <typename T>
-__global__ void __launch_bounds__(256) k_filtfilt_bwd(const T* __restrict__ y1, T* __restrict__ out, int64_t n, int edge,
-                                                      const double* __restrict__ taps, int K) {
-    const int64_t N = n + 2 * (int64_t)edge;
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n) return;
-    const int64_t i = N - 1 - (m + edge);
-    T acc = dd_acc<T>::zero();
-    for (int k = 0; k < K; ++k) {
-        const int64_t j = i - k;
-        const int64_t jj = j > 0 ? j : 0;
-        acc = dd_acc<T>::mad(taps[k], y1[N - 1 - jj], acc);
-    }
-    out[m] = acc;
-}
+#include "dd_filtfilt_kernels.h"
 
 template <typename T>
 static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, int64_t n, hipStream_t s) {
@@ -166,8 +111,17 @@ static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, in
         return DD_ERR_NOMEM;
     }
     hipMemcpyAsync(taps, taps_host, sizeof(double) * K, hipMemcpyHostToDevice, s);
-    hipLaunchKernelGGL(k_filtfilt_fwd<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, y1, n, edge, taps, K);
-    hipLaunchKernelGGL(k_filtfilt_bwd<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y1, out, n, edge, taps, K);
+    if constexpr (sizeof(T) == 8) {
+        if (dd_ff_tiled_ok(K, sizeof(T))) {
+            dd_filtfilt_launch<T>(in, n, y1, out, n, n, K, taps, 1, s);
+        } else {
+            hipLaunchKernelGGL(k_filtfilt_fwd<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, y1, n, edge, taps, K);
+            hipLaunchKernelGGL(k_filtfilt_bwd<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y1, out, n, edge, taps, K);
+        }
+    } else {
+        hipLaunchKernelGGL(k_filtfilt_fwd<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, y1, n, edge, taps, K);
+        hipLaunchKernelGGL(k_filtfilt_bwd<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y1, out, n, edge, taps, K);
+    }
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
     hipFree(taps);

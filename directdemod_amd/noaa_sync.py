@@ -110,20 +110,64 @@ class noaa_sync:
         pk, ht, ts = self.correlate_and_find_peaks(sig, sync, use_filter=True, extra=True)
         return int(pk[0]) + startI, ht[0], ts[0]
 
-    def getAccurateSync(self):
+    def accurate_windows(self, starts, length, sync):
+        """All search windows of one sync type in one batched device call (dd_noaa_sync_windows): the chain
+        of accurate_window over [windows][samples] arrays.  Returns (indices, heights, times) like the
+        per-window loop of decode_noaa.py:828-835."""
+        import ctypes as C
+        from . import _hip
+        src = self.__sigsrc
+        fs = src.sampFreq
+        nw = len(starts)
+        if nw == 0:
+            return np.zeros(0, dtype=np.int64), [], []
+        raw = np.empty((nw, length, 2), dtype=np.uint8)
+        for w, a in enumerate(starts):
+            raw[w] = src.read_raw_u8(a, a + length).reshape(length, 2)
+        d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
+        st = (np.arange(nw, dtype=np.int64) * length)
+        bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
+        pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
+        needle = np.ascontiguousarray(sync_needle(sync, fs), dtype=np.float64)
+        pk = np.empty(nw, dtype=np.int64)
+        ht = np.empty(nw, dtype=np.float64)
+        ts = np.empty(nw, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _hip.check(_hip.lib().dd_noaa_sync_windows(
+            d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), nw, int(length), _hip.cycles_q64(self.__offset, fs),
+            bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre), needle.ctypes.data_as(dp), len(needle),
+            float(fs), pk.ctypes.data_as(C.POINTER(C.c_int64)), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None),
+            "dd_noaa_sync_windows")
+        if np.any(pk == np.iinfo(np.int64).min):
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")      # pk[0] of an empty pick (:853)
+        idx = pk + np.asarray(starts, dtype=np.int64)
+        return idx, [float(v) for v in ht], [None if np.isnan(v) else float(v) for v in ts]
+
+    def getAccurateSync(self, batched=True):
         sa, sb = self.getCrudeSync()
         src = self.__sigsrc
         width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
         out = []
         for crude, sync in ((sa, constants.NOAA_SYNCA), (sb, constants.NOAA_SYNCB)):
-            idx, pks, tms = [], [], []
+            starts = []
             for c in crude / self.__rate * src.sampFreq:                                  # :828-835
                 startI, endI = int(c) - width, int(c) + width
                 if startI < 0 or endI > src.length:
                     continue
-                i, h, t = self.accurate_window(startI, endI, sync)
-                idx.append(i)
-                pks.append(h)
-                tms.append(t)
+                starts.append(startI)
+            if batched:
+                idx, pks, tms = [], [], []
+                for i in range(0, len(starts), 256):                                      # bounds the staging upload
+                    a, b, c = self.accurate_windows(starts[i:i + 256], 2 * width, sync)
+                    idx.extend(a.tolist())
+                    pks.extend(b)
+                    tms.extend(c)
+            else:
+                idx, pks, tms = [], [], []
+                for startI in starts:
+                    i, h, t = self.accurate_window(startI, startI + 2 * width, sync)
+                    idx.append(i)
+                    pks.append(h)
+                    tms.append(t)
             out.append((np.array(idx, dtype=np.int64), pks, tms))
         return out

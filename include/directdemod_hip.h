@@ -206,6 +206,28 @@ int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needle_host, int
 int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate, int needle_len,
                       int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream);
 
+/* ---- accurate-sync windows, batched (decode_noaa.getAccurateSync, decode_noaa.py:808-880;
+ *      SURVEY.md 8f-2).  For each of n_windows windows of win_len IQ samples starting at
+ *      iq[starts_host[w]] (iq on the device; iq_kind 0 = complex64, 1 = interleaved uint8 pairs
+ *      minus 127.5, source.py:117-118) runs the per-window chain of :852-853 --
+ *      offsetFreq (sample index restarting at 0, cycles_q64 as in dd_nco_c64) -> zero-phase FIR
+ *      fir_taps (blackmanHarris(151)) -> demod_fm (stateless) -> demod_am -> zero-phase FIR
+ *      pre_taps on the envelope (hamming(492), the default argument of :677; pre_ntaps 0 = none)
+ *      -> normalised correlation with the needle (:659-675) -> peak pick (:713-751) -- and
+ *      returns per window: peak_host = picked index in the window, already minus needle_len/2
+ *      (INT64_MIN if no sample exceeds the threshold); height_host = correlation at the peak
+ *      (:762); tsync_host = mean of the envelope over the needle length following the sync
+ *      (:755-757), NaN where the reference appends None.  Windows must be shorter than the
+ *      0.45 s peak-group distance (true for getAccurateSync's windows at any sample rate);
+ *      longer ones are DD_ERR_INVALID -- run them through the per-stage entry points.
+ *      All taps / needle pointers are host float64.  Synchronous. */
+int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host, int n_windows,
+                         int64_t win_len, uint64_t cycles_q64,
+                         const double* fir_taps_host, int fir_ntaps,
+                         const double* pre_taps_host, int pre_ntaps,
+                         const double* needle_host, int needle_len, double samp_rate,
+                         int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
+
 /* ---- AFSK1200 correlators (decode_afsk1200.py:99-158) ------------ */
 /* binary_filter[s] = mi^2 + mq^2 - si^2 - sq^2, the four sums over buffer_size samples
  * from s against tables_host[4][bs] = mark cos/sin, space cos/sin (:110-123); entries

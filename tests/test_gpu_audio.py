@@ -437,3 +437,80 @@ def test_afsk_front_end_matches_the_reference_run(dd, golden_dir):
     bf_ref = O.afsk_binary_filter(ref, O.afsk_tables(bw)[0])
     strong = np.abs(bf_ref) > 0.05 * np.max(np.abs(bf_ref))
     assert np.array_equal(np.sign(bf[strong]).astype(np.int8), g["sign"][strong])
+
+
+# ---------------------------------------------------------------- zero-phase FIR, tiled kernels
+@pytest.mark.parametrize("n", [1477, 2048, 2049, 4095, 6000, 118151])
+def test_filtfilt_tiled_real_vs_oracle(dd, n):
+    """hamming(492) zero-phase on float64 at lengths around the 2048-output tiles (and the shortest legal one)"""
+    x = np.random.default_rng(n).standard_normal(n) + 0.5
+    got = dd.filters.hamming(492, zeroPhase=True).applyOn(x)
+    ref = O.filtfilt(O.win_hamming(492), [1.0], x)
+    assert rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize("k", [1, 7, 8, 9, 151, 152])
+def test_filtfilt_tiled_tap_counts(dd, k):
+    """tap counts on both sides of the 8-tap chunks of the tiled kernel; complex64 (f32 arithmetic) and float64"""
+    rng = np.random.default_rng(100 + k)
+    taps = rng.standard_normal(k)
+    x = rng.standard_normal(5000)
+    assert rel_err(dd.ops.filtfilt(taps, dd.hip.DevArray.from_host(x)).to_host(), O.filtfilt(taps, [1.0], x)) < 1e-11
+    xc = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    got = dd.ops.filtfilt(taps, dd.hip.DevArray.from_host(xc)).to_host()
+    assert got.dtype == np.complex64
+    assert rel_err(got, O.filtfilt(taps, [1.0], xc.astype(np.complex128))) < 2e-5
+
+
+def test_filtfilt_long_filter_uses_plain_kernels(dd):
+    """a filter too long for the LDS tile still runs (one lane per output)"""
+    rng = np.random.default_rng(9)
+    taps = rng.standard_normal(6000) / 6000
+    x = rng.standard_normal(20000)
+    assert rel_err(dd.ops.filtfilt(taps, dd.hip.DevArray.from_host(x)).to_host(), O.filtfilt(taps, [1.0], x)) < 1e-10
+
+
+# ---------------------------------------------------------------- accurate-sync windows, batched (SURVEY 8f-2)
+def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
+    g, raw = noaa_inputs
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    one = ns.getAccurateSync(batched=False)
+    for env in (None, "3"):                      # default batch, and batches smaller than the window count
+        if env:
+            monkeypatch.setenv("DD_SYNC_BATCH", env)
+        many = ns.getAccurateSync(batched=True)
+        for (i1, p1, t1), (i2, p2, t2) in zip(one, many):
+            assert len(i1) >= 2 and np.array_equal(i1, i2)
+            assert np.max(np.abs(np.array(p1) - np.array(p2))) < 1e-9
+            assert [v is None for v in t1] == [v is None for v in t2]
+            a = np.array([v for v in t1 if v is not None])
+            b = np.array([v for v in t2 if v is not None])
+            assert np.max(np.abs(a - b)) < 1e-9 * np.max(np.abs(a))
+    # golden index lists of the reference through both forms
+    assert np.array_equal(one[0][0], g["acc_syncA"]) and np.array_equal(many[1][0], g["acc_syncB"])
+
+
+def test_accurate_sync_windows_oracle_chain(dd):
+    """one window against the oracle's restatement of decode_noaa.py:852-853 (float64 SciPy chain)"""
+    raw = O.synth_apt_iq(1.2, 2048000, seed=3)
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    width = int(3 * dd.constants.NOAA_T * len(dd.constants.NOAA_SYNCA) * 2048000)
+    starts = [1024000 - width, 1024000 - width + 5000]
+    idx, pks, tms = ns.accurate_windows(starts, 2 * width, dd.constants.NOAA_SYNCA)
+    for w, a in enumerate(starts):
+        i, h, t = O.accurate_sync_window(O.read_iq_u8(raw, a, a + 2 * width), 2048000, 30000.0, dd.constants.NOAA_SYNCA)
+        assert idx[w] == i + a
+        assert abs(pks[w] - h) < 1e-4
+        assert (tms[w] is None) == (t is None)
+        if t is not None:
+            assert abs(tms[w] - t) < 1e-4
+
+
+def test_accurate_sync_windows_rejects_long_windows(dd):
+    raw = O.synth_apt_iq(0.6, 2048000, seed=4)
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    with pytest.raises(Exception, match="0.45 s"):
+        ns.accurate_windows([0], 1000000, dd.constants.NOAA_SYNCA)
