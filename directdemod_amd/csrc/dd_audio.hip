@@ -305,6 +305,11 @@ struct GtThr {
     __host__ __device__ bool operator()(const int64_t& i) const { return cor[i] > thr; }
 };
 
+__global__ void __launch_bounds__(256) k_gather_f64(const double* __restrict__ src, const int64_t* __restrict__ idx, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
 extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate, int needle_len,
                                  int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream) {
     DD_REQUIRE(cor && n >= 1 && samp_rate > 0 && peaks_host && n_peaks && max_peaks >= 1, "arguments");
@@ -347,18 +352,15 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
     std::vector<int64_t> ci(count);
     std::vector<double> cv(count);
     if (count > 0) {
-        DD_HIP_CHECK(hipMemcpy(ci.data(), cand, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
-        // candidate heights: gather on the host side from a device copy of the few values
-        std::vector<double> all;
-        // the candidates are few (a handful of samples around each sync): fetch them one run at a time
-        int64_t run_start = 0;
-        while (run_start < count) {
-            int64_t run_end = run_start;
-            while (run_end + 1 < count && ci[run_end + 1] == ci[run_end] + 1) ++run_end;
-            DD_HIP_CHECK(hipMemcpy(cv.data() + run_start, cor + ci[run_start], sizeof(double) * (run_end - run_start + 1),
-                                   hipMemcpyDeviceToHost));
-            run_start = run_end + 1;
-        }
+        // candidate heights gathered on the device: two downloads whatever the number of candidate runs
+        double* d_cv = nullptr;
+        DD_HIP_CHECK(hipMalloc((void**)&d_cv, sizeof(double) * count));
+        hipLaunchKernelGGL(k_gather_f64, dim3(grid1(count)), dim3(256), 0, s, cor, cand, count, d_cv);
+        hipError_t g1 = hipMemcpyAsync(ci.data(), cand, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s);
+        hipError_t g2 = hipMemcpyAsync(cv.data(), d_cv, sizeof(double) * count, hipMemcpyDeviceToHost, s);
+        hipError_t g3 = hipStreamSynchronize(s);
+        hipFree(d_cv);
+        DD_HIP_CHECK(g1); DD_HIP_CHECK(g2); DD_HIP_CHECK(g3);
     }
     hipFree(tmp);
     hipFree(cand);

@@ -110,7 +110,15 @@ class noaa_sync:
         pk, ht, ts = self.correlate_and_find_peaks(sig, sync, use_filter=True, extra=True)
         return int(pk[0]) + startI, ht[0], ts[0]
 
-    def accurate_windows(self, starts, length, sync):
+    def _gather_windows(self, starts, length):
+        """the raw uint8 pairs of the windows, packed [windows][length][2] for one upload"""
+        src = self.__sigsrc
+        raw = np.empty((len(starts), length, 2), dtype=np.uint8)
+        for w, a in enumerate(starts):
+            raw[w] = src.read_raw_u8(a, a + length).reshape(length, 2)
+        return raw
+
+    def accurate_windows(self, starts, length, sync, raw=None):
         """All search windows of one sync type in one batched device call (dd_noaa_sync_windows): the chain
         of accurate_window over [windows][samples] arrays.  Returns (indices, heights, times) like the
         per-window loop of decode_noaa.py:828-835."""
@@ -121,9 +129,7 @@ class noaa_sync:
         nw = len(starts)
         if nw == 0:
             return np.zeros(0, dtype=np.int64), [], []
-        raw = np.empty((nw, length, 2), dtype=np.uint8)
-        for w, a in enumerate(starts):
-            raw[w] = src.read_raw_u8(a, a + length).reshape(length, 2)
+        raw = self._gather_windows(starts, length) if raw is None else raw
         d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
         st = (np.arange(nw, dtype=np.int64) * length)
         bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
@@ -147,7 +153,7 @@ class noaa_sync:
         sa, sb = self.getCrudeSync()
         src = self.__sigsrc
         width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
-        out = []
+        out, jobs = [], []
         for crude, sync in ((sa, constants.NOAA_SYNCA), (sb, constants.NOAA_SYNCB)):
             starts = []
             for c in crude / self.__rate * src.sampFreq:                                  # :828-835
@@ -156,18 +162,32 @@ class noaa_sync:
                     continue
                 starts.append(startI)
             if batched:
-                idx, pks, tms = [], [], []
-                for i in range(0, len(starts), 256):                                      # bounds the staging upload
-                    a, b, c = self.accurate_windows(starts[i:i + 256], 2 * width, sync)
-                    idx.extend(a.tolist())
-                    pks.extend(b)
-                    tms.extend(c)
-            else:
-                idx, pks, tms = [], [], []
-                for startI in starts:
-                    i, h, t = self.accurate_window(startI, startI + 2 * width, sync)
-                    idx.append(i)
-                    pks.append(h)
-                    tms.append(t)
+                jobs.append((len(out), starts, sync))
+                out.append(None)
+                continue
+            idx, pks, tms = [], [], []
+            for startI in starts:
+                i, h, t = self.accurate_window(startI, startI + 2 * width, sync)
+                idx.append(i)
+                pks.append(h)
+                tms.append(t)
             out.append((np.array(idx, dtype=np.int64), pks, tms))
+        if jobs:
+            # batches of 64 windows (the device batch); the host-side gather of the next batch
+            # runs on a worker thread while the device works on the current one
+            from concurrent.futures import ThreadPoolExecutor
+            parts = [(slot, st[i:i + 64], sync) for slot, st, sync in jobs for i in range(0, max(1, len(st)), 64)]
+            res = {slot: ([], [], []) for slot, _, _ in jobs}
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                nxt = ex.submit(self._gather_windows, parts[0][1], 2 * width)
+                for k, (slot, st, sync) in enumerate(parts):
+                    raw = nxt.result()
+                    if k + 1 < len(parts):
+                        nxt = ex.submit(self._gather_windows, parts[k + 1][1], 2 * width)
+                    a, b, c = self.accurate_windows(st, 2 * width, sync, raw=raw)
+                    res[slot][0].extend(a.tolist())
+                    res[slot][1].extend(b)
+                    res[slot][2].extend(c)
+            for slot, _, _ in jobs:
+                out[slot] = (np.array(res[slot][0], dtype=np.int64), res[slot][1], res[slot][2])
         return out

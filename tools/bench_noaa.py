@@ -23,3 +23,17 @@ for rep in range(2):
     nwin = len(acc[0][0]) + len(acc[1][0])
     print("run %d: %.0f s recording (%d IQ samples): crude sync %.1f ms (%d + %d syncs), accurate sync %.1f ms for %d windows = %.2f ms/window"
           % (rep, dur, src.length, (t1 - t0) * 1e3, len(sa), len(sb), (t2 - t1) * 1e3, nwin, (t2 - t1) * 1e3 / max(1, nwin)))
+
+if "--stages" in sys.argv:
+    from directdemod_amd import constants
+    def T(label, fn):
+        _hip.sync(); t = time.perf_counter(); r = fn(); _hip.sync()
+        print("  %-34s %7.2f ms" % (label, (time.perf_counter() - t) * 1e3)); return r
+    obj = noaa_sync.noaa_sync(src, 30000.0)
+    aud = T("audio (fused chain, 2 chunks)", lambda: obj.audio(constants.NOAA_CRUDESYNCSAMPRATE, False))
+    env = T("envelope (240000-blocks)", lambda: obj.envelope(aud))
+    T("correlate + peaks, sync A", lambda: obj.correlate_and_find_peaks(env, constants.NOAA_SYNCA))
+    T("correlate + peaks, sync B", lambda: obj.correlate_and_find_peaks(env, constants.NOAA_SYNCB))
+    width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)
+    starts = [int(c) - width for c in sa / env.sampRate * src.sampFreq if int(c) - width >= 0 and int(c) + width <= src.length]
+    T("accurate windows, sync A (%d)" % len(starts), lambda: obj.accurate_windows(starts, 2 * width, constants.NOAA_SYNCA))
