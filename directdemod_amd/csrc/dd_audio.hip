@@ -582,6 +582,88 @@ __global__ void __launch_bounds__(1024) k_sync_peak(const double* __restrict__ c
     }
 }
 
+// ---- the envelope as one real convolution.  abs(hilbert(x)) = |x + j (x (*) hh)| where (*) is the length-N
+// circular convolution and hh = imag(ifft(h)) the Hilbert kernel of scipy's spectrum mask h (the real part
+// of ifft(h) is the unit impulse).  The window length N = 118 151 has a large prime factor, so the library's
+// length-N transforms are Bluestein chirp-z: two padded power-of-two transforms each way, complex.  The
+// circular convolution needs only outputs [0, N), which a length-M >= 2N-1 cyclic convolution with the kernel
+// laid out at offsets -(N-1)..N-1 gives without wrap-around: one real-to-complex and one complex-to-real
+// power-of-two transform per window, a quarter of the work.  The kernel spectrum is built once per length
+// from the library's own length-N inverse transform of h.
+__global__ void __launch_bounds__(256) k_hilb_mask_init(double2* __restrict__ X, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double h;
+    if ((n & 1) == 0) h = (i == 0 || i == n / 2) ? 1.0 : (i < n / 2 ? 2.0 : 0.0);
+    else h = (i == 0) ? 1.0 : (i < (n + 1) / 2 ? 2.0 : 0.0);
+    X[i] = make_double2(h, 0.0);
+}
+// buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
+__global__ void __launch_bounds__(256) k_hilb_kernel_pad(const double2* __restrict__ g, int64_t n, int64_t M, double inv_n,
+                                                         double* __restrict__ buf) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    double v = 0.0;
+    if (j < n) v = g[j].y * inv_n;
+    else if (j > M - n) v = g[j - (M - n)].y * inv_n;
+    buf[j] = v;
+}
+__global__ void __launch_bounds__(256) k_sync_fm_pad(const float2* __restrict__ Y, int64_t L, double* __restrict__ XR, int64_t M) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const float2* y = Y + (int64_t)blockIdx.y * L;
+    XR[(int64_t)blockIdx.y * M + j] = j < L - 1 ? (double)dd_fm_angle(y[j + 1], y[j]) : 0.0;
+}
+__global__ void __launch_bounds__(256) k_spec_mul(double2* __restrict__ S, const double2* __restrict__ HH, int64_t nb) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nb) return;
+    double2* p = S + (int64_t)blockIdx.y * nb + k;
+    const double2 a = *p, h = HH[k];
+    *p = make_double2(a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x);
+}
+__global__ void __launch_bounds__(256) k_env_hypot(const double* __restrict__ XR, const double* __restrict__ YR, int64_t M, int64_t n,
+                                                   double* __restrict__ env) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    env[(int64_t)blockIdx.y * n + i] = hypot(XR[(int64_t)blockIdx.y * M + i], YR[(int64_t)blockIdx.y * M + i]);
+}
+
+static std::map<std::pair<int, int64_t>, double2*> g_hilb;      // (device, N) -> spectrum of the padded kernel / M
+
+static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    auto key = std::make_pair(dev, n);
+    auto it = g_hilb.find(key);
+    if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
+    const int64_t nb = M / 2 + 1;
+    double2 *g = nullptr, *HH = nullptr;
+    double* buf = nullptr;
+    DD_HIP_CHECK(hipMalloc((void**)&g, sizeof(double2) * n));
+    DD_HIP_CHECK(hipMalloc((void**)&buf, sizeof(double) * M));
+    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * nb));
+    hipfftHandle pn, pm;
+    int rc = get_plan(&pn, HIPFFT_Z2Z, n, 1, s);
+    if (rc == DD_OK) rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
+    if (rc != DD_OK) { hipFree(g); hipFree(buf); hipFree(HH); return rc; }
+    hipLaunchKernelGGL(k_hilb_mask_init, dim3(grid1(n)), dim3(256), 0, s, g, n);
+    hipfftResult r1 = hipfftExecZ2Z(pn, (hipfftDoubleComplex*)g, (hipfftDoubleComplex*)g, HIPFFT_BACKWARD);
+    hipLaunchKernelGGL(k_hilb_kernel_pad, dim3(grid1(M)), dim3(256), 0, s, g, n, M, 1.0 / (double)n, buf);
+    hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
+    hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(g);
+    hipFree(buf);
+    if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
+        hipFree(HH);
+        dd_set_error("Hilbert kernel spectrum: hipfft %d/%d, hip %s", (int)r1, (int)r2, hipGetErrorString(e));
+        return DD_ERR_HIP;
+    }
+    g_hilb[key] = HH;
+    *out = HH;
+    return DD_OK;
+}
+
 // grow-only scratch per device: the chain's intermediates (no allocation in the steady state)
 static std::mutex g_sync_mu;
 static void* g_sync_scratch[64] = {nullptr};
@@ -666,7 +748,14 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     const size_t o_X = o_res + al(24 * (size_t)n_windows);
     const size_t o_Y1 = o_X + al(sizeof(float2) * B * L);                 // X: c64 [B][L]; later the filtered IQ again
     const size_t o_W = o_Y1 + al(sizeof(float2) * B * N1);                // Y1: c64 [B][N1]
-    const size_t o_ENV = o_W + al(sizeof(double2) * B * (L2 + 1));        // W: c128 [B][L2]; later P, Q: f64 [B][L2+1] each
+    int64_t M = 1;
+    while (M < 2 * L2 + 2) M <<= 1;                                       // cyclic convolution length of the envelope stage
+    const int64_t nb = M / 2 + 1;
+    const char* hm = getenv("DD_SYNC_HILBERT");
+    const bool hilbert_fft = hm && !strcmp(hm, "fft");                    // A/B switch: the library's length-N transforms
+    const size_t o_SP = o_W + al(sizeof(double) * B * M);                 // W/XR: f64 [B][M] (or c128 [B][L2]); later P, Q: f64 [B][L2+1] each
+    const size_t o_YR = o_SP + al(sizeof(double2) * B * nb);              // SP: c128 [B][M/2+1]
+    const size_t o_ENV = o_YR + al(sizeof(double) * B * M);               // YR: f64 [B][M]
     const size_t o_F1 = o_ENV + al(sizeof(double) * B * L2);              // ENV f64 [B][L2]
     const size_t o_H = o_F1 + al(sizeof(double) * B * N2);                // F1: f64 [B][N2]; later COR [B][L2]
     const size_t total = o_H + al(sizeof(double) * B * L2);               // H: f64 [B][L2]
@@ -683,6 +772,14 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     float2* X = (float2*)(base + o_X);
     float2* Y1 = (float2*)(base + o_Y1);
     double2* W = (double2*)(base + o_W);
+    double* XR = (double*)(base + o_W);
+    double2* SP = (double2*)(base + o_SP);
+    double* YR = (double*)(base + o_YR);
+    const double2* HH = nullptr;
+    if (!hilbert_fft) {
+        rc = hilbert_kernel_spectrum(L2, M, &HH, s);
+        if (rc != DD_OK) return rc;
+    }
     double* ENV = (double*)(base + o_ENV);
     double* F1 = (double*)(base + o_F1);
     double* H = (double*)(base + o_H);
@@ -695,14 +792,26 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
         else hipLaunchKernelGGL(k_sync_front<false>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
         dd_filtfilt_launch<float2>(X, L, Y1, X, L, L, fir_ntaps, d_taps1, b, s);            // X <- filtfilt(X): pass 2 reads only Y1
-        hipLaunchKernelGGL(k_sync_fm, gL2, dim3(256), 0, s, X, L, W);
-        hipfftHandle plan;
-        rc = get_plan(&plan, HIPFFT_Z2Z, L2, b, s);
-        if (rc != DD_OK) return rc;
-        DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_FORWARD));
-        hipLaunchKernelGGL(k_hilbert_mask_b, gL2, dim3(256), 0, s, W, L2);
-        DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_BACKWARD));
-        hipLaunchKernelGGL(k_cplx_abs_b, gL2, dim3(256), 0, s, W, ENV, L2, 1.0 / (double)L2);
+        if (hilbert_fft) {
+            hipLaunchKernelGGL(k_sync_fm, gL2, dim3(256), 0, s, X, L, W);
+            hipfftHandle plan;
+            rc = get_plan(&plan, HIPFFT_Z2Z, L2, b, s);
+            if (rc != DD_OK) return rc;
+            DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_FORWARD));
+            hipLaunchKernelGGL(k_hilbert_mask_b, gL2, dim3(256), 0, s, W, L2);
+            DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_BACKWARD));
+            hipLaunchKernelGGL(k_cplx_abs_b, gL2, dim3(256), 0, s, W, ENV, L2, 1.0 / (double)L2);
+        } else {
+            hipfftHandle pf, pb;
+            rc = get_plan(&pf, HIPFFT_D2Z, M, b, s);
+            if (rc == DD_OK) rc = get_plan(&pb, HIPFFT_Z2D, M, b, s);
+            if (rc != DD_OK) return rc;
+            hipLaunchKernelGGL(k_sync_fm_pad, dim3(grid1(M), b), dim3(256), 0, s, X, L, XR, M);
+            DD_FFT_CHECK(hipfftExecD2Z(pf, XR, (hipfftDoubleComplex*)SP));
+            hipLaunchKernelGGL(k_spec_mul, dim3(grid1(nb), b), dim3(256), 0, s, SP, HH, nb);
+            DD_FFT_CHECK(hipfftExecZ2D(pb, (hipfftDoubleComplex*)SP, YR));
+            hipLaunchKernelGGL(k_env_hypot, gL2, dim3(256), 0, s, XR, YR, M, L2, ENV);
+        }
         const double* hay = ENV;
         if (pre_ntaps) {
             dd_filtfilt_launch<double>(ENV, L2, F1, H, L2, L2, pre_ntaps, d_taps2, b, s);

@@ -476,9 +476,15 @@ def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
     src = dd.source.IQarray(raw, 2048000)
     ns = dd.noaa.noaa_sync(src, 30000.0)
     one = ns.getAccurateSync(batched=False)
-    for env in (None, "3"):                      # default batch, and batches smaller than the window count
-        if env:
-            monkeypatch.setenv("DD_SYNC_BATCH", env)
+    # default batch and batches smaller than the window count; the envelope as one real convolution (default)
+    # and through the library's length-N transforms
+    for batch, hilbert in ((None, None), ("3", None), (None, "fft")):
+        monkeypatch.delenv("DD_SYNC_BATCH", raising=False)
+        monkeypatch.delenv("DD_SYNC_HILBERT", raising=False)
+        if batch:
+            monkeypatch.setenv("DD_SYNC_BATCH", batch)
+        if hilbert:
+            monkeypatch.setenv("DD_SYNC_HILBERT", hilbert)
         many = ns.getAccurateSync(batched=True)
         for (i1, p1, t1), (i2, p2, t2) in zip(one, many):
             assert len(i1) >= 2 and np.array_equal(i1, i2)
