@@ -449,73 +449,67 @@ __global__ void __launch_bounds__(256) k_cplx_abs_b(const double2* __restrict__ 
     out[(int64_t)blockIdx.y * n + i] = hypot(v.x * inv_n, v.y * inv_n);
 }
 
-// P[b][i] = sum h[b][0..i), Q likewise of h^2; one workgroup walks one window in tiles of 4096
-__global__ void __launch_bounds__(1024) k_scan_pq(const double* __restrict__ h, double* __restrict__ P, double* __restrict__ Q, int64_t n) {
-    __shared__ double sp[16], sq[16];
-    h += (int64_t)blockIdx.x * n;
-    P += (int64_t)blockIdx.x * (n + 1);
-    Q += (int64_t)blockIdx.x * (n + 1);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    double cp = 0.0, cq = 0.0;
-    if (t == 0) { P[0] = 0.0; Q[0] = 0.0; }
-    for (int64_t base = 0; base < n; base += 4096) {
-        const int64_t i0 = base + 4 * t;
-        double p[4], q[4];
+// P[b][i] = sum h[b][0..i), Q likewise of h^2, in two launches over tiles of 2048 samples: tile sums, then each
+// tile adds the sums of the tiles before it (ascending) to its own scan -- every tile of every window in parallel
+#define DD_SCAN_TILE 2048
+__device__ __forceinline__ void dd_scan_tile_load(const double* __restrict__ h, int64_t n, int64_t i0, double (&p)[8], double (&q)[8]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double v = (i0 + j < n) ? h[i0 + j] : 0.0;
-            p[j] = j ? p[j - 1] + v : v;
-            q[j] = j ? q[j - 1] + v * v : v * v;
-        }
-        double tp = p[3], tq = q[3];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double a = __shfl_up(tp, d), c = __shfl_up(tq, d);
-            if (lane >= d) { tp += a; tq += c; }
-        }
-        if (lane == 63) { sp[wv] = tp; sq[wv] = tq; }
-        double ep = __shfl_up(tp, 1), eq = __shfl_up(tq, 1);
-        if (lane == 0) { ep = 0.0; eq = 0.0; }
-        __syncthreads();
-        double totp = 0.0, totq = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            if (w == wv) { ep += cp + totp; eq += cq + totq; }
-            totp += sp[w];
-            totq += sq[w];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j < n) { P[i0 + j + 1] = ep + p[j]; Q[i0 + j + 1] = eq + q[j]; }
-        cp += totp;
-        cq += totq;
-        __syncthreads();
+    for (int j = 0; j < 8; ++j) {
+        const double v = (i0 + j < n) ? h[i0 + j] : 0.0;
+        p[j] = j ? p[j - 1] + v : v;
+        q[j] = j ? q[j - 1] + v * v : v * v;
     }
 }
-
-__global__ void __launch_bounds__(256) k_xcorr_runs_b(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
-                                                      const DDRuns R, double vv, double* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+__global__ void __launch_bounds__(256) k_scan_part(const double* __restrict__ h, int64_t n, int tiles, double2* __restrict__ part) {
+    __shared__ double sp[4], sq[4];
+    h += (int64_t)blockIdx.y * n;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double p[8], q[8];
+    dd_scan_tile_load(h, n, (int64_t)blockIdx.x * DD_SCAN_TILE + 8 * t, p, q);
+    double tp = p[7], tq = q[7];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { tp += __shfl_down(tp, d); tq += __shfl_down(tq, d); }
+    if (lane == 0) { sp[wv] = tp; sq[wv] = tq; }
+    __syncthreads();
+    if (t == 0) part[(int64_t)blockIdx.y * tiles + blockIdx.x] = make_double2(((sp[0] + sp[1]) + sp[2]) + sp[3], ((sq[0] + sq[1]) + sq[2]) + sq[3]);
+}
+__global__ void __launch_bounds__(256) k_scan_final(const double* __restrict__ h, int64_t n, int tiles, const double2* __restrict__ part,
+                                                    double* __restrict__ P, double* __restrict__ Q) {
+    __shared__ double sp[4], sq[4];
+    h += (int64_t)blockIdx.y * n;
     P += (int64_t)blockIdx.y * (n + 1);
     Q += (int64_t)blockIdx.y * (n + 1);
-    const int64_t a0 = i + (m - 1) / 2 - (m - 1);
-    auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
-    double c = 0.0;
-    double lo = at(P, a0);
-    for (int r = 0; r < R.nr; ++r) {
-        const double hi = at(P, a0 + R.start[r + 1]);
-        c = fma(R.val[r], hi - lo, c);
-        lo = hi;
+    part += (int64_t)blockIdx.y * tiles;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * DD_SCAN_TILE + 8 * t;
+    double p[8], q[8];
+    dd_scan_tile_load(h, n, i0, p, q);
+    double cp = 0.0, cq = 0.0;                       // sums of the tiles before this one
+    for (int k = 0; k < (int)blockIdx.x; ++k) { const double2 v = part[k]; cp += v.x; cq += v.y; }
+    double tp = p[7], tq = q[7];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double a = __shfl_up(tp, d), c = __shfl_up(tq, d);
+        if (lane >= d) { tp += a; tq += c; }
     }
-    double e = at(Q, a0 + m) - at(Q, a0);
-    if (!(e > 1e-13 * Q[n])) { c = 0.0; e = 0.0; }
-    out[(int64_t)blockIdx.y * n + i] = c / sqrt(e * vv);
+    if (lane == 63) { sp[wv] = tp; sq[wv] = tq; }
+    double ep = __shfl_up(tp, 1), eq = __shfl_up(tq, 1);
+    if (lane == 0) { ep = 0.0; eq = 0.0; }
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) { cp += sp[w]; cq += sq[w]; }
+    ep += cp;
+    eq += cq;
+    if (blockIdx.x == 0 && t == 0) { P[0] = 0.0; Q[0] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (i0 + j < n) { P[i0 + j + 1] = ep + p[j]; Q[i0 + j + 1] = eq + q[j]; }
 }
 
 // Peak pick of one window (decode_noaa.py:713-762) when the window is shorter than the 0.45 s group
 // distance: expectedPeaks K = 2, every candidate falls in one group, and the pick is the first index of
 // the maximum provided it exceeds the threshold.  Also the two "extras": peak height and the mean of the
-// next needle-length of the envelope.
+// next needle-length of the envelope.  The correlation values are reduced where they are produced (first
+// maximum, two largest, two smallest per tile of 1024 outputs); the correlation array itself is never stored.
 struct DDPk {
     double m1, m2, l1, l2;
     int64_t i1;
@@ -540,42 +534,87 @@ __device__ __forceinline__ DDPk dd_pk_shfl(const DDPk& a, int d) {
     r.i1 = __shfl_down(a.i1, d); r.nan = __shfl_down(a.nan, d);
     return r;
 }
-
-__global__ void __launch_bounds__(1024) k_sync_peak(const double* __restrict__ cor, const double* __restrict__ env, int64_t n, int m,
-                                                    int64_t* __restrict__ peak, double* __restrict__ height, double* __restrict__ tsync) {
-    __shared__ DDPk sw[16];
-    __shared__ double ssum[16];
-    const double* c = cor + (int64_t)blockIdx.x * n;
-    const double* ev = env + (int64_t)blockIdx.x * n;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+__device__ __forceinline__ DDPk dd_pk_empty() {
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     DDPk a = {-inf, -inf, inf, inf, INT64_MAX, 0};
-    for (int64_t i = t; i < n; i += 1024) {
-        const double x = c[i];
-        DDPk b = {x, -inf, x, inf, i, (x != x) ? 1 : 0};
-        a = dd_pk_merge(a, b);
+    return a;
+}
+
+// Normalised correlation in the run-length form (k_xcorr_runs) of a batch of windows, reduced per tile.
+// Workgroups are dealt to the XCDs window by window (dispatch is round-robin over the 8 XCDs), so the ~14
+// reads of every prefix-sum element come out of one XCD's L2.
+#define DD_XC_TILE 1024
+__global__ void __launch_bounds__(256) k_xcorr_runs_pk(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
+                                                       const DDRuns R, double vv, int tiles, int nwin, DDPk* __restrict__ part) {
+    __shared__ DDPk sw[4];
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int win = (k / tiles) * 8 + xcd, tile = k % tiles;
+    if (win >= nwin) return;
+    P += (int64_t)win * (n + 1);
+    Q += (int64_t)win * (n + 1);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
+    const double qn = 1e-13 * Q[n];
+    DDPk a = dd_pk_empty();
+#pragma unroll
+    for (int j = 0; j < DD_XC_TILE / 256; ++j) {
+        const int64_t i = (int64_t)tile * DD_XC_TILE + j * 256 + t;
+        if (i >= n) break;
+        const int64_t a0 = i + (m - 1) / 2 - (m - 1);
+        double c = 0.0;
+        double lo = at(P, a0);
+        for (int r = 0; r < R.nr; ++r) {
+            const double hi = at(P, a0 + R.start[r + 1]);
+            c = fma(R.val[r], hi - lo, c);
+            lo = hi;
+        }
+        double e = at(Q, a0 + m) - at(Q, a0);
+        if (!(e > qn)) { c = 0.0; e = 0.0; }
+        const double x = c / sqrt(e * vv);
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        DDPk bq = {x, -inf, x, inf, i, (x != x) ? 1 : 0};
+        a = dd_pk_merge(a, bq);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) a = dd_pk_merge(a, dd_pk_shfl(a, d));
     if (lane == 0) sw[wv] = a;
     __syncthreads();
-    a = sw[0];
-    for (int w = 1; w < 16; ++w) a = dd_pk_merge(a, sw[w]);
+    if (t == 0) part[(int64_t)win * tiles + tile] = dd_pk_merge(dd_pk_merge(sw[0], sw[1]), dd_pk_merge(sw[2], sw[3]));
+}
+
+__global__ void __launch_bounds__(256) k_sync_peak(const DDPk* __restrict__ part, int tiles, const double* __restrict__ env, int64_t n, int m,
+                                                   int64_t* __restrict__ peak, double* __restrict__ height, double* __restrict__ tsync) {
+    __shared__ DDPk sw[4];
+    __shared__ double ssum[4];
+    const double* ev = env + (int64_t)blockIdx.x * n;
+    part += (int64_t)blockIdx.x * tiles;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    DDPk a = dd_pk_empty();
+    for (int k = t; k < tiles; k += 256) a = dd_pk_merge(a, part[k]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a = dd_pk_merge(a, dd_pk_shfl(a, d));
+    if (lane == 0) sw[wv] = a;
+    __syncthreads();
+    a = dd_pk_merge(dd_pk_merge(sw[0], sw[1]), dd_pk_merge(sw[2], sw[3]));
     double avgpk = (0.0 + a.m2 + a.m1) / 2.0;                       // mean of the K = 2 largest (:717-721)
     avgpk -= 0.25 * (avgpk - (0.0 + a.l1 + a.l2) / 2.0);            // NOAA_PEAKHEIGHTWIGGLE (:723)
     const bool found = !a.nan && a.m1 > avgpk;
     const int64_t i = a.i1 - m / 2;                                 // :749
-    double s = 0.0;
     const bool tail = found && i + 2 * (int64_t)m < n;              // :755
-    if (tail)
-        for (int64_t j = i + m + t; j < i + 2 * (int64_t)m; j += 1024) s += ev[j];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (tail) {
+        int64_t j = i + m + t;
+        const int64_t end = i + 2 * (int64_t)m;
+        for (; j + 768 < end; j += 1024) { s0 += ev[j]; s1 += ev[j + 256]; s2 += ev[j + 512]; s3 += ev[j + 768]; }
+        for (; j < end; j += 256) s0 += ev[j];
+    }
+    double sacc = (s0 + s1) + (s2 + s3);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
-    if (lane == 0) ssum[wv] = s;
+    for (int d = 32; d >= 1; d >>= 1) sacc += __shfl_down(sacc, d);
+    if (lane == 0) ssum[wv] = sacc;
     __syncthreads();
     if (t == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < 16; ++w) tot += ssum[w];
+        const double tot = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
         peak[blockIdx.x] = found ? i : INT64_MIN;
         height[blockIdx.x] = found ? a.m1 : __longlong_as_double(0x7ff8000000000000ll);
         tsync[blockIdx.x] = tail ? tot / (double)m : __longlong_as_double(0x7ff8000000000000ll);
@@ -757,7 +796,7 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     const size_t o_YR = o_SP + al(sizeof(double2) * B * nb);              // SP: c128 [B][M/2+1]
     const size_t o_ENV = o_YR + al(sizeof(double) * B * M);               // YR: f64 [B][M]
     const size_t o_F1 = o_ENV + al(sizeof(double) * B * L2);              // ENV f64 [B][L2]
-    const size_t o_H = o_F1 + al(sizeof(double) * B * N2);                // F1: f64 [B][N2]; later COR [B][L2]
+    const size_t o_H = o_F1 + al(sizeof(double) * B * N2);                // F1: f64 [B][N2]; later the scan tile sums and per-tile peak records
     const size_t total = o_H + al(sizeof(double) * B * L2);               // H: f64 [B][L2]
     char* base = nullptr;
     std::lock_guard<std::mutex> lk(g_sync_mu);
@@ -819,10 +858,13 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         }
         double* P = (double*)W;                                            // prefix sums into the (now free) FFT buffer
         double* Q = P + (size_t)b * (L2 + 1);
-        hipLaunchKernelGGL(k_scan_pq, dim3(b), dim3(1024), 0, s, hay, P, Q, L2);
-        double* COR = F1;
-        hipLaunchKernelGGL(k_xcorr_runs_b, gL2, dim3(256), 0, s, P, Q, L2, needle_len, R, vv, COR);
-        hipLaunchKernelGGL(k_sync_peak, dim3(b), dim3(1024), 0, s, COR, ENV, L2, needle_len, d_peak + w0, d_height + w0, d_tsync + w0);
+        const int stiles = (int)((L2 + DD_SCAN_TILE - 1) / DD_SCAN_TILE), xtiles = (int)((L2 + DD_XC_TILE - 1) / DD_XC_TILE);
+        double2* spart = (double2*)F1;                                     // tile sums, then the per-tile peak records:
+        DDPk* ppart = (DDPk*)(F1 + 2 * (size_t)b * stiles);                // both in the pre-filter's (now free) work buffer
+        hipLaunchKernelGGL(k_scan_part, dim3(stiles, b), dim3(256), 0, s, hay, L2, stiles, spart);
+        hipLaunchKernelGGL(k_scan_final, dim3(stiles, b), dim3(256), 0, s, hay, L2, stiles, spart, P, Q);
+        hipLaunchKernelGGL(k_xcorr_runs_pk, dim3(8 * ((b + 7) / 8) * xtiles), dim3(256), 0, s, P, Q, L2, needle_len, R, vv, xtiles, b, ppart);
+        hipLaunchKernelGGL(k_sync_peak, dim3(b), dim3(256), 0, s, ppart, xtiles, ENV, L2, needle_len, d_peak + w0, d_height + w0, d_tsync + w0);
         DD_LAUNCH_CHECK();
     }
     DD_HIP_CHECK(hipMemcpyAsync(peak_host, d_peak, sizeof(int64_t) * n_windows, hipMemcpyDeviceToHost, s));

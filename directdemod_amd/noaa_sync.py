@@ -113,9 +113,9 @@ class noaa_sync:
     def _gather_windows(self, starts, length):
         """the raw uint8 pairs of the windows, packed [windows][length][2] for one upload"""
         src = self.__sigsrc
-        raw = np.empty((len(starts), length, 2), dtype=np.uint8)
+        raw = np.empty(len(starts) * length * 2, dtype=np.uint8)
         for w, a in enumerate(starts):
-            raw[w] = src.read_raw_u8(a, a + length).reshape(length, 2)
+            src.read_raw_u8_into(raw[2 * w * length:2 * (w + 1) * length], a, a + length)
         return raw
 
     def accurate_windows(self, starts, length, sync, raw=None):
@@ -153,6 +153,8 @@ class noaa_sync:
         sa, sb = self.getCrudeSync()
         src = self.__sigsrc
         width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
+        if not hasattr(src, "read_raw_u8_into"):
+            batched = False         # a foreign source object (only .read): window by window through the drop-in classes
         out, jobs = [], []
         for crude, sync in ((sa, constants.NOAA_SYNCA), (sb, constants.NOAA_SYNCB)):
             starts = []

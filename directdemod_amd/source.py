@@ -63,6 +63,11 @@ class _u8source:
         a, b = self._range(fromIndex, toIndex)
         return np.ascontiguousarray(self._data[a:b]).reshape(-1)
 
+    def read_raw_u8_into(self, dst, fromIndex, toIndex=None):
+        '''the raw pairs copied straight into a caller buffer (e.g. a pinned staging slot): one host copy'''
+        a, b = self._range(fromIndex, toIndex)
+        dst[:2 * (b - a)] = self._data[a:b].reshape(-1)
+
     def read_device(self, fromIndex, toIndex=None):
         '''Complex64 samples as a device array: 2 B/sample over PCIe, widened in HBM'''
         raw = self.read_raw_u8(fromIndex, toIndex)
