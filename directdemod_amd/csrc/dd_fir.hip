@@ -345,92 +345,88 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
     }
 }
 
-// u <- M u + e with M = hi + lo (double-double), products and sum carried in double-double
+// u <- M u + e with M = hi + lo (double-double), products and sum carried in double-double.
+// One chain (a group of blocks, or the sweep over the groups) is spread over RP = 8 or 16 adjacent lanes,
+// lane r owning row r of M in registers and component r of u: a step is S shuffles and S double-double
+// multiply-adds per lane instead of S*S in one lane (the serial form kept a single wave per chain busy for
+// ~2500 cycles per step: 720 dependent-ish f64 operations at 4 cycles each).  Row sums accumulate in the
+// same order as before, so the states are bit-identical.
 template <int S>
-__device__ __forceinline__ void dd_iir_affine(const double* __restrict__ mh, const double* __restrict__ ml,
-                                              double (&u)[IIR_S], const double* e) {
+struct IirRows {
+    static constexpr int RP = S <= 8 ? 8 : 16;
+};
+template <int S>
+__device__ __forceinline__ double dd_iir_affine_row(const double (&mh)[S], const double (&ml)[S], double u, double e, int base) {
 #pragma clang fp contract(off)      // error-free transformations below: no fusing of their multiplies and adds
-    double v[IIR_S];
+    double ah = e, al = 0.0;
 #pragma unroll
-    for (int r = 0; r < IIR_S; ++r) {
-        double ah = (r < S) ? e[r] : 0.0, al = 0.0;
-#pragma unroll
-        for (int q = 0; q < IIR_S; ++q) {
-            if (r < S && q < S) {
-                const double m = mh[r * IIR_S + q], x = u[q];
-                const double p = m * x;
-                const double pe = fma(m, x, -p) + ml[r * IIR_S + q] * x;      // exact product tail + low limb
-                const double sh = ah + p;                                      // two-sum
-                const double bb = sh - ah;
-                const double se = (ah - (sh - bb)) + (p - bb);
-                ah = sh;
-                al += se + pe;
-            }
-        }
-        v[r] = ah + al;
+    for (int q = 0; q < S; ++q) {
+        const double x = __shfl(u, base + q);
+        const double m = mh[q];
+        const double p = m * x;
+        const double pe = fma(m, x, -p) + ml[q] * x;                   // exact product tail + low limb
+        const double sh = ah + p;                                      // two-sum
+        const double bb = sh - ah;
+        const double se = (ah - (sh - bb)) + (p - bb);
+        ah = sh;
+        al += se + pe;
     }
-#pragma unroll
-    for (int r = 0; r < IIR_S; ++r) u[r] = v[r];
+    return ah + al;
 }
 
 // phase 0: group end vectors from zero (grp[]); phase 2: block start states written over blk[]
 template <int S>
 __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, double* __restrict__ grp, int64_t nb, int ncomp,
                                                    const double* __restrict__ mats, int phase) {
+    constexpr int RP = IirRows<S>::RP;
     const int64_t ng = (nb + IIR_G - 1) / IIR_G;
-    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= ng * ncomp) return;
+    const int lane = threadIdx.x, r = lane % RP, base = lane - r;
+    int64_t t = (int64_t)blockIdx.x * (64 / RP) + lane / RP;           // chain = (group, component)
+    const bool live = t < ng * ncomp;
+    if (!live) t = ng * ncomp - 1;                                     // idle chains shadow the last one (shuffles stay convergent)
+    const bool row = r < S;
+    const int rr = row ? r : 0;
     const int64_t g = t / ncomp;
     const int c = (int)(t - g * ncomp);
-    double u[IIR_S];
+    double mh[S], ml[S];
 #pragma unroll
-    for (int k = 0; k < IIR_S; ++k) u[k] = (phase == 2 && k < S) ? grp[t * IIR_S + k] : 0.0;
+    for (int q = 0; q < S; ++q) { mh[q] = mats[rr * IIR_S + q]; ml[q] = mats[IIR_MAT + rr * IIR_S + q]; }
+    double u = (phase == 2) ? grp[t * IIR_S + rr] : 0.0;
     const int64_t b0 = g * IIR_G, b1 = b0 + IIR_G < nb ? b0 + IIR_G : nb;
     // the chain u <- M u + e is serial; the e vectors are not: the next one is fetched while this step runs
-    double e[IIR_S], en[IIR_S];
-#pragma unroll
-    for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? blk[(b0 * ncomp + c) * IIR_S + k] : 0.0;
+    double e = blk[(b0 * ncomp + c) * IIR_S + rr];
     for (int64_t b = b0; b < b1; ++b) {
         double* slot = blk + (b * ncomp + c) * IIR_S;
-        const double* nslot = blk + ((b + 1 < b1 ? b + 1 : b) * ncomp + c) * IIR_S;
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) en[k] = (k < S) ? nslot[k] : 0.0;
-        if (phase == 2) {
-#pragma unroll
-            for (int k = 0; k < IIR_S; ++k) if (k < S) slot[k] = u[k];       // this block's start state
-        }
-        dd_iir_affine<S>(mats, mats + IIR_MAT, u, e);
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) e[k] = en[k];
+        const double en = blk[((b + 1 < b1 ? b + 1 : b) * ncomp + c) * IIR_S + rr];
+        if (phase == 2 && live && row) slot[r] = u;                    // this block's start state
+        u = dd_iir_affine_row<S>(mh, ml, u, e, base);
+        e = en;
     }
-    if (phase == 0) {
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) if (k < S) grp[t * IIR_S + k] = u[k];
-    }
+    if (phase == 0 && live && row) grp[t * IIR_S + r] = u;
 }
 
-// phase 1: sequential sweep over the groups (one lane per component): grp[g] <- start state of group g
+// phase 1: sequential sweep over the groups (one chain per component): grp[g] <- start state of group g
 template <int S>
-__global__ void k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, const double* __restrict__ mats,
-                                  const double* __restrict__ state, int zero_state) {
-    const int c = threadIdx.x;
-    if (c >= ncomp) return;
-    double u[IIR_S];
+__global__ void __launch_bounds__(64) k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, const double* __restrict__ mats,
+                                                        const double* __restrict__ state, int zero_state) {
+    constexpr int RP = IirRows<S>::RP;
+    const int lane = threadIdx.x, r = lane % RP, base = lane - r;
+    int c = lane / RP;
+    const bool live = c < ncomp;
+    if (!live) c = ncomp - 1;
+    const bool row = r < S;
+    const int rr = row ? r : 0;
+    double mh[S], ml[S];
 #pragma unroll
-    for (int k = 0; k < IIR_S; ++k) u[k] = (!zero_state && k < S) ? state[c * IIR_S + k] : 0.0;
-    double e[IIR_S], en[IIR_S];
-#pragma unroll
-    for (int k = 0; k < IIR_S; ++k) e[k] = (k < S) ? grp[c * IIR_S + k] : 0.0;
+    for (int q = 0; q < S; ++q) { mh[q] = mats[2 * IIR_MAT + rr * IIR_S + q]; ml[q] = mats[3 * IIR_MAT + rr * IIR_S + q]; }
+    double u = zero_state ? 0.0 : state[c * IIR_S + rr];
+    double e = grp[c * IIR_S + rr];
     for (int64_t g = 0; g < ng; ++g) {
         double* slot = grp + (g * ncomp + c) * IIR_S;
-        const double* nslot = grp + ((g + 1 < ng ? g + 1 : g) * ncomp + c) * IIR_S;
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) en[k] = (k < S) ? nslot[k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) if (k < S) slot[k] = u[k];
-        dd_iir_affine<S>(mats + 2 * IIR_MAT, mats + 3 * IIR_MAT, u, e);
-#pragma unroll
-        for (int k = 0; k < IIR_S; ++k) e[k] = en[k];
+        const double en = grp[((g + 1 < ng ? g + 1 : g) * ncomp + c) * IIR_S + rr];
+        if (live && row) slot[r] = u;
+        u = dd_iir_affine_row<S>(mh, ml, u, e, base);
+        e = en;
     }
 }
 
@@ -495,16 +491,17 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     }
     DDIirCoef C;
     iir_coef(h, &C);
-    const unsigned gb = (unsigned)((nb * ncomp + 255) / 256), gg = (unsigned)((ng * ncomp + 63) / 64);
+    const unsigned gb = (unsigned)((nb * ncomp + 255) / 256);
     hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
     // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
     // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
 #define DD_IIR_SCAN(SS)                                                                                              \
-    case SS:                                                                                                         \
+    case SS: {                                                                                                       \
+        const unsigned cpw = 64 / IirRows<SS>::RP, gg = (unsigned)((ng * ncomp + cpw - 1) / cpw);                  \
         hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 0);             \
         hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, mats, h->state, carry ? 0 : 1); \
         hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 2);             \
-        break;
+    } break;
     switch (S) {
         DD_IIR_SCAN(1) DD_IIR_SCAN(2) DD_IIR_SCAN(3) DD_IIR_SCAN(4) DD_IIR_SCAN(5) DD_IIR_SCAN(6) DD_IIR_SCAN(7) DD_IIR_SCAN(8)
         DD_IIR_SCAN(9) DD_IIR_SCAN(10) DD_IIR_SCAN(11) DD_IIR_SCAN(12) DD_IIR_SCAN(13) DD_IIR_SCAN(14) DD_IIR_SCAN(15)
