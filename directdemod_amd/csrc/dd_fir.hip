@@ -345,6 +345,113 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
     }
 }
 
+// The same two passes with the samples staged through LDS.  In the form above a lane walks its own block, so a
+// wave's load touches 32-64 different cache lines and uses 16 bytes of each; the lines do get used up over the
+// next iterations, but only if they survive in L1 meanwhile (pass 1 ran at 1.5 TB/s).  Here the workgroup's
+// 256 chains (128 blocks x re/im, or 256 real blocks) fetch 16 samples per block as whole 16-byte units, a
+// block's 256 bytes on 16 adjacent lanes, and park them in LDS rows padded by 16 (8) bytes so that the
+// per-chain reads fall on distinct banks; outputs overwrite the inputs in the same LDS slots and leave the same
+// way.  The next step's units are requested before the current one is computed and written to the other LDS
+// buffer afterwards.  The recurrence itself is the same float64 sequence per sample.
+#define IIR_CH 16
+__host__ __device__ __forceinline__ int iir_lds_row(int ncomp) { return IIR_CH * ncomp + (ncomp == 2 ? 2 : 1); }
+
+template <int S>
+__device__ __forceinline__ double dd_iir_step_t(const DDIirCoef& C, double (&z)[S], double x) {
+    const double y = fma(C.b[0], x, z[0]);
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const double zn = (k + 1 < S) ? z[k + 1] : 0.0;
+        z[k] = zn + C.b[k + 1] * x - C.a[k + 1] * y;
+    }
+    return y;
+}
+
+template <int S, bool WRITE>
+__global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__ in, double* __restrict__ out, int64_t n, int ncomp,
+                                                      DDIirCoef C, double* __restrict__ blk, int64_t nb,
+                                                      double* __restrict__ state, int save, int lb) {
+    extern __shared__ double iir_lds[];
+    const int nbw = 256 / ncomp, row = iir_lds_row(ncomp), upb = IIR_CH * ncomp / 2;      // blocks per workgroup, row length, 16-byte units per row
+    const int nunit = nbw * upb / 256;                                                   // units per lane and step (8)
+    const int t = threadIdx.x, bl = t / ncomp, c = t - bl * ncomp;
+    const int64_t bw0 = (int64_t)blockIdx.x * nbw, b = bw0 + bl;
+    const bool live = b < nb;
+    const int64_t total = n * ncomp;
+    double z[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * ncomp + c) * IIR_S + k] : 0.0;
+    const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;            // samples of this chain's block
+    double2 rg[8];
+    const double xlast = in[total - 1];
+    auto issue = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < nunit) {
+                const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
+                int64_t d = ((bw0 + ub) * lb + i) * ncomp + 2 * w;
+                const int64_t dmax = (total - 2) & ~(int64_t)1;
+                const bool straggler = d == total - 1;                                   // odd length: the last sample starts a unit
+                d = d < dmax ? d : dmax;                                                 // past the end: re-read, never consumed
+                rg[k] = *reinterpret_cast<const double2*>(in + d);
+                if (straggler) rg[k].x = xlast;
+            }
+        }
+    };
+    auto park = [&](double* buf) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < nunit) {
+                const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
+                buf[ub * row + 2 * w] = rg[k].x;
+                buf[ub * row + 2 * w + 1] = rg[k].y;
+            }
+        }
+    };
+    double* cur = iir_lds;
+    double* nxt = iir_lds + nbw * row;
+    issue(0);
+    park(cur);
+    __syncthreads();
+    for (int i = 0; i < lb; i += IIR_CH) {
+        if (i + IIR_CH < lb) issue(i + IIR_CH);
+        double* mine = cur + bl * row + c;
+#pragma unroll
+        for (int u = 0; u < IIR_CH; ++u) {
+            if (i + u < ilen) {
+                const double y = dd_iir_step_t<S>(C, z, mine[u * ncomp]);
+                if (WRITE) mine[u * ncomp] = y;
+            }
+        }
+        if (WRITE) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < nunit) {
+                    const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
+                    const int64_t bb = bw0 + ub;
+                    const int64_t d = (bb * lb + i) * ncomp + 2 * w;
+                    const int64_t dend = (bb + 1) * lb * ncomp < total ? (bb + 1) * lb * ncomp : total;   // end of this block's data
+                    if (bb < nb && d + 1 < dend) *reinterpret_cast<double2*>(out + d) = make_double2(cur[ub * row + 2 * w], cur[ub * row + 2 * w + 1]);
+                    else if (bb < nb && d < dend) out[d] = cur[ub * row + 2 * w];
+                }
+            }
+        }
+        if (i + IIR_CH < lb) park(nxt);
+        __syncthreads();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (!WRITE) {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) blk[(b * ncomp + c) * IIR_S + k] = z[k];
+        }
+    } else if (save && live && b == nb - 1) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) state[c * IIR_S + k] = z[k];
+    }
+}
+
 // u <- M u + e with M = hi + lo (double-double), products and sum carried in double-double.
 // One chain (a group of blocks, or the sweep over the groups) is spread over RP = 8 or 16 adjacent lanes,
 // lane r owning row r of M in registers and component r of u: a step is S shuffles and S double-double
@@ -492,7 +599,29 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     DDIirCoef C;
     iir_coef(h, &C);
     const unsigned gb = (unsigned)((nb * ncomp + 255) / 256);
-    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
+    // LDS-staged block kernels need 16-byte aligned buffers (always true for whole device arrays)
+    const bool staged = !(((uintptr_t)in | (uintptr_t)out) & 15) && !getenv("DD_IIR_UNSTAGED");
+    const unsigned gbt = (unsigned)((nb + 256 / ncomp - 1) / (256 / ncomp));
+    const size_t lds_t = sizeof(double) * 2 * (256 / ncomp) * iir_lds_row(ncomp);
+#define DD_IIR_BLOCKS(SS, WR, SAVE)                                                                                  \
+    case SS: {                                                                                                       \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipFuncSetAttribute((const void*)k_iir_blocks_t<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_iir_blocks_t<SS, WR>), dim3(gbt), dim3(256), lds_t, s, in, out, n, ncomp, C, blk, nb, h->state, SAVE, lb); \
+    } break;
+#define DD_IIR_BLOCKS_ALL(WR, SAVE)                                                                                  \
+    switch (S) {                                                                                                     \
+        DD_IIR_BLOCKS(1, WR, SAVE) DD_IIR_BLOCKS(2, WR, SAVE) DD_IIR_BLOCKS(3, WR, SAVE) DD_IIR_BLOCKS(4, WR, SAVE)   \
+        DD_IIR_BLOCKS(5, WR, SAVE) DD_IIR_BLOCKS(6, WR, SAVE) DD_IIR_BLOCKS(7, WR, SAVE) DD_IIR_BLOCKS(8, WR, SAVE)   \
+        DD_IIR_BLOCKS(9, WR, SAVE) DD_IIR_BLOCKS(10, WR, SAVE) DD_IIR_BLOCKS(11, WR, SAVE) DD_IIR_BLOCKS(12, WR, SAVE) \
+        DD_IIR_BLOCKS(13, WR, SAVE) DD_IIR_BLOCKS(14, WR, SAVE) DD_IIR_BLOCKS(15, WR, SAVE)                           \
+        default: break;                                                                                              \
+    }
+    if (staged) { DD_IIR_BLOCKS_ALL(false, 0) }
+    else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
     // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
     // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
 #define DD_IIR_SCAN(SS)                                                                                              \
@@ -508,7 +637,10 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         default: break;
     }
 #undef DD_IIR_SCAN
-    hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
+    if (staged) { DD_IIR_BLOCKS_ALL(true, carry ? 1 : 0) }
+    else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
+#undef DD_IIR_BLOCKS_ALL
+#undef DD_IIR_BLOCKS
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
     hipFree(blk);
