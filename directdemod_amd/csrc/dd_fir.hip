@@ -158,6 +158,8 @@ struct dd_iir {
     double* state;          // device: 2 * (n-1) doubles (re, im)
     double* mats;           // device: block-parallel path, [M_hi, M_lo, MG_hi, MG_lo] each IIR_S x IIR_S (see below), short blocks
     double* mats_long;      //         the same for the long block length
+    double* scratch;        // device: block / group vectors of the block-parallel path (grow-only)
+    size_t scratch_bytes;
 };
 struct DDIirCoef {
     int n;
@@ -233,6 +235,8 @@ extern "C" int dd_iir_create(dd_iir** h, const double* b, const double* a, int n
     f->state = nullptr;
     f->mats = nullptr;
     f->mats_long = nullptr;
+    f->scratch = nullptr;
+    f->scratch_bytes = 0;
     hipError_t e = hipMalloc((void**)&f->state, sizeof(double) * 2 * (DD_IIR_MAXN - 1));
     if (e != hipSuccess) {
         delete f;
@@ -254,6 +258,7 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
         hipFree(h->state);
         if (h->mats) hipFree(h->mats);
         if (h->mats_long) hipFree(h->mats_long);
+        if (h->scratch) hipFree(h->scratch);
         delete h;
     }
     return DD_OK;
@@ -264,9 +269,10 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 // with M = A^LB (A = the homogeneous DF2T step, a constant S x S matrix, S = n-1) and e = the
 // block's end state when started from zero.  So:
 //   1. every block's e in parallel (one lane per block and real component, no output);
-//   2. the block start states by the same idea one level up (groups of IIR_G blocks: group
-//      end vectors in parallel, a short sequential sweep over the groups with M^G, then the
-//      blocks of each group in parallel);
+//   2. the block start states by the same idea one and two levels up (groups of 64 blocks: group end
+//      vectors in parallel; if there are more than 128 groups, super-groups of 64 groups likewise; a
+//      short sequential sweep over the top level with the matching power of M; then back down, the
+//      members of each group in parallel);
 //   3. every block again in parallel from its true start state, this time writing y.
 // Twice the arithmetic of the sequential form, n / LB lanes wide.  Same float64 recurrence
 // per sample.  Conditioning: the DF2T state map is far from normal for narrow-band filters
@@ -277,11 +283,13 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 // the digits again), stored as double-double, and applied in double-double arithmetic; the
 // state handed from block to block is a plain double, exactly as in the sequential form.
 // block length: 256 samples, or 1024 from 2^25 samples up (measured on 2^24 / 2^26 complex128 samples: 256 ->
-// 1.45 / 3.69 ms, 1024 -> 1.82 / 2.72 ms: long blocks shorten the scan, short blocks keep the block kernels wide)
+// 0.42 / 1.50 ms, 1024 -> 0.92 / 1.37 ms: short blocks keep the block kernels wide, long blocks give each
+// block longer contiguous runs)
 #define IIR_LB_SHORT 256
 #define IIR_LB_LONG 1024
 #define IIR_LONG_FROM ((int64_t)1 << 25)
-#define IIR_G 256
+#define IIR_G1 64
+#define IIR_G2 64
 #define IIR_S (DD_IIR_MAXN - 1)
 #define IIR_MAT (IIR_S * IIR_S)
 
@@ -353,7 +361,9 @@ __global__ void __launch_bounds__(256) k_iir_blocks(const double* __restrict__ i
 // per-chain reads fall on distinct banks; outputs overwrite the inputs in the same LDS slots and leave the same
 // way.  The next step's units are requested before the current one is computed and written to the other LDS
 // buffer afterwards.  The recurrence itself is the same float64 sequence per sample.
+#ifndef IIR_CH
 #define IIR_CH 16
+#endif
 __host__ __device__ __forceinline__ int iir_lds_row(int ncomp) { return IIR_CH * ncomp + (ncomp == 2 ? 2 : 1); }
 
 template <int S>
@@ -484,9 +494,9 @@ __device__ __forceinline__ double dd_iir_affine_row(const double (&mh)[S], const
 // phase 0: group end vectors from zero (grp[]); phase 2: block start states written over blk[]
 template <int S>
 __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, double* __restrict__ grp, int64_t nb, int ncomp,
-                                                   const double* __restrict__ mats, int phase) {
+                                                   const double* __restrict__ mats, int phase, int G) {
     constexpr int RP = IirRows<S>::RP;
-    const int64_t ng = (nb + IIR_G - 1) / IIR_G;
+    const int64_t ng = (nb + G - 1) / G;
     const int lane = threadIdx.x, r = lane % RP, base = lane - r;
     int64_t t = (int64_t)blockIdx.x * (64 / RP) + lane / RP;           // chain = (group, component)
     const bool live = t < ng * ncomp;
@@ -499,7 +509,7 @@ __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, dou
 #pragma unroll
     for (int q = 0; q < S; ++q) { mh[q] = mats[rr * IIR_S + q]; ml[q] = mats[IIR_MAT + rr * IIR_S + q]; }
     double u = (phase == 2) ? grp[t * IIR_S + rr] : 0.0;
-    const int64_t b0 = g * IIR_G, b1 = b0 + IIR_G < nb ? b0 + IIR_G : nb;
+    const int64_t b0 = g * G, b1 = b0 + G < nb ? b0 + G : nb;
     // the chain u <- M u + e is serial; the e vectors are not: the next one is fetched while this step runs
     double e = blk[(b0 * ncomp + c) * IIR_S + rr];
     for (int64_t b = b0; b < b1; ++b) {
@@ -525,7 +535,7 @@ __global__ void __launch_bounds__(64) k_iir_group_sweep(double* __restrict__ grp
     const int rr = row ? r : 0;
     double mh[S], ml[S];
 #pragma unroll
-    for (int q = 0; q < S; ++q) { mh[q] = mats[2 * IIR_MAT + rr * IIR_S + q]; ml[q] = mats[3 * IIR_MAT + rr * IIR_S + q]; }
+    for (int q = 0; q < S; ++q) { mh[q] = mats[rr * IIR_S + q]; ml[q] = mats[IIR_MAT + rr * IIR_S + q]; }
     double u = zero_state ? 0.0 : state[c * IIR_S + rr];
     double e = grp[c * IIR_S + rr];
     for (int64_t g = 0; g < ng; ++g) {
@@ -538,11 +548,12 @@ __global__ void __launch_bounds__(64) k_iir_group_sweep(double* __restrict__ grp
 }
 
 // M = A^LB by stepping the homogeneous DF2T recurrence (z0' = z1 - a1 z0, ...) from each unit
-// vector, MG = M^G by stepping the block map; both in __float128, split into double-double.
-static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 4 * IIR_MAT */) {
+// vector, M1 = M^G1 by stepping the block map, M2 = M1^G2 by stepping the group map; all in
+// __float128, split into double-double: out = [M hi, M lo, M1 hi, M1 lo, M2 hi, M2 lo].
+static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 6 * IIR_MAT */) {
     const int S = h->n - 1;
     typedef __float128 q_t;
-    q_t M[IIR_S][IIR_S], MG[IIR_S][IIR_S];
+    q_t M[3][IIR_S][IIR_S];
     for (int j = 0; j < S; ++j) {
         q_t z[IIR_S + 1];
         for (int k = 0; k <= IIR_S; ++k) z[k] = 0;
@@ -551,51 +562,63 @@ static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 4 * IIR_M
             const q_t y = z[0];
             for (int k = 0; k < S; ++k) z[k] = (k + 1 < S ? z[k + 1] : (q_t)0) - (q_t)h->a[k + 1] * y;
         }
-        for (int k = 0; k < S; ++k) M[k][j] = z[k];
+        for (int k = 0; k < S; ++k) M[0][k][j] = z[k];
     }
-    for (int j = 0; j < S; ++j) {
-        q_t u[IIR_S], v[IIR_S];
-        for (int k = 0; k < S; ++k) u[k] = (k == j) ? 1 : 0;
-        for (int t = 0; t < IIR_G; ++t) {
-            for (int r = 0; r < S; ++r) {
-                q_t acc = 0;
-                for (int q = 0; q < S; ++q) acc += M[r][q] * u[q];
-                v[r] = acc;
+    const int steps[2] = {IIR_G1, IIR_G2};
+    for (int lv = 1; lv < 3; ++lv) {
+        for (int j = 0; j < S; ++j) {
+            q_t u[IIR_S], v[IIR_S];
+            for (int k = 0; k < S; ++k) u[k] = (k == j) ? 1 : 0;
+            for (int t = 0; t < steps[lv - 1]; ++t) {
+                for (int r = 0; r < S; ++r) {
+                    q_t acc = 0;
+                    for (int q = 0; q < S; ++q) acc += M[lv - 1][r][q] * u[q];
+                    v[r] = acc;
+                }
+                for (int r = 0; r < S; ++r) u[r] = v[r];
             }
-            for (int r = 0; r < S; ++r) u[r] = v[r];
+            for (int k = 0; k < S; ++k) M[lv][k][j] = u[k];
         }
-        for (int k = 0; k < S; ++k) MG[k][j] = u[k];
     }
-    for (int i = 0; i < 4 * IIR_MAT; ++i) out[i] = 0.0;
-    for (int r = 0; r < S; ++r)
-        for (int c = 0; c < S; ++c) {
-            const double mh = (double)M[r][c], gh = (double)MG[r][c];
-            out[r * IIR_S + c] = mh;
-            out[IIR_MAT + r * IIR_S + c] = (double)(M[r][c] - (q_t)mh);
-            out[2 * IIR_MAT + r * IIR_S + c] = gh;
-            out[3 * IIR_MAT + r * IIR_S + c] = (double)(MG[r][c] - (q_t)gh);
-        }
+    for (int i = 0; i < 6 * IIR_MAT; ++i) out[i] = 0.0;
+    for (int lv = 0; lv < 3; ++lv)
+        for (int r = 0; r < S; ++r)
+            for (int c = 0; c < S; ++c) {
+                const double mh = (double)M[lv][r][c];
+                out[(2 * lv) * IIR_MAT + r * IIR_S + c] = mh;
+                out[(2 * lv + 1) * IIR_MAT + r * IIR_S + c] = (double)(M[lv][r][c] - (q_t)mh);
+            }
 }
 
 static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int ncomp, int carry, hipStream_t s) {
     const int S = h->n - 1;
-    const int lb = n >= IIR_LONG_FROM ? IIR_LB_LONG : IIR_LB_SHORT;
-    const int64_t nb = (n + lb - 1) / lb, ng = (nb + IIR_G - 1) / IIR_G;
+    int lb = n >= IIR_LONG_FROM ? IIR_LB_LONG : IIR_LB_SHORT;
+    if (const char* e = getenv("DD_IIR_LB")) lb = atoi(e) == IIR_LB_LONG ? IIR_LB_LONG : IIR_LB_SHORT;      // A/B switch
+    // block start states: blocks -> groups of G1 -> (if there are many groups) super-groups of G2 -> one short serial sweep
+    const int64_t nb = (n + lb - 1) / lb, ng = (nb + IIR_G1 - 1) / IIR_G1;
+    const bool three = ng > 2 * IIR_G2;
+    const int64_t ns = three ? (ng + IIR_G2 - 1) / IIR_G2 : 0;
     double*& mats = (lb == IIR_LB_LONG) ? h->mats_long : h->mats;
     if (!mats) {                                            // first input of this length class on this handle
-        double hm[4 * IIR_MAT];
+        double hm[6 * IIR_MAT];
         iir_block_matrices(h, lb, hm);
         DD_HIP_CHECK(hipMalloc((void**)&mats, sizeof(hm)));
         DD_HIP_CHECK(hipMemcpy(mats, hm, sizeof(hm), hipMemcpyHostToDevice));
     }
-    double *blk = nullptr, *grp = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&blk, sizeof(double) * IIR_S * nb * ncomp));
-    hipError_t e = hipMalloc((void**)&grp, sizeof(double) * IIR_S * ng * ncomp);
-    if (e != hipSuccess) {
-        hipFree(blk);
-        dd_set_error("hipMalloc: %s", hipGetErrorString(e));
-        return DD_ERR_NOMEM;
+    // block and group vectors live in a scratch buffer kept on the handle (allocation and release cost ~0.4 ms per call)
+    const size_t blk_bytes = (sizeof(double) * IIR_S * nb * ncomp + 255) & ~(size_t)255;
+    const size_t grp_bytes = (sizeof(double) * IIR_S * ng * ncomp + 255) & ~(size_t)255;
+    const size_t need = blk_bytes + grp_bytes + sizeof(double) * IIR_S * (ns + 1) * ncomp;
+    if (h->scratch_bytes < need) {
+        if (h->scratch) DD_HIP_CHECK(hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+        DD_HIP_CHECK(hipMalloc((void**)&h->scratch, need));
+        h->scratch_bytes = need;
     }
+    double* blk = h->scratch;
+    double* grp = (double*)((char*)h->scratch + blk_bytes);
+    double* sup = (double*)((char*)h->scratch + blk_bytes + grp_bytes);
     DDIirCoef C;
     iir_coef(h, &C);
     const unsigned gb = (unsigned)((nb * ncomp + 255) / 256);
@@ -626,10 +649,18 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
 #define DD_IIR_SCAN(SS)                                                                                              \
     case SS: {                                                                                                       \
-        const unsigned cpw = 64 / IirRows<SS>::RP, gg = (unsigned)((ng * ncomp + cpw - 1) / cpw);                  \
-        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 0);             \
-        hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, mats, h->state, carry ? 0 : 1); \
-        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 2);             \
+        const unsigned cpw = 64 / IirRows<SS>::RP;                                                                   \
+        const unsigned gg = (unsigned)((ng * ncomp + cpw - 1) / cpw), gs = (unsigned)((ns * ncomp + cpw - 1) / cpw); \
+        const int zero = carry ? 0 : 1;                                                                              \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 0, IIR_G1);     \
+        if (three) {                                                                                                 \
+            hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gs), dim3(64), 0, s, grp, sup, ng, ncomp, mats + 2 * IIR_MAT, 0, IIR_G2); \
+            hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, sup, ns, ncomp, mats + 4 * IIR_MAT, h->state, zero); \
+            hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gs), dim3(64), 0, s, grp, sup, ng, ncomp, mats + 2 * IIR_MAT, 2, IIR_G2); \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL(k_iir_group_sweep<SS>, dim3(1), dim3(64), 0, s, grp, ng, ncomp, mats + 2 * IIR_MAT, h->state, zero); \
+        }                                                                                                            \
+        hipLaunchKernelGGL(k_iir_groups<SS>, dim3(gg), dim3(64), 0, s, blk, grp, nb, ncomp, mats, 2, IIR_G1);     \
     } break;
     switch (S) {
         DD_IIR_SCAN(1) DD_IIR_SCAN(2) DD_IIR_SCAN(3) DD_IIR_SCAN(4) DD_IIR_SCAN(5) DD_IIR_SCAN(6) DD_IIR_SCAN(7) DD_IIR_SCAN(8)
@@ -641,12 +672,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
 #undef DD_IIR_BLOCKS_ALL
 #undef DD_IIR_BLOCKS
-    hipError_t le = hipGetLastError();
-    hipError_t se = hipStreamSynchronize(s);
-    hipFree(blk);
-    hipFree(grp);
-    DD_HIP_CHECK(le);
-    DD_HIP_CHECK(se);
+    DD_LAUNCH_CHECK();
     return DD_OK;
 }
 

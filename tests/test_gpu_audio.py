@@ -409,6 +409,22 @@ def test_iir_block_parallel_long_block_length(dd):
     assert rel_err(got, ref) < 1e-7
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_iir_three_level_scan_short_blocks(dd, cplx):
+    """3 000 001 samples: 256-sample blocks, 184 groups -> the scan goes through super-groups; odd length
+    (the staged block kernels fetch 16-byte units: the last sample starts a unit of its own)"""
+    import scipy.signal as ss
+    rng = np.random.default_rng(21)
+    n = 3000001
+    x = rng.standard_normal(n + 7000) + (1j * rng.standard_normal(n + 7000) if cplx else 0)
+    x = x.astype(np.complex128 if cplx else np.float64)
+    f = dd.filters.butter(2048000, 20000.0)
+    b, a = np.asarray(f.getB), np.asarray(f.getA)
+    got = np.concatenate([f.applyOn(x[:n]), f.applyOn(x[n:])])
+    ref = ss.lfilter(b, a, x, zi=ss.lfilter_zi(b, a).astype(x.dtype))[0]
+    assert rel_err(got, ref) < 1e-7
+
+
 def test_afsk_front_end_matches_the_reference_run(dd, golden_dir):
     """config 1's route (decode_afsk1200.py:67-98: offsetFreq -> blackmanHarris(151) -> bwLim(22050) -> demod_fm ->
     butter band-pass) on the device against the audio the reference itself produced for the same synthetic
