@@ -114,8 +114,9 @@ int dd_filtfilt_c64(const double* taps_host, int ntaps, const float* in_c64, flo
 /* ---- F4: filters.butter -> scipy.signal.lfilter with a != [1] (filters.py:232-273) ---
  * Transposed direct form II recurrence, float64, state carried on the device.
  * Short inputs: one lane per real component.  From 4096 samples up: block-parallel
- * (block end states from zero, two-level scan of the block start states with the block
- * map A^256 held in double-double, blocks re-run from their true start states), which
+ * (block end states from zero, two- or three-level scan of the block start states with
+ * the block map A^256 held in double-double, blocks re-run from their true start states;
+ * asynchronous on `stream`, intermediates in a scratch buffer owned by the handle), which
  * is what full-rate IQ through a butter takes (decode_funcube.py:160,230; SURVEY.md
  * 8f-3).  b, a: `n` coefficients each
  * (pad the shorter with zeros), a[0] != 0.  zi_host: n-1 initial state values
