@@ -74,6 +74,28 @@ def cpu_baseline(n):
             "host_cpus": os.cpu_count()}
 
 
+def cpu_baseline_all_cores(log2_per_worker=22, timeout_s=240):
+    """The same CPU path on every host core the process may use: one process per contiguous shard
+    (tools/cpu_allcores.py, a child process that never touches the GPU), bounded by a timeout."""
+    import signal
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "cpu_allcores.py")
+    try:
+        p = subprocess.Popen([sys.executable, tool, str(log2_per_worker)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             start_new_session=True, text=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)          # the child's own process group (its worker pool included)
+            p.communicate()
+            return {"error": "timed out after %d s" % timeout_s}
+        if p.returncode != 0:
+            return {"error": "exit code %d" % p.returncode}
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as e:                            # a reported baseline, never a reason to lose the bench line
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +259,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_log2n)
+            res["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores()
         print(json.dumps(res))
     lib.dd_chain_destroy(h)
     if world > 1:
