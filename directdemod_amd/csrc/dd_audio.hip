@@ -628,25 +628,7 @@ __global__ void __launch_bounds__(256) k_sync_peak(const DDPk* __restrict__ part
 // circular convolution needs only outputs [0, N), which a length-M >= 2N-1 cyclic convolution with the kernel
 // laid out at offsets -(N-1)..N-1 gives without wrap-around: one real-to-complex and one complex-to-real
 // power-of-two transform per window, a quarter of the work.  The kernel spectrum is built once per length
-// from the library's own length-N inverse transform of h.
-__global__ void __launch_bounds__(256) k_hilb_mask_init(double2* __restrict__ X, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double h;
-    if ((n & 1) == 0) h = (i == 0 || i == n / 2) ? 1.0 : (i < n / 2 ? 2.0 : 0.0);
-    else h = (i == 0) ? 1.0 : (i < (n + 1) / 2 ? 2.0 : 0.0);
-    X[i] = make_double2(h, 0.0);
-}
-// buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
-__global__ void __launch_bounds__(256) k_hilb_kernel_pad(const double2* __restrict__ g, int64_t n, int64_t M, double inv_n,
-                                                         double* __restrict__ buf) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= M) return;
-    double v = 0.0;
-    if (j < n) v = g[j].y * inv_n;
-    else if (j > M - n) v = g[j - (M - n)].y * inv_n;
-    buf[j] = v;
-}
+// from the closed form of hh.
 __global__ void __launch_bounds__(256) k_sync_fm_pad(const float2* __restrict__ Y, int64_t L, double* __restrict__ XR, int64_t M) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= M) return;
@@ -669,33 +651,46 @@ __global__ void __launch_bounds__(256) k_env_hypot(const double* __restrict__ XR
 
 static std::map<std::pair<int, int64_t>, double2*> g_hilb;      // (device, N) -> spectrum of the padded kernel / M
 
+// sin(pi num / den) for integers num >= 0, den > 0: the argument is reduced to [0, pi/2] exactly in integers first
+static double dd_sinpi_frac(int64_t num, int64_t den) {
+    int64_t r = num % (2 * den);
+    double sg = 1.0;
+    if (r >= den) { r -= den; sg = -1.0; }
+    if (2 * r > den) r = den - r;
+    return sg * sin(3.14159265358979323846 * (double)r / (double)den);
+}
+
+// hh[n] = imag(ifft(h))[n] = (2/N) sum_{k=1..m} sin(2 pi k n / N), m = the number of doubled bins of scipy's mask
+// ((N-1)/2 for odd N, N/2 - 1 for even N) = (2/N) sin(pi m n/N) sin(pi (m+1) n/N) / sin(pi n/N): a closed form, so no
+// length-N (Bluestein) plan is ever built for it; accurate to a few 1e-17 (checked against a long-double sum).
 static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
     int dev = 0;
     DD_HIP_CHECK(hipGetDevice(&dev));
     auto key = std::make_pair(dev, n);
     auto it = g_hilb.find(key);
     if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
-    const int64_t nb = M / 2 + 1;
-    double2 *g = nullptr, *HH = nullptr;
+    const int64_t nb = M / 2 + 1, m = (n & 1) ? (n - 1) / 2 : n / 2 - 1;
+    std::vector<double> host((size_t)M, 0.0);                 // buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
+    for (int64_t j = 1; j < n; ++j) {
+        const double v = (2.0 / (double)n) * dd_sinpi_frac(m * j, n) * dd_sinpi_frac((m + 1) * j, n) / dd_sinpi_frac(j, n);
+        host[(size_t)j] = v;
+        host[(size_t)(M - n + j)] = v;
+    }
+    double2* HH = nullptr;
     double* buf = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&g, sizeof(double2) * n));
     DD_HIP_CHECK(hipMalloc((void**)&buf, sizeof(double) * M));
     DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * nb));
-    hipfftHandle pn, pm;
-    int rc = get_plan(&pn, HIPFFT_Z2Z, n, 1, s);
-    if (rc == DD_OK) rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
-    if (rc != DD_OK) { hipFree(g); hipFree(buf); hipFree(HH); return rc; }
-    hipLaunchKernelGGL(k_hilb_mask_init, dim3(grid1(n)), dim3(256), 0, s, g, n);
-    hipfftResult r1 = hipfftExecZ2Z(pn, (hipfftDoubleComplex*)g, (hipfftDoubleComplex*)g, HIPFFT_BACKWARD);
-    hipLaunchKernelGGL(k_hilb_kernel_pad, dim3(grid1(M)), dim3(256), 0, s, g, n, M, 1.0 / (double)n, buf);
+    hipfftHandle pm;
+    int rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
+    if (rc != DD_OK) { hipFree(buf); hipFree(HH); return rc; }
+    hipError_t e0 = hipMemcpyAsync(buf, host.data(), sizeof(double) * M, hipMemcpyHostToDevice, s);
     hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
     hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
     hipError_t e = hipStreamSynchronize(s);
-    hipFree(g);
     hipFree(buf);
-    if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
+    if (e0 != hipSuccess || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
         hipFree(HH);
-        dd_set_error("Hilbert kernel spectrum: hipfft %d/%d, hip %s", (int)r1, (int)r2, hipGetErrorString(e));
+        dd_set_error("Hilbert kernel spectrum: hipfft %d, hip %s", (int)r2, hipGetErrorString(e0 != hipSuccess ? e0 : e));
         return DD_ERR_HIP;
     }
     g_hilb[key] = HH;
