@@ -62,28 +62,33 @@ __global__ void __launch_bounds__(256) k_real_to_cplx(const double* __restrict__
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = make_double2(in[i], 0.0);
 }
-__global__ void __launch_bounds__(256) k_hilbert_mask(double2* __restrict__ X, int64_t n) {
+// blockIdx.y = block (or window) of the batch
+__global__ void __launch_bounds__(256) k_hilbert_mask_b(double2* __restrict__ X, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double h;
     if ((n & 1) == 0) h = (i == 0 || i == n / 2) ? 1.0 : (i < n / 2 ? 2.0 : 0.0);
     else h = (i == 0) ? 1.0 : (i < (n + 1) / 2 ? 2.0 : 0.0);
-    X[i] = make_double2(X[i].x * h, X[i].y * h);
+    double2* p = X + (int64_t)blockIdx.y * n + i;
+    *p = make_double2(p->x * h, p->y * h);
 }
-__global__ void __launch_bounds__(256) k_cplx_abs(const double2* __restrict__ in, double* __restrict__ out, int64_t n, double inv_n) {
+__global__ void __launch_bounds__(256) k_cplx_abs_b(const double2* __restrict__ in, double* __restrict__ out, int64_t n, double inv_n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = hypot(in[i].x * inv_n, in[i].y * inv_n);
+    if (i >= n) return;
+    const double2 v = in[(int64_t)blockIdx.y * n + i];
+    out[(int64_t)blockIdx.y * n + i] = hypot(v.x * inv_n, v.y * inv_n);
 }
 
-static int envelope_block(const double* in, double* out, int64_t n, double2* work, hipStream_t s) {
+// `batch` consecutive blocks of n samples each: one batched transform pair
+static int envelope_blocks(const double* in, double* out, int64_t n, int batch, double2* work, hipStream_t s) {
     hipfftHandle plan;
-    int rc = get_plan(&plan, HIPFFT_Z2Z, n, 1, s);
+    int rc = get_plan(&plan, HIPFFT_Z2Z, n, batch, s);
     if (rc != DD_OK) return rc;
-    hipLaunchKernelGGL(k_real_to_cplx, dim3(grid1(n)), dim3(256), 0, s, in, work, n);
+    hipLaunchKernelGGL(k_real_to_cplx, dim3(grid1(n * batch)), dim3(256), 0, s, in, work, n * batch);
     DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)work, (hipfftDoubleComplex*)work, HIPFFT_FORWARD));
-    hipLaunchKernelGGL(k_hilbert_mask, dim3(grid1(n)), dim3(256), 0, s, work, n);
+    hipLaunchKernelGGL(k_hilbert_mask_b, dim3(grid1(n), batch), dim3(256), 0, s, work, n);
     DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)work, (hipfftDoubleComplex*)work, HIPFFT_BACKWARD));
-    hipLaunchKernelGGL(k_cplx_abs, dim3(grid1(n)), dim3(256), 0, s, work, out, n, 1.0 / (double)n);
+    hipLaunchKernelGGL(k_cplx_abs_b, dim3(grid1(n), batch), dim3(256), 0, s, work, out, n, 1.0 / (double)n);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
@@ -93,24 +98,21 @@ extern "C" int dd_am_envelope_f64(const double* in, double* out, int64_t n, int6
     if (n == 0) return DD_OK;
     DD_REQUIRE(in && out, "null buffer");
     hipStream_t s = dd_stream(stream);
-    // block list by the chunker rule (decode_noaa.py:644-653 via chunker.py:36-45)
-    std::vector<std::pair<int64_t, int64_t>> blocks;
-    int64_t i = 0;
-    while (i + block < n) {
-        blocks.push_back({i, i + block});
-        i += block;
-    }
-    if (blocks.empty()) blocks.push_back({0, n});
-    else if (blocks.back().second != n) blocks.push_back({blocks.back().second, n});
-    int64_t maxlen = 0;
-    for (auto& b : blocks) maxlen = std::max(maxlen, b.second - b.first);
+    // block list by the chunker rule (decode_noaa.py:644-653 via chunker.py:36-45): full blocks while one more
+    // fits strictly inside, then the remainder (a full-size last block when n is an exact multiple)
+    int64_t nfull = 0;
+    while ((nfull + 1) * block < n) ++nfull;
+    const int64_t rem = n - nfull * block;                  // 1 .. block
+    const int GB = 16;                                       // full blocks per batched transform
+    const int64_t wlen = nfull ? (nfull < GB ? nfull : GB) * block : 0;
     double2* work = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&work, sizeof(double2) * maxlen));
+    DD_HIP_CHECK(hipMalloc((void**)&work, sizeof(double2) * (wlen > rem ? wlen : rem)));
     int rc = DD_OK;
-    for (auto& b : blocks) {
-        rc = envelope_block(in + b.first, out + b.first, b.second - b.first, work, s);
-        if (rc != DD_OK) break;
+    for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) {
+        const int nbk = (int)(nfull - b0 < GB ? nfull - b0 : GB);
+        rc = envelope_blocks(in + b0 * block, out + b0 * block, block, nbk, work, s);
     }
+    if (rc == DD_OK) rc = envelope_blocks(in + nfull * block, out + nfull * block, rem, 1, work, s);
     hipError_t e = hipStreamSynchronize(s);
     hipFree(work);
     if (rc != DD_OK) return rc;
@@ -431,22 +433,6 @@ __global__ void __launch_bounds__(256) k_sync_fm(const float2* __restrict__ Y, i
     if (j >= L - 1) return;
     const float2* y = Y + (int64_t)blockIdx.y * L;
     W[(int64_t)blockIdx.y * (L - 1) + j] = make_double2((double)dd_fm_angle(y[j + 1], y[j]), 0.0);
-}
-
-__global__ void __launch_bounds__(256) k_hilbert_mask_b(double2* __restrict__ X, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double h;
-    if ((n & 1) == 0) h = (i == 0 || i == n / 2) ? 1.0 : (i < n / 2 ? 2.0 : 0.0);
-    else h = (i == 0) ? 1.0 : (i < (n + 1) / 2 ? 2.0 : 0.0);
-    double2* p = X + (int64_t)blockIdx.y * n + i;
-    *p = make_double2(p->x * h, p->y * h);
-}
-__global__ void __launch_bounds__(256) k_cplx_abs_b(const double2* __restrict__ in, double* __restrict__ out, int64_t n, double inv_n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double2 v = in[(int64_t)blockIdx.y * n + i];
-    out[(int64_t)blockIdx.y * n + i] = hypot(v.x * inv_n, v.y * inv_n);
 }
 
 // P[b][i] = sum h[b][0..i), Q likewise of h^2, in two launches over tiles of 2048 samples: tile sums, then each
