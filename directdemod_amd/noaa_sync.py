@@ -129,8 +129,11 @@ class noaa_sync:
         nw = len(starts)
         if nw == 0:
             return np.zeros(0, dtype=np.int64), [], []
-        raw = self._gather_windows(starts, length) if raw is None else raw
-        d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
+        if isinstance(raw, DevArray):
+            d_raw = raw
+        else:
+            raw = self._gather_windows(starts, length) if raw is None else raw
+            d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
         st = (np.arange(nw, dtype=np.int64) * length)
         bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
         pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
@@ -175,21 +178,31 @@ class noaa_sync:
                 tms.append(t)
             out.append((np.array(idx, dtype=np.int64), pks, tms))
         if jobs:
-            # batches of 64 windows (the device batch); the host-side gather of the next batch
-            # runs on a worker thread while the device works on the current one
+            # batches of 64 windows (the device batch); the host-side gather of the next batch and its upload
+            # (on a side stream) run on a worker thread while the device works on the current one
+            import ctypes as C
             from concurrent.futures import ThreadPoolExecutor
+            from . import _hip
+            up = C.c_void_p()
+            _hip.check(_hip.lib().dd_stream_create(C.byref(up)), "dd_stream_create")
+
+            def feed(st):
+                if not st:
+                    return None
+                return DevArray.from_host(self._gather_windows(st, 2 * width), dtype=np.uint8, stream=up)
             parts = [(slot, st[i:i + 64], sync) for slot, st, sync in jobs for i in range(0, max(1, len(st)), 64)]
             res = {slot: ([], [], []) for slot, _, _ in jobs}
             with ThreadPoolExecutor(max_workers=1) as ex:
-                nxt = ex.submit(self._gather_windows, parts[0][1], 2 * width)
+                nxt = ex.submit(feed, parts[0][1])
                 for k, (slot, st, sync) in enumerate(parts):
                     raw = nxt.result()
                     if k + 1 < len(parts):
-                        nxt = ex.submit(self._gather_windows, parts[k + 1][1], 2 * width)
+                        nxt = ex.submit(feed, parts[k + 1][1])
                     a, b, c = self.accurate_windows(st, 2 * width, sync, raw=raw)
                     res[slot][0].extend(a.tolist())
                     res[slot][1].extend(b)
                     res[slot][2].extend(c)
+            _hip.lib().dd_stream_destroy(up)
             for slot, _, _ in jobs:
                 out[slot] = (np.array(res[slot][0], dtype=np.int64), res[slot][1], res[slot][2])
         return out
