@@ -54,6 +54,8 @@ def fused(x, filt, nco_op, decim, fm):
         out = DevArray(n_expect, _C64)
     no = C.c_int64(0)
     flags = _hip.DD_CHAIN_FORCE_DIRECT if FORCE_DIRECT else 0
+    if x.dtype == _hip.IQ8:
+        flags |= _hip.DD_CHAIN_U8_INPUT
     check(lib().dd_fused_process(fir_h, fm_h, x.ptr, out.ptr, x.n,
                                  1 if nco_op is not None else 0,
                                  nco_op[1] if nco_op is not None else 0,

@@ -25,6 +25,7 @@ from ._hip import DevArray
 _C64 = np.dtype(np.complex64)
 _F32 = np.dtype(np.float32)
 _F64 = np.dtype(np.float64)
+_IQ8 = _hip.IQ8
 
 # FIFO of commSignal objects that still have recorded, un-executed operations
 _pending = []
@@ -109,6 +110,8 @@ class commSignal:
         holds complex128 after ``filter``).'''
         self._materialise()
         if self._host is None:
+            if self._dev.dtype == _IQ8:
+                self._dev = _convert(self._dev, _C64)
             a = self._dev.to_host()
             if a.dtype == _F32:
                 a = a.astype(np.float64)
@@ -202,6 +205,8 @@ class commSignal:
         """What a foreign operator receives: this package's operators accept device
         arrays; anything else gets the NumPy array like in the reference."""
         self._materialise()
+        if self._dev is not None and self._dev.dtype == _IQ8:
+            self._dev = _convert(self._dev, _C64)             # raw pairs are an ingest format: operators see complex samples
         return self._dev if self._dev is not None else self._host
 
     # ------------------------------------------------------------------ container ops
@@ -218,6 +223,8 @@ class commSignal:
         if sig.length == 0:
             return self
         other = sig._device()
+        if other.dtype == _IQ8:
+            other = _convert(other, _C64)
         if self.__len == 0:
             mine_dt = other.dtype
         else:
@@ -281,7 +288,7 @@ class commSignal:
                 if j < len(ops) and ops[j][0] == "fm":
                     fm = ops[j][1]
                     j += 1
-                if x.dtype == _C64:
+                if x.dtype == _C64 or x.dtype == _IQ8:       # raw u8 pairs are widened inside the fused kernel
                     x = _ops.fused(x, filt, nco, decim, fm)
                     i = j
                     continue
@@ -289,6 +296,8 @@ class commSignal:
                 x = filt.applyOn(x)
                 i += 1
                 continue
+            if x.dtype == _IQ8:
+                x = _convert(x, _C64)
             if kind == "nco":
                 x = _ops.nco(x, ops[i][1], ops[i][2])
             elif kind == "decim":
@@ -313,6 +322,8 @@ def _convert(d, want):
         _hip.check(lib.dd_f64_to_f32(d.ptr, out.ptr, d.n, None), "f64->f32")
     elif d.dtype == np.dtype(np.complex64) and want == np.dtype(np.complex128):
         _hip.check(lib.dd_f32_to_f64(d.ptr, out.ptr, 2 * d.n, None), "c64->c128")      # interleaved re, im
+    elif d.dtype == _IQ8 and want == np.dtype(np.complex64):
+        _hip.check(lib.dd_u8iq_to_c64(d.ptr, out.ptr, d.n, None), "dd_u8iq_to_c64")
     elif d.dtype == np.dtype(np.complex128) and want == np.dtype(np.complex64):
         _hip.check(lib.dd_f64_to_f32(d.ptr, out.ptr, 2 * d.n, None), "c128->c64")
     else:

@@ -174,6 +174,27 @@ extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int
     return DD_OK;
 }
 
+// grow-only scratch per device for the audio-rate entry points' intermediates (no allocation in the steady state:
+// a hipMalloc/hipFree pair costs 50-100 us, a dozen of them were half of a correlate + peak-pick call)
+static std::mutex g_sync_mu;
+static void* g_sync_scratch[64] = {nullptr};
+static size_t g_sync_scratch_bytes[64] = {0};
+
+static int sync_scratch(size_t bytes, char** out) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (g_sync_scratch_bytes[dev] < bytes) {
+        if (g_sync_scratch[dev]) DD_HIP_CHECK(hipFree(g_sync_scratch[dev]));
+        g_sync_scratch[dev] = nullptr;
+        g_sync_scratch_bytes[dev] = 0;
+        DD_HIP_CHECK(hipMalloc(&g_sync_scratch[dev], bytes));
+        g_sync_scratch_bytes[dev] = bytes;
+    }
+    *out = (char*)g_sync_scratch[dev];
+    return DD_OK;
+}
+
 // ---------------------------------------------------------------- X1: normalised correlation
 // cor = correlate(h, needle, 'same'); sums = convolve(h*h, ones(m), 'same');
 // out = cor / sqrt(sums * sum(needle^2))  (decode_noaa.py:671-673).  Both windows are
@@ -238,14 +259,14 @@ static int xcorr_runs(const double* h, int64_t n, const double* needle_host, int
     DD_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb1, h, P, (int)n, s));
     DD_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, h2, Q, (int)n, s));
     const size_t tb = tb1 > tb2 ? tb1 : tb2;
-    DD_HIP_CHECK(hipMalloc((void**)&P, sizeof(double) * (2 * (n + 1))));
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    char* base = nullptr;
+    const size_t pq_bytes = (sizeof(double) * (2 * (n + 1)) + 255) & ~(size_t)255;
+    int rc = sync_scratch(pq_bytes + (tb ? tb : 16), &base);
+    if (rc != DD_OK) return rc;
+    P = (double*)base;
     Q = P + (n + 1);
-    hipError_t e = hipMalloc(&tmp, tb ? tb : 16);
-    if (e != hipSuccess) {
-        hipFree(P);
-        dd_set_error("hipMalloc: %s", hipGetErrorString(e));
-        return DD_ERR_NOMEM;
-    }
+    tmp = base + pq_bytes;
     hipError_t e1 = hipMemsetAsync(P, 0, sizeof(double), s);
     hipError_t e2 = hipMemsetAsync(Q, 0, sizeof(double), s);
     size_t t1 = tb, t2 = tb;
@@ -254,8 +275,6 @@ static int xcorr_runs(const double* h, int64_t n, const double* needle_host, int
     hipLaunchKernelGGL(k_xcorr_runs, dim3(grid1(n)), dim3(256), 0, s, P, Q, n, m, R, vv, out);
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
-    hipFree(tmp);
-    hipFree(P);
     (void)needle_host;
     DD_HIP_CHECK(e1); DD_HIP_CHECK(e2); DD_HIP_CHECK(e3); DD_HIP_CHECK(e4); DD_HIP_CHECK(le); DD_HIP_CHECK(se);
     return DD_OK;
@@ -318,36 +337,45 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
     hipStream_t s = dd_stream(stream);
     const int K = (int)(2 * ((double)n / samp_rate)) + 2;                 // expectedPeaks (:714)
     DD_REQUIRE(K <= n, "signal shorter than the expected peak count");
+    // ---- all intermediates from the scratch arena: [sorted n f64 | cand n i64 | gathered heights n f64 | count | library temp]
+    size_t sort_tmp = 0, sel_tmp = 0;
+    {
+        double* nul = nullptr;
+        int64_t* nuli = nullptr;
+        int* nulc = nullptr;
+        hipcub::CountingInputIterator<int64_t> idx0(0);
+        GtThr pred0{cor, 0.0};
+        DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, cor, nul, (int)n, 0, 64, s));
+        DD_HIP_CHECK(hipcub::DeviceSelect::If(nullptr, sel_tmp, idx0, nuli, nulc, (int)n, pred0, s));
+    }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_cand = al(sizeof(double) * n), o_cv = o_cand + al(sizeof(int64_t) * n), o_cnt = o_cv + al(sizeof(double) * n);
+    const size_t o_tmp = o_cnt + 256, tmp_bytes = sort_tmp > sel_tmp ? sort_tmp : sel_tmp;
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    char* base = nullptr;
+    int rc = sync_scratch(o_tmp + tmp_bytes + 256, &base);
+    if (rc != DD_OK) return rc;
+    double* sorted = (double*)base;
+    int64_t* cand = (int64_t*)(base + o_cand);
+    double* d_cv = (double*)(base + o_cv);
+    int* d_count = (int*)(base + o_cnt);
+    void* tmp = base + o_tmp;
     // ---- mean of the K largest and K smallest values (argpartition, :717-723): device sort
-    double* sorted = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = 0;
-    DD_HIP_CHECK(hipMalloc((void**)&sorted, sizeof(double) * n));
-    DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, cor, sorted, (int)n, 0, 64, s));
-    DD_HIP_CHECK(hipMalloc(&tmp, tmp_bytes));
-    DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, cor, sorted, (int)n, 0, 64, s));
+    size_t tb = tmp_bytes;
+    DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, cor, sorted, (int)n, 0, 64, s));
     std::vector<double> lo(K), hi(K);
     DD_HIP_CHECK(hipMemcpyAsync(lo.data(), sorted, sizeof(double) * K, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipMemcpyAsync(hi.data(), sorted + (n - K), sizeof(double) * K, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
-    hipFree(tmp);
-    hipFree(sorted);
     double sum_hi = 0.0, sum_lo = 0.0;
     for (int i = 0; i < K; ++i) { sum_hi += hi[i]; sum_lo += lo[i]; }
     double avgpk = sum_hi / K;
     avgpk -= 0.25 * (avgpk - sum_lo / K);                                 // NOAA_PEAKHEIGHTWIGGLE (:723)
     // ---- candidates cor > threshold, ascending index (:726): device stream compaction
-    int64_t* cand = nullptr;
-    int* d_count = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&cand, sizeof(int64_t) * n));
-    DD_HIP_CHECK(hipMalloc((void**)&d_count, sizeof(int)));
     hipcub::CountingInputIterator<int64_t> idx(0);
     GtThr pred{cor, avgpk};
-    tmp = nullptr;
-    tmp_bytes = 0;
-    DD_HIP_CHECK(hipcub::DeviceSelect::If(nullptr, tmp_bytes, idx, cand, d_count, (int)n, pred, s));
-    DD_HIP_CHECK(hipMalloc(&tmp, tmp_bytes));
-    DD_HIP_CHECK(hipcub::DeviceSelect::If(tmp, tmp_bytes, idx, cand, d_count, (int)n, pred, s));
+    tb = tmp_bytes;
+    DD_HIP_CHECK(hipcub::DeviceSelect::If(tmp, tb, idx, cand, d_count, (int)n, pred, s));
     int count = 0;
     DD_HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
@@ -355,18 +383,11 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
     std::vector<double> cv(count);
     if (count > 0) {
         // candidate heights gathered on the device: two downloads whatever the number of candidate runs
-        double* d_cv = nullptr;
-        DD_HIP_CHECK(hipMalloc((void**)&d_cv, sizeof(double) * count));
         hipLaunchKernelGGL(k_gather_f64, dim3(grid1(count)), dim3(256), 0, s, cor, cand, count, d_cv);
-        hipError_t g1 = hipMemcpyAsync(ci.data(), cand, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s);
-        hipError_t g2 = hipMemcpyAsync(cv.data(), d_cv, sizeof(double) * count, hipMemcpyDeviceToHost, s);
-        hipError_t g3 = hipStreamSynchronize(s);
-        hipFree(d_cv);
-        DD_HIP_CHECK(g1); DD_HIP_CHECK(g2); DD_HIP_CHECK(g3);
+        DD_HIP_CHECK(hipMemcpyAsync(ci.data(), cand, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
+        DD_HIP_CHECK(hipMemcpyAsync(cv.data(), d_cv, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+        DD_HIP_CHECK(hipStreamSynchronize(s));
     }
-    hipFree(tmp);
-    hipFree(cand);
-    hipFree(d_count);
     // ---- group by >= 0.45 s from the running maximum, first maximum wins (:729-746)
     const double min_dist = 0.45 * samp_rate;                             // NOAA_MINPEAKDIST
     std::vector<int64_t> peaks;
@@ -681,26 +702,6 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
     }
     g_hilb[key] = HH;
     *out = HH;
-    return DD_OK;
-}
-
-// grow-only scratch per device: the chain's intermediates (no allocation in the steady state)
-static std::mutex g_sync_mu;
-static void* g_sync_scratch[64] = {nullptr};
-static size_t g_sync_scratch_bytes[64] = {0};
-
-static int sync_scratch(size_t bytes, char** out) {
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
-    if (g_sync_scratch_bytes[dev] < bytes) {
-        if (g_sync_scratch[dev]) DD_HIP_CHECK(hipFree(g_sync_scratch[dev]));
-        g_sync_scratch[dev] = nullptr;
-        g_sync_scratch_bytes[dev] = 0;
-        DD_HIP_CHECK(hipMalloc(&g_sync_scratch[dev], bytes));
-        g_sync_scratch_bytes[dev] = bytes;
-    }
-    *out = (char*)g_sync_scratch[dev];
     return DD_OK;
 }
 

@@ -162,9 +162,9 @@ const float2* dd_nco_table(void) {
 
 // ---------------------------------------------------------------- S1: u8 -> c64
 // 16 B per lane in (8 samples), 4 x 16 B per lane out.
-__global__ void __launch_bounds__(256) k_u8iq_to_c64(const uint8_t* __restrict__ in, float2* __restrict__ out, int64_t n) {
+__global__ void __launch_bounds__(256) k_u8iq_to_c64(const uint8_t* __restrict__ in, float2* __restrict__ out, int64_t n, int vec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n8 = n >> 3;
+    const int64_t n8 = vec ? n >> 3 : 0;                   // unaligned buffers (a view into a recording): pair by pair
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
         const uint4 v = reinterpret_cast<const uint4*>(in)[i];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -197,12 +197,9 @@ extern "C" int dd_u8iq_to_c64(const uint8_t* in_iq, float* out_c64, int64_t n, v
     DD_REQUIRE(n >= 0, "n");
     if (n == 0) return DD_OK;
     DD_REQUIRE(in_iq && out_c64, "null buffer");
-    if (((uintptr_t)in_iq & 15) || ((uintptr_t)out_c64 & 15)) {
-        dd_set_error("dd_u8iq_to_c64: buffers must be 16-byte aligned");
-        return DD_ERR_INVALID;
-    }
-    hipLaunchKernelGGL(k_u8iq_to_c64, dim3(dd_grid_for(n / 8 + 1, 256)), dim3(256), 0, dd_stream(stream),
-                       in_iq, (float2*)out_c64, n);
+    const int vec = !(((uintptr_t)in_iq & 15) || ((uintptr_t)out_c64 & 15));
+    hipLaunchKernelGGL(k_u8iq_to_c64, dim3(dd_grid_for(vec ? n / 8 + 1 : n, 256)), dim3(256), 0, dd_stream(stream),
+                       in_iq, (float2*)out_c64, n, vec);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

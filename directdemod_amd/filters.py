@@ -116,12 +116,15 @@ class filter:
             d = DevArray.from_host(a, dtype=(_C64 if self.__isFIR else np.complex128) if np.iscomplexobj(a) else _F64)
         else:
             d = x
+            if d.dtype == _hip.IQ8 and not self._fusable():
+                from .comm import _convert
+                d = _convert(d, _C64)
         if not self.__isFIR:
             out = self._apply_iir(d)
             return out.to_host() if host else out
         if self.__zeroPhase:
             out = _ops.filtfilt(self.__taps, d)
-        elif d.dtype == _C64:
+        elif d.dtype == _C64 or d.dtype == _hip.IQ8:
             out = _ops.fused(d, self, None, (1, 0), None)
         else:
             if d.dtype == _F32:

@@ -39,6 +39,8 @@ class noaa_sync:
         fmDemodulator = demod_fm.demod_fm()
         chunkerObj = chunker.chunker(src, chunkSize)
         read = src.read_device if hasattr(src, "read_device") else src.read
+        if hasattr(src, "read_device_raw") and src.read_device_raw(0, 1) is not None:
+            read = src.read_device_raw          # the recording stays in HBM as raw pairs; the fused kernel widens them
         for a, b in chunkerObj.getChunks:
             sig = comm.commSignal(src.sampFreq, read(a, b), chunkerObj).offsetFreq(self.__offset) \
                 .filter(bhFilter).bwLim(self.__bw, uniq="First").funcApply(fmDemodulator.demod) \
@@ -118,7 +120,7 @@ class noaa_sync:
             src.read_raw_u8_into(raw[2 * w * length:2 * (w + 1) * length], a, a + length)
         return raw
 
-    def accurate_windows(self, starts, length, sync, raw=None):
+    def accurate_windows(self, starts, length, sync, raw=None, resident=True):
         """All search windows of one sync type in one batched device call (dd_noaa_sync_windows): the chain
         of accurate_window over [windows][samples] arrays.  Returns (indices, heights, times) like the
         per-window loop of decode_noaa.py:828-835."""
@@ -129,12 +131,19 @@ class noaa_sync:
         nw = len(starts)
         if nw == 0:
             return np.zeros(0, dtype=np.int64), [], []
-        if isinstance(raw, DevArray):
+        st = (np.arange(nw, dtype=np.int64) * length)
+        res = None
+        if raw is None and resident and hasattr(src, "resident_raw"):
+            lo = int(min(starts))
+            res = src.resident_raw(lo, int(max(starts)) + length)       # the recording is (now) in HBM: no gather, no upload
+        if res is not None:
+            d_raw = res[0]
+            st = np.asarray(starts, dtype=np.int64) - lo + res[1]
+        elif isinstance(raw, DevArray):
             d_raw = raw
         else:
             raw = self._gather_windows(starts, length) if raw is None else raw
             d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
-        st = (np.arange(nw, dtype=np.int64) * length)
         bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
         pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
         needle = np.ascontiguousarray(sync_needle(sync, fs), dtype=np.float64)
@@ -152,7 +161,7 @@ class noaa_sync:
         idx = pk + np.asarray(starts, dtype=np.int64)
         return idx, [float(v) for v in ht], [None if np.isnan(v) else float(v) for v in ts]
 
-    def getAccurateSync(self, batched=True):
+    def getAccurateSync(self, batched=True, resident=True):
         sa, sb = self.getCrudeSync()
         src = self.__sigsrc
         width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
@@ -177,6 +186,12 @@ class noaa_sync:
                 pks.append(h)
                 tms.append(t)
             out.append((np.array(idx, dtype=np.int64), pks, tms))
+        if jobs and resident and hasattr(src, "resident_raw") and src.read_device_raw(0, 1) is not None:
+            # the recording sits in HBM as raw pairs (the crude pass put it there): the windows are read in place
+            for slot, st, sync in jobs:
+                a, b, c = self.accurate_windows(st, 2 * width, sync)
+                out[slot] = (np.asarray(a, dtype=np.int64), b, c)
+            jobs = []
         if jobs:
             # batches of 64 windows (the device batch); the host-side gather of the next batch and its upload
             # (on a side stream) run on a worker thread while the device works on the current one

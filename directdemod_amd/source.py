@@ -78,6 +78,43 @@ class _u8source:
         _hip.sync()
         return out
 
+    # -- the recording resident in HBM as raw pairs (2 B/sample): uploaded once, page by page on first use --
+    _PAGE = 1 << 22                     # samples per upload page (8 MiB)
+
+    def read_device_raw(self, fromIndex, toIndex=None):
+        '''The samples as a device array of raw uint8 pairs (dtype _hip.IQ8), a view into a buffer that holds
+        the whole recording on the device.  Pages are uploaded the first time they are touched and stay: the
+        fused kernels widen the pairs themselves (DD_CHAIN_U8_INPUT), and a later pass over the same recording
+        (the accurate-sync windows after the crude sync) costs no host copy and no PCIe traffic.
+        Returns None when the recording is larger than DD_RESIDENT_BYTES (default 64 GiB).'''
+        import os
+        a, b = self._range(fromIndex, toIndex)
+        total = self._data.shape[0]
+        if 2 * total > int(os.environ.get("DD_RESIDENT_BYTES", str(64 << 30))):
+            return None
+        if getattr(self, "_res", None) is None:
+            self._res = DevArray(total, _hip.IQ8)
+            self._res_pages = np.zeros((total + self._PAGE - 1) // self._PAGE, dtype=bool)
+        for pg in range(a // self._PAGE, (b - 1) // self._PAGE + 1):
+            if not self._res_pages[pg]:
+                lo, hi = pg * self._PAGE, min(total, (pg + 1) * self._PAGE)
+                src = self._data[lo:hi]
+                if not src.flags["C_CONTIGUOUS"]:
+                    src = np.ascontiguousarray(src)
+                check(lib().dd_memcpy_h2d(self._res.ptr + 2 * lo, src.ctypes.data, 2 * (hi - lo), None), "h2d")
+                self._res_pages[pg] = True
+        _hip.sync()
+        return self._res.view(a, b - a)
+
+    def resident_raw(self, fromIndex, toIndex):
+        '''(device pointer of the resident recording, absolute index of fromIndex) with [fromIndex, toIndex) uploaded,
+        or None'''
+        v = self.read_device_raw(fromIndex, toIndex)
+        if v is None:
+            return None
+        a, _ = self._range(fromIndex, toIndex)
+        return self._res, a
+
     def limitData(self, initOffset=None, finalLimit=None):
         '''Limit source data (source.py:120-138)'''
         self.__offset = initOffset if initOffset is not None else 0

@@ -492,6 +492,9 @@ def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
     src = dd.source.IQarray(raw, 2048000)
     ns = dd.noaa.noaa_sync(src, 30000.0)
     one = ns.getAccurateSync(batched=False)
+    gathered = ns.getAccurateSync(batched=True, resident=False)      # windows gathered on the host, uploaded per batch
+    for (i1, p1, t1), (i2, p2, t2) in zip(one, gathered):
+        assert np.array_equal(i1, i2) and np.max(np.abs(np.array(p1) - np.array(p2))) < 1e-9
     # default batch and batches smaller than the window count; the envelope as one real convolution (default)
     # and through the library's length-N transforms
     for batch, hilbert in ((None, None), ("3", None), (None, "fft")):
