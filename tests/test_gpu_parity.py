@@ -645,3 +645,33 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         fm_check(got, a_ref, np.abs(y[1:] * np.conj(y[:-1])))
     else:
         assert rel_err(got, y) < FIR_TOL
+
+
+def test_resident_raw_recording_through_commsignal(dd):
+    """source.read_device_raw: views of the recording kept in HBM as raw uint8 pairs.  A commSignal built on one
+    runs the fused chain with the u8 ingest flavour (equal to the chain on read()'s complex64 samples, chunked,
+    state carried); anything that is not fused sees widened complex samples; odd (2-byte aligned) view starts work."""
+    from directdemod_amd import source
+    raw = O.synth_iq_fm(700001, 2048000, 31)
+    src = source.IQarray(raw, 2048000)
+    v = src.read_device_raw(0, 1000)
+    assert v is not None and v.dtype == dd.hip.IQ8 and v.n == 1000
+    # .signal of an untouched raw view == read()
+    assert np.array_equal(dd.comm.commSignal(2048000, src.read_device_raw(12345, 20001)).signal, src.read(12345, 20001))
+    res = []
+    for reader in (src.read_device_raw, src.read):
+        ck = dd.chunker.chunker(src, 200001)                    # odd chunk starts: views 2-byte aligned only
+        flt, fm = dd.filters.blackmanHarris(151), dd.demod_fm.demod_fm()
+        out = dd.comm.commSignal(2048000)
+        for a, b in ck.getChunks:
+            out.extend(dd.comm.commSignal(2048000, reader(a, b), ck).offsetFreq(30000.0).filter(flt)
+                       .bwLim(60240, uniq="First").funcApply(fm.demod))
+        res.append(np.asarray(out.signal))
+    assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1])
+    # a zero-phase (not fused) filter and a lone offsetFreq on a raw view
+    a = dd.comm.commSignal(2048000, src.read_device_raw(1001, 9001)).offsetFreq(25000.0).filter(dd.filters.hamming(31, zeroPhase=True)).signal
+    b = dd.comm.commSignal(2048000, src.read(1001, 9001)).offsetFreq(25000.0).filter(dd.filters.hamming(31, zeroPhase=True)).signal
+    assert np.array_equal(a, b)
+    # limitData shifts the window the views come from
+    src.limitData(5000, 300000)
+    assert np.array_equal(dd.comm.commSignal(2048000, src.read_device_raw(0, 777)).signal, src.read(0, 777))
