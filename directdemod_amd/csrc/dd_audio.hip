@@ -562,25 +562,36 @@ __global__ void __launch_bounds__(256) k_xcorr_runs_pk(const double* __restrict_
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
     const double qn = 1e-13 * Q[n];
-    DDPk a = dd_pk_empty();
+    // four outputs per lane, the run loop outermost: the four lookups of a run boundary are independent loads
+    constexpr int NJ = DD_XC_TILE / 256;
+    int64_t a0[NJ];
+    double c[NJ], lo[NJ];
 #pragma unroll
-    for (int j = 0; j < DD_XC_TILE / 256; ++j) {
+    for (int j = 0; j < NJ; ++j) {
+        a0[j] = (int64_t)tile * DD_XC_TILE + j * 256 + t + (m - 1) / 2 - (m - 1);
+        c[j] = 0.0;
+        lo[j] = at(P, a0[j]);
+    }
+    for (int r = 0; r < R.nr; ++r) {
+        double hi[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) hi[j] = at(P, a0[j] + R.start[r + 1]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { c[j] = fma(R.val[r], hi[j] - lo[j], c[j]); lo[j] = hi[j]; }
+    }
+    DDPk a = dd_pk_empty();
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         const int64_t i = (int64_t)tile * DD_XC_TILE + j * 256 + t;
-        if (i >= n) break;
-        const int64_t a0 = i + (m - 1) / 2 - (m - 1);
-        double c = 0.0;
-        double lo = at(P, a0);
-        for (int r = 0; r < R.nr; ++r) {
-            const double hi = at(P, a0 + R.start[r + 1]);
-            c = fma(R.val[r], hi - lo, c);
-            lo = hi;
+        double e = at(Q, a0[j] + m) - at(Q, a0[j]);
+        double cc = c[j];
+        if (!(e > qn)) { cc = 0.0; e = 0.0; }
+        const double x = cc / sqrt(e * vv);
+        if (i < n) {
+            DDPk bq = {x, -inf, x, inf, i, (x != x) ? 1 : 0};
+            a = dd_pk_merge(a, bq);
         }
-        double e = at(Q, a0 + m) - at(Q, a0);
-        if (!(e > qn)) { c = 0.0; e = 0.0; }
-        const double x = c / sqrt(e * vv);
-        const double inf = __longlong_as_double(0x7ff0000000000000ll);
-        DDPk bq = {x, -inf, x, inf, i, (x != x) ? 1 : 0};
-        a = dd_pk_merge(a, bq);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) a = dd_pk_merge(a, dd_pk_shfl(a, d));
