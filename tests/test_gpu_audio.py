@@ -539,3 +539,40 @@ def test_accurate_sync_windows_rejects_long_windows(dd):
     ns = dd.noaa.noaa_sync(src, 30000.0)
     with pytest.raises(Exception, match="0.45 s"):
         ns.accurate_windows([0], 1000000, dd.constants.NOAA_SYNCA)
+
+
+def test_accurate_sync_windows_c64_input_and_no_prefilter(dd):
+    """dd_noaa_sync_windows called directly: complex64 windows give exactly what the raw uint8 pairs give, and
+    without the envelope pre-filter (pre_ntaps = 0) the picks equal the per-stage route without `useFilter`"""
+    import ctypes as C
+    hip, lib = dd.hip, dd.hip.lib()
+    raw = O.synth_apt_iq(1.2, 2048000, seed=5)
+    src = dd.source.IQarray(raw, 2048000)
+    width = int(3 * dd.constants.NOAA_T * len(dd.constants.NOAA_SYNCA) * 2048000)
+    L = 2 * width
+    starts = np.array([1024000 - width, 1024000 - width + 777, 400000], dtype=np.int64)
+    bh = np.ascontiguousarray(dd.filters.blackmanHarris(151).getB, dtype=np.float64)
+    pre = np.ascontiguousarray(dd.filters.hamming(492).getB, dtype=np.float64)
+    needle = np.ascontiguousarray(dd.noaa.sync_needle(dd.constants.NOAA_SYNCA, 2048000), dtype=np.float64)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    d_u8 = hip.DevArray.from_host(raw.reshape(-1))
+    d_c64 = hip.DevArray.from_host(src.read(0, src.length))
+
+    def call(buf, kind, npre):
+        pk, ht, ts = np.empty(3, np.int64), np.empty(3), np.empty(3)
+        hip.check(lib.dd_noaa_sync_windows(buf.ptr, kind, starts.ctypes.data_as(ip), 3, L, hip.cycles_q64(30000.0, 2048000),
+                                           bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), npre,
+                                           needle.ctypes.data_as(dp), len(needle), 2048000.0,
+                                           pk.ctypes.data_as(ip), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None))
+        return pk, ht, ts
+    a, b = call(d_u8, 1, len(pre)), call(d_c64, 0, len(pre))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    pk, ht, ts = call(d_u8, 1, 0)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    for w, s0 in enumerate(starts):
+        sig = dd.comm.commSignal(2048000, src.read_device(int(s0), int(s0) + L)).offsetFreq(30000.0) \
+            .filter(dd.filters.blackmanHarris(151, zeroPhase=True)) \
+            .funcApply(dd.demod_fm.demod_fm().demod).funcApply(dd.demod_am.demod_am().demod)
+        p1, h1, t1 = ns.correlate_and_find_peaks(sig, dd.constants.NOAA_SYNCA, use_filter=False, extra=True)
+        assert pk[w] == p1[0] and abs(ht[w] - h1[0]) < 1e-9
+        assert (t1[0] is None) == bool(np.isnan(ts[w]))
