@@ -63,6 +63,12 @@ class _u8source:
         a, b = self._range(fromIndex, toIndex)
         return np.ascontiguousarray(self._data[a:b]).reshape(-1)
 
+    def raw_view(self, fromIndex, toIndex=None):
+        '''the raw pairs as a C-contiguous uint8 array WITHOUT a copy where the backing store allows (array, memmap)'''
+        a, b = self._range(fromIndex, toIndex)
+        v = self._data[a:b]
+        return v if v.flags["C_CONTIGUOUS"] else np.ascontiguousarray(v)
+
     def read_raw_u8_into(self, dst, fromIndex, toIndex=None):
         '''the raw pairs copied straight into a caller buffer (e.g. a pinned staging slot): one host copy'''
         a, b = self._range(fromIndex, toIndex)
