@@ -118,12 +118,24 @@ __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __rest
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = dd_acc<T>::zero();
     // fwd: out[t0+r] = sum_k b[k] s[t0 + r + K-1 - k]      bwd: out[t0+r] = sum_k b[k] s[t0 + r + k]
-    const int Kfull = K - (K % U);
-    for (int k0 = 0; k0 < Kfull; k0 += U) {
-        const int lo = BWD ? (t0 + k0) : (t0 + K - 1 - k0 - (U - 1));
+    // Taps in ascending k throughout.  The K % 8 taps that do not fill a chunk go first (fwd) or last (bwd), so
+    // that every chunk's window starts at a logical index that is a multiple of 8: its 15 skewed LDS addresses
+    // are then one base register plus compile-time offsets c + (c >> 3) -- no address arithmetic per read.
+    const int KR = K % U;
+    if (!BWD) {
+        for (int k = 0; k < KR; ++k) {
+            const tap_t b = (tap_t)taps[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = dd_acc<T>::mad(b, s[dd_ff_phys(t0 + r + K - 1 - k)], acc[r]);
+        }
+    }
+    const int kbeg = BWD ? 0 : KR, kend = BWD ? K - KR : K;
+    for (int k0 = kbeg; k0 < kend; k0 += U) {
+        const int lo = BWD ? (t0 + k0) : (t0 + K - 1 - k0 - (U - 1));      // multiple of 8 (t0, k0 - kbeg and K - KR are)
+        const T* w = s + dd_ff_phys(lo);
         T win[R + U - 1];
 #pragma unroll
-        for (int c = 0; c < R + U - 1; ++c) win[c] = s[dd_ff_phys(lo + c)];
+        for (int c = 0; c < R + U - 1; ++c) win[c] = w[c + (c >> 3)];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const tap_t b = (tap_t)taps[k0 + u];
@@ -131,10 +143,12 @@ __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __rest
             for (int r = 0; r < R; ++r) acc[r] = dd_acc<T>::mad(b, win[BWD ? (r + u) : (U - 1 + r - u)], acc[r]);
         }
     }
-    for (int k = Kfull; k < K; ++k) {
-        const tap_t b = (tap_t)taps[k];
+    if (BWD) {
+        for (int k = K - KR; k < K; ++k) {
+            const tap_t b = (tap_t)taps[k];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = dd_acc<T>::mad(b, s[dd_ff_phys(BWD ? (t0 + r + k) : (t0 + r + K - 1 - k))], acc[r]);
+            for (int r = 0; r < R; ++r) acc[r] = dd_acc<T>::mad(b, s[dd_ff_phys(t0 + r + k)], acc[r]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
