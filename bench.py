@@ -74,7 +74,7 @@ def cpu_baseline(n):
             "host_cpus": os.cpu_count()}
 
 
-def cpu_baseline_all_cores(log2_per_worker=22, timeout_s=240):
+def cpu_baseline_all_cores(log2_per_worker=22, timeout_s=120):
     """The same CPU path on every host core the process may use: one process per contiguous shard
     (tools/cpu_allcores.py, a child process that never touches the GPU), bounded by a timeout."""
     import signal

@@ -30,7 +30,7 @@ def work(job):
     halo = NTAPS - 1 if lo > 0 else 0
     x = O.grid_c64(O.synth_iq_fm(hi - lo + halo, FS, 1235, start=lo - halo))     # shard plus the samples before it
     taps = O.win_hamming(NTAPS)
-    _barrier.wait(timeout=150)                                # every shard's input is ready: all cores compute together
+    _barrier.wait(timeout=90)                                 # every shard's input is ready: all cores compute together
     t0 = time.time()
     xr = O.nco(x, F_OFFSET, FS, lo - halo)                    # absolute-index phase (no carried NCO state)
     f = O.FilterState(taps)
