@@ -392,11 +392,11 @@ __global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__
 #pragma unroll
     for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * ncomp + c) * IIR_S + k] : 0.0;
     const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;            // samples of this chain's block
-    double2 rg[8];
+    double2 rg[IIR_CH / 2];
     const double xlast = in[total - 1];
     auto issue = [&](int i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < IIR_CH / 2; ++k) {
             if (k < nunit) {
                 const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
                 int64_t d = ((bw0 + ub) * lb + i) * ncomp + 2 * w;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__
     };
     auto park = [&](double* buf) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < IIR_CH / 2; ++k) {
             if (k < nunit) {
                 const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
                 buf[ub * row + 2 * w] = rg[k].x;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__
         if (WRITE) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < IIR_CH / 2; ++k) {
                 if (k < nunit) {
                     const int j = t + 256 * k, ub = j / upb, w = j - ub * upb;
                     const int64_t bb = bw0 + ub;
