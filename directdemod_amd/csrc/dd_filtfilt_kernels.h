@@ -83,25 +83,31 @@ __host__ __device__ __forceinline__ int dd_ff_phys(int j) { return j + (j >> 3);
 static inline size_t dd_ff_lds_bytes(int K) { return (size_t)(dd_ff_phys(DD_FF_TILE + K - 1) + 1) * 8; }
 static inline bool dd_ff_tiled_ok(int K, size_t elem_bytes) { return elem_bytes == 8 && dd_ff_lds_bytes(K) <= DD_FF_LDS_MAX; }
 
-// blockIdx.y = window of the batch; src/dst advance by their strides (elements) per window
-template <typename T, bool BWD>
+// blockIdx.y = window of the batch; src/dst advance by their strides (elements) per window.
+// MODE 0: zero-phase pass 1, MODE 1: zero-phase pass 2, MODE 2: plain causal FIR y[i] = sum_k b[k] x[i-k] whose
+// samples before the array come from `hist` (the K-1 inputs that preceded it: filters.py:64-70 with the state kept).
+template <typename T, int MODE>
 __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int edge,
                                                                  const double* __restrict__ taps, int K,
-                                                                 int64_t src_stride, int64_t dst_stride) {
+                                                                 int64_t src_stride, int64_t dst_stride, const T* __restrict__ hist = nullptr) {
+    constexpr bool BWD = MODE == 1;
     typedef typename dd_acc<T>::tap_t tap_t;
     static_assert(sizeof(T) == 8, "tiled filtfilt: 8-byte elements");
     extern __shared__ double dd_ff_smem[];
     T* s = reinterpret_cast<T*>(dd_ff_smem);
     constexpr int R = DD_FF_R, U = 8;
     const int64_t N = n + 2 * (int64_t)edge;
-    const int64_t nout = BWD ? n : N;
+    const int64_t nout = MODE == 0 ? N : n;
     const T* x = src + (int64_t)blockIdx.y * src_stride;
     T* y = dst + (int64_t)blockIdx.y * dst_stride;
     const int64_t o0 = (int64_t)blockIdx.x * DD_FF_TILE;
     const int W = DD_FF_TILE + K - 1;
     for (int j = threadIdx.x; j < W; j += DD_FF_THREADS) {
         T v;
-        if (!BWD) {                       // s[j] = ext[max(o0 - (K-1) + j, 0)]
+        if (MODE == 2) {                  // s[j] = x[o0 - (K-1) + j], the carried history before the array
+            const int64_t i = o0 - (K - 1) + j;
+            v = i >= 0 ? (i < n ? x[i] : dd_acc<T>::zero()) : hist[(K - 1) + i];
+        } else if (!BWD) {                // s[j] = ext[max(o0 - (K-1) + j, 0)]
             int64_t i = o0 - (K - 1) + j;
             if (i < 0) i = 0;
             v = i < N ? dd_ext_at(x, n, edge, i) : dd_acc<T>::zero();
@@ -165,8 +171,8 @@ static inline void dd_filtfilt_launch(const T* in, int64_t in_stride, T* y1, T* 
     const int edge = 3 * K;
     const int64_t N = n + 2 * (int64_t)edge;
     const size_t lds = dd_ff_lds_bytes(K);
-    hipLaunchKernelGGL((k_filtfilt_tile<T, false>), dim3((unsigned)((N + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
-                       lds, s, in, y1, n, edge, taps_dev, K, in_stride, N);
-    hipLaunchKernelGGL((k_filtfilt_tile<T, true>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
-                       lds, s, (const T*)y1, out, n, edge, taps_dev, K, N, out_stride);
+    hipLaunchKernelGGL((k_filtfilt_tile<T, 0>), dim3((unsigned)((N + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
+                       lds, s, in, y1, n, edge, taps_dev, K, in_stride, N, (const T*)nullptr);
+    hipLaunchKernelGGL((k_filtfilt_tile<T, 1>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
+                       lds, s, (const T*)y1, out, n, edge, taps_dev, K, N, out_stride, (const T*)nullptr);
 }

@@ -2,9 +2,11 @@
 // filters.py:72-73) entry points.
 //  - complex64 full-rate data goes through the fused-chain kernels of dd_chain.hip
 //    with NCO/FM/decimation disabled (same LDS-tiled direct form / MFMA path);
-//  - float64 audio-rate data (NOAA tail) uses a plain one-thread-
-//    per-output kernel: sizes there are ~1e5 samples, far from any roofline.
+//  - float64 audio-rate data (NOAA tail): LDS-tiled, register-blocked
+//    kernels shared with the zero-phase path (dd_filtfilt_kernels.h); one lane per
+//    output remains for filters longer than the tile.
 #include "dd_chain_kernels.h"
+#include "dd_filtfilt_kernels.h"
 
 __global__ void k_fill_f64(double* p, int n, double v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,8 +76,15 @@ extern "C" int dd_fir_f64(dd_fir* f, const double* in, double* out, int64_t n, i
     hipStream_t s = dd_stream(stream);
     int rc = fir_f64_state(f, s);
     if (rc != DD_OK) return rc;
-    hipLaunchKernelGGL(k_fir_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, f->taps_dev, f->K,
-                       f->hist[f->hpar]);
+    if (dd_ff_tiled_ok(f->K, sizeof(double)) && in != out) {
+        // LDS-tiled, register-blocked form (dd_filtfilt_kernels.h), same summation order as the plain kernel
+        hipLaunchKernelGGL((k_filtfilt_tile<double, 2>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), 1), dim3(DD_FF_THREADS),
+                           dd_ff_lds_bytes(f->K), s, in, out, n, 0, f->taps_dev, f->K, (int64_t)0, (int64_t)0,
+                           (const double*)f->hist[f->hpar]);
+    } else {
+        hipLaunchKernelGGL(k_fir_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, f->taps_dev, f->K,
+                           f->hist[f->hpar]);
+    }
     DD_LAUNCH_CHECK();
     if (carry && f->K > 1) {
         hipLaunchKernelGGL(k_hist_update_f64, dim3((f->K + 254) / 256), dim3(256), 0, s, in, n, f->K,
@@ -91,8 +100,6 @@ extern "C" int dd_fir_f64(dd_fir* f, const double* in, double* out, int64_t n, i
 // history = ext[0] (zi * x0), reverse, filter again with history = first sample,
 // reverse, crop.  Each pass is a direct FIR whose out-of-range taps read the
 // pass's first input sample.
-#include "dd_filtfilt_kernels.h"
-
 template <typename T>
 static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, int64_t n, hipStream_t s) {
     const int edge = 3 * K;

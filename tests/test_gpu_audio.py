@@ -576,3 +576,19 @@ def test_accurate_sync_windows_c64_input_and_no_prefilter(dd):
         p1, h1, t1 = ns.correlate_and_find_peaks(sig, dd.constants.NOAA_SYNCA, use_filter=False, extra=True)
         assert pk[w] == p1[0] and abs(ht[w] - h1[0]) < 1e-9
         assert (t1[0] is None) == bool(np.isnan(ts[w]))
+
+
+@pytest.mark.parametrize("k", [1, 5, 37, 101, 492])
+def test_real_fir_with_state_tiled(dd, k):
+    """float64 FIR with the delay line carried from call to call (filters.py:64-70) through the LDS-tiled kernel:
+    uneven chunks around the 2048-output tiles, one chunk shorter than the filter, against the oracle's lfilter"""
+    rng = np.random.default_rng(300 + k)
+    taps = rng.standard_normal(k)
+    x = rng.standard_normal(12001)
+    cuts = [0, 4097, 4097 + 20, 4097 + 20 + 2048, 12001]
+    f = dd.filters.filter(taps, [1.0])
+    got = np.concatenate([f.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    ref = O.FilterState(taps)
+    want = np.concatenate([ref.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    assert got.dtype == np.float64
+    assert rel_err(got, want) < 1e-12
