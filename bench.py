@@ -7,12 +7,24 @@ roofline.  Workload = BASELINE.json configs[1] ("C2"):
   synthetic 2.4 MS/s complex64 IQ on the 8-bit source grid, device resident,
   N = 2^26 samples per GPU, commSignal.offsetFreq(25 kHz) NCO + filters.hamming(255)
   + demod_fm.demod, one chunk per step, output float32 radians (N-1 values).
-A "step" = one pass of the fused hot path over the GPU's shard.  With --gpus N>1
-(launched by torch.distributed.run, one rank per GPU) the stream is N shards of
-2^26 samples; rank r re-filters the 256 samples before its shard as a lead-in of
-the same launch (absolute-index state, no halo exchange) and no collective sits on
-the data path (weak scaling).  `--gather` additionally times an RCCL all_gather of the
-decoded output and reports it in "extra" (never in `value`).
+A "step" = one pass of the fused hot path over the GPU's shard.  With --gpus N>1 the
+stream is N shards of 2^26 samples, one rank per GPU: rank r re-filters the 256 samples
+before its shard as a lead-in of the same launch (absolute-index state, no halo exchange)
+and no collective sits on the data path (weak scaling).  `--gather` additionally times an
+RCCL all_gather of the decoded output and reports it in "extra" (never in `value`).
+
+Launching.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank.  Started
+plainly with --gpus N>1 it is the *launcher*: it builds the extension once (in a child
+process), starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same
+args>` as a child and relays its output (rank 0's JSON line); the launcher itself never
+imports torch and never touches the GPU.
+
+Timing.  `value` and `ms_per_step` are wall clock around the K timed steps (barrier +
+device sync on both sides, max over ranks).  `roofline.kernel_ms` is HIP-event time on the
+launch stream around the same K launches / K (one kernel launch per step).  20 steps are
+only ~4 ms of device time, so the same step is also run for >= 100 ms right after the
+timed region (`extra.steady_check`); a cold run (first 20 steps of the process, before the
+clock pre-roll) is reported in `extra.cold_ms_per_step`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -55,9 +67,35 @@ def make_input(torch, n, start, device, seed):
     return out
 
 
-def cpu_baseline(n):
-    """Reference CPU path restated (oracle; kind 'port'): np.exp NCO multiply,
-    FIR with carried state, np.angle discriminator, one thread."""
+# ----------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_scipy(n):
+    """The reference's own CPU arithmetic for this chain, call for call (kind 'scipy'):
+    comm.py:77 (np.exp NCO, in place on complex64), filters.py:45,69 (lfilter_zi + lfilter
+    with carried zi), demod_fm.py:40-49 (np.angle of the conj-lagged product).  One thread."""
+    import scipy.signal as ss
+    from oracle import dd_oracle as O           # input generator only (cpu_baseline leg)
+    x = O.grid_c64(O.synth_iq_fm(n, FS, 1235))
+    b = ss.windows.hamming(NTAPS)
+    a = [1]
+    best = None
+    for _ in range(2):
+        sig = np.array(x)                                                    # commSignal ctor copies (comm.py:38)
+        t0 = time.perf_counter()
+        sig *= np.exp(-1.0j * 2.0 * np.pi * F_OFFSET * np.arange(0, n) / FS)
+        zi = ss.lfilter_zi(b, a)
+        y, zi = ss.lfilter(b, a, sig, zi=zi)
+        ang = np.angle(y[1:] * np.conj(y[:-1]))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert len(ang) == n - 1
+    return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "scipy",
+            "sample": "2^%d samples of the same workload: np.exp NCO, scipy.signal.lfilter(b,[1],x,zi=lfilter_zi), "
+                      "np.angle (comm.py:77, filters.py:45,69, demod_fm.py:40-49), best of 2, %.2f s"
+                      % (int(np.log2(n)), best)}
+
+
+def cpu_baseline_port(n):
+    """The oracle's restatement of the same path (kind 'port': np.convolve-based FIR), one thread."""
     from oracle import dd_oracle as O
     x = O.grid_c64(O.synth_iq_fm(n, FS, 1235))
     taps = O.win_hamming(NTAPS)
@@ -70,18 +108,17 @@ def cpu_baseline(n):
         best = dt if best is None else min(best, dt)
     assert len(a) == n - 1
     return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
-            "sample": "2^%d samples of the same workload (numpy float64, best of 2, %.2f s)" % (int(np.log2(n)), best),
-            "host_cpus": os.cpu_count()}
+            "sample": "2^%d samples (numpy float64, best of 2, %.2f s)" % (int(np.log2(n)), best)}
 
 
-def cpu_baseline_all_cores(log2_per_worker=22, timeout_s=120):
-    """The same CPU path on every host core the process may use: one process per contiguous shard
+def cpu_baseline_all_cores(timeout_s=150):
+    """The SciPy path on every host core the process may use: one process per contiguous shard
     (tools/cpu_allcores.py, a child process that never touches the GPU), bounded by a timeout."""
     import signal
     import subprocess
-    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "cpu_allcores.py")
+    tool = os.path.join(ROOT, "tools", "cpu_allcores.py")
     try:
-        p = subprocess.Popen([sys.executable, tool, str(log2_per_worker)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+        p = subprocess.Popen([sys.executable, tool], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                              start_new_session=True, text=True)
         try:
             out, _ = p.communicate(timeout=timeout_s)
@@ -96,86 +133,258 @@ def cpu_baseline_all_cores(log2_per_worker=22, timeout_s=120):
         return {"error": repr(e)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--ramp-ms", type=float, default=250.0,
-                    help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
-                         "chip holds under sustained load (a cold MI355X runs its first ~10 ms of kernels 15-20 %% slower)")
-    ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the decoded output")
-    ap.add_argument("--force-direct", action="store_true", help="f32 direct-form kernel instead of the MFMA path")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=24)
-    ap.add_argument("--simulate-rank", type=int, default=None,
-                    help="debug: run this rank's shard (halo priming path) on one GPU without torch.distributed")
-    args = ap.parse_args()
+def cpu_baseline(n):
+    res = cpu_baseline_scipy(n)
+    res["host_cpus"] = os.cpu_count()
+    res["usable_cpus"] = len(os.sched_getaffinity(0))
+    res["port"] = cpu_baseline_port(n)
+    res["all_cores"] = cpu_baseline_all_cores()
+    return res
 
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.simulate_rank is not None:
-        rank = args.simulate_rank
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; no GPU visible")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+# ----------------------------------------------------------------------------- launcher (parent of the ranks)
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def launch(n_gpus, argv):
+    """--gpus N > 1 without WORLD_SIZE: build once, then run the N ranks under torch.distributed.run
+    as a child process and relay what they print.  Nothing here imports torch or calls HIP (a process
+    that has initialised the GPU must not fork/exec the ranks)."""
+    import subprocess
+    if not os.environ.get("DD_BENCH_STUB"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], stdout=subprocess.DEVNULL)
+        if r.returncode != 0:
+            raise SystemExit("bench.py: building the HIP extension failed (exit %d)" % r.returncode)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
+def build_once_per_node():
+    """Ranks started directly by torch.distributed.run: one rank at a time looks at the build (file lock),
+    so N ranks never compile the same objects concurrently; a finished build is a few stat() calls."""
+    import fcntl
     import __graft_entry__ as ge
-    if not os.path.exists(ge.LIB):
-        ge.build()
-    from directdemod_amd import _hip
-    _hip.require_gpu()
-    lib = _hip.lib()
-    _hip.check(lib.dd_set_device(local_rank), "dd_set_device")
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    with open(os.path.join(ROOT, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(ge.LIB):
+                ge.build()
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
 
-    n = 1 << args.log2n
-    halo = 256                             # >= ntaps-1+decim (255) and a multiple of 2 samples: keeps the shard 16-byte aligned
-    start = rank * n                       # absolute index of this rank's first sample
-    pre = halo if rank > 0 else 0
-    xin = make_input(torch, n + pre, start - pre, device, 1235 + rank)
-    out = torch.empty(n + pre, dtype=torch.float32, device=device)
-    first = max(0, pre - 1)                    # index of the shard's first output in `out` (ranks > 0: after the lead-in's)
-    torch.cuda.synchronize()
 
-    taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
-    flags = _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_FORCE_DIRECT if args.force_direct else 0)
-    h = C.c_void_p()
-    _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), NTAPS,
-                                   _hip.cycles_q64(F_OFFSET, FS), 1, flags), "dd_chain_create")
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    n_out = C.c_int64(0)
+# ----------------------------------------------------------------------------- engines
+class HipStep:
+    """One rank's shard of the C2 workload through the C-ABI chain (dd_chain_*): the product path."""
 
-    def step():
+    def __init__(self, args, rank, local_rank):
+        import torch
+        from directdemod_amd import _hip
+        self.torch, self._hip = torch, _hip
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; no GPU visible")
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        _hip.require_gpu()
+        self.lib = lib = _hip.lib()
+        _hip.check(lib.dd_set_device(local_rank), "dd_set_device")
+        self.n = n = 1 << args.log2n
+        halo = 256                         # >= ntaps-1+decim (255) and a multiple of 2 samples: keeps the shard 16-byte aligned
+        self.start = rank * n              # absolute index of this rank's first sample
+        self.pre = pre = halo if rank > 0 else 0
+        self.xin = make_input(torch, n + pre, self.start - pre, self.device, 1235 + rank)
+        self.out = torch.zeros(n + pre + 1, dtype=torch.float32, device=self.device)
+        self.first = max(0, pre - 1)       # index of the shard's first output in `out` (ranks > 0: after the lead-in's)
+        torch.cuda.synchronize()
+        taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
+        flags = _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_FORCE_DIRECT if args.force_direct else 0)
+        self.h = C.c_void_p()
+        _hip.check(lib.dd_chain_create(C.byref(self.h), taps.ctypes.data_as(C.POINTER(C.c_double)), NTAPS,
+                                       _hip.cycles_q64(F_OFFSET, FS), 1, flags), "dd_chain_create")
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.n_out = C.c_int64(0)
+
+    def step(self):
         # new stream position, state derived from the absolute index alone.  Rank 0: the stream start
         # (history of ones).  Rank r: its shard plus the 256-sample lead-in in front of it as one chunk
         # from a zero history -- the lead-in's outputs (the first pre-1, with the filter still filling)
         # are not part of the shard; out[pre-1 : pre-1+n] is what rank r contributes (SURVEY.md 8e:
         # the halo is re-filtered locally, no exchange, no collective).  One launch per step on every rank.
-        _hip.check(lib.dd_chain_seek(h, start - pre, stream), "dd_chain_seek")
-        _hip.check(lib.dd_chain_process(h, xin.data_ptr(), out.data_ptr(), n + pre, C.byref(n_out), stream), "dd_chain_process")
+        hip, lib = self._hip, self.lib
+        hip.check(lib.dd_chain_seek(self.h, self.start - self.pre, self.stream), "dd_chain_seek")
+        hip.check(lib.dd_chain_process(self.h, self.xin.data_ptr(), self.out.data_ptr(), self.n + self.pre,
+                                       C.byref(self.n_out), self.stream), "dd_chain_process")
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def events(self):
+        return self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+
+    def shard_output(self):
+        """(tensor view, count): this rank's decoded outputs (rank 0 of the stream has one fewer, quirk Q3)"""
+        cnt = int(self.n_out.value) - self.first
+        return self.out[self.first:self.first + self.n], cnt
+
+    def path(self):
+        return {0: "direct-f32", 1: "mfma-f16x3"}.get(self.lib.dd_chain_path(self.h), str(self.lib.dd_chain_path(self.h)))
+
+    def close(self):
+        self.lib.dd_chain_destroy(self.h)
+
+
+class StubStep:
+    """DD_BENCH_STUB=1 (tests/test_bench_launcher.py): exercises the launcher, the rank set-up, the
+    barriers, the max-over-ranks reduction and the gather leg on CPU with the gloo backend.  It computes
+    nothing and its JSON line says so (`data: "stub"`); it is never a measurement."""
+
+    class _Ev:
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def __init__(self, args, rank, local_rank):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.n = 1 << min(args.log2n, 12)
+        self.first = 0 if rank == 0 else 255
+        self.rank = rank
+        self.out = torch.full((self.n + 257,), float(rank), dtype=torch.float32)
+
+    def step(self):
+        time.sleep(0.0005)
+
+    def sync(self):
+        pass
+
+    def events(self):
+        return StubStep._Ev(), StubStep._Ev()
+
+    def shard_output(self):
+        return self.out[self.first:self.first + self.n], self.n - (1 if self.rank == 0 else 0)
+
+    def path(self):
+        return "stub"
+
+    def close(self):
+        pass
+
+
+# ----------------------------------------------------------------------------- side configs (N = 1 only)
+def side_configs(eng, steps=10):
+    """C3 / C4 front ends on the same device-resident buffer: the decimating fused chain,
+    chunked with carried state as the reference's chunk loops do (decode_fm.py:54-70, decode_noaa.py:614-624).
+    Reported in extra.side, never in `value`."""
+    import scipy.signal as ss
+    hip, lib = eng._hip, eng.lib
+    n = eng.n
+    k = np.arange(151)
+    bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * k / 150) + 0.14128 * np.cos(4 * np.pi * k / 150) - 0.01168 * np.cos(6 * np.pi * k / 150)
+    rz = ss.remez(127, [0, 100e3, 150e3, 4999999], [1, 0], fs=1e7)
+    res = []
+    for name, taps, M, fs, f, chunk in (
+            ("C3 front end: offsetFreq 250 kHz + remez127 + bwLim /50 + FM, 2^26 samples @10 MS/s in 16 chunks of 2^22", rz, 50, 10000000, 250000.0, 1 << 22),
+            ("C4 front end: offsetFreq 30 kHz + blackmanHarris151 + bwLim /34 + FM, 2^26 samples @2.048 MS/s in chunks of 2e7", bh, 34, 2048000, 30000.0, 20000000)):
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps),
+                                      hip.cycles_q64(f, fs), M, hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "dd_chain_create")
+        got = C.c_int64(0)
+        bounds = [(a, min(n, a + chunk)) for a in range(0, n, chunk)]
+        xin, out = eng.xin, eng.out
+
+        def one_pass():
+            hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+            o = 0
+            for a, b in bounds:
+                hip.check(lib.dd_chain_process(h, xin.data_ptr() + 8 * a, out.data_ptr() + 4 * o, b - a, C.byref(got), eng.stream),
+                          "dd_chain_process")
+                o += got.value
+            return o
+        for _ in range(3):
+            n_out = one_pass()
+        eng.sync()
+        e0, e1 = eng.events()
+        e0.record()
+        for _ in range(steps):
+            one_pass()
+        e1.record()
+        eng.sync()
+        ms = e0.elapsed_time(e1) / steps
+        bps = 8.0 + 4.0 / M
+        res.append({"config": name, "launches_per_pass": len(bounds), "ms_per_pass": round(ms, 4), "outputs": n_out,
+                    "GS_per_s": round(n / ms / 1e6, 1), "bytes_per_sample": round(bps, 3),
+                    "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
+        lib.dd_chain_destroy(h)
+    return res
+
+
+# ----------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+
+    stub = bool(os.environ.get("DD_BENCH_STUB"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.simulate_rank is not None:
+        rank = args.simulate_rank
+    if not stub:
+        build_once_per_node()                      # before any rendezvous: ranks never race on the build
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+    eng = (StubStep if stub else HipStep)(args, rank, local_rank)
+    device = eng.device
+    if world > 1:
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    n = eng.n
+    step = eng.step
 
     def barrier():
+        eng.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        eng.sync()
+
+    # cold figure: the first steps this process runs, before any pre-roll (HIP events on the launch stream)
+    cold_steps = 20
+    c0, c1 = eng.events()
+    c0.record()
+    for _ in range(cold_steps):
+        step()
+    c1.record()
+    eng.sync()
+    cold_ms = c0.elapsed_time(c1) / cold_steps
 
     ramp_steps = 0
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:          # untimed clock pre-roll
         for _ in range(25):
             step()
-        torch.cuda.synchronize()
+        eng.sync()
         ramp_steps += 25
     for _ in range(args.warmup):
         step()
@@ -183,7 +392,7 @@ def main():
     # the hot kernel's launch duration: HIP events on the launch stream around the K timed launches
     # (the chain is ONE kernel launch per step -- edge tiles ride along in it -- so elapsed / K is the
     # average launch duration, launch gaps included)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = eng.events()
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
@@ -192,17 +401,35 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    path = lib.dd_chain_path(h)
 
-    tmax = torch.tensor([dt, kern_ms], dtype=torch.float64, device=device)
+    # the same step for >= 100 ms of device time (20 steps are ~4 ms): consistency check of the short region
+    long_steps = max(args.steps, int(np.ceil(100.0 / max(kern_ms, 1e-3))))
+    l0, l1 = eng.events()
+    l0.record()
+    for i in range(long_steps):
+        step()
+    l1.record()
+    barrier()
+    long_ms = l0.elapsed_time(l1) / long_steps
+
+    tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms], dtype=torch.float64, device=device)
+    per_rank = None
     if world > 1:
+        allk = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(allk, tmax)
+        per_rank = [round(float(t[1]), 4) for t in allk]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max, kern_ms_max = float(tmax[0]), float(tmax[1])
+    dt_max, kern_ms_max, long_ms_max, cold_ms_max = (float(v) for v in tmax)
 
     extra = {}
     if args.gather and world > 1:
-        shard_out = out[first:first + n]                    # this rank's n outputs (a view)
-        bufs = [torch.empty_like(shard_out) for _ in range(world)]
+        from directdemod_amd import shard
+        shard_out, cnt = eng.shard_output()                 # this rank's outputs (a view) and how many are valid
+        parts = shard.gather_outputs(shard_out, cnt, world, dist)      # variable counts: checks the assembled stream length
+        total_out = sum(int(p.numel()) for p in parts)
+        assert total_out == world * n - 1, (total_out, world * n - 1)
+        del parts
+        bufs = [torch.empty_like(shard_out) for _ in range(world)]      # timed leg: fixed-size RCCL all_gather per step
         for _ in range(2):
             dist.all_gather(bufs, shard_out)
         barrier()
@@ -215,23 +442,39 @@ def main():
         tg = torch.tensor([dtg], dtype=torch.float64, device=device)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         extra["with_all_gather_MSamples_per_s"] = round(world * n * args.steps / float(tg[0]) / 1e6, 1)
+        extra["all_gather_ms_per_step"] = round(float(tg[0]) / args.steps * 1e3, 4)
+        extra["gathered_outputs"] = total_out
 
-    # sanity: the output is a demodulated 1 kHz tone of deviation 5 rad * 2 pi * 1 kHz / fs
-    chk = out[first + 1000:first + 1000 + 4096].double().cpu().numpy()
-    extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
+    if not stub:
+        # sanity: the output is a demodulated 1 kHz tone of deviation 5 rad * 2 pi * 1 kHz / fs
+        chk = eng.out[eng.first + 1000:eng.first + 1000 + 4096].double().cpu().numpy()
+        extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
     extra["clock_preroll"] = {"ms": args.ramp_ms, "steps": ramp_steps}
+    extra["cold_ms_per_step"] = round(cold_ms_max, 4)
+    extra["steady_check"] = {"steps": long_steps, "kernel_ms": round(long_ms_max, 4)}
+    if per_rank is not None:
+        extra["kernel_ms_per_rank"] = per_rank
 
     if rank == 0 or args.simulate_rank is not None:
         total = world * n * args.steps
         value = total / dt_max / 1e6
         achieved = BYTES_PER_SAMPLE * n / (kern_ms_max * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and not stub:
             try:
-                traffic = json.load(open(tf)).get("bytes_per_launch_log2n_%d" % args.log2n)
+                tj = json.load(open(tf))
+                traffic = tj.get("bytes_per_launch_log2n_%d" % args.log2n)
+                traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                  "tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
+                                  % (tj.get("kernel", "k_chain_mfma_ws"), tj.get("git", "2ba8115")))
             except Exception:
                 traffic = None
+        if world == 1 and not stub and not args.no_side:
+            try:
+                extra["side"] = side_configs(eng)
+            except Exception as e:                        # side lines never cost the headline line
+                extra["side"] = {"error": repr(e)}
         res = {
             "metric": "IQ MSamples/s through 255-tap FIR+FM demod",
             "value": round(value, 1),
@@ -244,26 +487,51 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "stub" if stub else "synthetic",
             "config": {"workload": "C2: 2.4 MS/s complex64 IQ (u8 grid, FM tone + noise), offsetFreq 25 kHz NCO + "
                                    "255-tap Hamming FIR + FM demod, single chunk, 2^%d samples per GPU, device resident"
                                    % args.log2n,
                        "samples_per_gpu": n, "ntaps": NTAPS, "decimation": 1,
-                       "kernel_path": {0: "direct-f32", 1: "mfma-f16x3"}.get(path, str(path)),
+                       "kernel_path": eng.path(),
                        "sharding": "contiguous sample ranges, absolute-index state, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kern_ms_max, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n},
             "extra": extra,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not stub:
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_log2n)
-            res["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores()
-        print(json.dumps(res))
-    lib.dd_chain_destroy(h)
+        print(json.dumps(res), flush=True)
+    eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-ms", type=float, default=250.0,
+                    help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
+                         "chip holds under sustained load (a cold MI355X runs its first ~10 ms of kernels 15-20 %% slower)")
+    ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the decoded output")
+    ap.add_argument("--force-direct", action="store_true", help="f32 direct-form kernel instead of the MFMA path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 side lines (extra.side)")
+    ap.add_argument("--cpu-log2n", type=int, default=24)
+    ap.add_argument("--simulate-rank", type=int, default=None,
+                    help="debug: run this rank's shard (halo priming path) on one GPU without torch.distributed")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.simulate_rank is None:
+        raise SystemExit(launch(args.gpus, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

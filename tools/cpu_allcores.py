@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """All-cores CPU baseline of the headline workload: one process per contiguous shard of the
-sample stream, each running the oracle's NumPy/SciPy restatement (NCO, 255-tap FIR with the shard's halo as
-history, FM discriminator) on its shard.  Prints one JSON line.  Never touches the GPU; bench.py runs it as a
-child process under a timeout.  usage: cpu_allcores.py [log2 samples per worker = 22] [max workers = 64]
-(the worker count is capped so that the inputs of all shards fit comfortably in host memory: ~0.3 GB each)"""
+sample stream, each running the reference's SciPy/NumPy calls (np.exp NCO comm.py:77, scipy.signal.lfilter with
+zi filters.py:45,69, np.angle of the conj-lagged product demod_fm.py:40-49) on its shard, the shard's
+(ntaps-1)-sample halo re-filtered locally.  Prints one JSON line.  Never touches the GPU; bench.py runs it as a
+child process under a timeout.
+usage: cpu_allcores.py [log2 samples per worker = 21] [max workers = every core of sched_getaffinity]
+Workers = min(usable cores, what fits in half of MemAvailable at ~40 B/sample working set + 150 MB per
+interpreter); both counts are printed."""
 import json
 import multiprocessing as mp
 import os
@@ -26,24 +29,40 @@ def _init(b):
 def work(job):
     r, lo, hi = job
     import numpy as np
-    from oracle import dd_oracle as O
+    import scipy.signal as ss
+    from oracle import dd_oracle as O                          # input generator only
     halo = NTAPS - 1 if lo > 0 else 0
     x = O.grid_c64(O.synth_iq_fm(hi - lo + halo, FS, 1235, start=lo - halo))     # shard plus the samples before it
-    taps = O.win_hamming(NTAPS)
-    _barrier.wait(timeout=90)                                 # every shard's input is ready: all cores compute together
+    b = ss.windows.hamming(NTAPS)
+    _barrier.wait(timeout=120)                                # every shard's input is ready: all cores compute together
     t0 = time.time()
-    xr = O.nco(x, F_OFFSET, FS, lo - halo)                    # absolute-index phase (no carried NCO state)
-    f = O.FilterState(taps)
-    y = f.applyOn(xr)[halo:] if halo else f.applyOn(xr)       # halo recomputed locally: its outputs are discarded
-    a, _ = O.fm_demod(y, None)
+    sig = x
+    sig *= np.exp(-1.0j * 2.0 * np.pi * F_OFFSET * np.arange(lo - halo, hi) / FS)   # absolute-index phase
+    zi = ss.lfilter_zi(b, [1]) if lo == 0 else np.zeros(NTAPS - 1)               # stream start: Q1; shards: halo refills it
+    y, _ = ss.lfilter(b, [1], sig, zi=zi)
+    y = y[halo:] if halo else y                               # halo recomputed locally: its outputs are discarded
+    a = np.angle(y[1:] * np.conj(y[:-1]))
     t1 = time.time()
     return t0, t1, len(a)
 
 
+def _mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return 16 << 30
+
+
 def main():
-    log2w = int(sys.argv[1]) if len(sys.argv) > 1 else 22
-    cap = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    workers = max(1, min(cap, len(os.sched_getaffinity(0))))
+    log2w = int(sys.argv[1]) if len(sys.argv) > 1 else 21
+    usable = len(os.sched_getaffinity(0))
+    cap = int(sys.argv[2]) if len(sys.argv) > 2 else usable
+    per_worker = (40 << log2w) + (150 << 20)
+    fit = max(1, int(_mem_available() // 2 // per_worker))
+    workers = max(1, min(cap, usable, fit))
     n = workers << log2w
     bounds = [(r, r * (1 << log2w), (r + 1) * (1 << log2w)) for r in range(workers)]
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -53,7 +72,8 @@ def main():
         res = pool.map(work, bounds, chunksize=1)
     t0 = min(r[0] for r in res)
     t1 = max(r[1] for r in res)
-    print(json.dumps({"value": round(n / (t1 - t0) / 1e6, 3), "unit": "MSamples/s", "cores": workers,
+    print(json.dumps({"value": round(n / (t1 - t0) / 1e6, 3), "unit": "MSamples/s", "cores": workers, "kind": "scipy",
+                      "usable_cpus": usable, "host_cpus": os.cpu_count(),
                       "sample": "%d x 2^%d samples in contiguous shards, one process each, started together (%.2f s)"
                                 % (workers, log2w, t1 - t0)}))
 
