@@ -140,15 +140,49 @@ class IQarray(_u8source):
         super().__init__(raw, sampFreq, constants.SOURCE_IQWAV)
 
 
+def _wav_data_chunk(filename):
+    """Walk the RIFF chunks of a WAV file to its ``fmt `` and ``data`` chunks, like
+    scipy.io.wavfile.read does for the reference (source.py:68): SDRSharp recordings carry an
+    ``auxi`` chunk (and others may carry ``LIST``) in front of ``data``, so the samples do not
+    start at byte 44.  Returns (sample rate, channels, bits, data offset, data bytes)."""
+    import os
+    import struct
+    size = os.path.getsize(filename)
+    with open(filename, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError("%s is not a little-endian RIFF/WAVE file" % filename)
+        fmt = None
+        pos = 12
+        while pos + 8 <= size:
+            f.seek(pos)
+            cid, csz = struct.unpack("<4sI", f.read(8))
+            body = pos + 8
+            if cid == b"fmt ":
+                raw = f.read(min(csz, 16))
+                if len(raw) < 16:
+                    raise ValueError("%s: truncated fmt chunk" % filename)
+                tag, ch, rate, _, _, bits = struct.unpack("<HHIIHH", raw)
+                fmt = (rate, ch, bits, tag)
+            elif cid == b"data":
+                if fmt is None:
+                    raise ValueError("%s: data chunk before fmt chunk" % filename)
+                return fmt[0], fmt[1], fmt[2], body, min(csz, size - body)
+            pos = body + csz + (csz & 1)          # chunks are word aligned
+    raise ValueError("%s: no data chunk" % filename)
+
+
 class IQwav(_u8source):
-    '''8-bit stereo IQ.wav (SDRSharp style): 44-byte header assumed, like the reference
-    (source.py:66); the sample rate comes from the header unless given.'''
+    '''8-bit stereo IQ.wav (SDRSharp style).  The ``data`` chunk is located by walking the RIFF
+    chunks and the sample rate comes from ``fmt `` unless given -- what scipy.io.wavfile.read
+    gives the reference (source.py:66-72).'''
 
     def __init__(self, filename, givenSampFreq=None):
-        hdr = np.fromfile(filename, dtype=np.uint8, count=44)
-        rate = int(np.frombuffer(hdr[24:28].tobytes(), dtype="<u4")[0])
-        mm = np.memmap(filename, dtype=np.uint8, mode="r", offset=44)
-        n = mm.shape[0] // 2
+        rate, ch, bits, off, nbytes = _wav_data_chunk(filename)
+        if ch != 2 or bits != 8:
+            raise TypeError("IQ.wav must be 8-bit stereo (I, Q); got %d channel(s) of %d bits" % (ch, bits))
+        mm = np.memmap(filename, dtype=np.uint8, mode="r", offset=off, shape=(nbytes,))
+        n = nbytes // 2
         super().__init__(mm[:2 * n].reshape(n, 2), givenSampFreq if givenSampFreq is not None else rate,
                          constants.SOURCE_IQWAV)
 

@@ -184,11 +184,8 @@ def test_source_readers(dd, tmp_path):
     s.limitData(100, 600)
     assert s.length == 500 and np.array_equal(s.read(0, 5), O.read_iq_u8(raw, 100, 105))
     w = tmp_path / "x.wav"
-    hdr = np.zeros(44, dtype=np.uint8)
-    hdr[24:28] = np.frombuffer(np.uint32(2400000).tobytes(), dtype=np.uint8)
-    with open(w, "wb") as fh:
-        fh.write(hdr.tobytes())
-        fh.write(raw.tobytes())
+    from _wav import write_iq_wav
+    write_iq_wav(w, raw, 2400000)                                     # canonical 44-byte header
     sw = dd.source.IQwav(str(w))
     assert sw.sampFreq == 2400000 and sw.length == 5000
     assert np.array_equal(sw.read(0, 5000), O.grid_c64(raw))

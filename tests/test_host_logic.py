@@ -160,3 +160,39 @@ def test_afsk_correlator_tables_match_the_oracle():
         tb, spb = afsk.correlator_tables(bw)
         tb_o, spb_o = O.afsk_tables(bw)
         assert spb == spb_o and np.array_equal(tb, tb_o)
+
+
+def test_iqwav_walks_riff_chunks_to_data(tmp_path):
+    """source.py:66-68: the reference reads IQ.wav through scipy.io.wavfile.read, which finds the
+    ``data`` chunk wherever it is; SDRSharp recordings (the file BASELINE config 1 names) carry an
+    ``auxi`` chunk in front of it.  IQwav must return the same samples and rate as that call;
+    IQwavAlt keeps the reference's fixed 44-byte offset (source.py:247)."""
+    import scipy.io.wavfile
+    from _wav import write_iq_wav
+    from directdemod_amd import source
+    raw = O.synth_iq_noise(3001, 5)
+    plain, aux = tmp_path / "plain.wav", tmp_path / "sdrsharp.wav"
+    write_iq_wav(plain, raw, 2400000)
+    write_iq_wav(aux, raw, 2048000, before=[(b"auxi", bytes(range(164))), (b"LIST", b"INFOISFT\x05\0\0\0abcde")],
+                 after=[(b"LIST", b"xyz")])
+    for f, rate in ((plain, 2400000), (aux, 2048000)):
+        ref_rate, ref_data = scipy.io.wavfile.read(str(f), True)                  # what the reference calls
+        s = source.IQwav(str(f))
+        assert s.sampFreq == ref_rate == rate and s.length == ref_data.shape[0] == 3001
+        want = (ref_data[:, 0] + 1j * ref_data[:, 1]).astype("complex64") - (127.5 + 1j * 127.5)   # source.py:117-118
+        assert np.array_equal(s.read(0, 3001), want)
+        assert np.array_equal(s.read(17, 1200), O.read_iq_u8(raw, 17, 1200))
+        assert np.array_equal(s.read_raw_u8(5, 9), raw[5:9].reshape(-1))
+    assert source.IQwav(str(aux), 1234).sampFreq == 1234
+    alt = source.IQwavAlt(str(plain))
+    assert alt.length == 3001 and np.array_equal(alt.read(0, 3001), O.grid_c64(raw))
+    with pytest.raises(ValueError):
+        source.IQwav(str(aux)).read(0, 3002)
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"\0" * 100)
+    with pytest.raises(ValueError):
+        source.IQwav(str(bad))
+    mono = tmp_path / "mono.wav"
+    write_iq_wav(mono, raw, 8000, channels=1)
+    with pytest.raises(TypeError):
+        source.IQwav(str(mono))
