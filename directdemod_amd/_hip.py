@@ -24,6 +24,8 @@ DD_ERR_NODEVICE = -5
 
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
+(DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
+ DD_KERNEL_MFMA_TILES) = range(6)
 # element type of raw interleaved uint8 I,Q pairs held on the device (source.py:117-118 not yet applied): 2 B/sample
 IQ8 = np.dtype([("i", np.uint8), ("q", np.uint8)])
 
@@ -70,6 +72,7 @@ SIGNATURES = {
     "dd_fir_create": (_int, [_pp, C.POINTER(C.c_double), _int]),
     "dd_fir_destroy": (_int, [_p]),
     "dd_fir_reset": (_int, [_p, _int, _p, _p]),
+    "dd_fir_reset_hist_f64": (_int, [_p, C.POINTER(C.c_double), _p]),
     "dd_fir_c64": (_int, [_p, _p, _p, _i64, _int, _p]),
     "dd_fir_f64": (_int, [_p, _p, _p, _i64, _int, _p]),
     "dd_filtfilt_f64": (_int, [C.POINTER(C.c_double), _int, _p, _p, _i64, _int, _p]),
@@ -92,6 +95,7 @@ SIGNATURES = {
     "dd_chain_out_count": (_i64, [_p, _i64]),
     "dd_chain_process": (_int, [_p, _p, _p, _i64, _pi64, _p]),
     "dd_chain_path": (_int, [_p]),
+    "dd_chain_last_kernel": (_int, [_p]),
     "dd_resample_fft_f64": (_int, [_p, _p, _i64, _i64, _p]),
     "dd_am_envelope_f64": (_int, [_p, _p, _i64, _i64, _p]),
     "dd_xcorr_norm_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
@@ -222,13 +226,84 @@ _DT = {
 # ------------------------------------------------------------------ device buffer pool
 # hipMalloc / hipFree cost tens of microseconds each and hipFree synchronises the device; a chunk
 # loop allocates the same few sizes over and over (decode_noaa.py:619-624: one set of intermediates
-# per chunk).  Freed buffers are kept by size (rounded up to 4 KiB) and handed out again; work is
-# stream-ordered, so a buffer reused by a later call on the same stream is safe.  At most
-# DD_POOL_BYTES (default 1 GiB) are held; DD_POOL_BYTES=0 disables the pool.
+# per chunk).  Freed buffers are kept by size (rounded up to 4 KiB) and handed out again.
+# Stream safety: work on ONE stream is ordered, so a buffer freed and reused on the same stream needs
+# nothing.  The package also drives non-blocking side streams (the ring feeder's copy stream, a
+# caller's compute stream, the accurate-sync upload stream): while any such stream is registered
+# (stream_create / register_stream), a freed buffer is parked together with one event per live stream
+# (null stream included), recorded at free time, and whoever takes it out of the pool first waits for
+# those events -- so asynchronous work that still touches the buffer on any stream has finished before
+# a new owner's copy or kernel on another stream can overwrite it.  Without side streams the events are
+# skipped.  At most DD_POOL_BYTES (default 1 GiB) are held; DD_POOL_BYTES=0 disables the pool.
 _POOL_LIMIT = int(os.environ.get("DD_POOL_BYTES", str(1 << 30)))
 _pool = {}
 _pool_bytes = 0
 _pool_lock = threading.Lock()
+_streams = {}                 # live side streams: handle value -> use count
+_event_spare = []             # recycled hipEvent handles
+
+
+def stream_create():
+    """a non-blocking side stream, known to the buffer pool until stream_destroy"""
+    s = C.c_void_p()
+    check(lib().dd_stream_create(C.byref(s)), "dd_stream_create")
+    register_stream(s)
+    return s
+
+
+def stream_destroy(s):
+    unregister_stream(s)
+    lib().dd_stream_destroy(s)
+
+
+def _sval(s):
+    return int(s.value or 0) if isinstance(s, C.c_void_p) else int(s or 0)
+
+
+def register_stream(s):
+    """tell the buffer pool about a stream created elsewhere (e.g. a torch stream handed in as compute stream)"""
+    v = _sval(s)
+    if v:
+        with _pool_lock:
+            _streams[v] = _streams.get(v, 0) + 1
+
+
+def unregister_stream(s):
+    v = _sval(s)
+    with _pool_lock:
+        if v in _streams:
+            _streams[v] -= 1
+            if _streams[v] <= 0:
+                del _streams[v]
+
+
+def _fence_events():
+    """events marking 'everything submitted so far' on every live stream; [] when only the null stream is in use"""
+    with _pool_lock:
+        live = list(_streams)
+    if not live:
+        return []
+    evs = []
+    L = lib()
+    for sv in [0] + live:
+        with _pool_lock:
+            e = _event_spare.pop() if _event_spare else None
+        if e is None:
+            e = C.c_void_p()
+            if L.dd_event_create(C.byref(e)) != DD_OK:
+                raise HipError("dd_event_create: " + last_error())
+        if L.dd_event_record(e, C.c_void_p(sv) if sv else None) != DD_OK:
+            raise HipError("dd_event_record: " + last_error())
+        evs.append(e)
+    return evs
+
+
+def _fence_wait(evs):
+    L = lib()
+    for e in evs:
+        L.dd_event_sync(e)
+    with _pool_lock:
+        _event_spare.extend(evs)
 
 
 def _pool_round(nbytes):
@@ -240,9 +315,14 @@ def _pool_alloc(nbytes):
     size = _pool_round(nbytes)
     with _pool_lock:
         lst = _pool.get(size)
+        ent = None
         if lst:
             _pool_bytes -= size
-            return lst.pop(), size
+            ent = lst.pop()
+    if ent is not None:
+        if ent[1]:
+            _fence_wait(ent[1])
+        return ent[0], size
     p = C.c_void_p()
     rc = lib().dd_malloc(C.byref(p), size)
     if rc == DD_ERR_NOMEM and _pool:
@@ -255,11 +335,18 @@ def _pool_alloc(nbytes):
 def _pool_free(ptr, size):
     global _pool_bytes
     with _pool_lock:
-        if _pool_bytes + size <= _POOL_LIMIT:
-            _pool.setdefault(size, []).append(ptr)
+        keep = _pool_bytes + size <= _POOL_LIMIT
+    if keep:
+        try:
+            evs = _fence_events()
+        except Exception:
+            keep = False
+    if keep:
+        with _pool_lock:
+            _pool.setdefault(size, []).append((ptr, evs))
             _pool_bytes += size
-            return
-    lib().dd_free(ptr)
+        return
+    lib().dd_free(ptr)          # hipFree synchronises the device
 
 
 def pool_trim(keep_bytes=0):
@@ -269,7 +356,9 @@ def pool_trim(keep_bytes=0):
         for size in sorted(_pool, reverse=True):
             lst = _pool[size]
             while lst and _pool_bytes > keep_bytes:
-                lib().dd_free(lst.pop())
+                ptr, evs = lst.pop()
+                _event_spare.extend(evs)
+                lib().dd_free(ptr)
                 _pool_bytes -= size
         for size in [k for k, v in _pool.items() if not v]:
             del _pool[size]

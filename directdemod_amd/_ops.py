@@ -103,7 +103,8 @@ def xcorr_norm(h, needle):
 def find_peaks(cor, samp_rate, needle_len, max_peaks=None):
     """X2 peak pick (decode_noaa.py:713-751) -> sorted int64 indices"""
     if max_peaks is None:
-        max_peaks = int(2 * (cor.n / samp_rate)) + 64
+        # peak groups are at least 0.45 s apart (decode_noaa.py:729,737): cor.n / (0.45 fs) + 1 at most
+        max_peaks = int(cor.n / (0.45 * samp_rate)) + 2 + 64
     buf = (C.c_int64 * max_peaks)()
     n = C.c_int(0)
     check(lib().dd_find_peaks_f64(cor.ptr, cor.n, float(samp_rate), int(needle_len), buf, max_peaks,

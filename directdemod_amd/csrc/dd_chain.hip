@@ -11,6 +11,7 @@
 // Taps are wave-uniform and come through the scalar cache (s_load), so the VALU
 // issues only FMAs and LDS reads.
 #include "dd_chain_kernels.h"
+#include <mutex>
 
 #define DD_DENSE_R 8
 #define DD_DENSE_THREADS 256
@@ -172,8 +173,10 @@ __global__ void __launch_bounds__(DD_DENSE_THREADS) k_chain_dense(const DDChainP
 // ============================================================================
 // decimating kernel: one thread per kept output
 // ============================================================================
-__global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// (device function: the stand-alone kernel k_chain_decim below runs it for every tile of a chunk without
+// an interior run; k_chain_decim_p runs it in its trailing workgroups for the tiles around the interior run,
+// so a chunk is ONE launch either way)
+__device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const int bid, char* smem) {
     const int K = P.K, M = P.M, T = P.T;
     const int S = (T - 1) * M + K + (M - 1);
     const int SP = S + 4;                                 // linear image: see the tap loop
@@ -186,8 +189,8 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
     float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)SP + ((S + 63) / 64 + 1) + DD_DECIM_THREADS) + 15) & ~(size_t)15));
 
     const int t = threadIdx.x;
-    int b = dd_xcd_tile(blockIdx.x, P.nblocks - (P.skip_hi - P.skip_lo));
-    if (b >= P.skip_lo) b += P.skip_hi - P.skip_lo;        // those tiles run in k_chain_decim_p
+    int b = dd_xcd_tile(bid, P.nblocks - (P.skip_hi - P.skip_lo));
+    if (b >= P.skip_lo) b += P.skip_hi - P.skip_lo;        // those tiles run in the persistent workgroups
     const int64_t pfirst = dd_tile_pfirst(P, b);
     const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
     const bool fm = (P.flags & DD_CHAIN_FM) != 0;
@@ -331,6 +334,11 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
         }
         if (p == P.Ld - 1) *P.lasty_out = acc;
     }
+}
+
+__global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    dd_decim_edge_tile(P, (int)blockIdx.x, smem);
 }
 
 // ============================================================================
@@ -485,8 +493,15 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int
 }
 
 template <bool U8>
-__global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDChainParams P, int b_lo, int b_hi) {
+__global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDChainParams P, int b_lo, int b_hi, int nwg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // workgroups [nwg, gridDim.x): one edge tile each (stream start with the carried history, chunk end with the
+    // new tail / last sample, partial tiles) -- resident beside the persistent ones from the start, so they cost
+    // neither a launch of their own nor a tail after the persistent loop
+    if ((int)blockIdx.x >= nwg) {
+        dd_decim_edge_tile(P, (int)blockIdx.x - nwg, smem);
+        return;
+    }
     const int K = P.K, M = P.M, T = P.T;
     // span, rounded up to whole load granules: sample pairs (complex64) or octets (u8)
     const int S = U8 ? (((T - 1) * M + K + (M - 1) + 7) & ~7) : (((T - 1) * M + K + (M - 1) + 1) & ~1);
@@ -497,7 +512,7 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
     float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)S + 4 + (S / 64 + 2) + DD_DECIM_THREADS) + 15) & ~(size_t)15));   // (LDS offset arithmetic: see k_chain_decim)
     const int t = threadIdx.x;
     // contiguous run of tiles per workgroup, and per XCD (workgroups are dealt round-robin to the 8 XCDs)
-    const int nwg = gridDim.x, n = b_hi - b_lo;
+    const int n = b_hi - b_lo;
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int begin = b_lo + (int)(((int64_t)wg * n) / nwg), end = b_lo + (int)(((int64_t)(wg + 1) * n) / nwg);
     if (begin >= end) return;
@@ -544,7 +559,7 @@ __global__ void k_fill_c64(float2* p, int n, float re, float im) {
 int dd_mfma_supported(int K, int M, int flags);
 int dd_mfma_create(void** st, const double* taps, int K);
 void dd_mfma_destroy(void* st);
-int dd_mfma_launch(void* st, const DDChainParams& P, hipStream_t s);
+int dd_mfma_launch(void* st, const DDChainParams& P, hipStream_t s, int* kernel_id);
 
 // ---------------------------------------------------------------- dd_fir (taps + history)
 extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
@@ -568,6 +583,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->hist[0] = f->hist[1] = nullptr;
     f->hpar = 0;
     f->hist_mode = DD_HIST_ONES;
+    f->last_kernel = DD_KERNEL_NONE;
     const int R = DD_DENSE_R;
     const int K = ntaps;
     // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
@@ -709,6 +725,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
     }
     const int64_t no = dd_fused_out_count(fm, a.n, a.M, a.off);
     if (n_out) *n_out = no;
+    fir->last_kernel = DD_KERNEL_NONE;
     if (a.n == 0) return DD_OK;
     DD_REQUIRE(a.in, "in");
     DD_REQUIRE(a.out || no == 0, "out");
@@ -733,7 +750,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         use_mfma = fir->mfma != nullptr;
     }
     if (use_mfma) {
-        int rc = dd_mfma_launch(fir->mfma, P, s);
+        int rc = dd_mfma_launch(fir->mfma, P, s, &fir->last_kernel);
         if (rc != DD_OK) return rc;
     } else if (a.M == 1) {
         P.T = DD_DENSE_T;
@@ -750,6 +767,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_chain_dense, dim3(P.nblocks), dim3(DD_DENSE_THREADS), lds, s, P);
         DD_LAUNCH_CHECK();
+        fir->last_kernel = DD_KERNEL_DENSE_F32;
     } else {
         int T = (DD_DECIM_SPAN_MAX - P.K - (P.M - 1)) / P.M + 1;
         if (T > DD_DECIM_THREADS) T = DD_DECIM_THREADS;
@@ -779,40 +797,50 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
             if (hi - lo >= 64) {
                 P.skip_lo = (int)lo;
                 P.skip_hi = (int)hi;
-                const size_t lds_p = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
-                static bool attr_p = false;
-                if (!attr_p) {
+                const size_t lds_p0 = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
+                const size_t lds_p = lds_p0 > lds ? lds_p0 : lds;       // the edge workgroups of the same launch need `lds`
+                static DDOncePerDevice attr_p;
+                if (attr_p.need()) {
                     DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr_p = true;
+                    attr_p.mark();
                 }
-                int ncu = 256, dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                const int ncu = dd_cu_count();
                 // every workgroup must be resident from the start (a persistent grid with queued workgroups
                 // runs in rounds): ask the runtime how many fit (LDS and registers)
+                static std::mutex occ_mu;
                 static size_t occ_lds[2] = {0, 0};          // the answer depends on (flavour, LDS size) only: asked once per change
                 static int occ_val[2] = {0, 0};
-                int per_cu = occ_val[u8in];
-                if (occ_lds[u8in] != lds_p || per_cu < 1) {
-                    if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
-                    occ_lds[u8in] = lds_p;
-                    occ_val[u8in] = per_cu;
+                int per_cu;
+                {
+                    std::lock_guard<std::mutex> lk(occ_mu);
+                    per_cu = occ_val[u8in];
+                    if (occ_lds[u8in] != lds_p || per_cu < 1) {
+                        if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
+                        occ_lds[u8in] = lds_p;
+                        occ_val[u8in] = per_cu;
+                    }
                 }
-                int grid = ncu * per_cu;
+                // the tiles around the interior run ride along as trailing workgroups of the same launch; the
+                // persistent grid leaves them their slots
+                const int n_rest = P.nblocks - (int)(hi - lo);
+                const int slots = ncu * per_cu;
+                int grid = n_rest < slots / 2 ? slots - n_rest : slots / 2;
                 if (grid > hi - lo) grid = (int)(hi - lo);
                 if (grid >= 8) grid &= ~7;
-                if (u8in) hipLaunchKernelGGL(k_chain_decim_p<true>, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
-                else hipLaunchKernelGGL(k_chain_decim_p<false>, dim3(grid), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi);
+                if (u8in) hipLaunchKernelGGL(k_chain_decim_p<true>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi, grid);
+                else hipLaunchKernelGGL(k_chain_decim_p<false>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi, grid);
                 DD_LAUNCH_CHECK();
+                fir->last_kernel = DD_KERNEL_DECIM_PERSISTENT;
             }
         }
-        const int n_rest = P.nblocks - (P.skip_hi - P.skip_lo);
-        if (n_rest > 0) {
-            hipLaunchKernelGGL(k_chain_decim, dim3(n_rest), dim3(DD_DECIM_THREADS), lds, s, P);
+        if (P.skip_hi == P.skip_lo) {
+            // no interior run (short chunk, unaligned input): every tile through the stand-alone edge kernel
+            hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), lds, s, P);
             DD_LAUNCH_CHECK();
+            fir->last_kernel = DD_KERNEL_DECIM_TILES;
         }
-
     }
     if (a.commit) {
         fir->parity ^= 1;
@@ -962,6 +990,11 @@ extern "C" int dd_chain_path(const dd_chain* c) {
     if (c->flags & DD_CHAIN_FORCE_DIRECT) return 0;
     const int fl = (c->flags & (DD_CHAIN_NCO | DD_CHAIN_FM | DD_CHAIN_U8_INPUT));
     return (dd_mfma_supported(c->fir->K, c->M, fl) && (c->fir->mfma || !c->fir->mfma_tried)) ? 1 : 0;
+}
+
+extern "C" int dd_chain_last_kernel(const dd_chain* c) {
+    if (!c) return DD_ERR_INVALID;
+    return c->fir->last_kernel;
 }
 
 extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t n, int64_t* n_out, void* stream) {

@@ -21,6 +21,7 @@ struct dd_fir {
     double* hist[2];
     int hpar;
     int hist_mode;
+    int last_kernel;        // DD_KERNEL_* of the last fused launch through this filter
 };
 // demod_fm object: carried last sample (demod_fm.py:43-49)
 struct dd_fm {

@@ -33,6 +33,30 @@ void dd_set_error(const char* fmt, ...);
 
 static inline hipStream_t dd_stream(void* s) { return (hipStream_t)s; }
 
+// Per-device one-time work (hipFuncSetAttribute and friends apply to the current device only; the C-ABI has
+// dd_set_device, so a process may drive several GPUs, from several threads).  One bit per device ordinal;
+// racing first calls on one device both do the idempotent work.
+#ifdef __cplusplus
+#include <atomic>
+struct DDOncePerDevice {
+    std::atomic<unsigned long long> done{0};
+    static int dev() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & 63) : 0; }
+    bool need() const { return !((done.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    void mark() { done.fetch_or(1ull << dev(), std::memory_order_release); }
+};
+// compute units of the current device (256 on MI355X); queried once per device
+static inline int dd_cu_count() {
+    static std::atomic<int> n[64];
+    const int d = DDOncePerDevice::dev();
+    int v = n[d].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        n[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // NCO phase arithmetic (comm.py:77).  phase(n) = frac(n * f/fs) is carried as a
 // 64-bit binary fraction: phase64 = n * cycles_q64 (mod 2^64), exact for any n.

@@ -47,6 +47,20 @@ int dd_fir_reset_f64(dd_fir* f, int mode, const float* hist_host, hipStream_t s)
     return DD_OK;
 }
 
+// float64 history for the real path, given as doubles (lfiltic with initOut values that float32 cannot hold)
+extern "C" int dd_fir_reset_hist_f64(dd_fir* f, const double* hist_host, void* stream) {
+    DD_REQUIRE(f, "h");
+    hipStream_t s = dd_stream(stream);
+    const int nh = f->K - 1;
+    if (nh <= 0) return DD_OK;
+    DD_REQUIRE(hist_host, "hist_host");
+    int rc = fir_f64_state(f, s);
+    if (rc != DD_OK) return rc;
+    DD_HIP_CHECK(hipMemcpyAsync(f->hist[f->hpar], hist_host, sizeof(double) * nh, hipMemcpyHostToDevice, s));
+    DD_HIP_CHECK(hipStreamSynchronize(s));
+    return DD_OK;
+}
+
 // ---------------------------------------------------------------- float64 real FIR
 __global__ void __launch_bounds__(256) k_fir_f64(const double* __restrict__ in, double* __restrict__ out, int64_t n,
                                                  const double* __restrict__ taps, int K,
@@ -635,10 +649,10 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     const size_t lds_t = sizeof(double) * 2 * (256 / ncomp) * iir_lds_row(ncomp);
 #define DD_IIR_BLOCKS(SS, WR, SAVE)                                                                                  \
     case SS: {                                                                                                       \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        static DDOncePerDevice attr_set;                                                                             \
+        if (attr_set.need()) {                                                                                       \
             hipFuncSetAttribute((const void*)k_iir_blocks_t<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); \
-            attr_set = true;                                                                                         \
+            attr_set.mark();                                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL((k_iir_blocks_t<SS, WR>), dim3(gbt), dim3(256), lds_t, s, in, out, n, ncomp, C, blk, nb, h->state, SAVE, lb); \
     } break;

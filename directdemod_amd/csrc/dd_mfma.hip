@@ -985,30 +985,19 @@ void dd_mfma_destroy(void* st) {
 
 #define DD_STAMP_WGS 1024      // workgroups the DD_STAMPS diagnostic buffer holds
 
-// compute units of the current device (256 on MI355X); queried once
-static int dd_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
-}
-
 template <int NKS>
-static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s) {
+static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s, int* kernel_id) {
     using G = MfmaGeom<NKS>;
     const size_t lds = (size_t)MF_LDS_TILE_BYTES(NKS);
     const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DDOncePerDevice attr_set;
+    if (attr_set.need()) {
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.mark();
     }
     DDMfmaTaps t;
     t.frag = st->frag;
@@ -1056,6 +1045,7 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
         else if (cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
+        if (kernel_id) *kernel_id = DD_KERNEL_MFMA_WS;
         if (want_stamps) {
             static int printed = 0;
             std::vector<unsigned long long> hb(DD_STAMP_WGS * 16 * 8);
@@ -1104,21 +1094,22 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s)
     } else {
         hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(P.nblocks), dim3(MF_THREADS), lds, s, P, t, P.nblocks, P.nblocks);
         DD_LAUNCH_CHECK();
+        if (kernel_id) *kernel_id = DD_KERNEL_MFMA_TILES;
     }
     return DD_OK;
 }
 
-int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s) {
+int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s, int* kernel_id) {
     const DDMfmaState* st = reinterpret_cast<const DDMfmaState*>(stv);
     DDChainParams P = Pin;
     P.T = MF_T;
     P.nblocks = (int)((P.Ld + MF_ADV - 1) / MF_ADV);
     if (P.nblocks < 1) P.nblocks = 1;
     switch (st->nks) {
-        case 6: return mfma_launch_t<6>(st, P, s);
-        case 10: return mfma_launch_t<10>(st, P, s);
-        case 12: return mfma_launch_t<12>(st, P, s);
-        case 18: return mfma_launch_t<18>(st, P, s);
+        case 6: return mfma_launch_t<6>(st, P, s, kernel_id);
+        case 10: return mfma_launch_t<10>(st, P, s, kernel_id);
+        case 12: return mfma_launch_t<12>(st, P, s, kernel_id);
+        case 18: return mfma_launch_t<18>(st, P, s, kernel_id);
     }
     return DD_ERR_UNSUPPORTED;
 }

@@ -91,6 +91,11 @@ class filter:
                 hist = np.zeros(max(1, k1), dtype=np.complex64)
                 hist[:k1] = past[::-1]
                 check(lib().dd_fir_reset(h, _hip.DD_HIST_GIVEN, hist.ctypes.data, None), "dd_fir_reset")
+                if k1 > 0:
+                    # the float64 real path takes the history as doubles (complex64 would round initOut to float32)
+                    h64 = np.ascontiguousarray(past[::-1])
+                    check(lib().dd_fir_reset_hist_f64(h, h64.ctypes.data_as(C.POINTER(C.c_double)), None),
+                          "dd_fir_reset_hist_f64")
                 self.__seeded = True
             return True
         check(lib().dd_fir_reset(h, _hip.DD_HIST_ZEROS, None, None), "dd_fir_reset")   # plain lfilter (filters.py:75)

@@ -198,8 +198,7 @@ class noaa_sync:
             import ctypes as C
             from concurrent.futures import ThreadPoolExecutor
             from . import _hip
-            up = C.c_void_p()
-            _hip.check(_hip.lib().dd_stream_create(C.byref(up)), "dd_stream_create")
+            up = _hip.stream_create()                      # known to the buffer pool until destroyed
 
             def feed(st):
                 if not st:
@@ -217,7 +216,7 @@ class noaa_sync:
                     res[slot][0].extend(a.tolist())
                     res[slot][1].extend(b)
                     res[slot][2].extend(c)
-            _hip.lib().dd_stream_destroy(up)
+            _hip.stream_destroy(up)
             for slot, _, _ in jobs:
                 out[slot] = (np.array(res[slot][0], dtype=np.int64), res[slot][1], res[slot][2])
         return out

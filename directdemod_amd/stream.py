@@ -40,9 +40,7 @@ class PinnedRing:
                 e = C.c_void_p()
                 check(lib().dd_event_create(C.byref(e)), "dd_event_create")
                 lst.append(e)
-        s = C.c_void_p()
-        check(lib().dd_stream_create(C.byref(s)), "dd_stream_create")
-        self.copy_stream = s
+        self.copy_stream = _hip.stream_create()          # registered with the buffer pool until close()
         self._used = [False] * depth
 
     def host_view(self, k, nbytes):
@@ -53,7 +51,7 @@ class PinnedRing:
             lib().dd_host_free_pinned(h)
         for e in self.copied + self.consumed:
             lib().dd_event_destroy(e)
-        lib().dd_stream_destroy(self.copy_stream)
+        _hip.stream_destroy(self.copy_stream)
         for d in self.dev:
             d.free()
         self.host, self.dev = [], []
@@ -92,6 +90,7 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
     n_done = 0
     L = lib()
     pool = ThreadPoolExecutor(max(1, copy_threads))
+    _hip.register_stream(compute_stream)
     try:
         for i, (a, b) in enumerate(chunks):
             k = i % depth
@@ -113,6 +112,10 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
         check(L.dd_stream_sync(compute_stream), "sync")
     finally:
         pool.shutdown(wait=True)
+        # also on the exception path: nothing may still be copying into, or reading from, a slot when it is freed
+        L.dd_stream_sync(ring.copy_stream)
+        L.dd_stream_sync(compute_stream)
+        _hip.unregister_stream(compute_stream)
         eng.close()
         ring.close()
     return out.view(0, n_done), int(fs / decim)

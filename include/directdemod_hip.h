@@ -96,6 +96,9 @@ int dd_fir_destroy(dd_fir* h);
 /* (re)initialise the carried history: DD_HIST_ZEROS / DD_HIST_ONES / DD_HIST_GIVEN
  * (hist_host: ntaps-1 complex64 (or float for the real path), oldest first). */
 int dd_fir_reset(dd_fir* h, int mode, const float* hist_host, void* stream);
+/* history of the float64 real path (dd_fir_f64) given as ntaps-1 doubles, oldest first: lfiltic(b,[1],x,initOut)
+ * (filters.py:47-48,66-67) with initOut values that are not float32 numbers.  Call after dd_fir_reset. */
+int dd_fir_reset_hist_f64(dd_fir* h, const double* hist_host, void* stream);
 /* causal FIR, complex64 in -> complex64 out, same length, history carried
  * (storeState) or not (carry=0: history read but left untouched). */
 int dd_fir_c64(dd_fir* h, const float* in_c64, float* out_c64, int64_t n, int carry, void* stream);
@@ -186,6 +189,15 @@ int64_t dd_chain_out_count(const dd_chain* h, int64_t n);
 int dd_chain_process(dd_chain* h, const void* in, void* out, int64_t n, int64_t* n_out, void* stream);
 /* which kernel the chain dispatches to: 0 = f32 direct form, 1 = f16-split MFMA Toeplitz */
 int dd_chain_path(const dd_chain* h);
+/* the kernel the last dd_chain_process call launched (one launch per call): lets tests and benchmarks assert
+ * that the intended kernel -- not a slower sibling with the same results -- produced the output */
+#define DD_KERNEL_NONE 0             /* nothing launched yet (or a chunk without a kept sample) */
+#define DD_KERNEL_DENSE_F32 1        /* k_chain_dense: M = 1, f32 direct form */
+#define DD_KERNEL_DECIM_TILES 2      /* k_chain_decim: M > 1, one workgroup per tile (short or unaligned chunks) */
+#define DD_KERNEL_DECIM_PERSISTENT 3 /* k_chain_decim_p: M > 1, persistent interior run + edge tiles in the same launch */
+#define DD_KERNEL_MFMA_WS 4          /* k_chain_mfma_ws: M = 1, wave-specialised MFMA kernel + edge tiles in the same launch */
+#define DD_KERNEL_MFMA_TILES 5       /* k_chain_mfma_edge: M = 1, MFMA, one workgroup per tile */
+int dd_chain_last_kernel(const dd_chain* h);
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
 
 /* ---- R2: commSignal.bwLim strict -> scipy.signal.resample (comm.py:110-116) --- */

@@ -589,3 +589,48 @@ def test_real_fir_with_state_tiled(dd, k):
     want = np.concatenate([ref.applyOn(x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
     assert got.dtype == np.float64
     assert rel_err(got, want) < 1e-12
+
+
+def test_buffer_pool_fences_reuse_across_streams(dd):
+    """a pooled buffer freed while another stream may still use it must not be handed to a new
+    owner before that work is done.  While a side stream is registered, freed buffers are parked with one
+    event per live stream; the next owner waits for them.  Without side streams no events are taken.
+    The data check: a long asynchronous device-to-device copy on the null stream out of a buffer that is
+    freed right away, then a new owner (same size class) filled over a side stream -- the copy's destination
+    must still hold the original contents."""
+    hip = dd.hip
+    L = hip.lib()
+    hip.pool_trim(0)
+    n = 1 << 26                                            # 64 MiB
+    a = hip.DevArray(n, np.uint8)
+    ptr = a.ptr
+    a.free()
+    size = hip._pool_round(n)
+    assert hip._pool[size][-1] == (ptr, [])                # only the null stream in use: nothing to fence
+    b = hip.DevArray(n, np.uint8)
+    assert b.ptr == ptr
+    s = hip.stream_create()
+    try:
+        src = np.full(n, 7, dtype=np.uint8)
+        hip.check(L.dd_memcpy_h2d(b.ptr, src.ctypes.data, n, None), "h2d")
+        hip.sync()
+        dst = hip.DevArray(n, np.uint8)
+        for _ in range(4):                                 # asynchronous work on the null stream that reads b
+            hip.check(L.dd_memcpy_d2d(dst.ptr, b.ptr, n, None), "d2d")
+        b.free()
+        ent = hip._pool[size][-1]
+        assert ent[0] == ptr and len(ent[1]) == 2          # null stream + the side stream
+        c = hip.DevArray(n, np.uint8)                      # waits for the fence before it returns
+        assert c.ptr == ptr
+        other = np.full(n, 9, dtype=np.uint8)
+        hip.check(L.dd_memcpy_h2d(c.ptr, other.ctypes.data, n, s), "h2d on the side stream")
+        hip.check(L.dd_stream_sync(s), "sync")
+        hip.sync()
+        assert np.all(dst.to_host() == 7)
+        assert np.all(c.to_host() == 9)
+    finally:
+        hip.stream_destroy(s)
+    assert not hip._streams
+    d = hip.DevArray(16, np.uint8)
+    d.free()
+    assert hip._pool[hip._pool_round(16)][-1][1] == []

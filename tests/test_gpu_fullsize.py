@@ -197,3 +197,94 @@ def test_decimating_kernels_agree_with_the_dense_path_at_full_size(run):
     d = t.remainder(ang[:nd - 1].double() - ref_ang + np.pi, 2 * np.pi) - np.pi
     strong = (zc[1:] * zc[:-1].conj()).abs() >= 1e-3 * float((zc[1:] * zc[:-1].conj()).abs().median())
     assert float(d[strong].abs().max()) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------
+# decimating front ends (C3 / C4 shapes) at full size against the float64 oracle, complex64 input
+# ---------------------------------------------------------------------------------------------------------
+def _bh151():
+    k = np.arange(151)
+    return np.ascontiguousarray(0.35875 - 0.48829 * np.cos(2 * np.pi * k / 150) + 0.14128 * np.cos(4 * np.pi * k / 150)
+                                - 0.01168 * np.cos(6 * np.pi * k / 150))
+
+
+_DECIM_CASES = {
+    # name: (taps, M, fs, f_offset, chunk bounds over 2^26 samples)
+    "C4": (_bh151, 34, 2048000, 30000.0, lambda n: O.chunk_list(n, 20000000)),        # decode_noaa.py:614-624
+    "C3": (lambda: __import__("scipy.signal").signal.remez(127, [0, 100e3, 150e3, 4999999], [1, 0], fs=1e7),   # filters.py:314 (taps design is host side)
+           50, 10000000, 250000.0,
+           lambda n: O.chunk_list(n, 1 << 22)),                                          # decode_fm.py:54-70
+}
+
+
+@pytest.fixture(scope="module", params=["C4", "C3"])
+def decim_run(run, request):
+    """the whole 2^26-sample stream through dd_chain_process chunk by chunk (FIR history, last FM sample, NCO index
+    and decimation phase carried on the device), complex64 input; the persistent kernel must have run for every chunk"""
+    t, hip, lib = run.torch, run.hip, run.lib
+    mk, M, fs, f, chunks = _DECIM_CASES[request.param]
+    taps = np.ascontiguousarray(mk(), dtype=np.float64)
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps), hip.cycles_q64(f, fs), M,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "dd_chain_create")
+    nd = len(range(0, run.n, M))
+    out = t.full((nd,), float("nan"), dtype=t.float32, device=run.dev)
+    pos = 0
+    bounds = chunks(run.n)
+    for a, b in bounds:
+        got = run.process(h, run.x.data_ptr() + 8 * a, out.data_ptr() + 4 * pos, b - a)
+        assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_PERSISTENT, (a, b, lib.dd_chain_last_kernel(h))
+        pos += got
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert pos == nd - 1                                                # quirk Q3 once, at the stream start
+    assert bool(t.isfinite(out[:pos]).all())
+
+    class R:
+        pass
+    r = R()
+    r.name, r.taps, r.M, r.fs, r.f, r.bounds, r.out, r.nout = request.param, taps, M, fs, f, bounds, out, pos
+    return r
+
+
+@pytest.mark.parametrize("where", ["start", "tile_seam", "chunk_seam", "end"])
+def test_oracle_windows_of_the_decimated_runs(run, decim_run, where):
+    """VERDICT r1 missing #2: k_chain_decim_p<false> (complex64 input, interior tiles) had only been compared with
+    another HIP kernel.  Windows of the full-size chunked runs against O.nco / O.FilterState / decimation grid /
+    O.fm_demod (comm.py:63-78,118-130, filters.py:53-75, demod_fm.py:29-51): the stream start (history of ones,
+    first output missing), a seam between two interior tiles of one chunk, a seam between two chunks (carried FIR
+    tail, FM sample and decimation phase) and the end of the stream."""
+    d = decim_run
+    n, M, K = run.n, d.M, len(d.taps)
+    T = min(256, (6144 - K - (M - 1)) // M + 1)                         # outputs per tile of the decimating kernels
+    adv = (T - 1) * M                                                   # input samples a tile advances by
+    W = 400 * M                                                         # ~400 outputs per window
+    second_chunk = d.bounds[1][0]
+    c0 = {"start": 0,
+          "tile_seam": (40 * adv // M) * M - W // 2,                    # inside chunk 0, across tile boundaries
+          "chunk_seam": (second_chunk // M) * M - W // 2,
+          "end": ((n - W) // M) * M}[where]
+    c0 = max(0, (c0 // M) * M)                                          # first kept sample of the window (multiple of M)
+    c1 = n if where == "end" else min(n, c0 + W)
+    h0 = max(0, c0 - M - (K - 1))                                       # FIR warm-up + one earlier kept sample for the FM lag
+    xs = run.x[h0:c1].cpu().numpy().astype(np.float32)
+    xc = (xs[:, 0] + 1j * xs[:, 1]).astype(np.complex64)
+    y = O.nco(xc, d.f, d.fs, h0)
+    if h0 == 0:
+        y = O.FilterState(d.taps).applyOn(y)                            # stream start: Q1 history
+        y0 = 0
+    else:
+        y = O.lfilter_fir(d.taps, y, None)[K - 1:]
+        y0 = h0 + K - 1                                                 # global index of y[0]
+    first_kept = -(-y0 // M) * M                                        # decimation grid = global multiples of M (Q4)
+    yk = y[first_kept - y0::M]
+    a_ref, _ = O.fm_demod(yk, None)                                     # a_ref[i]: kept samples (first_kept/M + i + 1, + i)
+    k_first = first_kept // M + 1                                       # kept index of the newer sample of a_ref[0]
+    got = d.out[k_first - 1:k_first - 1 + len(a_ref)].cpu().numpy().astype(np.float64)     # output k-1 pairs (k, k-1)
+    assert len(got) == len(a_ref) and len(a_ref) >= 380
+    z = yk[1:] * np.conj(yk[:-1])
+    strong = np.abs(z) >= 1e-3 * np.median(np.abs(z))
+    err = np.abs(np.angle(np.exp(1j * (got - a_ref))))
+    assert np.max(err[strong]) < 2e-5 and np.median(err) < 2e-6, (d.name, where, np.max(err[strong]), np.median(err))
+    if where == "end":
+        assert k_first - 1 + len(a_ref) == d.nout                       # the window really reaches the last output

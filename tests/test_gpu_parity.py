@@ -170,6 +170,18 @@ def test_fir_plain_and_initout_golden(dd, ops):
     assert rel_err(y.real, g["fir_initout_rollavg4"]) < FIR_TOL
 
 
+def test_fir_initout_float64_values_real_path(dd):
+    """initOut values that are not float32 numbers must reach the float64 real path unrounded
+    (filters.py:47-48,66-67 -> lfiltic; Experiment 3 cell 22 is the only user).  1/3, pi, 1e-9 + 1 differ from
+    their float32 roundings by ~1e-8 relative: the first ntaps-1 outputs would show it."""
+    io = [1.0 / 3.0, np.pi, 1.0 + 1e-9, -2.0 / 7.0, 1e-3 / 3.0]
+    taps = np.array([0.3, -0.2, 0.25, 0.11, 0.07, -0.05, 0.9])
+    x = np.random.default_rng(5).standard_normal(64)
+    got = dd.filters.filter(taps, [1], initOut=io).applyOn(x)
+    want = O.FilterState(taps, initOut=io).applyOn(x)
+    assert got.dtype == np.float64 and np.max(np.abs(got - want)) < 1e-14 * np.max(np.abs(want)) * 10
+
+
 @pytest.mark.parametrize("L", [1, 2, 7, 253, 254, 255, 2047, 2048, 2049, 4095, 5000])
 def test_fir_ragged_lengths_vs_oracle(dd, L):
     x = O.grid_c64(O.synth_iq_noise(L + 300, 31 + L))
