@@ -11,7 +11,7 @@ plus oracle spot checks on windows of the same run.
   * oracle windows: 8192-sample windows at the start, an interior tile seam, and the very end.
 
 Angles are compared wrapped; the bench input (FM tone, SNR ~20 dB) keeps |y[n] conj y[n-1]| far from
-zero, so no conditioning mask is needed.  Tolerance 1e-4 rad (the FM bound of the small-size tests).
+zero, so no conditioning mask is needed.  Tolerance 2e-5 rad.
 """
 import ctypes as C
 import os
@@ -24,7 +24,7 @@ from oracle import dd_oracle as O
 pytestmark = pytest.mark.gpu
 
 FS, F_OFF, NTAPS, LOG2N = 2400000, 25000.0, 255, 26
-TOL = 1e-4
+TOL = 2e-5          # the bench input is well conditioned everywhere (FM tone, SNR ~20 dB); SURVEY.md's f32 bound is 1.2e-5
 
 
 def _wrapped_max(torch, a, b, blk=1 << 24):
@@ -283,8 +283,12 @@ def test_oracle_windows_of_the_decimated_runs(run, decim_run, where):
     got = d.out[k_first - 1:k_first - 1 + len(a_ref)].cpu().numpy().astype(np.float64)     # output k-1 pairs (k, k-1)
     assert len(got) == len(a_ref) and len(a_ref) >= 380
     z = yk[1:] * np.conj(yk[:-1])
-    strong = np.abs(z) >= 1e-3 * np.median(np.abs(z))
+    # the C3 filter rejects the bench tone (it sits at -225 kHz after the 250 kHz shift): its output is filtered noise,
+    # and the angle of a nearly cancelled product amplifies the FIR's f32 error by median/|z| -- two tiers as in
+    # test_gpu_parity.fm_check
+    strong, well = np.abs(z) >= 1e-3 * np.median(np.abs(z)), np.abs(z) >= 0.1 * np.median(np.abs(z))
     err = np.abs(np.angle(np.exp(1j * (got - a_ref))))
-    assert np.max(err[strong]) < 2e-5 and np.median(err) < 2e-6, (d.name, where, np.max(err[strong]), np.median(err))
+    assert np.max(err[well]) < 2e-5 and np.max(err[strong]) < 1e-4 and np.median(err) < 2e-6, \
+        (d.name, where, np.max(err[well]), np.max(err[strong]), np.median(err))
     if where == "end":
         assert k_first - 1 + len(a_ref) == d.nout                       # the window really reaches the last output

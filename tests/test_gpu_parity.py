@@ -8,7 +8,7 @@ drop-in classes and through the raw C-ABI, against
 Stated float32 tolerances (the reference computes in float64):
   NCO   |err| <= 1e-6 * max|x|
   FIR   |err| <= 2e-6 * max|y|
-  FM    wrapped |dphi| <= 1e-4 rad wherever |y[n] conj y[n-1]| >= 1e-3 * median,
+  FM    wrapped |dphi| <= 2e-5 rad wherever |y[n] conj y[n-1]| >= 0.1 * median, <= 1e-4 rad wherever >= 1e-3 * median,
         and median |dphi| <= 2e-6 rad
 Index/length/rate bookkeeping is exact.
 """
@@ -24,7 +24,8 @@ pytestmark = pytest.mark.gpu
 
 NCO_TOL = 1e-6
 FIR_TOL = 2e-6
-FM_MAX = 1e-4
+FM_MAX = 1e-4        # |z| >= 1e-3 median: the angle of a nearly cancelled product amplifies the FIR error by median/|z|
+FM_WELL = 2e-5       # well-conditioned outputs (|z| >= 0.1 median; SURVEY.md's own f32 bound is 1.2e-5): VERDICT r1 weak #11
 FM_MED = 2e-6
 
 
@@ -70,6 +71,9 @@ def fm_check(got, ref_angle, y_ref_prod_mag=None):
     else:
         mask = np.ones(len(d), dtype=bool)
     assert np.max(d[mask]) <= FM_MAX, "max wrapped FM error %g" % np.max(d[mask])
+    if y_ref_prod_mag is not None:
+        well = y_ref_prod_mag >= 0.1 * np.median(y_ref_prod_mag)
+        assert np.max(d[well]) <= FM_WELL, "max wrapped FM error on well-conditioned outputs %g" % np.max(d[well])
     assert np.median(d) <= FM_MED, "median FM error %g" % np.median(d)
 
 
