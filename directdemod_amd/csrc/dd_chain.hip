@@ -254,10 +254,44 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
                 sx[e] = x;
             }
         } else {
-            for (int e = t; e < S; e += DD_DECIM_THREADS) {
-                float2 ph = make_float2(1.f, 0.f);
-                if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
-                sx[e] = dd_load_sample(P, ns + e, ph);
+            // edge tile (stream start with the carried history, chunk end, u8 input): batches of 8 UNCONDITIONAL loads
+            // on clamped indices, the value selected afterwards.  A predicated load (dd_load_sample) makes hipcc branch
+            // and wait per element: 24 dependent round trips, ~20 us for one tile -- which set the duration of the
+            // whole launch for chunks of a few million samples (C3: 2^22-sample chunks, 21 us each)
+            const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+            const bool need_tail = ns < 0;                             // block uniform
+            const int K1 = K - 1;
+            for (int e0 = t; e0 < S; e0 += 8 * DD_DECIM_THREADS) {
+                float2 x[8], h[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t n = ns + e0 + u * DD_DECIM_THREADS;
+                    const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
+                    if (u8) {
+                        const uchar2 q = reinterpret_cast<const uchar2*>(P.in)[nc];
+                        x[u] = make_float2((float)q.x - 127.5f, (float)q.y - 127.5f);
+                    } else {
+                        x[u] = reinterpret_cast<const float2*>(P.in)[nc];
+                    }
+                    h[u] = make_float2(0.f, 0.f);
+                    if (need_tail) {
+                        const int64_t ti = n + K1;
+                        h[u] = P.tail_in[ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti)];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * DD_DECIM_THREADS;
+                    if (e < S) {
+                        const int64_t n = ns + e;
+                        float2 v = x[u];
+                        if (P.flags & DD_CHAIN_NCO) v = dd_cmul(v, dd_cmul(w2[e >> 6], w1));
+                        // history samples are already rotated; before the history and past the chunk: zeros
+                        if (n < 0) v = (n + K1 >= 0) ? h[u] : make_float2(0.f, 0.f);
+                        if (n >= P.L) v = make_float2(0.f, 0.f);
+                        sx[e] = v;
+                    }
+                }
             }
         }
     }

@@ -909,6 +909,8 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     else dd_ws_vector<NKS, U8, CX>(P, taps, smem, t_begin, t_end, nph);
 }
 
+#include "dd_mfma_ab.h"
+
 // ============================================================================
 // host side
 // ============================================================================
@@ -997,6 +999,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
         attr_set.mark();
     }
     DDMfmaTaps t;
@@ -1040,20 +1044,32 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
         const bool cx = !(P.flags & DD_CHAIN_FM);
         const dim3 g(grid + n_edge), b(WS_THREADS);
+        // FM output: the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
+        static const char* kern_env = getenv("DD_MFMA_KERNEL");
+        const bool use_ab = !cx && !(kern_env && strcmp(kern_env, "ws") == 0);
+        if (use_ab) {
+            if (u8in) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+            else hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+        } else
         if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();
-        if (kernel_id) *kernel_id = DD_KERNEL_MFMA_WS;
+        if (kernel_id) *kernel_id = use_ab ? DD_KERNEL_MFMA_AB : DD_KERNEL_MFMA_WS;
         if (want_stamps) {
             static int printed = 0;
             std::vector<unsigned long long> hb(DD_STAMP_WGS * 16 * 8);
             DD_HIP_CHECK(hipMemcpyAsync(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
             if (printed++ == 0) {
-                const char* vn[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
-                const char* mn[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
+                const char* vn_ws[6] = {"V:issue loads", "V:epilogue", "V:convert", "V:next tile max", "V:barrier wait", "-"};
+                const char* mn_ws[4] = {"M:epilogue unit", "M:108 mfma", "M:y wait + write", "M:barrier wait"};
+                const char* vn_ab[6] = {"V:issue loads", "V:convert", "V:next tile range", "V:barrier wait", "-", "-"};
+                const char* mn_ab[4] = {"M:108 mfma + publish (per pair of phases)", "M:discriminator", "M:barrier waits", "-"};
+                const char** vn = use_ab ? vn_ab : vn_ws;
+                const char** mn = use_ab ? mn_ab : mn_ws;
+                const int n_m = use_ab ? 8 : 4;              // matrix waves per workgroup
                 const double nphd = (double)(hb[7] & 0xffffffffull);
                 {   // wave placement: SIMD id (HW_ID bits 5:4) of each of the 16 waves, histogram over workgroups
                     int bad = 0;
@@ -1080,12 +1096,12 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
                             0.0, (e_max - e_min) * 0.01, (ls_min - e_min) * 0.01, (ls_max - e_min) * 0.01, (le_min - e_min) * 0.01, (le_max - e_min) * 0.01);
                 }
                 for (int wv = 0; wv < 16; ++wv) {
-                    const int nq = wv < 4 ? 4 : 5;
+                    const int nq = use_ab ? (wv < n_m ? 3 : 4) : (wv < 4 ? 4 : 5);
                     fprintf(stderr, "[stamps] wave %2d:", wv);
                     for (int q = 0; q < nq; ++q) {
                         double sum = 0;
                         for (int w = 0; w < grid; ++w) sum += (double)hb[((size_t)w * 16 + wv) * 8 + q];
-                        fprintf(stderr, " %s=%.0f", wv < 4 ? mn[q] : vn[q], sum / grid / nphd);
+                        fprintf(stderr, " %s=%.0f", wv < n_m ? mn[q] : vn[q], sum / grid / nphd);
                     }
                     fprintf(stderr, "\n");
                 }
