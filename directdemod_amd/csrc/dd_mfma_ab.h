@@ -24,8 +24,19 @@
 
 #define AB_VWAVES 8
 #define AB_VTHREADS (64 * AB_VWAVES)
+#ifndef AB_REG_ROWS
+#define AB_REG_ROWS 16        // accumulator registers (of 16) whose outputs the owning matrix wave turns into angles itself.  With 8,
+                              // the rest (outputs 512..1023 of the strip) go through LDS to the vector waves so that the three
+                              // vector-issuing waves of a SIMD carry equal shares -- measured SLOWER (0.2393 ms against 0.2340):
+                              // the 34 extra LDS stores sit behind the last MFMA of the matrix wave's phase and the LDS is
+                              // already 50 % busy with fragment reads.  Kept selectable (-DAB_REG_ROWS=8) for the record.
+#endif
+#define AB_RED_ENTRIES 12     // range-check slots per tile: 8 vector waves, the halo step (entry 8), padding to 16 bytes
 #ifndef DD_AB_EPI_PRIO
 #define DD_AB_EPI_PRIO 0
+#endif
+#ifndef DD_AB_VEC_PRIO
+#define DD_AB_VEC_PRIO 0
 #endif
 // timing ablations (tools/mkvariant.sh ... -DDD_AB_NO_xxx; results are wrong by construction, never shipped):
 //   DD_AB_NO_EPI      matrix waves skip the discriminator      DD_AB_NO_MFMA   matrix waves skip the MFMAs
@@ -34,94 +45,176 @@
 template <int NKS>
 struct AbGeom {
     using G = MfmaGeom<NKS>;
-    static constexpr int NQ = G::SPAN / 2;                               // sample pairs per tile
-    static constexpr int NIT = (NQ + AB_VTHREADS - 1) / AB_VTHREADS;     // 5 for 255 taps (4.25: the oldest two vector waves take the fifth step)
     static constexpr int PLANES_BYTES = 4 * G::PLANE;
     static constexpr int TAPS_OFF = 2 * PLANES_BYTES;
     static constexpr int TAPS_BYTES = 2 * NKS * 64 * 16;
-    static constexpr int RED_OFF = TAPS_OFF + TAPS_BYTES;                // [2][AB_VWAVES] float
-    static constexpr int NONUNIT_OFF = RED_OFF + 2 * AB_VWAVES * 4;      // [4] int
+    static constexpr int RED_OFF = TAPS_OFF + TAPS_BYTES;                // [2][AB_RED_ENTRIES] float: 8 vector waves + the halo step
+    static constexpr int NONUNIT_OFF = RED_OFF + 2 * AB_RED_ENTRIES * 4; // [4] int
     // left-hand neighbours that DPP row_shr:1 cannot deliver (the first lane of each 16-lane row), per matrix set, float2:
     //   X0[4 waves][16] (+1: the slot the last strip's last output falls into)  for lanes 0   (column 0, rows of half 0)
     //   XA[4][16] for lanes 16 (= lane 15, same register)    X1[4][16] for lanes 32 (column 0, half 1)    XB[4][16] for lanes 48 (= lane 47)
     static constexpr int X0_ENTRIES = 4 * 16 + 1;
     static constexpr int BCOL_OFF = NONUNIT_OFF + 16;
     static constexpr int BCOL_SET_BYTES = (X0_ENTRIES + 3 * 4 * 16 + 1) * 8;
-    static constexpr int LDS_BYTES = (BCOL_OFF + 2 * BCOL_SET_BYTES + 15) & ~15;
+    // second half of every strip's FIR outputs (registers 8..15 = outputs 512..1023), per matrix set, for the vector
+    // waves' share of the discriminator: planar [re | im][4 strips][4 floats of slack (the last = output 511) + 512]
+    static constexpr int YH_STRIDE = 4 + 512;
+    static constexpr int YH_OFF = (BCOL_OFF + 2 * BCOL_SET_BYTES + 15) & ~15;
+    static constexpr int YH_SET_BYTES = 2 * 4 * YH_STRIDE * 4;
+    static constexpr int LDS_BYTES = (YH_OFF + (AB_REG_ROWS < 16 ? 2 * YH_SET_BYTES : 0) + 15) & ~15;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(MF_LDS_TILE_BYTES(NKS) <= TAPS_OFF, "the edge tile's image must not reach the tap fragments");
 };
 
-template <int NKS, bool U8>
-__device__ __forceinline__ void dd_ab_load(const DDChainParams& P, int b, int vt, float4 (&raw)[AbGeom<NKS>::NIT]) {
+// ---- vector side: "quads".  A lane owns FOUR consecutive samples of a step (two 16-byte loads, 32 contiguous bytes):
+// each f16 plane then receives 8 bytes per lane and step (ds_write_b64) instead of two 4-byte stores -- the LDS store
+// path, not the arithmetic, was what the conversion waited for (ablation: without its ds_write_b32 the conversion
+// phase took 1600 cycles instead of 3600).  A tile's span is 1088 quads (255 taps): the 8 vector waves take
+// 2 steps x 512 quads = the last 4096 samples; the first 64 quads (the 256-sample halo) are ONE more wave-step, which
+// as a third step of one vector wave made that wave the slowest of the workgroup -- it goes to the matrix wave
+// (strip 0) that is in its discriminator phase, which has the time.
+#define AB_VSTEPS 2
+
+template <int NKS>
+struct AbQ {
     using G = MfmaGeom<NKS>;
-    using A = AbGeom<NKS>;
+    static constexpr int NQUAD = G::SPAN / 4;                         // 1088
+    static constexpr int XQUADS = NQUAD - AB_VSTEPS * AB_VTHREADS;    // the halo step: 64 quads for 255 taps (fewer for the shorter tap classes)
+    static_assert(XQUADS >= 1 && XQUADS <= 64, "the halo must fit one wave-step of quads");
+};
+
+struct AbRaw { float4 a, b; };                                         // samples 4q, 4q+1 | 4q+2, 4q+3
+
+// quad q (0 <= q < NQUAD, wave-uniform base) of tile b
+template <int NKS, bool U8>
+__device__ __forceinline__ AbRaw dd_ab_load_quad(const DDChainParams& P, int b, int q) {
+    using G = MfmaGeom<NKS>;
     const int64_t ns = (int64_t)b * MF_ADV - 32 - G::HALO;
+    AbRaw r;
     if (U8) {
         const char* base = reinterpret_cast<const char*>(P.in) + 2 * ns;                            // wave-uniform
-#pragma unroll
-        for (int it = 0; it < A::NIT; ++it) {
-            int q = vt + AB_VTHREADS * it;
-            if (AB_VTHREADS * (it + 1) > A::NQ) q = q < A::NQ ? q : A::NQ - 1;
-            const uint32_t d = *reinterpret_cast<const uint32_t*>(base + 4u * (unsigned)q);
-            raw[it] = make_float4((float)(d & 0xff) - 127.5f, (float)((d >> 8) & 0xff) - 127.5f,
-                                  (float)((d >> 16) & 0xff) - 127.5f, (float)(d >> 24) - 127.5f);
-        }
-        return;
+        const uint2 d = *reinterpret_cast<const uint2*>(base + 8u * (unsigned)q);                  // 4 u8 pairs (source.py:117-118)
+        r.a = make_float4((float)(d.x & 0xff) - 127.5f, (float)((d.x >> 8) & 0xff) - 127.5f,
+                          (float)((d.x >> 16) & 0xff) - 127.5f, (float)(d.x >> 24) - 127.5f);
+        r.b = make_float4((float)(d.y & 0xff) - 127.5f, (float)((d.y >> 8) & 0xff) - 127.5f,
+                          (float)((d.y >> 16) & 0xff) - 127.5f, (float)(d.y >> 24) - 127.5f);
+        return r;
     }
     const char* base = reinterpret_cast<const char*>(reinterpret_cast<const float2*>(P.in) + ns);   // wave-uniform
-#pragma unroll
-    for (int it = 0; it < A::NIT; ++it) {
-        int q = vt + AB_VTHREADS * it;
-        if (AB_VTHREADS * (it + 1) > A::NQ) q = q < A::NQ ? q : A::NQ - 1;   // partial last step: re-read, write masked
-        raw[it] = *reinterpret_cast<const float4*>(base + 16u * (unsigned)q);   // two consecutive samples
-    }
+    r.a = *reinterpret_cast<const float4*>(base + 32u * (unsigned)q);
+    r.b = *reinterpret_cast<const float4*>(base + 32u * (unsigned)q + 16u);
+    return r;
 }
 
-// rotate (tile-relative NCO phase, see dd_ws_convert), split into f16 limbs, write the four planes
+// f16 limb split of two values: hi = RNE_f16(x) packed (v_cvt_pk_f16_f32), unpacked again (v_cvt_f32_f16 on either
+// half), lo = RNE_f16(x - hi): 6 plain vector instructions.  Left to the compiler the split of a sample pair is 16-17
+// instructions, six of them v_fma_mixlo/mixhi_f16 fused with the rotation -- and beside a busy matrix pipe a mix op
+// costs 8.7 cycles of the SIMD's issue against 4.6 for a plain conversion (tools/ubench/valu_beside_mfma.hip).
+__device__ __forceinline__ void dd_ab_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    float t0, t1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(t0) : "v"(hi));
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(t1) : "v"(hi));
+    t0 = x0 - t0;
+    t1 = x1 - t1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(t0), "v"(t1));
+}
+
+// rotate (tile-relative NCO phase, see dd_ws_convert), split into f16 limbs, write 8 bytes into each of the four planes
 template <int NKS, bool UNIT_SCALE>
-__device__ __forceinline__ void dd_ab_convert(const float4 (&raw)[AbGeom<NKS>::NIT], char* planes,
-                                              const float2 (&wk)[AbGeom<NKS>::NIT][2], float scale, int vt) {
+__device__ __forceinline__ void dd_ab_convert_quad(const AbRaw& raw, char* planes, int q, const float2 (&wk)[4], float scale) {
     using G = MfmaGeom<NKS>;
-    using A = AbGeom<NKS>;
-#pragma unroll
-    for (int it = 0; it < A::NIT; ++it) {
-        const int q = vt + AB_VTHREADS * it;
-        if (AB_VTHREADS * (it + 1) > A::NQ && q >= A::NQ) continue;
-        const int e = 2 * q;
-        float2 pa = wk[it][0], pb = wk[it][1];
-        if (!UNIT_SCALE) {
-            pa = make_float2(pa.x * scale, pa.y * scale);
-            pb = make_float2(pb.x * scale, pb.y * scale);
-        }
-        const float2 xa = dd_cmul(make_float2(raw[it].x, raw[it].y), pa);
-        const float2 xb = dd_cmul(make_float2(raw[it].z, raw[it].w), pb);
-        // f16 limb split in 12 plain vector instructions per sample pair, written out: hi = RNE_f16(x) packed two at
-        // a time (v_cvt_pk_f16_f32), unpacked again (v_cvt_f32_f16 on either half), lo = RNE_f16(x - hi).  Left to the
-        // compiler this is 16-17 instructions, six of them v_fma_mixlo/mixhi_f16 fused with the rotation -- and
-        // beside a busy matrix pipe a mix op costs 8.7 cycles of the SIMD's issue against 4.6 for a plain
-        // conversion (tools/ubench/valu_beside_mfma.hip).
-        uint32_t rh, rl, ih, il;
-        {
-            float t0, t1, t2, t3;
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(rh) : "v"(xa.x), "v"(xb.x));
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ih) : "v"(xa.y), "v"(xb.y));
-            asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(t0) : "v"(rh));
-            asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(t1) : "v"(rh));
-            asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(t2) : "v"(ih));
-            asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(t3) : "v"(ih));
-            t0 = xa.x - t0; t1 = xb.x - t1; t2 = xa.y - t2; t3 = xb.y - t3;
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(rl) : "v"(t0), "v"(t1));
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(il) : "v"(t2), "v"(t3));
-        }
-        const int off = 2 * e + 16 * (e >> 5);
+    float2 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
+    if (!UNIT_SCALE) {
+        w0 = make_float2(w0.x * scale, w0.y * scale); w1 = make_float2(w1.x * scale, w1.y * scale);
+        w2 = make_float2(w2.x * scale, w2.y * scale); w3 = make_float2(w3.x * scale, w3.y * scale);
+    }
+    const float2 x0 = dd_cmul(make_float2(raw.a.x, raw.a.y), w0), x1 = dd_cmul(make_float2(raw.a.z, raw.a.w), w1);
+    const float2 x2 = dd_cmul(make_float2(raw.b.x, raw.b.y), w2), x3 = dd_cmul(make_float2(raw.b.z, raw.b.w), w3);
+    uint2 rh, rl, ih, il;
+    dd_ab_split2(x0.x, x1.x, rh.x, rl.x);
+    dd_ab_split2(x2.x, x3.x, rh.y, rl.y);
+    dd_ab_split2(x0.y, x1.y, ih.x, il.x);
+    dd_ab_split2(x2.y, x3.y, ih.y, il.y);
+    const int e = 4 * q;
+    const int off = 2 * e + 16 * (e >> 5);                 // 8-byte aligned: a quad never straddles a 32-sample pad
 #ifdef DD_AB_NO_DSWRITE
-        if (scale != 12345.f) continue;                    // (ablation: the limbs are computed, never written)
+    if (scale != 12345.f) return;                          // (ablation: the limbs are computed, never written)
 #endif
-        *reinterpret_cast<uint32_t*>(planes + off) = rh;
-        *reinterpret_cast<uint32_t*>(planes + G::PLANE + off) = rl;
-        *reinterpret_cast<uint32_t*>(planes + 2 * G::PLANE + off) = ih;
-        *reinterpret_cast<uint32_t*>(planes + 3 * G::PLANE + off) = il;
+    *reinterpret_cast<uint2*>(planes + off) = rh;
+    *reinterpret_cast<uint2*>(planes + G::PLANE + off) = rl;
+    *reinterpret_cast<uint2*>(planes + 2 * G::PLANE + off) = ih;
+    *reinterpret_cast<uint2*>(planes + 3 * G::PLANE + off) = il;
+}
+
+__device__ __forceinline__ float dd_ab_absmax(const AbRaw& r, float m) {
+    m = fmaxf(fmaxf(m, fabsf(r.a.x)), fmaxf(fabsf(r.a.y), fmaxf(fabsf(r.a.z), fabsf(r.a.w))));
+    return fmaxf(fmaxf(m, fabsf(r.b.x)), fmaxf(fabsf(r.b.y), fmaxf(fabsf(r.b.z), fabsf(r.b.w))));
+}
+
+// "does the tile fit the f16 limbs unscaled" -- this wave's share of the answer for the tile in slot `slot`:
+// red entry `ent` = 1.0 (any value of the unit range) when all of the wave's samples lie below 32768 and at least one
+// reaches 0.25, else the wave's true maximum together with the tile's non-unit flag (see dd_ws_vphase)
+__device__ __forceinline__ void dd_ab_publish_range(float m, char* smem, int red_off, int nonunit_off, int slot, int ent, int lane) {
+    const bool hi_any = __builtin_amdgcn_ballot_w64(!(m < 32768.0f)) != 0;
+    const bool lo_any = __builtin_amdgcn_ballot_w64(m >= 0.25f) != 0;
+    if (hi_any || !lo_any) {
+        m = dd_wave_max(m);
+        if (lane == 63) atomicOr(reinterpret_cast<int*>(smem + nonunit_off) + (slot & 3), 1);
+    } else m = 1.0f;
+    if (lane == 63) reinterpret_cast<float*>(smem + red_off)[(slot & 1) * AB_RED_ENTRIES + ent] = m;
+}
+
+// the power-of-two scale of tile p (1 in the common case: no wave raised the tile's non-unit flag)
+__device__ __forceinline__ float dd_ab_tile_scale(const char* smem, int red_off, int flag, int p, bool& unit) {
+    const float* red = reinterpret_cast<const float*>(smem + red_off) + (p & 1) * AB_RED_ENTRIES;
+    float m = 1.0f;
+    if (__builtin_amdgcn_readfirstlane(flag) != 0) {
+        m = red[0];
+#pragma unroll
+        for (int k = 1; k < AB_RED_ENTRIES; ++k) m = fmaxf(m, red[k]);
+    }
+    unit = (m >= 0.25f) && (m < 32768.0f);                 // the f16 limbs hold the tile unscaled (see dd_ws_vphase)
+    return unit ? 1.0f : dd_pow2_scale_for(m);
+}
+
+// one 256-output unit of the vector waves' share: outputs 512 + 256 u + 4 lane + {0..3} of strip s, tile b
+struct AbUnit { float4 r4, i4; float2 ym; };
+template <int NKS>
+__device__ __forceinline__ AbUnit dd_ab_unit_read(const float* yh_set, int vw, int lane) {
+    using A = AbGeom<NKS>;
+    const float* yre = yh_set + (vw >> 1) * A::YH_STRIDE + 4 + 256 * (vw & 1) + 4 * lane;
+    const float* yim = yre + 4 * A::YH_STRIDE;
+    AbUnit d;
+    d.r4 = *reinterpret_cast<const float4*>(yre);
+    d.i4 = *reinterpret_cast<const float4*>(yim);
+    d.ym = make_float2(yre[-1], yim[-1]);
+    return d;
+}
+__device__ __forceinline__ void dd_ab_unit_store(const DDChainParams& P, int b, int vw, int lane, const AbUnit& d) {
+    const float4 r4 = d.r4, i4 = d.i4;
+    const float2 ym = d.ym;
+    // z_k = y_k conj(y_{k-1})
+    const float re0 = fmaf(r4.x, ym.x, i4.x * ym.y), im0 = fmaf(i4.x, ym.x, -r4.x * ym.y);
+    const float re1 = fmaf(r4.y, r4.x, i4.y * i4.x), im1 = fmaf(i4.y, r4.x, -r4.y * i4.x);
+    const float re2 = fmaf(r4.z, r4.y, i4.z * i4.y), im2 = fmaf(i4.z, r4.y, -r4.z * i4.y);
+    const float re3 = fmaf(r4.w, r4.z, i4.w * i4.z), im3 = fmaf(i4.w, r4.z, -r4.w * i4.z);
+    const float mn = fminf(fminf(fmaf(0.41421354f, re0, -fabsf(im0)), fmaf(0.41421354f, re1, -fabsf(im1))),
+                           fminf(fmaf(0.41421354f, re2, -fabsf(im2)), fmaf(0.41421354f, re3, -fabsf(im3))));
+    float a0, a1, a2, a3;
+    if (__builtin_amdgcn_ballot_w64(!(mn >= 0.f)) == 0) {
+        a0 = dd_atan_small(im0, re0); a1 = dd_atan_small(im1, re1);
+        a2 = dd_atan_small(im2, re2); a3 = dd_atan_small(im3, re3);
+    } else {
+        a0 = dd_fast_atan2(im0, re0); a1 = dd_fast_atan2(im1, re1);
+        a2 = dd_fast_atan2(im2, re2); a3 = dd_fast_atan2(im3, re3);
+    }
+    const int64_t p = (int64_t)b * MF_ADV - 32 + (int64_t)(vw >> 1) * MF_STRIP + 512 + 256 * (vw & 1) + 4 * lane;
+    float* out = reinterpret_cast<float*>(P.out) + (p - P.s);
+    if (P.s == 0) {
+        *reinterpret_cast<float4*>(out) = make_float4(a0, a1, a2, a3);
+    } else {                                               // first chunk of a stream: outputs shifted by one
+        out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
     }
 }
 
@@ -130,49 +223,54 @@ __device__ __forceinline__ void dd_ab_convert(const float4 (&raw)[AbGeom<NKS>::N
 // one vector-wave phase p: loads of tile p+2 | conversion of tile p | range check of tile p+1 | barrier
 template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem, int t_begin, int n, int p,
-                                             float4 (&rcur)[AbGeom<NKS>::NIT], float4 (&rnext)[AbGeom<NKS>::NIT],
-                                             float4 (&rld)[AbGeom<NKS>::NIT], const float2 (&wk)[AbGeom<NKS>::NIT][2],
+                                             AbRaw (&rcur)[AB_VSTEPS], AbRaw (&rnext)[AB_VSTEPS], AbRaw (&rld)[AB_VSTEPS],
+                                             const float2 (&wk)[AB_VSTEPS][4],
                                              int vt, int vw, int lane, bool stamp, unsigned long long (&acc_t)[8]) {
     using A = AbGeom<NKS>;
+    using Q = AbQ<NKS>;
     unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
-    float* redall = reinterpret_cast<float*>(smem + A::RED_OFF);
-    int* nonunit = reinterpret_cast<int*>(smem + A::NONUNIT_OFF);
+    // the tile's non-unit flag is requested first: its LDS round trip (hundreds of cycles behind the matrix waves'
+    // fragment stream) passes under the address arithmetic and the issue of the tile loads
+    const int nu_flag = reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[p & 3];
 #ifndef DD_AB_NO_LOAD
     {
         const int bl = t_begin + (p + 2 < n ? p + 2 : n - 1);   // past the end: harmless re-read, never used
-        dd_ab_load<NKS, U8>(P, bl, vt, rld);
+#pragma unroll
+        for (int st = 0; st < AB_VSTEPS; ++st) rld[st] = dd_ab_load_quad<NKS, U8>(P, bl, Q::XQUADS + vt + AB_VTHREADS * st);
     }
+#endif
+    // this wave's unit of the discriminator of tile p-2 (its MFMAs ran in phase p-1, by set (p-1) & 1): the outputs
+    // are requested from LDS now and turned into angles behind the conversion
+    const bool do_unit = AB_REG_ROWS < 16 && p >= 2 && p - 2 < n;
+    AbUnit ud;
+    ud.r4 = ud.i4 = make_float4(1.f, 0.f, 0.f, 0.f);
+    ud.ym = make_float2(1.f, 0.f);
+#ifndef DD_AB_NO_EPI
+    if (do_unit) ud = dd_ab_unit_read<NKS>(reinterpret_cast<const float*>(smem + A::YH_OFF + ((p - 1) & 1) * A::YH_SET_BYTES), vw, lane);
 #endif
     DD_AB_STAMP(0)
 #ifndef DD_AB_NO_CONVERT
     if (p < n) {                                            // convert tile p (range published in phase p-1)
-        const float* red = redall + (p & 1) * AB_VWAVES;
-        float m = 1.0f;
-        if (__builtin_amdgcn_readfirstlane(nonunit[p & 3]) != 0) {
-            m = red[0];
+        bool unit;
+        const float scale = dd_ab_tile_scale(smem, A::RED_OFF, nu_flag, p, unit);
+        if (vt == 0) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[(p + 2) & 3] = 0;   // re-arm the slot tile p+2's producers raise in phase p+1
+        char* planes = smem + (p & 1) * A::PLANES_BYTES;
 #pragma unroll
-            for (int k = 1; k < AB_VWAVES; ++k) m = fmaxf(m, red[k]);
+        for (int st = 0; st < AB_VSTEPS; ++st) {
+            if (unit) dd_ab_convert_quad<NKS, true>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
+            else dd_ab_convert_quad<NKS, false>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
         }
-        if (vt == 0) nonunit[(p + 2) & 3] = 0;              // re-arm the slot tile p+2's producers raise in phase p+1
-        const bool unit = (m >= 0.25f) && (m < 32768.0f);   // the f16 limbs hold the tile unscaled (see dd_ws_vphase)
-        const float scale = unit ? 1.0f : dd_pow2_scale_for(m);
-        if (unit) dd_ab_convert<NKS, true>(rcur, smem + (p & 1) * A::PLANES_BYTES, wk, scale, vt);
-        else dd_ab_convert<NKS, false>(rcur, smem + (p & 1) * A::PLANES_BYTES, wk, scale, vt);
     }
 #endif
     DD_AB_STAMP(1)
+#ifndef DD_AB_NO_EPI
+    if (do_unit) dd_ab_unit_store(P, t_begin + p - 2, vw, lane, ud);
+#endif
     if (p + 1 < n) {                                        // does tile p+1 fit the f16 limbs unscaled?
         float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < A::NIT; ++it)
-            m = fmaxf(fmaxf(m, fabsf(rnext[it].x)), fmaxf(fabsf(rnext[it].y), fmaxf(fabsf(rnext[it].z), fabsf(rnext[it].w))));
-        const bool hi_any = __builtin_amdgcn_ballot_w64(!(m < 32768.0f)) != 0;
-        const bool lo_any = __builtin_amdgcn_ballot_w64(m >= 0.25f) != 0;
-        if (hi_any || !lo_any) {
-            m = dd_wave_max(m);
-            if (lane == 63) atomicOr(nonunit + ((p + 1) & 3), 1);
-        } else m = 1.0f;
-        if (lane == 63) redall[((p + 1) & 1) * AB_VWAVES + vw] = m;
+        for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(rnext[st], m);
+        dd_ab_publish_range(m, smem, A::RED_OFF, A::NONUNIT_OFF, p + 1, vw, lane);
     }
     DD_AB_STAMP(2)
     __syncthreads();
@@ -182,30 +280,34 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
 template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using A = AbGeom<NKS>;
+    using Q = AbQ<NKS>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int vt = tid - 64 * 8, vw = vt >> 6;
     const int n = t_end - t_begin;
-    float4 r0[A::NIT], r1[A::NIT], r2[A::NIT];
-    dd_ab_load<NKS, U8>(P, t_begin, vt, r0);
-    dd_ab_load<NKS, U8>(P, t_begin + (n > 1 ? 1 : 0), vt, r1);
-    float2 wk[A::NIT][2];                                  // tile-relative NCO phasors of this lane's sample positions
+    AbRaw r0[AB_VSTEPS], r1[AB_VSTEPS], r2[AB_VSTEPS];
 #pragma unroll
-    for (int it = 0; it < A::NIT; ++it) {
+    for (int st = 0; st < AB_VSTEPS; ++st) {
+        r0[st] = dd_ab_load_quad<NKS, U8>(P, t_begin, Q::XQUADS + vt + AB_VTHREADS * st);
+        r1[st] = dd_ab_load_quad<NKS, U8>(P, t_begin + (n > 1 ? 1 : 0), Q::XQUADS + vt + AB_VTHREADS * st);
+    }
+    float2 wk[AB_VSTEPS][4];                               // tile-relative NCO phasors of this lane's sample positions
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pos = 2 * (vt + AB_VTHREADS * it) + k;
-            wk[it][k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)pos * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+    for (int st = 0; st < AB_VSTEPS; ++st) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = 4 * (Q::XQUADS + vt + AB_VTHREADS * st) + k;
+            wk[st][k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)pos * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
         }
     }
     {   // range of tile 0 (what phase p-1 does for tile p); its non-unit flag is preset: the true maximum is read
         float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < A::NIT; ++it)
-            m = fmaxf(fmaxf(m, fabsf(r0[it].x)), fmaxf(fabsf(r0[it].y), fmaxf(fabsf(r0[it].z), fabsf(r0[it].w))));
+        for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(r0[st], m);
         m = dd_wave_max(m);
         if (lane == 63) reinterpret_cast<float*>(smem + A::RED_OFF)[vw] = m;
     }
     __syncthreads();                                        // prologue barrier (matched in dd_ab_matrix)
+    if (DD_AB_VEC_PRIO) __builtin_amdgcn_s_setprio(DD_AB_VEC_PRIO);
     const bool stamp = taps.stamps != nullptr;
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 6
@@ -232,33 +334,34 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     // One wave turns 1024 outputs into angles: written as ONE straight-line block over all 16 rows (16-way
     // instruction-level parallelism; a single in-order wave issues a dependent chain at ~12 cycles per
     // instruction, measured, and four rows at a time with a branch per group took 3500 cycles per strip).
-    // 1. the left-hand neighbours of the row-leading lanes (0, 16, 32, 48) for all 16 registers, requested up front
-    float2 bv[16];
+    // 1. the left-hand neighbours of the row-leading lanes (0, 16, 32, 48), requested up front
+    constexpr int NR = AB_REG_ROWS;
+    float2 bv[NR];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = xrd[r];
+    for (int r = 0; r < NR; ++r) bv[r] = xrd[r];
     // 2. z = y[n] conj(y[n-1]); y[n-1] is the same register one lane to the left: DPP row_shr:1, which leaves the
     //    first lane of each 16-lane row (no source lane) at the old value of the destination = its table entry
-    float re[16], im[16];
+    float re[NR], im[NR];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const float pre = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].x), __float_as_int(cre[r]), 0x111, 0xf, 0xf, false));
         const float pim = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].y), __float_as_int(cim[r]), 0x111, 0xf, 0xf, false));
         re[r] = fmaf(cre[r], pre, cim[r] * pim);
         im[r] = fmaf(cim[r], pre, -cre[r] * pim);
     }
     // 3. wave-uniform fast path: every |angle| below 22.5 degrees (an oversampled FM signal always is), i.e.
-    //    min over the 16 rows of (tan(22.5 deg) re - |im|) >= 0 in every lane (a NaN fails the test)
+    //    min over the rows of (tan(22.5 deg) re - |im|) >= 0 in every lane (a NaN fails the test)
     float mn = fmaf(0.41421354f, re[0], -fabsf(im[0]));
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mn = fminf(mn, fmaf(0.41421354f, re[r], -fabsf(im[r])));
+    for (int r = 1; r < NR; ++r) mn = fminf(mn, fmaf(0.41421354f, re[r], -fabsf(im[r])));
     const bool all_small = __builtin_amdgcn_ballot_w64(!(mn >= 0.f)) == 0;
-    float a[16];
+    float a[NR];
     if (all_small) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = dd_atan_small(im[r], re[r]);
+        for (int r = 0; r < NR; ++r) a[r] = dd_atan_small(im[r], re[r]);
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = dd_fast_atan2(im[r], re[r]);
+        for (int r = 0; r < NR; ++r) a[r] = dd_fast_atan2(im[r], re[r]);
     }
     // 4. row r of the lane is output 32 (rowbase(r) + 4 h) + j: 128 contiguous bytes per half wave and row.
     //    The tile's first 32 outputs (strip 0, row 0) belong to the previous tile.
@@ -266,14 +369,32 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     if (P.K != 12345) {                                    // (ablation: angles computed, one store per strip)
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum += a[r];
+        for (int r = 0; r < NR; ++r) sum += a[r];
         out[0] = sum;
         return;
     }
 #endif
     if (mw != 0 || h != 0) out[0] = a[0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) out[32 * ((r & 3) + 8 * (r >> 2))] = a[r];
+    for (int r = 1; r < NR; ++r) out[32 * ((r & 3) + 8 * (r >> 2))] = a[r];
+}
+
+// after the MFMAs: registers AB_REG_ROWS..15 (outputs 512..1023 of the strip, plus output 511 in the slack) to the set's
+// y-half buffer, in output order: the vector waves run their discriminator in the next phase
+__device__ __forceinline__ void dd_ab_write_yhalf(int lane, const v16f& cre, const v16f& cim, float* yre_strip, int plane_floats) {
+    const int j = lane & 31, h = lane >> 5;
+    float* wre = yre_strip + 4 + 128 * h + j;
+    float* wim = wre + plane_floats;
+#pragma unroll
+    for (int r = AB_REG_ROWS; r < 16; ++r) {
+        const int row = (r & 3) + 8 * ((r >> 2) - 2);      // row - 16
+        wre[32 * row] = cre[r];
+        wim[32 * row] = cim[r];
+    }
+    if (lane == 63) {                                      // output 511 = register 7, lane 63
+        yre_strip[3] = cre[7];
+        yre_strip[3 + plane_floats] = cim[7];
+    }
 }
 
 // after the MFMAs: the last lane of each 16-lane row leaves its 16 outputs where the first lane of the next row (the
@@ -310,7 +431,30 @@ __device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* t
     DD_WS_STEP((NKS - 1) % 3, (NKS + 1) % 3, NKS - 1, false)
 }
 
-template <int NKS, int SET>
+// the halo step (quads 0..63 of a tile) on the matrix wave of strip 0, set SET: conversion in the set's discriminator
+// phase, range check of the next one at the end of its MFMA phase (the data were requested a phase earlier)
+template <int NKS, bool U8>
+__device__ __forceinline__ void dd_ab_halo_convert(const DDChainParams& P, char* smem, int t_begin, int n, int q, int lane,
+                                                   AbRaw& xraw, const float2 (&wkx)[4], int nu_flag) {
+    using A = AbGeom<NKS>;
+#ifndef DD_AB_NO_CONVERT
+    if (q < n) {
+        bool unit;
+        const float scale = dd_ab_tile_scale(smem, A::RED_OFF, nu_flag, q, unit);
+        char* planes = smem + (q & 1) * A::PLANES_BYTES;
+        if (AbQ<NKS>::XQUADS == 64 || lane < AbQ<NKS>::XQUADS) {
+            if (unit) dd_ab_convert_quad<NKS, true>(xraw, planes, lane, wkx, scale);
+            else dd_ab_convert_quad<NKS, false>(xraw, planes, lane, wkx, scale);
+        }
+    }
+#endif
+#ifndef DD_AB_NO_LOAD
+    // the set's next tile (two phases ahead); lanes past the halo re-read its last quad (never written)
+    xraw = dd_ab_load_quad<NKS, U8>(P, t_begin + (q + 2 < n ? q + 2 : n - 1), lane < AbQ<NKS>::XQUADS ? lane : AbQ<NKS>::XQUADS - 1);
+#endif
+}
+
+template <int NKS, int SET, bool U8>
 __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using A = AbGeom<NKS>;
@@ -327,6 +471,24 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     float2* xb = xtab + A::X0_ENTRIES + 128 + 16 * mw;
     const int lg = lane >> 4;
     const float2* xrd = lg == 0 ? x0 : (lg == 1 ? xa : (lg == 2 ? x1 : xb));
+    // halo step: set 1 owns the even tiles' (its discriminator phases are the even ones), set 0 the odd tiles'
+    const bool halo = mw == 0;
+    AbRaw xraw;
+    float2 wkx[4];
+    xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wkx[k] = make_float2(1.f, 0.f);
+    if (halo) {
+        xraw = dd_ab_load_quad<NKS, U8>(P, t_begin + (SET == 1 ? 0 : (n > 1 ? 1 : 0)), lane < AbQ<NKS>::XQUADS ? lane : AbQ<NKS>::XQUADS - 1);
+        if (P.flags & DD_CHAIN_NCO) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wkx[k] = dd_phasor((uint64_t)(4 * lane + k) * P.cyc, P.nco_tbl);
+        }
+        if (SET == 1) {                                     // tile 0: the true maximum (its non-unit flag is preset)
+            const float m = dd_wave_max(dd_ab_absmax(xraw, 0.f));
+            if (lane == 63) reinterpret_cast<float*>(smem + A::RED_OFF)[AB_VWAVES] = m;
+        }
+    }
     __syncthreads();                                        // prologue barrier (tile 0's range is published)
 
     const bool stamp = taps.stamps != nullptr;
@@ -340,9 +502,16 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     for (int p = 0; p < nph; p += 2) {
         unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
         const int qm = p + SET;                             // this set's MFMA phase of the pair
-        if (SET == 1) {                                     // phase p: discriminator of tile p - 2 (computed in phase p - 1)
+        if (SET == 1) {                                     // phase p: halo step of tile p, discriminator of tile p - 2
+            const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[p & 3] : 0;
+#ifndef DD_AB_HALO_LATE
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p, lane, xraw, wkx, nu_flag);
+#endif
 #ifndef DD_AB_NO_EPI
             if (p >= 2 && p - 2 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 2, mw, lane, cre, cim, xrd);
+#endif
+#ifdef DD_AB_HALO_LATE
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p, lane, xraw, wkx, nu_flag);
 #endif
             DD_AB_STAMP(1)
             __syncthreads();
@@ -357,14 +526,25 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
             (void)abase; (void)tb;
 #endif
             dd_ab_publish(lane, cre, cim, x0, xa, x1, xb);
+            if (AB_REG_ROWS < 16)
+                dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
             __builtin_amdgcn_s_setprio(DD_AB_EPI_PRIO);
         }
+        // range of the halo the set converts in its next discriminator phase (tile qm + 1, requested a phase ago)
+        if (halo && qm + 1 < n) dd_ab_publish_range(dd_ab_absmax(xraw, 0.f), smem, A::RED_OFF, A::NONUNIT_OFF, qm + 1, AB_VWAVES, lane);
         DD_AB_STAMP(0)
         __syncthreads();
         DD_AB_STAMP(2)
-        if (SET == 0) {                                     // phase p + 1: discriminator of tile p - 1 (computed in phase p)
+        if (SET == 0) {                                     // phase p + 1: halo step of tile p + 1, discriminator of tile p - 1
+            const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[(p + 1) & 3] : 0;
+#ifndef DD_AB_HALO_LATE
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p + 1, lane, xraw, wkx, nu_flag);
+#endif
 #ifndef DD_AB_NO_EPI
             if (p >= 1 && p - 1 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 1, mw, lane, cre, cim, xrd);
+#endif
+#ifdef DD_AB_HALO_LATE
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p + 1, lane, xraw, wkx, nu_flag);
 #endif
             DD_AB_STAMP(1)
             __syncthreads();
@@ -409,10 +589,11 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
         v8h* tl = reinterpret_cast<v8h*>(smem + A::TAPS_OFF);
         for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
         if (threadIdx.x < 4) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[threadIdx.x] = threadIdx.x == 0 ? 1 : 0;   // tile 0: read the true max
+        if (threadIdx.x < 2 * AB_RED_ENTRIES) reinterpret_cast<float*>(smem + A::RED_OFF)[threadIdx.x] = 0.f;          // (unused entries stay 0)
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 5) / 6) * 6;      // phases: a multiple of the vector loop's 3 and the matrix sets' 2
-    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0>(P, taps, smem, t_begin, t_end, nph);
-    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1>(P, taps, smem, t_begin, t_end, nph);
+    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0, U8>(P, taps, smem, t_begin, t_end, nph);
+    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1, U8>(P, taps, smem, t_begin, t_end, nph);
     else dd_ab_vector<NKS, U8>(P, taps, smem, t_begin, t_end, nph);
 }
