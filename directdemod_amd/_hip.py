@@ -54,6 +54,8 @@ SIGNATURES = {
     "dd_memset": (_int, [_p, _int, _sz, _p]),
     "dd_host_alloc_pinned": (_int, [_pp, _sz]),
     "dd_host_free_pinned": (_int, [_p]),
+    "dd_host_register": (_int, [_p, _sz]),
+    "dd_host_unregister": (_int, [_p]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2h": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2d": (_int, [_p, _p, _sz, _p]),

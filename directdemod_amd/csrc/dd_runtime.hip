@@ -72,6 +72,22 @@ extern "C" int dd_host_free_pinned(void* hptr) {
     if (hptr) DD_HIP_CHECK(hipHostFree(hptr));
     return DD_OK;
 }
+// pin a range of the caller's own memory in place (an array, or a file mapping of the recording): a
+// hipMemcpyAsync out of it is then a true asynchronous DMA with no staging copy in the runtime
+extern "C" int dd_host_register(void* hptr, size_t bytes) {
+    DD_REQUIRE(hptr && bytes, "hptr/bytes");
+    hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dd_set_error("hipHostRegister(%p, %zu): %s", hptr, bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? DD_ERR_NOMEM : DD_ERR_UNSUPPORTED;   // e.g. a read-only mapping: the caller falls back
+    }
+    return DD_OK;
+}
+extern "C" int dd_host_unregister(void* hptr) {
+    if (hptr) DD_HIP_CHECK(hipHostUnregister(hptr));
+    return DD_OK;
+}
 extern "C" int dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream) {
     if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, dd_stream(stream)));
     return DD_OK;

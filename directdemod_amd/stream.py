@@ -74,16 +74,26 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
     """offsetFreq -> FIR -> decimate -> FM over a u8 source, chunk by chunk, with the
     ingest overlapped.  Returns (device float32 array of all outputs, output rate).
 
-    staging: "direct" -- the chunk's raw pairs go from the source's own memory (array or memmap view, no host copy)
-    to the device slot by hipMemcpyAsync on the copy stream; the runtime's pageable-memory path moves ~44 GB/s on
-    this host, more than `copy_threads` memcpy threads filling a pinned slot first ("pinned", ~24 GB/s with 4)."""
+    staging:
+      "direct"     -- the chunk's raw pairs go from the source's own memory (array or memmap view, no host copy) to the
+                      device slot by hipMemcpyAsync on the copy stream (the runtime stages pageable memory itself);
+      "registered" -- the same, but the chunk's pages are pinned IN PLACE first (hipHostRegister, a window of `depth`
+                      chunks in flight, unpinned when the slot is reused): a true asynchronous DMA out of the
+                      recording's own memory, no staging copy anywhere; falls back to "direct" for ranges that cannot
+                      be pinned (e.g. a read-only file mapping on some kernels);
+      "pinned"     -- `copy_threads` memcpy threads fill a pinned slot first (for sources without `raw_view`)."""
     from .shard import HipChainEngine
     fs = int(src.sampFreq)
     eng = HipChainEngine(taps, freq_hz, fs, decim, fm=True, nco=True, u8=True, stream=compute_stream)
     ck = chunker.chunker(src, chunk_size)
     chunks = ck.getChunks
     maxlen = max(b - a for a, b in chunks)
-    direct = staging == "direct" and hasattr(src, "raw_view")
+    direct = staging in ("direct", "registered") and hasattr(src, "raw_view")
+    # (chunks of at least a few pages: then a pinned range holds nothing younger than the head of the NEXT chunk,
+    # which is what the unregister rule below relies on; pinning pays off for megabyte chunks only anyway)
+    register = direct and staging == "registered" and 2 * min(b - a for a, b in chunks) >= 65536
+    registered = [None] * depth                     # host address pinned for the chunk in slot k (page aligned)
+    reg_hi = 0                                      # end of the last pinned range
     ring = PinnedRing(2 * maxlen, depth, pinned=not direct)
     total_out = max(1, len(range(0, src.length, decim)))
     out = DevArray(total_out, np.float32)
@@ -99,7 +109,32 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
                 check(L.dd_event_sync(ring.consumed[k]), "dd_event_sync")       # slot free again?
             if direct:
                 v = src.raw_view(a, b)                                                        # no host copy
-                check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, 2 * n, ring.copy_stream), "h2d")
+                if register:
+                    if registered[k] is not None:
+                        # the slot's previous chunk (i - depth).  Its pinned range also holds the first bytes of chunk
+                        # i - depth + 1 (ranges tile whole pages, see below): that copy must be over as well
+                        check(L.dd_event_sync(ring.copied[(k + 1) % depth]), "dd_event_sync")
+                        L.dd_host_unregister(registered[k])
+                        registered[k] = None
+                    # pinned ranges tile the recording in whole pages without overlap (a page can be registered once):
+                    # this chunk's range starts where the previous one ended
+                    lo = max(v.ctypes.data & ~4095, reg_hi)
+                    hi = (v.ctypes.data + 2 * n + 4095) & ~4095
+                    split = 0                                                                 # bytes of this chunk that lie in the previous range
+                    if hi > lo:
+                        if L.dd_host_register(lo, hi - lo) == _hip.DD_OK:
+                            registered[k] = lo
+                            split = max(0, min(2 * n, lo - v.ctypes.data)) if reg_hi else 0
+                            reg_hi = hi
+                        else:
+                            register = False                                                  # cannot pin this memory: plain "direct" from here on
+                    if split:                                                                 # one copy per pinned range (a copy may not span two registrations)
+                        check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, split, ring.copy_stream), "h2d")
+                        check(L.dd_memcpy_h2d(ring.dev[k].ptr + split, v.ctypes.data + split, 2 * n - split, ring.copy_stream), "h2d")
+                    else:
+                        check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, 2 * n, ring.copy_stream), "h2d")
+                else:
+                    check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, 2 * n, ring.copy_stream), "h2d")
             else:
                 _stage(ring.host_view(k, 2 * n), src.read_raw_u8(a, b), pool, copy_threads)      # file/memmap -> pinned
                 check(L.dd_memcpy_h2d(ring.dev[k].ptr, ring.host[k], 2 * n, ring.copy_stream), "h2d")
@@ -115,6 +150,9 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
         # also on the exception path: nothing may still be copying into, or reading from, a slot when it is freed
         L.dd_stream_sync(ring.copy_stream)
         L.dd_stream_sync(compute_stream)
+        for r in registered:
+            if r is not None:
+                L.dd_host_unregister(r)
         _hip.unregister_stream(compute_stream)
         eng.close()
         ring.close()

@@ -60,6 +60,11 @@ int  dd_free(void* dptr);
 int  dd_memset(void* dptr, int value, size_t bytes, void* stream);
 int  dd_host_alloc_pinned(void** hptr, size_t bytes);
 int  dd_host_free_pinned(void* hptr);
+/* pin / unpin a range of caller-owned host memory in place (hipHostRegister): lets source.IQwav's memmap or an
+ * in-memory recording feed hipMemcpyAsync directly (BASELINE north_star: "pinned-host ring buffers with
+ * hipMemcpyAsync overlapped on a side stream").  DD_ERR_UNSUPPORTED when the range cannot be pinned. */
+int  dd_host_register(void* hptr, size_t bytes);
+int  dd_host_unregister(void* hptr);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

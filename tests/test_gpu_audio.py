@@ -202,13 +202,16 @@ def test_streaming_ring_feeder_equals_one_shot(dd):
     src = dd.source.IQarray(raw, 2048000)
     taps = O.win_blackmanharris(151)
     for M in (34, 1):
-        out, rate = stream.stream_fm_chain(src, taps, 30000.0, M, chunk_size=70001, depth=3)
-        got = out.to_host().astype(np.float64)
         ref, r2 = O.audio_chain(lambda a, b: O.read_iq_u8(raw, a, b), len(raw), 2048000, 30000.0, taps,
                                 2048000 // M if M > 1 else 2048000)
-        assert rate == r2 and got.shape == ref.shape
-        d = np.abs(np.angle(np.exp(1j * (got - ref))))
-        assert np.max(d) < 1e-4 and np.median(d) < 2e-6
+        # every staging route: pageable hipMemcpyAsync, the recording's pages pinned in place (hipHostRegister windows:
+        # chunks of 70001 samples end in the middle of a page, so consecutive windows meet inside one), pinned slots
+        for staging, chunk in (("direct", 70001), ("registered", 70001), ("registered", 1000), ("pinned", 70001)):
+            out, rate = stream.stream_fm_chain(src, taps, 30000.0, M, chunk_size=chunk, depth=3, staging=staging)
+            got = out.to_host().astype(np.float64)
+            assert rate == r2 and got.shape == ref.shape, (M, staging)
+            d = np.abs(np.angle(np.exp(1j * (got - ref))))
+            assert np.max(d) < 1e-4 and np.median(d) < 2e-6, (M, staging, np.max(d))
 
 
 def test_iir_butter_golden(dd, ops):
