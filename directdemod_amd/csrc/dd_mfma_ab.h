@@ -61,7 +61,8 @@ struct AbGeom {
     static constexpr int YH_STRIDE = 4 + 512;
     static constexpr int YH_OFF = (BCOL_OFF + 2 * BCOL_SET_BYTES + 15) & ~15;
     static constexpr int YH_SET_BYTES = 2 * 4 * YH_STRIDE * 4;
-    static constexpr int LDS_BYTES = (YH_OFF + (AB_REG_ROWS < 16 ? 2 * YH_SET_BYTES : 0) + 15) & ~15;
+    static constexpr int YHCNT_OFF = YH_OFF + (AB_REG_ROWS < 16 ? 2 * YH_SET_BYTES : 0);   // [2] int: y-half buffers written (x4 waves), per set
+    static constexpr int LDS_BYTES = (YHCNT_OFF + 16 + 15) & ~15;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(MF_LDS_TILE_BYTES(NKS) <= TAPS_OFF, "the edge tile's image must not reach the tap fragments");
 };
@@ -245,7 +246,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
     AbUnit ud;
     ud.r4 = ud.i4 = make_float4(1.f, 0.f, 0.f, 0.f);
     ud.ym = make_float2(1.f, 0.f);
-#ifndef DD_AB_NO_EPI
+#if !defined(DD_AB_NO_EPI) && !defined(AB_YH_LATE)
     if (do_unit) ud = dd_ab_unit_read<NKS>(reinterpret_cast<const float*>(smem + A::YH_OFF + ((p - 1) & 1) * A::YH_SET_BYTES), vw, lane);
 #endif
     DD_AB_STAMP(0)
@@ -264,6 +265,15 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
 #endif
     DD_AB_STAMP(1)
 #ifndef DD_AB_NO_EPI
+#ifdef AB_YH_LATE
+    if (do_unit) {
+        // the owning set writes its y-half at the START of this phase (not behind its MFMAs): wait for its four waves
+        const int* cnt = reinterpret_cast<const int*>(smem + A::YHCNT_OFF) + ((p - 1) & 1);
+        const int want = 4 * (((p - 2) >> 1) + 1);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
+        ud = dd_ab_unit_read<NKS>(reinterpret_cast<const float*>(smem + A::YH_OFF + ((p - 1) & 1) * A::YH_SET_BYTES), vw, lane);
+    }
+#endif
     if (do_unit) dd_ab_unit_store(P, t_begin + p - 2, vw, lane, ud);
 #endif
     if (p + 1 < n) {                                        // does tile p+1 fit the f16 limbs unscaled?
@@ -507,6 +517,13 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
 #ifndef DD_AB_HALO_LATE
             if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p, lane, xraw, wkx, nu_flag);
 #endif
+#if defined(AB_YH_LATE) && !defined(DD_AB_NO_EPI)
+            if (AB_REG_ROWS < 16 && p >= 2 && p - 2 < n) {
+                dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores have landed
+                if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + A::YHCNT_OFF) + SET, 1);
+            }
+#endif
 #ifndef DD_AB_NO_EPI
             if (p >= 2 && p - 2 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 2, mw, lane, cre, cim, xrd);
 #endif
@@ -526,8 +543,10 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
             (void)abase; (void)tb;
 #endif
             dd_ab_publish(lane, cre, cim, x0, xa, x1, xb);
+#ifndef AB_YH_LATE
             if (AB_REG_ROWS < 16)
                 dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
+#endif
             __builtin_amdgcn_s_setprio(DD_AB_EPI_PRIO);
         }
         // range of the halo the set converts in its next discriminator phase (tile qm + 1, requested a phase ago)
@@ -539,6 +558,13 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
             const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[(p + 1) & 3] : 0;
 #ifndef DD_AB_HALO_LATE
             if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p + 1, lane, xraw, wkx, nu_flag);
+#endif
+#if defined(AB_YH_LATE) && !defined(DD_AB_NO_EPI)
+            if (AB_REG_ROWS < 16 && p >= 1 && p - 1 < n) {
+                dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores have landed
+                if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + A::YHCNT_OFF) + SET, 1);
+            }
 #endif
 #ifndef DD_AB_NO_EPI
             if (p >= 1 && p - 1 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 1, mw, lane, cre, cim, xrd);
@@ -590,6 +616,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
         for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
         if (threadIdx.x < 4) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[threadIdx.x] = threadIdx.x == 0 ? 1 : 0;   // tile 0: read the true max
         if (threadIdx.x < 2 * AB_RED_ENTRIES) reinterpret_cast<float*>(smem + A::RED_OFF)[threadIdx.x] = 0.f;          // (unused entries stay 0)
+        if (threadIdx.x < 2) reinterpret_cast<int*>(smem + A::YHCNT_OFF)[threadIdx.x] = 0;
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 5) / 6) * 6;      // phases: a multiple of the vector loop's 3 and the matrix sets' 2
