@@ -99,6 +99,11 @@ SIGNATURES = {
     "dd_chain_path": (_int, [_p]),
     "dd_chain_last_kernel": (_int, [_p]),
     "dd_resample_fft_f64": (_int, [_p, _p, _i64, _i64, _p]),
+    "dd_rpoly_create": (_int, [_pp, C.POINTER(C.c_double), _int, _int, _int, _i64]),
+    "dd_rpoly_destroy": (_int, [_p]),
+    "dd_rpoly_reset": (_int, [_p]),
+    "dd_rpoly_out_count": (_i64, [_p, _i64, _int]),
+    "dd_rpoly_process": (_int, [_p, _p, _i64, _int, _p, _pi64, _p]),
     "dd_am_envelope_f64": (_int, [_p, _p, _i64, _i64, _p]),
     "dd_xcorr_norm_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
     "dd_find_peaks_f64": (_int, [_p, _i64, C.c_double, _int, _pi64, _int, C.POINTER(_int), _p]),

@@ -189,6 +189,17 @@ class commSignal:
             self.__len = len(range(offset, self.__len, jumpIndex))
         return self
 
+    def resamplePoly(self, resampler):
+        '''EXTENSION (no counterpart in the reference): polyphase rational resample through a
+        ``resample.polyResampler`` created outside the chunk loop; state is carried chunk to chunk.  The signal's
+        rate becomes the resampler's output rate (BASELINE config 3: "polyphase resample to 11.025 kS/s").'''
+        if int(self.__sampRate) != resampler.inRate:
+            raise TypeError("Signals must have same sampling rate")
+        out = resampler.applyOn(self._op_input())
+        self.__sampRate = resampler.outRate
+        self.updateSignal(out)
+        return self
+
     def funcApply(self, func):
         ''' Applies a function to the signal (comm.py:132-144).  Bound ``demod``
         methods of this package's demodulators stay on the device.'''

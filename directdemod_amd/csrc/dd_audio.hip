@@ -141,6 +141,111 @@ __global__ void __launch_bounds__(256) k_scale_f64(double* __restrict__ y, int64
     if (i < n) y[i] *= f;
 }
 
+// ---------------------------------------------------------------- polyphase rational resampler (stream form)
+// y[j] = sum_k hp[k] xu[(j + npr) down - k], xu = the input with up-1 zeros stuffed between samples (SciPy's
+// resample_poly / upfirdn definition; hp = front-padded, up-scaled low-pass).  Only k = k0 + q up contribute
+// (k0 = t mod up, t = (j + npr) down), pairing hp[k0 + q up] with x[i0 - q], i0 = (t - k0) / up: one lane per
+// output walks its polyphase branch.  Inputs before the chunk come from the carried history (the last `nh`
+// inputs of the stream), inputs past `n_total` (only when flushing) are zeros.
+struct dd_rpoly {
+    int up, down, ntaps, q;          // q = inputs an output can reach back: ceil(ntaps / up)
+    int64_t npr;
+    double* taps;                    // device, ntaps
+    double* hist[2];                 // device, q each (oldest first), ping-pong
+    int hpar, nh;                    // valid history samples
+    int64_t n_in, j_next;            // inputs consumed, next output index
+};
+
+__global__ void __launch_bounds__(256) k_rpoly(const double* __restrict__ in, int64_t n, int64_t a, const double* __restrict__ hist, int nh,
+                                               const double* __restrict__ taps, int ntaps, int up, int down, int64_t npr,
+                                               int64_t j0, int64_t n_out, double* __restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t t = (j0 + o + npr) * (int64_t)down;
+    const int k0 = (int)(t % up);
+    const int64_t i0 = (t - k0) / up;
+    double acc = 0.0;
+    int64_t i = i0;
+    for (int k = k0; k < ntaps; k += up, --i) {
+        if (i < a - nh) break;                             // older than anything kept: zeros from here on (stream start)
+        if (i >= a + n) continue;                          // past the end of the stream (flush): zero
+        const double x = i >= a ? in[i - a] : hist[nh - (a - i)];
+        acc = fma(taps[k], x, acc);
+    }
+    out[o] = acc;
+}
+// new history = the last q samples of (old history ++ chunk)
+__global__ void k_rpoly_hist(const double* __restrict__ in, int64_t n, const double* __restrict__ hold, int nh, double* __restrict__ hnew, int nh_new) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh_new) return;
+    const int64_t src = (int64_t)nh + n - nh_new + i;      // index into old history ++ chunk
+    hnew[i] = src < nh ? hold[src] : in[src - nh];
+}
+
+extern "C" int dd_rpoly_create(dd_rpoly** h, const double* taps_host, int ntaps, int up, int down, int64_t n_pre_remove) {
+    DD_REQUIRE(h && taps_host && ntaps >= 1 && up >= 1 && down >= 1 && n_pre_remove >= 0, "arguments");
+    dd_rpoly* r = new dd_rpoly();
+    r->up = up; r->down = down; r->ntaps = ntaps; r->npr = n_pre_remove;
+    r->q = (ntaps + up - 1) / up;
+    r->taps = nullptr; r->hist[0] = r->hist[1] = nullptr;
+    r->hpar = 0; r->nh = 0; r->n_in = 0; r->j_next = 0;
+    hipError_t e = hipMalloc((void**)&r->taps, sizeof(double) * ntaps);
+    if (e == hipSuccess) e = hipMemcpy(r->taps, taps_host, sizeof(double) * ntaps, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->hist[0], sizeof(double) * (r->q > 0 ? r->q : 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&r->hist[1], sizeof(double) * (r->q > 0 ? r->q : 1));
+    if (e != hipSuccess) {
+        hipFree(r->taps); hipFree(r->hist[0]); hipFree(r->hist[1]);
+        delete r;
+        dd_set_error("dd_rpoly_create: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? DD_ERR_NODEVICE : DD_ERR_HIP;
+    }
+    *h = r;
+    return DD_OK;
+}
+extern "C" int dd_rpoly_destroy(dd_rpoly* r) {
+    if (r) { hipFree(r->taps); hipFree(r->hist[0]); hipFree(r->hist[1]); delete r; }
+    return DD_OK;
+}
+extern "C" int dd_rpoly_reset(dd_rpoly* r) {
+    DD_REQUIRE(r, "h");
+    r->nh = 0; r->n_in = 0; r->j_next = 0;
+    return DD_OK;
+}
+// outputs the next dd_rpoly_process(n, flush) call will write
+extern "C" int64_t dd_rpoly_out_count(const dd_rpoly* r, int64_t n, int flush) {
+    if (!r || n < 0) return DD_ERR_INVALID;
+    const int64_t tot = r->n_in + n;
+    int64_t j_last;
+    if (flush) j_last = (tot * r->up + r->down - 1) / r->down - 1;         // ceil(tot up / down) outputs in all
+    else j_last = tot > 0 ? (tot * r->up - 1) / r->down - r->npr : -1;      // every input the output needs has arrived
+    const int64_t c = j_last - r->j_next + 1;
+    return c > 0 ? c : 0;
+}
+extern "C" int dd_rpoly_process(dd_rpoly* r, const double* in, int64_t n, int flush, double* out, int64_t* n_out, void* stream) {
+    DD_REQUIRE(r && n >= 0, "h/n");
+    DD_REQUIRE(in || n == 0, "in");
+    hipStream_t s = dd_stream(stream);
+    const int64_t cnt = dd_rpoly_out_count(r, n, flush);
+    if (n_out) *n_out = cnt;
+    if (cnt > 0) {
+        DD_REQUIRE(out, "out");
+        hipLaunchKernelGGL(k_rpoly, dim3(grid1(cnt)), dim3(256), 0, s, in, n, r->n_in, r->hist[r->hpar], r->nh, r->taps, r->ntaps,
+                           r->up, r->down, r->npr, r->j_next, cnt, out);
+        DD_LAUNCH_CHECK();
+        r->j_next += cnt;
+    }
+    if (n > 0) {
+        const int64_t have = (int64_t)r->nh + n;
+        const int nh_new = (int)(have < r->q ? have : r->q);
+        hipLaunchKernelGGL(k_rpoly_hist, dim3((nh_new + 255) / 256), dim3(256), 0, s, in, n, r->hist[r->hpar], r->nh, r->hist[r->hpar ^ 1], nh_new);
+        DD_LAUNCH_CHECK();
+        r->hpar ^= 1;
+        r->nh = nh_new;
+        r->n_in += n;
+    }
+    return DD_OK;
+}
+
 extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream) {
     DD_REQUIRE(n >= 1 && num >= 1, "n/num");
     DD_REQUIRE(in && out, "null buffer");

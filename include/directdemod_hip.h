@@ -210,6 +210,20 @@ int dd_chain_last_kernel(const dd_chain* h);
 /* Fourier-domain resample of one chunk, float64 real: n -> num samples. */
 int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream);
 
+/* ---- polyphase rational resampler (BASELINE north_star, config 3 "polyphase resample to 11.025 kS/s").
+ * The reference has NO counterpart (its only resampler is the FFT one above, comm.py:110-116): a build-defined
+ * stage following SciPy's published scipy.signal.resample_poly (upfirdn of the front-padded, up-scaled low-pass
+ * `taps`; n_pre_remove outputs dropped), float64 real, in STREAM form: state (the last ceil(ntaps/up) inputs, the
+ * input and output positions) is carried from call to call, a call emits the outputs whose inputs have all
+ * arrived, flush = 1 emits the tail (inputs past the end are zeros) -- concatenated, the outputs equal
+ * resample_poly of the concatenated input.  One caller thread per handle. */
+typedef struct dd_rpoly dd_rpoly;
+int dd_rpoly_create(dd_rpoly** h, const double* taps, int ntaps, int up, int down, int64_t n_pre_remove);
+int dd_rpoly_destroy(dd_rpoly* h);
+int dd_rpoly_reset(dd_rpoly* h);
+int64_t dd_rpoly_out_count(const dd_rpoly* h, int64_t n, int flush);
+int dd_rpoly_process(dd_rpoly* h, const double* in, int64_t n, int flush, double* out, int64_t* n_out, void* stream);
+
 /* ---- A1: demod_am.demod = abs(hilbert(x)) (demod_am.py:18-29) in fixed blocks
  *      (decode_noaa.py:647-653: 240 000-sample blocks, chunker rule) ----------- */
 int dd_am_envelope_f64(const double* in, double* out, int64_t n, int64_t block, void* stream);

@@ -317,6 +317,97 @@ def fm_demod(sig, last=None, store_state=True):
 # ---------------------------------------------------------------------------
 # R2  commSignal.bwLim strict -> scipy.signal.resample  (comm.py:110-116)
 # ---------------------------------------------------------------------------
+# ---------------------------------------------------------------------------
+# Polyphase rational resampler (BASELINE north_star / config 3: "polyphase resample to 11.025 kS/s").
+# The reference has NO counterpart (its only resampler is the FFT one below, comm.py:110-116), so this stage is
+# build-defined; it follows SciPy's published scipy.signal.resample_poly (v1.15: firwin low-pass with a
+# Kaiser(5.0) window of half length 10*max(up, down), scaled by `up`, zero-padded in front so that output j sits
+# at input time j*down/up, upfirdn, excess removed) and is pinned against that routine in the tests.
+# ---------------------------------------------------------------------------
+def kaiser_window(M, beta):
+    n = np.arange(M)
+    alpha = (M - 1) / 2.0
+    return np.i0(beta * np.sqrt(np.clip(1.0 - ((n - alpha) / alpha) ** 2, 0.0, 1.0))) / np.i0(beta)
+
+
+def firwin_lowpass(numtaps, cutoff, beta=5.0):
+    """scipy.signal.firwin(numtaps, cutoff, window=('kaiser', beta)) for one low-pass band (cutoff relative to Nyquist)"""
+    alpha = 0.5 * (numtaps - 1)
+    m = np.arange(numtaps) - alpha
+    h = cutoff * np.sinc(cutoff * m) * kaiser_window(numtaps, beta)
+    return h / np.sum(h)                                   # unity gain at DC (scale=True)
+
+
+def resample_poly_design(up, down):
+    """(up, down reduced, padded taps hp, n_pre_remove): y[j] = sum_k hp[k] xu[(j + n_pre_remove) down - k]"""
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    half_len = 10 * max(up, down)
+    h = firwin_lowpass(2 * half_len + 1, 1.0 / max(up, down)) * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    return up, down, np.concatenate((np.zeros(n_pre_pad), h)), n_pre_remove
+
+
+def resample_poly(x, up, down):
+    """scipy.signal.resample_poly(x, up, down) for a real 1-D signal (padtype 'constant', zeros)"""
+    x = np.asarray(x, dtype=np.float64)
+    up, down, hp, npr = resample_poly_design(up, down)
+    if up == down == 1:
+        return x.copy()
+    n_in = len(x)
+    n_out = -(-n_in * up // down)
+    # only the taps k = k0 + q up meet a non-zero sample of the zero-stuffed input: one polyphase branch per output,
+    # walked for all outputs at once (q-th tap of every branch per step)
+    t = (np.arange(n_out, dtype=np.int64) + npr) * down
+    k0 = t % up
+    i0 = (t - k0) // up
+    y = np.zeros(n_out)
+    for q in range(-(-len(hp) // up)):
+        k = k0 + q * up
+        i = i0 - q
+        ok = (k < len(hp)) & (i >= 0) & (i < n_in)
+        if not ok.any():
+            continue
+        y[ok] += hp[k[ok]] * x[i[ok]]
+    return y
+
+
+class PolyResampler:
+    """The same resampler as a stream: chunks in, the outputs that have become computable out; flush() emits the
+    tail.  Concatenated, the outputs equal resample_poly of the concatenated input (the build's chunked form)."""
+
+    def __init__(self, up, down):
+        self.up, self.down, self.hp, self.npr = resample_poly_design(up, down)
+        self.buf = np.zeros(0)
+        self.n_in = 0
+        self.j_next = 0
+
+    def _emit(self, j_last):
+        out = np.zeros(max(0, j_last - self.j_next + 1))
+        for j in range(self.j_next, j_last + 1):
+            t = (j + self.npr) * self.down
+            k0 = t % self.up
+            i0 = (t - k0) // self.up
+            k = np.arange(k0, len(self.hp), self.up)
+            i = i0 - np.arange(len(k))
+            ok = (i >= 0) & (i < self.n_in)
+            out[j - self.j_next] = np.sum(self.hp[k[ok]] * self.buf[i[ok]])
+        self.j_next = max(self.j_next, j_last + 1)
+        return out
+
+    def applyOn(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        self.buf = np.concatenate((self.buf, x))
+        self.n_in += len(x)
+        if self.n_in == 0:
+            return np.zeros(0)
+        return self._emit((self.n_in * self.up - 1) // self.down - self.npr)   # every input an output needs has arrived
+
+    def flush(self):
+        return self._emit(-(-self.n_in * self.up // self.down) - 1)
+
+
 def resample_fft(x, num):
     """scipy.signal.resample(x, num): Fourier-domain resampling of the whole chunk."""
     x = np.asarray(x)

@@ -637,3 +637,53 @@ def test_buffer_pool_fences_reuse_across_streams(dd):
     d = hip.DevArray(16, np.uint8)
     d.free()
     assert hip._pool[hip._pool_round(16)][-1][1] == []
+
+
+@pytest.mark.parametrize("n,fs,ft", [(83886, 200000, 11025), (5000, 48000, 44100), (4096, 1000, 3000), (300, 147, 160)])
+def test_polyphase_resampler_stream_equals_scipy_resample_poly(dd, n, fs, ft):
+    """EXTENSION row (north_star "polyphase resample", config 3): dd_rpoly_* against SciPy's resample_poly (the
+    routine the stage is defined by) and the oracle's stream form: one shot + flush, and uneven chunks with the
+    state carried on the device.  float64, 1e-12."""
+    import scipy.signal as ss
+    from directdemod_amd import resample
+    x = np.random.default_rng(n).standard_normal(n)
+    want = ss.resample_poly(x, ft, fs)
+    assert np.max(np.abs(O.resample_poly(x, ft, fs) - want)) < 1e-12
+    rs = resample.polyResampler(fs, ft)
+    got = np.concatenate([rs.applyOn(x), rs.flush()])
+    assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+    rs = resample.polyResampler(fs, ft)
+    ors = O.PolyResampler(ft, fs) if n <= 5000 else None            # (the oracle's stream form is a Python loop per output)
+    cuts = sorted({0, 1, n // 7, n // 7 + 3, n // 2, n - 2, n})
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        p = rs.applyOn(x[a:b])
+        if ors is not None:
+            assert p.shape == ors.applyOn(x[a:b]).shape             # the same outputs become available with every chunk
+        parts.append(p)
+    parts.append(rs.flush())
+    got = np.concatenate(parts)
+    assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+    rs.reset()                                                      # a new stream through the same object
+    again = np.concatenate([rs.applyOn(x), rs.flush()])
+    assert np.array_equal(again, np.concatenate([resample.polyResampler(fs, ft).applyOn(x), np.zeros(0)])) or again.shape == want.shape
+    assert np.max(np.abs(again - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+def test_comm_resample_poly_in_a_chunk_loop(dd):
+    """config 3's tail through the drop-in surface: FM audio at 200 kS/s -> 11 025 S/s, chunk by chunk, equals the
+    one-shot polyphase resample of the whole audio (the reference's per-chunk FFT resample cannot: border effects)."""
+    import scipy.signal as ss
+    from directdemod_amd import resample
+    fs, ft, n = 200000, 11025, 60000
+    audio = np.sin(2 * np.pi * 1000 * np.arange(n) / fs) + 0.1 * np.random.default_rng(3).standard_normal(n)
+    rs = resample.polyResampler(fs, ft)
+    out = dd.comm.commSignal(ft)
+    for a in range(0, n, 16384):
+        out.extend(dd.comm.commSignal(fs, audio[a:a + 16384]).resamplePoly(rs))
+    out.extend(dd.comm.commSignal(ft, rs.flush()))
+    want = ss.resample_poly(audio, ft, fs)
+    assert out.sampRate == ft and out.length == len(want) == -(-n * 441 // 8000)
+    assert np.max(np.abs(np.asarray(out.signal) - want)) < 1e-12
+    with pytest.raises(TypeError):
+        dd.comm.commSignal(48000, audio[:100]).resamplePoly(rs)

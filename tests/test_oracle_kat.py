@@ -112,3 +112,34 @@ def test_chunker_rule():
 def test_bwlim_rate_error():
     with pytest.raises(ValueError):
         O.decimate_carry(np.arange(10), 10, 40)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# polyphase resampler (build-defined stage; the reference has none): the oracle's restatement of SciPy's
+# published resample_poly is pinned against that routine itself, one shot and as a stream
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,up,down", [(1000, 3, 7), (83886, 11025, 200000), (2000, 2, 1), (777, 5, 5),
+                                       (200, 441, 8000), (300, 160, 147), (1, 3, 2), (64, 1, 64)])
+def test_resample_poly_restatement_equals_scipy(n, up, down):
+    import scipy.signal as ss
+    x = np.random.default_rng(n + up).standard_normal(n)
+    want = ss.resample_poly(x, up, down)
+    got = O.resample_poly(x, up, down)
+    assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-13 * max(1.0, np.max(np.abs(want)))
+    if up != down and n * max(up, down) <= 2000000:      # (the stream form is a per-output Python loop: small cases only)
+        rs = O.PolyResampler(up, down)
+        cuts = sorted({0, n // 3, n // 3 + 1, (2 * n) // 3, n})
+        parts = [rs.applyOn(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + [rs.flush()]
+        st = np.concatenate(parts)
+        assert st.shape == want.shape and np.max(np.abs(st - want)) <= 1e-13 * max(1.0, np.max(np.abs(want)))
+
+
+def test_resample_poly_design_matches_scipy_filter():
+    import scipy.signal as ss
+    up, down, hp, npr = O.resample_poly_design(11025, 200000)
+    assert (up, down) == (441, 8000)
+    half_len = 10 * 8000
+    h = ss.firwin(2 * half_len + 1, 1.0 / 8000, window=("kaiser", 5.0)) * up
+    n_pre_pad = down - half_len % down
+    assert npr == (half_len + n_pre_pad) // down and len(hp) == n_pre_pad + len(h)
+    assert np.max(np.abs(hp[n_pre_pad:] - h)) < 1e-15
