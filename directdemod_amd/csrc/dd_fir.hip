@@ -306,8 +306,12 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 // block length: 256 samples, or 1024 from 2^25 samples up (measured on 2^24 / 2^26 complex128 samples: 256 ->
 // 0.42 / 1.50 ms, 1024 -> 0.92 / 1.37 ms: short blocks keep the block kernels wide, long blocks give each
 // block longer contiguous runs)
+#ifndef IIR_LB_SHORT
 #define IIR_LB_SHORT 256
+#endif
+#ifndef IIR_LB_LONG
 #define IIR_LB_LONG 1024
+#endif
 #define IIR_LONG_FROM ((int64_t)1 << 25)
 #define IIR_G1 64
 #define IIR_G2 64
@@ -476,6 +480,103 @@ __global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__
         if (live) {
 #pragma unroll
             for (int k = 0; k < S; ++k) blk[(b * ncomp + c) * IIR_S + k] = z[k];
+        }
+    } else if (save && live && b == nb - 1) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) state[c * IIR_S + k] = z[k];
+    }
+}
+
+// The block passes for complex128 input as ONE WAVE per workgroup, its samples brought in by LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes = 1 KiB per instruction, no registers).
+// Why: the passes are bound by the bytes a CU keeps in flight, not by the access pattern (longer contiguous pieces
+// and non-power-of-two block strides changed nothing): k_iir_blocks_t holds one 32 KB step per 70 KB workgroup in
+// flight = 64 KB per CU, and at the ~4 us a request takes under load that is 3.3-3.5 TB/s -- what it measures.
+// LDS-DMA needs no staging registers, so the whole LDS is the prefetch queue: a wave owns 32 blocks (lane = block,
+// re/im), a step is 32 samples = 512 contiguous bytes from each block (one DMA instruction per PAIR of blocks), and
+// a ring of IIR_W_NB step buffers (3 x 16.6 KB, three waves per CU) keeps two steps per wave = 96 KB per CU on
+// the wire while the third is computed.  The lane walks its row exactly as before (same float64 recurrence per
+// sample); outputs overwrite the inputs in LDS and leave as 16-byte stores.  One wave: no barriers, only counted
+// waits (loads, DMAs and stores retire in order on vmcnt).
+#define IIR_W_BLOCKS 32
+#define IIR_W_CH 32
+#define IIR_W_NB 3
+#define IIR_W_PAIR (2 * IIR_W_CH * 16 + 16)              // two 512-byte rows, then 16 bytes of padding
+#define IIR_W_BUF ((IIR_W_BLOCKS / 2) * IIR_W_PAIR)
+template <int S, bool WRITE>
+__global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__ in, double2* __restrict__ out, int64_t n, DDIirCoef C,
+                                                     double* __restrict__ blk, int64_t nb, double* __restrict__ state, int save, int lb) {
+    extern __shared__ __attribute__((aligned(16))) char iir_w_lds[];
+    const int lane = threadIdx.x, bl = lane >> 1, c = lane & 1;
+    const int64_t b0 = (int64_t)blockIdx.x * IIR_W_BLOCKS, b = b0 + bl;
+    const bool live = b < nb;
+    double z[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * 2 + c) * IIR_S + k] : 0.0;
+    const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;            // samples of this chain's block
+    const int nsteps = lb / IIR_W_CH;
+    // sample this lane moves in a DMA / a store of pair r: lanes 0..31 the first block of the pair, 32..63 the second
+    const int half = lane >> 5, l32 = lane & 31;
+    auto issue = [&](int step) {
+        char* buf = iir_w_lds + (step % IIR_W_NB) * IIR_W_BUF;
+#pragma unroll
+        for (int r = 0; r < IIR_W_BLOCKS / 2; ++r) {
+            int64_t idx = (b0 + 2 * r + half) * lb + (int64_t)step * IIR_W_CH + l32;
+            idx = idx < n ? idx : n - 1;                                                  // past the end: re-read, never consumed
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + idx),
+                                             (__attribute__((address_space(3))) void*)(buf + r * IIR_W_PAIR), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < IIR_W_NB - 1; ++k)
+        if (k < nsteps) issue(k);
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + IIR_W_NB - 1 < nsteps) issue(st + IIR_W_NB - 1);
+        // step st must have landed.  Younger than its DMAs: the DMA batches of the steps after it and (write pass) the
+        // store batches of the iterations since -- 16 instructions each
+        const int ahead = nsteps - 1 - st < IIR_W_NB - 1 ? nsteps - 1 - st : IIR_W_NB - 1;       // DMA batches in flight behind step st
+        if (WRITE) {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");             // 2 x 16 DMAs + 2 x 16 stores = 64: one more than the counter holds
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        char* cur = iir_w_lds + (st % IIR_W_NB) * IIR_W_BUF;
+        double* mine = reinterpret_cast<double*>(cur + (bl >> 1) * IIR_W_PAIR + (bl & 1) * (IIR_W_CH * 16)) + c;
+        const int left = ilen - st * IIR_W_CH;
+#pragma unroll 1
+        for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = mine[2 * (u0 + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u0 + u < left) {
+                    const double y = dd_iir_step_t<S>(C, z, x[u]);
+                    if (WRITE) mine[2 * (u0 + u)] = y;
+                }
+            }
+        }
+        if (WRITE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // the rows hold the outputs
+#pragma unroll
+            for (int r = 0; r < IIR_W_BLOCKS / 2; ++r) {
+                const int64_t bb = b0 + 2 * r + half;
+                const int64_t pos = (int64_t)st * IIR_W_CH + l32;
+                const int64_t idx = bb * lb + pos;
+                const double2 v = *reinterpret_cast<const double2*>(cur + r * IIR_W_PAIR + lane * 16);
+                if (bb < nb && idx < n) out[idx] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // rows read before a later DMA overwrites them
+        }
+    }
+    if (!WRITE) {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) blk[(b * 2 + c) * IIR_S + k] = z[k];
         }
     } else if (save && live && b == nb - 1) {
 #pragma unroll
@@ -664,7 +765,31 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         DD_IIR_BLOCKS(13, WR, SAVE) DD_IIR_BLOCKS(14, WR, SAVE) DD_IIR_BLOCKS(15, WR, SAVE)                           \
         default: break;                                                                                              \
     }
-    if (staged) { DD_IIR_BLOCKS_ALL(false, 0) }
+    // complex128 input: the one-wave LDS-DMA form (DD_IIR_WAVE=0 keeps the 256-thread staged kernels: A/B switch)
+    static const bool wave_env = !(getenv("DD_IIR_WAVE") && atoi(getenv("DD_IIR_WAVE")) == 0);
+    const bool wave = staged && ncomp == 2 && wave_env && (lb % IIR_W_CH) == 0;
+    const unsigned gbw = (unsigned)((nb + IIR_W_BLOCKS - 1) / IIR_W_BLOCKS);
+    const size_t lds_w = (size_t)IIR_W_NB * IIR_W_BUF;
+#define DD_IIR_BLOCKS_W(SS, WR, SAVE)                                                                                \
+    case SS: {                                                                                                       \
+        static DDOncePerDevice attr_w;                                                                               \
+        if (attr_w.need()) {                                                                                         \
+            hipFuncSetAttribute((const void*)k_iir_blocks_w<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
+            attr_w.mark();                                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_iir_blocks_w<SS, WR>), dim3(gbw), dim3(64), lds_w, s, reinterpret_cast<const double2*>(in), \
+                           reinterpret_cast<double2*>(out), n, C, blk, nb, h->state, SAVE, lb);                      \
+    } break;
+#define DD_IIR_BLOCKS_W_ALL(WR, SAVE)                                                                                \
+    switch (S) {                                                                                                     \
+        DD_IIR_BLOCKS_W(1, WR, SAVE) DD_IIR_BLOCKS_W(2, WR, SAVE) DD_IIR_BLOCKS_W(3, WR, SAVE) DD_IIR_BLOCKS_W(4, WR, SAVE)   \
+        DD_IIR_BLOCKS_W(5, WR, SAVE) DD_IIR_BLOCKS_W(6, WR, SAVE) DD_IIR_BLOCKS_W(7, WR, SAVE) DD_IIR_BLOCKS_W(8, WR, SAVE)   \
+        DD_IIR_BLOCKS_W(9, WR, SAVE) DD_IIR_BLOCKS_W(10, WR, SAVE) DD_IIR_BLOCKS_W(11, WR, SAVE) DD_IIR_BLOCKS_W(12, WR, SAVE) \
+        DD_IIR_BLOCKS_W(13, WR, SAVE) DD_IIR_BLOCKS_W(14, WR, SAVE) DD_IIR_BLOCKS_W(15, WR, SAVE)                           \
+        default: break;                                                                                              \
+    }
+    if (wave) { DD_IIR_BLOCKS_W_ALL(false, 0) }
+    else if (staged) { DD_IIR_BLOCKS_ALL(false, 0) }
     else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
     // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
     // double-double loops kept all 15 x 15 predicated products (~4 us per block step)
@@ -689,8 +814,11 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         default: break;
     }
 #undef DD_IIR_SCAN
-    if (staged) { DD_IIR_BLOCKS_ALL(true, carry ? 1 : 0) }
+    if (wave) { DD_IIR_BLOCKS_W_ALL(true, carry ? 1 : 0) }
+    else if (staged) { DD_IIR_BLOCKS_ALL(true, carry ? 1 : 0) }
     else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
+#undef DD_IIR_BLOCKS_W_ALL
+#undef DD_IIR_BLOCKS_W
 #undef DD_IIR_BLOCKS_ALL
 #undef DD_IIR_BLOCKS
     DD_LAUNCH_CHECK();

@@ -5,6 +5,6 @@ for f in build/variants/lib_*.so; do
   cp $f directdemod_amd/libdirectdemod_hip.so
   echo "== $f"
   [ -z "$NO_PARITY" ] && python -m pytest tests/test_gpu_audio.py -m gpu -x -q -k "iir or butter" 2>&1 | tail -1
-  for k in 1 2; do python tools/bench_iir.py 2>/dev/null | tail -1; done
+  for k in 1 2; do python tools/bench_iir.py 2>/dev/null | tail -2 | cut -c30-100 | tr "\n" "|"; echo; done
 done
 cp /tmp/lib_orig.so directdemod_amd/libdirectdemod_hip.so
