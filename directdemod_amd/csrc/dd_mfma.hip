@@ -529,6 +529,21 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
         // hand-written 3.5-instruction form built on v_fma_mix with an f16 SOURCE operand made
         // the matrix waves' MFMAs on the same SIMD run at 50 cycles each instead of 35 -- like
         // packed f32 ops, that form does not coexist with the matrix pipe)
+#ifndef DD_WS_MIX_SPLIT
+        {   // the 12-instruction plain split of k_chain_mfma_ab (dd_ab_split2); round 2 A/B: FM 0.2361 -> 0.2356 ms, complex output
+            // 0.2866 -> 0.2767 ms (the compiler's form below, with six v_fma_mix* per sample pair, stays selectable: -DDD_WS_MIX_SPLIT)
+            float t0, t1, t2, t3;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(rh) : "v"(xa.x), "v"(xb.x));
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ih) : "v"(xa.y), "v"(xb.y));
+            asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(t0) : "v"(rh));
+            asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(t1) : "v"(rh));
+            asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(t2) : "v"(ih));
+            asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(t3) : "v"(ih));
+            t0 = xa.x - t0; t1 = xb.x - t1; t2 = xa.y - t2; t3 = xb.y - t3;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(rl) : "v"(t0), "v"(t1));
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(il) : "v"(t2), "v"(t3));
+        }
+#else
         {
             v2h rh_, rl_, ih_, il_;
             rh_.x = (_Float16)xa.x; rh_.y = (_Float16)xb.x;
@@ -538,6 +553,7 @@ __device__ __forceinline__ void dd_ws_convert(const float4 (&raw)[WsGeom<NKS>::N
             rh = __builtin_bit_cast(uint32_t, rh_); rl = __builtin_bit_cast(uint32_t, rl_);
             ih = __builtin_bit_cast(uint32_t, ih_); il = __builtin_bit_cast(uint32_t, il_);
         }
+#endif
         const int off = 2 * e + 16 * (e >> 5);
         *reinterpret_cast<uint32_t*>(planes + off) = rh;
         *reinterpret_cast<uint32_t*>(planes + G::PLANE + off) = rl;

@@ -67,7 +67,8 @@ def run():
     h = chain()
     one = torch.empty(n, dtype=torch.float32, device=dev)
     assert process(h, x.data_ptr(), one.data_ptr(), n) == n - 1          # quirk Q3: first chunk is one short
-    assert lib.dd_chain_path(h) == 1                                     # the MFMA path ran
+    assert lib.dd_chain_path(h) == 1                                     # the MFMA path ran ...
+    assert lib.dd_chain_last_kernel(h) == _hip.DD_KERNEL_MFMA_AB         # ... as the headline kernel (k_chain_mfma_ab)
     lib.dd_chain_destroy(h)
     torch.cuda.synchronize()
 

@@ -473,7 +473,7 @@ def test_k_shards_on_one_gpu_equal_one_shot(dd):
 
 
 # ----------------------------------------------------------------------------- dynamic range of the MFMA path
-@pytest.mark.parametrize("profile", ["tiny", "huge", "mixed_tiles", "one_spike", "zeros_then_signal"])
+@pytest.mark.parametrize("profile", ["tiny", "huge", "mixed_tiles", "one_spike", "halo_spike", "zeros_then_signal"])
 def test_mfma_tile_scaling_paths(dd, profile):
     """The f16-limb tiles are used unscaled while their peak lies in [0.25, 32768) and with a
     per-tile power-of-two scale otherwise; the decision is taken per wave with two ballots and
@@ -493,6 +493,10 @@ def test_mfma_tile_scaling_paths(dd, profile):
         env[50000:58000] = 5e4                  # whole tiles above it
     elif profile == "one_spike":
         env[41234] = 1e4                        # one sample (one wave of one tile) leaves the range
+    elif profile == "halo_spike":
+        # a sample above the unit range that tile 5 sees only in its 256-sample halo (its span starts at
+        # 5 * 4064 - 288): in k_chain_mfma_ab the halo step's range check is the matrix wave's (a ninth slot)
+        env[5 * 4064 - 288 + 70] = 3e3
     elif profile == "zeros_then_signal":
         env[:30000] = 0.0
     x = (x * env).astype(np.complex64)
@@ -650,6 +654,10 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         no = lib.dd_chain_out_count(h, n)
         o = hip.DevArray(no, np.float32 if fm else np.complex64)
         hip.check(lib.dd_chain_process(h, d.ptr + 2 * pos, o.ptr, n, None, None))
+        # first chunk (4-byte aligned bytes): FM output runs the two-matrix-set kernel's u8 flavour, complex output the
+        # y-buffer kernel's; the second chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
+        want = (hip.DD_KERNEL_MFMA_AB if fm else hip.DD_KERNEL_MFMA_WS) if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
+        assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
     assert lib.dd_chain_path(h) == 1
