@@ -319,20 +319,30 @@ def side_configs(eng, steps=10):
                           "dd_chain_process")
                 o += got.value
             return o
-        for _ in range(3):
-            n_out = one_pass()
-        eng.sync()
-        e0, e1 = eng.events()
-        e0.record()
-        for _ in range(steps):
-            one_pass()
-        e1.record()
-        eng.sync()
-        ms = e0.elapsed_time(e1) / steps
+        def timed(fn):
+            for _ in range(3):
+                r = fn()
+            eng.sync()
+            e0, e1 = eng.events()
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            eng.sync()
+            return e0.elapsed_time(e1) / steps, r
+        ms, n_out = timed(one_pass)
+        # the same 2^26 samples as ONE chunk (one launch): what the kernel does without the chunk loop's launch seams
+        chunked_bounds = bounds
+        bounds = [(0, n)]
+        ms1, n_out1 = timed(one_pass)
+        bounds = chunked_bounds
+        assert n_out1 == n_out
         bps = 8.0 + 4.0 / M
         res.append({"config": name, "launches_per_pass": len(bounds), "ms_per_pass": round(ms, 4), "outputs": n_out,
                     "GS_per_s": round(n / ms / 1e6, 1), "bytes_per_sample": round(bps, 3),
-                    "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
+                    "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4),
+                    "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),
+                                  "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4)}})
         lib.dd_chain_destroy(h)
     return res
 

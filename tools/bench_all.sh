@@ -10,5 +10,6 @@ mkdir -p gpurun_out
   echo "== tools/bench_iir.py";                 timeout 600 python tools/bench_iir.py 2>/dev/null | tail -3
   echo "== tools/bench_noaa.py 120";            timeout 600 python tools/bench_noaa.py 120 --stages 2>/dev/null | tail -8
   echo "== tools/bench_feeder.py";              timeout 600 python tools/bench_feeder.py 2>/dev/null | tail -5
+  echo "== tools/ubench/bin/valu_beside_mfma";  [ -x tools/ubench/bin/valu_beside_mfma ] && ./tools/ubench/bin/valu_beside_mfma 2>/dev/null | tail -42
 } > gpurun_out/bench_all.txt 2>&1
 cat gpurun_out/bench_all.txt
