@@ -466,7 +466,6 @@ __device__ __forceinline__ void dd_ab_halo_convert(const DDChainParams& P, char*
 
 template <int NKS, int SET, bool U8>
 __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
-    using G = MfmaGeom<NKS>;
     using A = AbGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63, mw = (tid >> 6) & 3;
     const int n = t_end - t_begin;
