@@ -261,37 +261,51 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
             const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
             const bool need_tail = ns < 0;                             // block uniform
             const int K1 = K - 1;
-            for (int e0 = t; e0 < S; e0 += 8 * DD_DECIM_THREADS) {
-                float2 x[8], h[8];
+            // the whole span in ONE round of loads (up to 24 per lane): an edge tile is on the critical path of every
+            // launch -- each chunk has a first and a last one -- and in three rounds of eight its three memory round
+            // trips were most of the ~9 us a launch costs before its first byte of payload
+            constexpr int NB = DD_DECIM_SPAN_MAX / DD_DECIM_THREADS;   // 24
+            constexpr int NT = 2;                                      // rounds whose samples may lie in the carried history (K - 1 <= 512)
+            float2 x[NB], h[NT];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t n = ns + e0 + u * DD_DECIM_THREADS;
-                    const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
-                    if (u8) {
-                        const uchar2 q = reinterpret_cast<const uchar2*>(P.in)[nc];
-                        x[u] = make_float2((float)q.x - 127.5f, (float)q.y - 127.5f);
-                    } else {
-                        x[u] = reinterpret_cast<const float2*>(P.in)[nc];
-                    }
-                    h[u] = make_float2(0.f, 0.f);
-                    if (need_tail) {
-                        const int64_t ti = n + K1;
-                        h[u] = P.tail_in[ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti)];
-                    }
+            for (int u = 0; u < NB; ++u) {
+                const int64_t n = ns + t + u * DD_DECIM_THREADS;
+                const int64_t nc = n < 0 ? 0 : (n >= P.L ? P.L - 1 : n);
+                if (u8) {
+                    const uchar2 q = reinterpret_cast<const uchar2*>(P.in)[nc];
+                    x[u] = make_float2((float)q.x - 127.5f, (float)q.y - 127.5f);
+                } else {
+                    x[u] = reinterpret_cast<const float2*>(P.in)[nc];
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * DD_DECIM_THREADS;
-                    if (e < S) {
-                        const int64_t n = ns + e;
-                        float2 v = x[u];
-                        if (P.flags & DD_CHAIN_NCO) v = dd_cmul(v, dd_cmul(w2[e >> 6], w1));
-                        // history samples are already rotated; before the history and past the chunk: zeros
-                        if (n < 0) v = (n + K1 >= 0) ? h[u] : make_float2(0.f, 0.f);
-                        if (n >= P.L) v = make_float2(0.f, 0.f);
-                        sx[e] = v;
-                    }
+            for (int u = 0; u < NT; ++u) {
+                h[u] = make_float2(0.f, 0.f);
+                if (need_tail) {
+                    const int64_t ti = ns + t + u * DD_DECIM_THREADS + K1;
+                    h[u] = P.tail_in[ti < 0 ? 0 : (ti >= K1 ? (K1 > 0 ? K1 - 1 : 0) : ti)];
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int e = t + u * DD_DECIM_THREADS;
+                if (e < S) {
+                    const int64_t n = ns + e;
+                    float2 v = x[u];
+                    if (P.flags & DD_CHAIN_NCO) v = dd_cmul(v, dd_cmul(w2[e >> 6], w1));
+                    // history samples are already rotated; before the history and past the chunk: zeros
+                    if (n < 0) {
+                        if (u < NT) v = (n + K1 >= 0) ? h[u] : make_float2(0.f, 0.f);
+                        else v = (n + K1 >= 0) ? P.tail_in[n + K1] : make_float2(0.f, 0.f);     // (filters longer than 513 taps)
+                    }
+                    if (n >= P.L) v = make_float2(0.f, 0.f);
+                    sx[e] = v;
+                }
+            }
+            for (int e = t + NB * DD_DECIM_THREADS; e < S; e += DD_DECIM_THREADS) {     // (spans beyond DD_DECIM_SPAN_MAX: long filters)
+                float2 ph = make_float2(1.f, 0.f);
+                if (P.flags & DD_CHAIN_NCO) ph = dd_cmul(w2[e >> 6], w1);
+                sx[e] = dd_load_sample(P, ns + e, ph);
             }
         }
     }
