@@ -356,6 +356,12 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DD_BENCH_ONE_DEVICE=1 (tests on a 1-GPU box): every rank computes on cuda:0 and the ranks talk over gloo -- the real
+    # engine, the halo lead-in of ranks > 0, the barriers and the gather are exercised by N processes sharing one GPU.
+    # Its line is marked `data: "synthetic (ranks share one GPU)"`; it is a functional check, not a scaling measurement.
+    one_device = bool(os.environ.get("DD_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     if args.simulate_rank is not None:
         rank = args.simulate_rank
     if not stub:
@@ -365,8 +371,9 @@ def run_rank(args):
         os.environ.setdefault("MASTER_PORT", "29511")
     eng = (StubStep if stub else HipStep)(args, rank, local_rank)
     device = eng.device
+    cdev = torch.device("cpu") if one_device else device       # where the small reduction tensors live
     if world > 1:
-        if stub:
+        if stub or one_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -422,7 +429,7 @@ def run_rank(args):
     barrier()
     long_ms = l0.elapsed_time(l1) / long_steps
 
-    tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms], dtype=torch.float64, device=cdev)
     per_rank = None
     if world > 1:
         allk = [torch.zeros_like(tmax) for _ in range(world)]
@@ -435,6 +442,8 @@ def run_rank(args):
     if args.gather and world > 1:
         from directdemod_amd import shard
         shard_out, cnt = eng.shard_output()                 # this rank's outputs (a view) and how many are valid
+        if one_device:
+            shard_out = shard_out.cpu()                     # gloo leg of the one-device functional check
         parts = shard.gather_outputs(shard_out, cnt, world, dist)      # variable counts: checks the assembled stream length
         total_out = sum(int(p.numel()) for p in parts)
         assert total_out == world * n - 1, (total_out, world * n - 1)
@@ -449,7 +458,7 @@ def run_rank(args):
             dist.all_gather(bufs, shard_out)
         barrier()
         dtg = time.perf_counter() - t0
-        tg = torch.tensor([dtg], dtype=torch.float64, device=device)
+        tg = torch.tensor([dtg], dtype=torch.float64, device=cdev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         extra["with_all_gather_MSamples_per_s"] = round(world * n * args.steps / float(tg[0]) / 1e6, 1)
         extra["all_gather_ms_per_step"] = round(float(tg[0]) / args.steps * 1e3, 4)
@@ -497,7 +506,7 @@ def run_rank(args):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "stub" if stub else "synthetic",
+            "data": "stub" if stub else ("synthetic (ranks share one GPU)" if one_device else "synthetic"),
             "config": {"workload": "C2: 2.4 MS/s complex64 IQ (u8 grid, FM tone + noise), offsetFreq 25 kHz NCO + "
                                    "255-tap Hamming FIR + FM demod, single chunk, 2^%d samples per GPU, device resident"
                                    % args.log2n,
