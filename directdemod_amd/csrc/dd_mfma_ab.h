@@ -434,11 +434,29 @@ __device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* t
     v8h f[3][6];
     DD_WS_LOADF(0, 0)
     DD_WS_LOADF(1, 1)
+#ifdef DD_AB_GROUPED_READS
+    // the six fragment reads of k-step ks+2 issued together in front of the six MFMAs of k-step ks, waits left to
+    // the compiler (tools/ubench/mfma_lds_stream.hip: 32.3 cycles per MFMA alone on the CU, against 33.6 for one
+    // pinned read per MFMA gap)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int b = ks % 3;
+        if (ks + 2 < NKS) { DD_WS_LOADF((ks + 2) % 3, ks + 2) }
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][0], f[b][4], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][2], f[b][4], cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][1], f[b][4], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][3], f[b][4], cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][0], f[b][5], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][2], f[b][5], cim, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < NKS - 1; ++ks) {
         DD_WS_STEP(ks % 3, (ks + 2) % 3, (ks + 2 < NKS ? ks + 2 : ks), (ks + 2 < NKS))
     }
     DD_WS_STEP((NKS - 1) % 3, (NKS + 1) % 3, NKS - 1, false)
+#endif
 }
 
 // the halo step (quads 0..63 of a tile) on the matrix wave of strip 0, set SET: conversion in the set's discriminator
