@@ -244,6 +244,11 @@ class HipStep:
     def path(self):
         return {0: "direct-f32", 1: "mfma-f16x3"}.get(self.lib.dd_chain_path(self.h), str(self.lib.dd_chain_path(self.h)))
 
+    def kernel(self):
+        """the kernel the last step launched (one launch per step)"""
+        return {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
+                6: "k_chain_mfma_ab"}.get(self.lib.dd_chain_last_kernel(self.h), "?")
+
     def close(self):
         self.lib.dd_chain_destroy(self.h)
 
@@ -282,6 +287,9 @@ class StubStep:
         return self.out[self.first:self.first + self.n], self.n - (1 if self.rank == 0 else 0)
 
     def path(self):
+        return "stub"
+
+    def kernel(self):
         return "stub"
 
     def close(self):
@@ -511,7 +519,7 @@ def run_rank(args):
                                    "255-tap Hamming FIR + FM demod, single chunk, 2^%d samples per GPU, device resident"
                                    % args.log2n,
                        "samples_per_gpu": n, "ntaps": NTAPS, "decimation": 1,
-                       "kernel_path": eng.path(),
+                       "kernel_path": eng.path(), "kernel": eng.kernel(),
                        "sharding": "contiguous sample ranges, absolute-index state, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
