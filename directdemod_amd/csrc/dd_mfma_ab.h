@@ -226,7 +226,8 @@ template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem, int t_begin, int n, int p,
                                              AbRaw (&rcur)[AB_VSTEPS], AbRaw (&rnext)[AB_VSTEPS], AbRaw (&rld)[AB_VSTEPS],
                                              const float2 (&wk)[AB_VSTEPS][4],
-                                             int vt, int vw, int lane, bool stamp, unsigned long long (&acc_t)[8]) {
+                                             int vt, int vw, int lane, bool stamp, unsigned long long (&acc_t)[8],
+                                             AbRaw& xraw, const float2 (&wkx)[4]) {
     using A = AbGeom<NKS>;
     using Q = AbQ<NKS>;
     unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
@@ -256,12 +257,24 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
         const float scale = dd_ab_tile_scale(smem, A::RED_OFF, nu_flag, p, unit);
         if (vt == 0) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[(p + 2) & 3] = 0;   // re-arm the slot tile p+2's producers raise in phase p+1
         char* planes = smem + (p & 1) * A::PLANES_BYTES;
+#ifdef AB_HALO_ON_VECTOR
+        // the halo step (quads 0..XQUADS-1) on the oldest vector wave: with the vector waves at a raised priority they
+        // finish long before the matrix waves, and the wave-step that does not divide among eight waves costs nothing
+        if (vw == 0 && (Q::XQUADS == 64 || lane < Q::XQUADS)) {
+            if (unit) dd_ab_convert_quad<NKS, true>(xraw, planes, lane, wkx, scale);
+            else dd_ab_convert_quad<NKS, false>(xraw, planes, lane, wkx, scale);
+        }
+#endif
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) {
             if (unit) dd_ab_convert_quad<NKS, true>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
             else dd_ab_convert_quad<NKS, false>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
         }
     }
+#endif
+#if defined(AB_HALO_ON_VECTOR) && !defined(DD_AB_NO_LOAD)
+    if (vw == 0)                                            // the next tile's halo (one phase ahead: used at the end of this phase and in the next)
+        xraw = dd_ab_load_quad<NKS, U8>(P, t_begin + (p + 1 < n ? p + 1 : n - 1), lane < Q::XQUADS ? lane : Q::XQUADS - 1);
 #endif
     DD_AB_STAMP(1)
 #ifndef DD_AB_NO_EPI
@@ -280,6 +293,9 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
         float m = 0.f;
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(rnext[st], m);
+#ifdef AB_HALO_ON_VECTOR
+        if (vw == 0) m = dd_ab_absmax(xraw, m);             // tile p+1's halo, requested above
+#endif
         dd_ab_publish_range(m, smem, A::RED_OFF, A::NONUNIT_OFF, p + 1, vw, lane);
     }
     DD_AB_STAMP(2)
@@ -309,10 +325,27 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
             wk[st][k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)pos * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
         }
     }
+    AbRaw xraw;
+    float2 wkx[4];
+    xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wkx[k] = make_float2(1.f, 0.f);
+#ifdef AB_HALO_ON_VECTOR
+    if (vw == 0) {
+        xraw = dd_ab_load_quad<NKS, U8>(P, t_begin, lane < Q::XQUADS ? lane : Q::XQUADS - 1);
+        if (P.flags & DD_CHAIN_NCO) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wkx[k] = dd_phasor((uint64_t)(4 * lane + k) * P.cyc, P.nco_tbl);
+        }
+    }
+#endif
     {   // range of tile 0 (what phase p-1 does for tile p); its non-unit flag is preset: the true maximum is read
         float m = 0.f;
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(r0[st], m);
+#ifdef AB_HALO_ON_VECTOR
+        if (vw == 0) m = dd_ab_absmax(xraw, m);
+#endif
         m = dd_wave_max(m);
         if (lane == 63) reinterpret_cast<float*>(smem + A::RED_OFF)[vw] = m;
     }
@@ -321,9 +354,9 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
     const bool stamp = taps.stamps != nullptr;
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 6
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, stamp, acc_t);
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, stamp, acc_t);
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, stamp, acc_t);
+        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
+        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
+        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
     }
     if (stamp && lane == 0) {
         for (int q = 0; q < 4; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -499,7 +532,11 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     const int lg = lane >> 4;
     const float2* xrd = lg == 0 ? x0 : (lg == 1 ? xa : (lg == 2 ? x1 : xb));
     // halo step: set 1 owns the even tiles' (its discriminator phases are the even ones), set 0 the odd tiles'
+#ifdef AB_HALO_ON_VECTOR
+    const bool halo = false;                                // the oldest vector wave takes the halo step (see dd_ab_vphase)
+#else
     const bool halo = mw == 0;
+#endif
     AbRaw xraw;
     float2 wkx[4];
     xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
