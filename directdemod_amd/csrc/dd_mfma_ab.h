@@ -102,8 +102,24 @@ __device__ __forceinline__ AbRaw dd_ab_load_quad(const DDChainParams& P, int b, 
         return r;
     }
     const char* base = reinterpret_cast<const char*>(reinterpret_cast<const float2*>(P.in) + ns);   // wave-uniform
+#ifndef DD_AB_NO_SADDR
+    // told to the compiler in so many words (both halves through readfirstlane, and back into the GLOBAL address space:
+    // a pointer rebuilt from an integer is a generic pointer, its loads are flat loads and a flat load's wait is
+    // vmcnt(0)): the loads then take the tile's base from scalar registers and a 32-bit lane offset -- no 64-bit
+    // vector address arithmetic per tile and step
+    typedef const __attribute__((address_space(1))) char* gptr_t;
+    const uint64_t bu = reinterpret_cast<uint64_t>(base);
+    const gptr_t gb = (gptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bu >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bu));
+    typedef float ab_v4f __attribute__((ext_vector_type(4)));
+    const ab_v4f va = *(const __attribute__((address_space(1))) ab_v4f*)(gb + 32u * (unsigned)q);
+    const ab_v4f vb = *(const __attribute__((address_space(1))) ab_v4f*)(gb + 32u * (unsigned)q + 16u);
+    r.a = make_float4(va.x, va.y, va.z, va.w);
+    r.b = make_float4(vb.x, vb.y, vb.z, vb.w);
+#else
     r.a = *reinterpret_cast<const float4*>(base + 32u * (unsigned)q);
     r.b = *reinterpret_cast<const float4*>(base + 32u * (unsigned)q + 16u);
+#endif
     return r;
 }
 
@@ -396,7 +412,9 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     //    min over the rows of (tan(22.5 deg) re - |im|) >= 0 in every lane (a NaN fails the test)
     float mn = fmaf(0.41421354f, re[0], -fabsf(im[0]));
 #pragma unroll
-    for (int r = 1; r < NR; ++r) mn = fminf(mn, fmaf(0.41421354f, re[r], -fabsf(im[r])));
+    for (int r = 1; r + 1 < NR; r += 2)                      // v_min3_f32: two rows per instruction
+        mn = fminf(fminf(mn, fmaf(0.41421354f, re[r], -fabsf(im[r]))), fmaf(0.41421354f, re[r + 1], -fabsf(im[r + 1])));
+    if ((NR & 1) == 0) mn = fminf(mn, fmaf(0.41421354f, re[NR - 1], -fabsf(im[NR - 1])));
     const bool all_small = __builtin_amdgcn_ballot_w64(!(mn >= 0.f)) == 0;
     float a[NR];
     if (all_small) {
@@ -450,11 +468,12 @@ __device__ __forceinline__ void dd_ab_publish(int lane, const v16f& cre, const v
         const int g = lane >> 4;
         float2* pa = g == 0 ? xaw : (g == 1 ? x0w + 1 : (g == 2 ? xbw : x1w + 1));     // (q & 3) != 3
         float2* pb = g == 0 ? xaw : (g == 1 ? x1w - 3 : (g == 2 ? xbw : x0w + 1));     // (q & 3) == 3
+        // (two 4-byte stores per entry: an 8-byte store wants re and im in adjacent registers, 32 v_mov per strip)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float2 v = make_float2(cre[q], cim[q]);
-            if ((q & 3) != 3) pa[q] = v;
-            else pb[q] = v;
+            float* d = reinterpret_cast<float*>(((q & 3) != 3 ? pa : pb) + q);
+            d[0] = cre[q];
+            d[1] = cim[q];
         }
     }
 }
