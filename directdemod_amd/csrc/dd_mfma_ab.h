@@ -463,7 +463,17 @@ __device__ __forceinline__ void dd_ab_write_yhalf(int lane, const v16f& cre, con
 // (column 31): the next row of the strip starts in another register -- lane 31 of register q is followed by lane 0 of
 // register q + 1 ((q & 3) != 3) or lane 32 of register q - 3; lane 63 by lane 32 of register q + 1 or lane 0 of
 // register q + 1 (q = 15: lane 0, register 0 of the NEXT strip: the X0 tables of the four waves are contiguous).
-__device__ __forceinline__ void dd_ab_publish(int lane, const v16f& cre, const v16f& cim, float2* x0w, float2* xaw, float2* x1w, float2* xbw) {
+// Entry 0 of strip 0's X0 table has no producer (the output before the tile's first one belongs to the previous tile, and
+// so do the 32 outputs of that row, which are not stored): the wave writes its own output there, so that the row's
+// lane-0 product is |y|^2 (angle 0) and the wave-uniform small-angle test never sees what the LDS held before the launch.
+__device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre, const v16f& cim, float2* x0w, float2* xaw, float2* x1w, float2* xbw) {
+#ifndef DD_AB_NO_X0_SELF          // (-DDD_AB_NO_X0_SELF: the round-2 bug, for checking that tests/test_gpu_determinism.py catches it)
+    if (mw == 0 && lane == 0) {
+        float* d = reinterpret_cast<float*>(x0w);
+        d[0] = cre[0];
+        d[1] = cim[0];
+    }
+#endif
     if ((lane & 15) == 15) {
         const int g = lane >> 4;
         float2* pa = g == 0 ? xaw : (g == 1 ? x0w + 1 : (g == 2 ? xbw : x1w + 1));     // (q & 3) != 3
@@ -615,7 +625,7 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
 #else
             (void)abase; (void)tb;
 #endif
-            dd_ab_publish(lane, cre, cim, x0, xa, x1, xb);
+            dd_ab_publish(lane, mw, cre, cim, x0, xa, x1, xb);
 #ifndef AB_YH_LATE
             if (AB_REG_ROWS < 16)
                 dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);

@@ -88,6 +88,28 @@ extern "C" int dd_host_unregister(void* hptr) {
     if (hptr) DD_HIP_CHECK(hipHostUnregister(hptr));
     return DD_OK;
 }
+// Diagnostic: leave every compute unit's LDS holding `pattern` (the hardware does not clear LDS between workgroups, so a
+// kernel that reads an LDS word it never wrote sees what the previous workgroup on that CU left there).  The tests run
+// the chain kernels after a fill with NaN patterns and after a fill with zeros and demand bit-identical outputs.
+__global__ void __launch_bounds__(256) k_fill_lds(uint32_t pattern, int words, int spin) {
+    extern __shared__ uint32_t dd_fill_words[];
+    for (int i = threadIdx.x; i < words; i += 256) dd_fill_words[i] = pattern;
+    __syncthreads();
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);   // keep the CU occupied until every CU has received a workgroup
+    uint32_t v = dd_fill_words[(threadIdx.x * 97) % words];
+    asm volatile("" ::"v"(v));
+}
+extern "C" int dd_debug_fill_lds(uint32_t pattern, void* stream) {
+    const int bytes = 160 * 1024;                              // the whole LDS of a CU: one workgroup per CU at a time
+    static DDOncePerDevice once;
+    if (once.need()) {
+        DD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        once.mark();
+    }
+    hipLaunchKernelGGL(k_fill_lds, dim3(4 * dd_cu_count()), dim3(256), bytes, dd_stream(stream), pattern, bytes / 4, 200);
+    DD_HIP_CHECK(hipGetLastError());
+    return DD_OK;
+}
 extern "C" int dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream) {
     if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, dd_stream(stream)));
     return DD_OK;

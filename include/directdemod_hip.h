@@ -65,6 +65,9 @@ int  dd_host_free_pinned(void* hptr);
  * hipMemcpyAsync overlapped on a side stream").  DD_ERR_UNSUPPORTED when the range cannot be pinned. */
 int  dd_host_register(void* hptr, size_t bytes);
 int  dd_host_unregister(void* hptr);
+/* diagnostic: fill the LDS of every compute unit with `pattern` (LDS is not cleared between workgroups).  The parity
+ * suite runs the chain kernels after a NaN fill and after a zero fill and requires bit-identical outputs. */
+int  dd_debug_fill_lds(uint32_t pattern, void* stream);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

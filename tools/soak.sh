@@ -1,6 +1,46 @@
 #!/bin/bash
 # soak: many launches of the persistent kernels (barrier / LDS-counter hand-overs), bounded by timeouts
 timeout 120 python bench.py --no-cpu-baseline --steps 20000 --warmup 10 --ramp-ms 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mfma ws 20000 steps:', d['value'], d['ms_per_step'], d['extra']['output_rms_rad'])"
+timeout 300 python - <<'PY'
+# headline kernel (k_chain_mfma_ab): the whole output must be bit-identical from launch to launch (no atomics on the data
+# path: a race in the LDS hand-overs -- boundary tables, range slots, plane buffers -- would show as a changing checksum)
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from directdemod_amd import _hip
+import bench
+_hip.require_gpu()
+lib = _hip.lib()
+dev = torch.device("cuda", 0)
+n = 1 << 26
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(255) / 254))
+for u8 in (False, True):
+    x = bench.make_input(torch, n, 0, dev, 11)
+    if u8:
+        x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    h = C.c_void_p()
+    _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, _hip.cycles_q64(25000.0, 2400000), 1,
+                                   _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_U8_INPUT if u8 else 0)), "create")
+    got = C.c_int64(0)
+    ref = None
+    t0 = time.time()
+    for i in range(3001):
+        lib.dd_chain_reset(h, stream)
+        _hip.check(lib.dd_chain_process(h, x.data_ptr(), out.data_ptr(), n, C.byref(got), stream), "process")
+        if i % 500 == 0:
+            torch.cuda.synchronize()
+            assert lib.dd_chain_last_kernel(h) == _hip.DD_KERNEL_MFMA_AB
+            s = (int(out[:n - 1].view(torch.int32).to(torch.int64).sum()), float(out[:n - 1].double().abs().max()))
+            assert ref is None or s == ref, (u8, i, s, ref)
+            ref = s
+    torch.cuda.synchronize()
+    lib.dd_chain_destroy(h)
+    print("k_chain_mfma_ab%s: 3000 launches, bit-identical output (checksum %d), %.1f s" % (" (u8 input)" if u8 else "", ref[0], time.time() - t0))
+    del x, out
+PY
 timeout 120 python - <<'PY'
 import ctypes as C, os, sys, time
 import numpy as np
