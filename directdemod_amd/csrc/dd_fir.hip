@@ -313,8 +313,8 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 #define IIR_LB_LONG 1024
 #endif
 #define IIR_LONG_FROM ((int64_t)1 << 25)
-#define IIR_G1 64
-#define IIR_G2 64
+#define IIR_G1 32
+#define IIR_G2 32
 #define IIR_S (DD_IIR_MAXN - 1)
 #define IIR_MAT (IIR_S * IIR_S)
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # soak: many launches of the persistent kernels (barrier / LDS-counter hand-overs), bounded by timeouts
-timeout 120 python bench.py --no-cpu-baseline --steps 20000 --warmup 10 --ramp-ms 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mfma ws 20000 steps:', d['value'], d['ms_per_step'], d['extra']['output_rms_rad'])"
+timeout 120 python bench.py --no-cpu-baseline --steps 20000 --warmup 10 --ramp-ms 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['kernel'], '20000 steps:', d['value'], d['ms_per_step'], d['extra']['output_rms_rad'])"
 timeout 300 python - <<'PY'
 # headline kernel (k_chain_mfma_ab): the whole output must be bit-identical from launch to launch (no atomics on the data
 # path: a race in the LDS hand-overs -- boundary tables, range slots, plane buffers -- would show as a changing checksum)
