@@ -159,3 +159,42 @@ def test_class_level_filters_are_bit_reproducible(g):
         for got, ref in zip(r, runs[0]):
             assert got.dtype == ref.dtype and got.shape == ref.shape
             assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+
+
+def test_audio_side_stages_are_bit_reproducible(g):
+    """config 4 end to end (crude + accurate sync: fused front end, Hilbert envelope, zero-phase filters, normalised
+    correlation, peak pick, the batched sync windows), the FFT resampler, filtfilt and the AFSK correlators."""
+    t, hip = g.torch, g.hip
+    import directdemod_amd.comm as comm
+    import directdemod_amd.demod_am as demod_am
+    import directdemod_amd.noaa_sync as noaa
+    import directdemod_amd.source as source
+    import directdemod_amd._ops as ops
+    from directdemod_amd import afsk
+    raw = O.synth_apt_iq(3.0, 2048000, seed=4)
+    rng = np.random.default_rng(12)
+    real = rng.standard_normal(50001)
+    cplx = (rng.standard_normal(4000) + 1j * rng.standard_normal(4000)).astype(np.complex128)
+    aud = rng.standard_normal(30000) * 0.3 + np.sin(2 * np.pi * 1700 * np.arange(30000) / 22050)
+
+    def once():
+        ns = noaa.noaa_sync(source.IQarray(raw, 2048000), 30000.0)
+        sa, sb = ns.getCrudeSync()
+        (ia, pa, ta), (ib, pb, tb) = ns.getAccurateSync()
+        outs = [np.asarray(v, dtype=np.float64) for v in (sa, sb, ia, pa, ta, ib, pb, tb)]
+        outs.append(np.asarray(demod_am.demod_am().demod_blocks(real, 3000)))
+        outs.append(np.asarray(comm.commSignal(60235, real).bwLim(40960, True).signal))
+        outs.append(ops.filtfilt(O.win_blackmanharris(151), hip.DevArray.from_host(cplx)).to_host())
+        bf = afsk.binary_filter(aud, 22050)
+        outs.append(np.asarray(bf))
+        outs.append(np.asarray(afsk.bit_edges(bf, 18)))
+        return outs
+    runs = []
+    for pat in PATTERNS[:3]:
+        hip.check(g.lib.dd_debug_fill_lds(pat, g.stream), "dd_debug_fill_lds")
+        t.cuda.synchronize()
+        runs.append(once())
+    for r in runs[1:]:
+        for k, (got, ref) in enumerate(zip(r, runs[0])):
+            assert got.dtype == ref.dtype and got.shape == ref.shape, k
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), "stage output %d differs between runs" % k
