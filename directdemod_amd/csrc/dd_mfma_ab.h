@@ -38,6 +38,13 @@
 #ifndef DD_AB_VEC_PRIO
 #define DD_AB_VEC_PRIO 0
 #endif
+// measured alternatives, correct and parity-tested, none faster (DESIGN.md 4.2b "round 2, second pass"); off by default:
+//   DD_AB_DEFER     all but one entry of a strip's boundary table written at the START of the discriminator phase instead
+//                   of between the last MFMA and the barrier (MFMA phase 4250 -> 3900 cycles, launch time unchanged)
+//   DD_AB_PREFETCH  the fragments of the first k-step requested before the barrier, behind a per-tile count of the
+//                   converting waves (needs 24 more live registers across the barrier: spills, slower)
+//   DD_AB_TINY      discriminator from the ratio im / re with a two-coefficient polynomial below 9 degrees (7 instead
+//                   of 9.5 instructions per row; the discriminator wave is no faster for it)
 // timing ablations (tools/mkvariant.sh ... -DDD_AB_NO_xxx; results are wrong by construction, never shipped):
 //   DD_AB_NO_EPI      matrix waves skip the discriminator      DD_AB_NO_MFMA   matrix waves skip the MFMAs
 //   DD_AB_NO_CONVERT  vector waves skip the rotation / split   DD_AB_NO_LOAD   vector waves skip the tile loads
@@ -62,7 +69,9 @@ struct AbGeom {
     static constexpr int YH_OFF = (BCOL_OFF + 2 * BCOL_SET_BYTES + 15) & ~15;
     static constexpr int YH_SET_BYTES = 2 * 4 * YH_STRIDE * 4;
     static constexpr int YHCNT_OFF = YH_OFF + (AB_REG_ROWS < 16 ? 2 * YH_SET_BYTES : 0);   // [2] int: y-half buffers written (x4 waves), per set
-    static constexpr int LDS_BYTES = (YHCNT_OFF + 16 + 15) & ~15;
+    static constexpr int CONVCNT_OFF = YHCNT_OFF + 8;                    // [2] int: waves that have finished converting a tile into plane buffer 0 / 1
+    static constexpr int WKX_OFF = (YHCNT_OFF + 16 + 15) & ~15;          // [2 sets][64 lanes][4] float2: the halo step's tile-relative phasors (kept out of the matrix waves' registers)
+    static constexpr int LDS_BYTES = WKX_OFF + 2 * 64 * 32;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(MF_LDS_TILE_BYTES(NKS) <= TAPS_OFF, "the edge tile's image must not reach the tap fragments");
 };
@@ -195,6 +204,24 @@ __device__ __forceinline__ float dd_ab_tile_scale(const char* smem, int red_off,
     return unit ? 1.0f : dd_pow2_scale_for(m);
 }
 
+// "this wave's share of tile t is in the plane buffer": one LDS add per wave, issued behind its plane stores (the LDS
+// executes a wave's operations in order, so whoever sees the count sees the stores).  The matrix set that computes
+// tile t next phase reads the count at the end of its discriminator phase; with all AB_CONV_WAVES shares in, it
+// requests its first two k-steps of fragments BEFORE the barrier and its MFMAs start the moment the barrier opens.
+#ifdef AB_HALO_ON_VECTOR
+#define AB_CONV_WAVES AB_VWAVES
+#else
+#define AB_CONV_WAVES (AB_VWAVES + 1)
+#endif
+__device__ __forceinline__ void dd_ab_conv_done(char* smem, int cnt_off, int t, int lane) {
+#ifdef DD_AB_PREFETCH
+    if (lane == 0) {
+        const unsigned addr = (unsigned)(uintptr_t)(smem + cnt_off) + 4u * (unsigned)(t & 1);
+        asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
+    }
+#endif
+}
+
 // one 256-output unit of the vector waves' share: outputs 512 + 256 u + 4 lane + {0..3} of strip s, tile b
 struct AbUnit { float4 r4, i4; float2 ym; };
 template <int NKS>
@@ -286,6 +313,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
             if (unit) dd_ab_convert_quad<NKS, true>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
             else dd_ab_convert_quad<NKS, false>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
         }
+        dd_ab_conv_done(smem, A::CONVCNT_OFF, p, lane);
     }
 #endif
 #if defined(AB_HALO_ON_VECTOR) && !defined(DD_AB_NO_LOAD)
@@ -381,6 +409,39 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
 }
 
 // ------------------------------------------------------------------ matrix waves
+// The discriminator's angle from the RATIO t = im / re (v_rcp_f32 + v_mul: 1.5 ulp) and re, so that im need not stay in
+// a register behind the ratio (the straight-line epilogue holds 16 rows of everything it still needs).
+//   dd_atan_ratio_small: |t| <= tan 22.5 deg, re > 0 (same polynomial as dd_atan_small)
+//   dd_atan_ratio_full : any t including +-inf (re = 0) and NaN (0 / 0 -> 0 like np.angle); re < 0 adds the half turn.
+//                        im's sign is sign(t) sign(re).  Same degree-15 polynomial as dd_fast_atan2.
+__device__ __forceinline__ float dd_atan_ratio_small(float t) {
+    const float z = t * t;
+    float p = fmaf(7.902598251e-02f, z, -1.382445378e-01f);
+    p = fmaf(p, z, 1.997187931e-01f);
+    p = fmaf(p, z, -3.333275667e-01f);
+    return fmaf(t, z * p, t);
+}
+__device__ __forceinline__ float dd_atan_ratio_full(float t, float re) {
+    const float at = fabsf(t);
+    const bool inv = at > 1.0f;
+    const float u = inv ? __builtin_amdgcn_rcpf(at) : at;  // rcp(inf) = 0
+    const float z = u * u;
+    float p = -4.054567120e-03f;
+    p = fmaf(p, z, 2.186295773e-02f);
+    p = fmaf(p, z, -5.591232695e-02f);
+    p = fmaf(p, z, 9.642197381e-02f);
+    p = fmaf(p, z, -1.390862959e-01f);
+    p = fmaf(p, z, 1.994656567e-01f);
+    p = fmaf(p, z, -3.332986079e-01f);
+    p = fmaf(p, z, 9.999993356e-01f);
+    float r = p * u;
+    r = inv ? 1.5707963267948966f - r : r;
+    const bool neg = __float_as_int(re) < 0;                // sign bit (re = -0 counts as negative: t carries rcp(-0) = -inf)
+    r = neg ? 3.141592653589793f - r : r;
+    r = copysignf(r, neg ? -t : t);                         // sign(im) = sign(t) sign(re)
+    return (t != t && re == 0.f) ? 0.f : r;                 // 0 / 0: atan2(0, 0) = 0
+}
+
 // discriminator of one strip out of the accumulators.  Lane (j = lane & 31, h = lane >> 5), register r holds output
 // 32 (rowbase(r) + 4 h) + j of the strip, rowbase(r) = (r & 3) + 8 (r >> 2).  xrd: this lane's column-0 table (X0 of the
 // wave for h = 0, X1 for h = 1), entry r = the output that precedes column 0 of register r's row.
@@ -400,6 +461,42 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     for (int r = 0; r < NR; ++r) bv[r] = xrd[r];
     // 2. z = y[n] conj(y[n-1]); y[n-1] is the same register one lane to the left: DPP row_shr:1, which leaves the
     //    first lane of each 16-lane row (no source lane) at the old value of the destination = its table entry
+#ifdef DD_AB_TINY
+    // 3. t = im / re for every row (every path starts from it; im is not kept), then wave-uniform fast paths: the
+    //    strip's largest |t| and smallest re pick the polynomial.  |t| <= 0.16 (9 degrees: an oversampled FM signal
+    //    always is): two coefficients, 1.0e-8 rad.  |t| <= tan 22.5 degrees: four.  Anything else -- re <= 0, a NaN --
+    //    the full-range form.  7 instructions per row on the first path (9.5 with a separate range test per row).
+    float re[NR], t[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float pre = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].x), __float_as_int(cre[r]), 0x111, 0xf, 0xf, false));
+        const float pim = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].y), __float_as_int(cim[r]), 0x111, 0xf, 0xf, false));
+        re[r] = fmaf(cre[r], pre, cim[r] * pim);
+        t[r] = fmaf(cim[r], pre, -cre[r] * pim) * __builtin_amdgcn_rcpf(re[r]);
+    }
+    float mx = fabsf(t[0]), mnre = re[0];
+#pragma unroll
+    for (int r = 1; r + 1 < NR; r += 2) {                    // v_max3_f32 / v_min3_f32: two rows per instruction
+        mx = fmaxf(fmaxf(mx, fabsf(t[r])), fabsf(t[r + 1]));
+        mnre = fminf(fminf(mnre, re[r]), re[r + 1]);
+    }
+    if ((NR & 1) == 0) { mx = fmaxf(mx, fabsf(t[NR - 1])); mnre = fminf(mnre, re[NR - 1]); }
+    const bool re_pos = mnre > 0.f;
+    float a[NR];
+    if (__builtin_amdgcn_ballot_w64(!(re_pos && mx <= 0.16f)) == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float z = t[r] * t[r];
+            a[r] = fmaf(t[r] * z, fmaf(1.946828067e-01f, z, -3.332866728e-01f), t[r]);
+        }
+    } else if (__builtin_amdgcn_ballot_w64(!(re_pos && mx <= 0.41421354f)) == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a[r] = dd_atan_ratio_small(t[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a[r] = dd_atan_ratio_full(t[r], re[r]);
+    }
+#else
     float re[NR], im[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -424,6 +521,7 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
 #pragma unroll
         for (int r = 0; r < NR; ++r) a[r] = dd_fast_atan2(im[r], re[r]);
     }
+#endif
     // 4. row r of the lane is output 32 (rowbase(r) + 4 h) + j: 128 contiguous bytes per half wave and row.
     //    The tile's first 32 outputs (strip 0, row 0) belong to the previous tile.
 #ifdef DD_AB_NO_STORE
@@ -466,10 +564,21 @@ __device__ __forceinline__ void dd_ab_write_yhalf(int lane, const v16f& cre, con
 // Entry 0 of strip 0's X0 table has no producer (the output before the tile's first one belongs to the previous tile, and
 // so do the 32 outputs of that row, which are not stored): the wave writes its own output there, so that the row's
 // lane-0 product is |y|^2 (angle 0) and the wave-uniform small-angle test never sees what the LDS held before the launch.
-__device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre, const v16f& cim, float2* x0w, float2* xaw, float2* x1w, float2* xbw) {
+// The one entry another wave reads -- the strip's last output, lane 63 of register 15, for lane 0 / register 0 of the
+// next strip -- is written at the end of the MFMA phase (dd_ab_publish_last, in front of the barrier); the 63 entries
+// the wave reads back itself wait until the start of its discriminator phase (dd_ab_publish), when the matrix pipe
+// is busy with the other set: the ~200 cycles of masked stores no longer sit between the last MFMA and the barrier.
+__device__ __forceinline__ void dd_ab_publish_last(int lane, const v16f& cre, const v16f& cim, float2* x0w) {
+    if (lane == 63) {
+        float* d = reinterpret_cast<float*>(x0w + 16);
+        d[0] = cre[15];
+        d[1] = cim[15];
+    }
+}
+__device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre, const v16f& cim, float2* xtab0, float2* x0w, float2* xaw, float2* x1w, float2* xbw) {
 #ifndef DD_AB_NO_X0_SELF          // (-DDD_AB_NO_X0_SELF: the round-2 bug, for checking that tests/test_gpu_determinism.py catches it)
     if (mw == 0 && lane == 0) {
-        float* d = reinterpret_cast<float*>(x0w);
+        float* d = reinterpret_cast<float*>(xtab0);          // (strip 0's X0 = the set's table base: a constant address, no register kept for it)
         d[0] = cre[0];
         d[1] = cim[0];
     }
@@ -481,6 +590,9 @@ __device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre,
         // (two 4-byte stores per entry: an 8-byte store wants re and im in adjacent registers, 32 v_mov per strip)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+#ifdef DD_AB_DEFER
+            if (q == 15 && g == 3) continue;                // written by dd_ab_publish_last in the MFMA phase
+#endif
             float* d = reinterpret_cast<float*>(((q & 3) != 3 ? pa : pb) + q);
             d[0] = cre[q];
             d[1] = cim[q];
@@ -488,14 +600,23 @@ __device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre,
     }
 }
 
+// fragments of k-steps 0 and 1 of a strip (what the MFMA loop needs before its first instruction)
+#ifndef AB_HEAD_KSTEPS
+#define AB_HEAD_KSTEPS 1      // k-steps requested a phase early: 2 would cover the whole start-up, and spills (48 live registers across the barrier)
+#endif
+template <int NKS, int FIRST, int LAST>
+__device__ __forceinline__ void dd_ab_frag_head(const char* abase, const v8h* tb, v8h (&f)[3][6]) {
+    using G = MfmaGeom<NKS>;
+    if (FIRST <= 0 && 0 < LAST) { DD_WS_LOADF(0, 0) }
+    if (FIRST <= 1 && 1 < LAST) { DD_WS_LOADF(1, 1) }
+}
 template <int NKS>
-__device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* tb, v16f& cre, v16f& cim) {
+__device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* tb, v16f& cre, v16f& cim, v8h (&f)[3][6], bool have_head) {
     using G = MfmaGeom<NKS>;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-    v8h f[3][6];
-    DD_WS_LOADF(0, 0)
-    DD_WS_LOADF(1, 1)
+    if (!have_head) dd_ab_frag_head<NKS, 0, AB_HEAD_KSTEPS>(abase, tb, f);
+    dd_ab_frag_head<NKS, AB_HEAD_KSTEPS, 2>(abase, tb, f);
 #ifdef DD_AB_GROUPED_READS
     // the six fragment reads of k-step ks+2 issued together in front of the six MFMAs of k-step ks, waits left to
     // the compiler (tools/ubench/mfma_lds_stream.hip: 32.3 cycles per MFMA alone on the CU, against 33.6 for one
@@ -521,21 +642,42 @@ __device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* t
 #endif
 }
 
+// End of a set's discriminator phase: if every converting wave has reported tile t = qnext - 1 (the set's next MFMA
+// tile) complete, request the fragments of its first two k-steps now; they land while the wave waits at the barrier.
+template <int NKS>
+__device__ __forceinline__ bool dd_ab_try_head(const char* smem, int n, int qnext, int aoff, const v8h* tb, v8h (&f)[3][6]) {
+#ifndef DD_AB_PREFETCH
+    return false;
+#else
+    using A = AbGeom<NKS>;
+    if (qnext < 1 || qnext > n) return false;
+    const int t = qnext - 1;
+    const int c = *reinterpret_cast<const volatile int*>(smem + A::CONVCNT_OFF + 4 * (t & 1));
+    if (__builtin_amdgcn_readfirstlane(c) < AB_CONV_WAVES * ((t >> 1) + 1)) return false;
+    asm volatile("" ::: "memory");                          // the plane reads stay behind the count
+    dd_ab_frag_head<NKS, 0, AB_HEAD_KSTEPS>(smem + (t & 1) * A::PLANES_BYTES + aoff, tb, f);
+    return true;
+#endif
+}
+
 // the halo step (quads 0..63 of a tile) on the matrix wave of strip 0, set SET: conversion in the set's discriminator
 // phase, range check of the next one at the end of its MFMA phase (the data were requested a phase earlier)
 template <int NKS, bool U8>
 __device__ __forceinline__ void dd_ab_halo_convert(const DDChainParams& P, char* smem, int t_begin, int n, int q, int lane,
-                                                   AbRaw& xraw, const float2 (&wkx)[4], int nu_flag) {
+                                                   AbRaw& xraw, const float4* wkx_lds, int nu_flag) {
     using A = AbGeom<NKS>;
 #ifndef DD_AB_NO_CONVERT
     if (q < n) {
         bool unit;
         const float scale = dd_ab_tile_scale(smem, A::RED_OFF, nu_flag, q, unit);
+        const float4 w01 = wkx_lds[0], w23 = wkx_lds[1];
+        const float2 wkx[4] = {make_float2(w01.x, w01.y), make_float2(w01.z, w01.w), make_float2(w23.x, w23.y), make_float2(w23.z, w23.w)};
         char* planes = smem + (q & 1) * A::PLANES_BYTES;
         if (AbQ<NKS>::XQUADS == 64 || lane < AbQ<NKS>::XQUADS) {
             if (unit) dd_ab_convert_quad<NKS, true>(xraw, planes, lane, wkx, scale);
             else dd_ab_convert_quad<NKS, false>(xraw, planes, lane, wkx, scale);
         }
+        dd_ab_conv_done(smem, A::CONVCNT_OFF, q, lane);
     }
 #endif
 #ifndef DD_AB_NO_LOAD
@@ -567,16 +709,15 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     const bool halo = mw == 0;
 #endif
     AbRaw xraw;
-    float2 wkx[4];
     xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wkx[k] = make_float2(1.f, 0.f);
+    float4* wkx_lds = reinterpret_cast<float4*>(smem + A::WKX_OFF) + (SET * 64 + lane) * 2;     // written and read by this lane only
     if (halo) {
         xraw = dd_ab_load_quad<NKS, U8>(P, t_begin + (SET == 1 ? 0 : (n > 1 ? 1 : 0)), lane < AbQ<NKS>::XQUADS ? lane : AbQ<NKS>::XQUADS - 1);
-        if (P.flags & DD_CHAIN_NCO) {
+        float2 w[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wkx[k] = dd_phasor((uint64_t)(4 * lane + k) * P.cyc, P.nco_tbl);
-        }
+        for (int k = 0; k < 4; ++k) w[k] = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(4 * lane + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        wkx_lds[0] = make_float4(w[0].x, w[0].y, w[1].x, w[1].y);
+        wkx_lds[1] = make_float4(w[2].x, w[2].y, w[3].x, w[3].y);
         if (SET == 1) {                                     // tile 0: the true maximum (its non-unit flag is preset)
             const float m = dd_wave_max(dd_ab_absmax(xraw, 0.f));
             if (lane == 63) reinterpret_cast<float*>(smem + A::RED_OFF)[AB_VWAVES] = m;
@@ -591,41 +732,63 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     v16f cre, cim;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
-    // set SET computes in the phases q with (q & 1) == SET (tile q - 1) and runs that tile's discriminator in phase q + 1
-    for (int p = 0; p < nph; p += 2) {
+    v8h f[3][6];                                            // fragment ring of the MFMA loop (k-steps 0, 1 requested a phase early)
+    bool head = false;
+    // Set SET computes tile t in phase t + 1 where ((t + 1) & 1) == SET and runs its discriminator in phase t + 2.  The
+    // loop body is [discriminator phase pe | MFMA phase pe + 1]: the fragments requested at the end of the first are
+    // consumed at the start of the second, so nothing but the accumulators is live across the loop's back edge.
+    // Set 0's phase 0 has no tile to compute: only the range of the halo it converts in phase 1.
+    if (SET == 0) {
         unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
-        const int qm = p + SET;                             // this set's MFMA phase of the pair
-        if (SET == 1) {                                     // phase p: halo step of tile p, discriminator of tile p - 2
-            const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[p & 3] : 0;
+        if (halo && 1 < n) dd_ab_publish_range(dd_ab_absmax(xraw, 0.f), smem, A::RED_OFF, A::NONUNIT_OFF, 1, AB_VWAVES, lane);
+        DD_AB_STAMP(0)
+        __syncthreads();
+        DD_AB_STAMP(2)
+    }
+    for (int pe = 1 - SET; pe < nph; pe += 2) {
+        unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
+        const int qm = pe + 1;                              // this set's MFMA phase of the pair (tile pe)
+        {   // phase pe: the rest of tile pe - 2's table, halo step of tile pe, discriminator of tile pe - 2
+            const bool epi = pe >= 2 && pe - 2 < n;
+#ifdef DD_AB_DEFER
+            if (epi) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
+#endif
+            const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[pe & 3] : 0;
 #ifndef DD_AB_HALO_LATE
-            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p, lane, xraw, wkx, nu_flag);
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, pe, lane, xraw, wkx_lds, nu_flag);
 #endif
 #if defined(AB_YH_LATE) && !defined(DD_AB_NO_EPI)
-            if (AB_REG_ROWS < 16 && p >= 2 && p - 2 < n) {
+            if (AB_REG_ROWS < 16 && epi) {
                 dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
                 __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores have landed
                 if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + A::YHCNT_OFF) + SET, 1);
             }
 #endif
 #ifndef DD_AB_NO_EPI
-            if (p >= 2 && p - 2 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 2, mw, lane, cre, cim, xrd);
+            if (epi) dd_ab_epilogue<NKS>(P, t_begin + pe - 2, mw, lane, cre, cim, xrd);
 #endif
 #ifdef DD_AB_HALO_LATE
-            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p, lane, xraw, wkx, nu_flag);
+            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, pe, lane, xraw, wkx_lds, nu_flag);
 #endif
+            head = dd_ab_try_head<NKS>(smem, n, qm, aoff, tb, f);
             DD_AB_STAMP(1)
             __syncthreads();
             DD_AB_STAMP(2)
         }
-        if (qm >= 1 && qm <= n) {
+        if (qm >= nph) break;                               // (set 0: the phase after the last one)
+        if (qm <= n) {
             __builtin_amdgcn_s_setprio(3);                  // MFMAs issue as soon as the pipe frees up
-            const char* abase = smem + ((qm - 1) & 1) * A::PLANES_BYTES + aoff;
+            const char* abase = smem + (pe & 1) * A::PLANES_BYTES + aoff;
 #ifndef DD_AB_NO_MFMA
-            dd_ab_mfma_strip<NKS>(abase, tb, cre, cim);
+            dd_ab_mfma_strip<NKS>(abase, tb, cre, cim, f, head);
 #else
             (void)abase; (void)tb;
 #endif
-            dd_ab_publish(lane, mw, cre, cim, x0, xa, x1, xb);
+#ifndef DD_AB_DEFER
+            dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
+#else
+            dd_ab_publish_last(lane, cre, cim, x0);         // the rest at the start of the discriminator phase
+#endif
 #ifndef AB_YH_LATE
             if (AB_REG_ROWS < 16)
                 dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
@@ -637,28 +800,6 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
         DD_AB_STAMP(0)
         __syncthreads();
         DD_AB_STAMP(2)
-        if (SET == 0) {                                     // phase p + 1: halo step of tile p + 1, discriminator of tile p - 1
-            const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[(p + 1) & 3] : 0;
-#ifndef DD_AB_HALO_LATE
-            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p + 1, lane, xraw, wkx, nu_flag);
-#endif
-#if defined(AB_YH_LATE) && !defined(DD_AB_NO_EPI)
-            if (AB_REG_ROWS < 16 && p >= 1 && p - 1 < n) {
-                dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
-                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores have landed
-                if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + A::YHCNT_OFF) + SET, 1);
-            }
-#endif
-#ifndef DD_AB_NO_EPI
-            if (p >= 1 && p - 1 < n) dd_ab_epilogue<NKS>(P, t_begin + p - 1, mw, lane, cre, cim, xrd);
-#endif
-#ifdef DD_AB_HALO_LATE
-            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, p + 1, lane, xraw, wkx, nu_flag);
-#endif
-            DD_AB_STAMP(1)
-            __syncthreads();
-            DD_AB_STAMP(2)
-        }
     }
     if (stamp && lane == 0) {
         const size_t w = (size_t)blockIdx.x * 16 + (tid >> 6);
@@ -699,7 +840,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
         for (int idx = threadIdx.x; idx < 2 * NKS * 64; idx += WS_THREADS) tl[idx] = taps.frag[idx];
         if (threadIdx.x < 4) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[threadIdx.x] = threadIdx.x == 0 ? 1 : 0;   // tile 0: read the true max
         if (threadIdx.x < 2 * AB_RED_ENTRIES) reinterpret_cast<float*>(smem + A::RED_OFF)[threadIdx.x] = 0.f;          // (unused entries stay 0)
-        if (threadIdx.x < 2) reinterpret_cast<int*>(smem + A::YHCNT_OFF)[threadIdx.x] = 0;
+        if (threadIdx.x < 4) reinterpret_cast<int*>(smem + A::YHCNT_OFF)[threadIdx.x] = 0;                            // (+ the two conversion counters)
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 5) / 6) * 6;      // phases: a multiple of the vector loop's 3 and the matrix sets' 2
