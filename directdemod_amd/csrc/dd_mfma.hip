@@ -647,7 +647,7 @@ __device__ __forceinline__ float dd_wave_max(float m) {
 //   they overwrite the buffer -- they get there thousands of cycles later, so the wait is
 //   free); conversion of tile p with the scale published during phase p-1; tile max and
 //   group phasors of tile p+1 for the next phase; barrier.
-template <int NKS, bool U8, bool CX>
+template <int NKS, bool U8, bool CX, bool ST>
 __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int n, int p,
                                              float4 (&rcur)[WsGeom<NKS>::NIT], float4 (&rnext)[WsGeom<NKS>::NIT],
                                              float4 (&rld)[WsGeom<NKS>::NIT],
@@ -655,7 +655,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
                                              unsigned long long (&acc_t)[8]) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
-    const bool stamp = taps.stamps != nullptr;
+    const bool stamp = ST && taps.stamps != nullptr;        // ST: in-kernel stamps compiled in (tools only)
     unsigned long long tp = stamp ? __builtin_readcyclecounter() : 0;
 #define DD_STAMP(i) if (stamp) { const unsigned long long tn = __builtin_readcyclecounter(); acc_t[i] += tn - tp; tp = tn; }
     float* redall = reinterpret_cast<float*>(smem + W::RED_OFF);
@@ -725,7 +725,7 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
     DD_STAMP(4)
 }
 
-template <int NKS, bool U8, bool CX>
+template <int NKS, bool U8, bool CX, bool ST>
 __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -761,18 +761,18 @@ __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfm
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 3: no conditional phases
-        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
-        dd_ws_vphase<NKS, U8, CX>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX, ST>(P, taps, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX, ST>(P, taps, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, acc_t);
+        dd_ws_vphase<NKS, U8, CX, ST>(P, taps, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, acc_t);
     }
-    if (taps.stamps && lane == 0) {
+    if (ST && taps.stamps && lane == 0) {
         for (int q = 0; q < 6; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
         taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + 7] = (unsigned long long)nph | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
     }
 }
 
 // ------------------------------------------------------------------ matrix waves
-template <int NKS, bool CX>
+template <int NKS, bool CX, bool ST>
 __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
@@ -788,7 +788,7 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
     __syncthreads();                                        // prologue barrier (tile 0's max is published)
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamp = taps.stamps != nullptr;
+    const bool stamp = ST && taps.stamps != nullptr;
     const unsigned long long t_clk0 = stamp ? __builtin_readcyclecounter() : 0;
     const unsigned long long t_rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int p = 0; p < nph; ++p) {
@@ -890,7 +890,7 @@ __device__ __forceinline__ void dd_ws_matrix(const DDChainParams& P, const DDMfm
 // CX: complex-output flavour (launched only without DD_CHAIN_FM): tile phasors handed over through LDS.  CX = false is
 // the code as it was before the flavour existed, token for token -- this kernel's speed depends on code generation in
 // ways its instruction mix does not explain, so the headline instantiation is kept byte-identical (assembly diff).
-template <int NKS, bool U8, bool CX>
+template <int NKS, bool U8, bool CX, bool ST = false>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using W = WsGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
         dd_edge_tile_lean<NKS>(P, taps, b, smem, tl);        // (its staging barriers order the tap copy)
         return;
     }
-    if (taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (ST && taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int nt = t_last - t_first;
     const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
     const int t_end = t_first + (int)(((int64_t)(wg + 1) * nt) / nwg);
@@ -921,8 +921,8 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ws(const DDChainParam
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 2) / 3) * 3;      // phases, rounded up to the vector loop's unroll of 3
-    if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS, CX>(P, taps, smem, t_begin, t_end, nph);
-    else dd_ws_vector<NKS, U8, CX>(P, taps, smem, t_begin, t_end, nph);
+    if (threadIdx.x < 64 * WS_MWAVES) dd_ws_matrix<NKS, CX, ST>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ws_vector<NKS, U8, CX, ST>(P, taps, smem, t_begin, t_end, nph);
 }
 
 #include "dd_mfma_ab.h"
@@ -1017,6 +1017,11 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        if (NKS == 18) {                                    // the instantiations with the in-kernel stamps (DD_STAMPS, tools only)
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<18, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<18>::LDS_BYTES));
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
+        }
         attr_set.mark();
     }
     DDMfmaTaps t;
@@ -1029,7 +1034,8 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
     static const char* stamps_env = getenv("DD_STAMPS");
     static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
     static int launches = 0;
-    const bool want_stamps = stamps_env != nullptr && launches++ == stamps_at;
+    const bool want_stamps_env = stamps_env != nullptr && launches++ == stamps_at;
+    const bool want_stamps = want_stamps_env && NKS == 18 && !(P.flags & DD_CHAIN_U8_INPUT);   // only these have a stamped instantiation
     if (want_stamps) {
         if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, DD_STAMP_WGS * 16 * 8 * 8));
         DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, DD_STAMP_WGS * 16 * 8 * 8, s));
@@ -1065,10 +1071,14 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         const bool use_ab = !cx && !(kern_env && strcmp(kern_env, "ws") == 0);
         if (use_ab) {
             if (u8in) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+            else if (NKS == 18 && t.stamps)                  // DD_STAMPS (tools): the instantiation with the in-kernel stamps compiled in
+                hipLaunchKernelGGL((k_chain_mfma_ab<18, false, true>), g, b, (size_t)AbGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
             else hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
         } else
         if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
+        else if (NKS == 18 && t.stamps && cx) hipLaunchKernelGGL((k_chain_mfma_ws<18, false, true, true>), g, b, (size_t)WsGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+        else if (NKS == 18 && t.stamps) hipLaunchKernelGGL((k_chain_mfma_ws<18, false, false, true>), g, b, (size_t)WsGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
         else if (cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         DD_LAUNCH_CHECK();

@@ -347,7 +347,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
     DD_AB_STAMP(3)
 }
 
-template <int NKS, bool U8>
+template <int NKS, bool U8, bool ST>
 __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using A = AbGeom<NKS>;
     using Q = AbQ<NKS>;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
     }
     __syncthreads();                                        // prologue barrier (matched in dd_ab_matrix)
     if (DD_AB_VEC_PRIO) __builtin_amdgcn_s_setprio(DD_AB_VEC_PRIO);
-    const bool stamp = taps.stamps != nullptr;
+    const bool stamp = ST && taps.stamps != nullptr;       // ST: the in-kernel stamps are compiled in (tools only: ~30 scalar instructions per wave and phase)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 6
         dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
@@ -686,7 +686,7 @@ __device__ __forceinline__ void dd_ab_halo_convert(const DDChainParams& P, char*
 #endif
 }
 
-template <int NKS, int SET, bool U8>
+template <int NKS, int SET, bool U8, bool ST>
 __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using A = AbGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63, mw = (tid >> 6) & 3;
@@ -725,7 +725,7 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     }
     __syncthreads();                                        // prologue barrier (tile 0's range is published)
 
-    const bool stamp = taps.stamps != nullptr;
+    const bool stamp = ST && taps.stamps != nullptr;       // ST: the in-kernel stamps are compiled in (tools only: ~30 scalar instructions per wave and phase)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_clk0 = stamp ? __builtin_readcyclecounter() : 0;
     const unsigned long long t_rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -815,7 +815,7 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
 }
 
 // FM output only (the complex-output flavour stays on k_chain_mfma_ws).  U8: raw interleaved uint8 I,Q input.
-template <int NKS, bool U8>
+template <int NKS, bool U8, bool ST = false>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using A = AbGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
         dd_edge_tile_lean<NKS>(P, taps, b, smem, tl);
         return;
     }
-    if (taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (ST && taps.stamps && threadIdx.x == 0) taps.stamps[((size_t)wg * 16) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int nt = t_last - t_first;
     const int t_begin = t_first + (int)(((int64_t)wg * nt) / nwg);
     const int t_end = t_first + (int)(((int64_t)(wg + 1) * nt) / nwg);
@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 5) / 6) * 6;      // phases: a multiple of the vector loop's 3 and the matrix sets' 2
-    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0, U8>(P, taps, smem, t_begin, t_end, nph);
-    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1, U8>(P, taps, smem, t_begin, t_end, nph);
-    else dd_ab_vector<NKS, U8>(P, taps, smem, t_begin, t_end, nph);
+    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0, U8, ST>(P, taps, smem, t_begin, t_end, nph);
+    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1, U8, ST>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ab_vector<NKS, U8, ST>(P, taps, smem, t_begin, t_end, nph);
 }
