@@ -210,7 +210,8 @@ int dd_chain_last_kernel(const dd_chain* h);
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
 
 /* ---- R2: commSignal.bwLim strict -> scipy.signal.resample (comm.py:110-116) --- */
-/* Fourier-domain resample of one chunk, float64 real: n -> num samples. */
+/* Fourier-domain resample of one chunk, float64 real: n -> num samples.  Asynchronous on `stream`; the intermediates
+ * live in a grow-only buffer kept by the library (no allocation, no synchronisation in the steady state). */
 int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream);
 
 /* ---- polyphase rational resampler (BASELINE north_star, config 3 "polyphase resample to 11.025 kS/s").
