@@ -105,19 +105,16 @@ extern "C" int dd_am_envelope_f64(const double* in, double* out, int64_t n, int6
     const int64_t rem = n - nfull * block;                  // 1 .. block
     const int GB = 16;                                       // full blocks per batched transform
     const int64_t wlen = nfull ? (nfull < GB ? nfull : GB) * block : 0;
-    double2* work = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&work, sizeof(double2) * (wlen > rem ? wlen : rem)));
-    int rc = DD_OK;
+    char* base = nullptr;
+    int rc = dd_scratch_get(sizeof(double2) * (size_t)(wlen > rem ? wlen : rem), s, &base);
+    if (rc != DD_OK) return rc;
+    double2* work = reinterpret_cast<double2*>(base);
     for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) {
         const int nbk = (int)(nfull - b0 < GB ? nfull - b0 : GB);
         rc = envelope_blocks(in + b0 * block, out + b0 * block, block, nbk, work, s);
     }
     if (rc == DD_OK) rc = envelope_blocks(in + nfull * block, out + nfull * block, rem, 1, work, s);
-    hipError_t e = hipStreamSynchronize(s);
-    hipFree(work);
-    if (rc != DD_OK) return rc;
-    DD_HIP_CHECK(e);
-    return DD_OK;
+    return rc;
 }
 
 // ---------------------------------------------------------------- R2: scipy.signal.resample (real input)
@@ -246,15 +243,8 @@ extern "C" int dd_rpoly_process(dd_rpoly* r, const double* in, int64_t n, int fl
     return DD_OK;
 }
 
-// Intermediates of the FFT resampler: a grow-only buffer per device, reused from call to call in stream order (a call
-// on another stream than the previous one first waits for that stream).  The call itself no longer allocates, frees or
-// synchronises: in the C3 chunk loop (one call per 2^22-sample chunk) those were 88 of the 140 us a chunk cost the host.
-static std::mutex g_rs_mu;
-static char* g_rs_buf[64] = {nullptr};
-static size_t g_rs_bytes[64] = {0};
-static hipStream_t g_rs_stream[64] = {nullptr};
-static bool g_rs_used[64] = {false};
-
+// The FFT resampler's intermediates come from dd_scratch_get: the call neither allocates, frees nor synchronises (in the
+// C3 chunk loop -- one call per 2^22-sample chunk -- those were 88 of the 140 us a chunk cost the host).
 extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream) {
     DD_REQUIRE(n >= 1 && num >= 1, "n/num");
     DD_REQUIRE(in && out, "null buffer");
@@ -267,26 +257,12 @@ extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int
     const int64_t nxb = n / 2 + 1, nyb = num / 2 + 1;
     const size_t bx = (sizeof(double2) * nxb + 255) & ~(size_t)255, by = (sizeof(double2) * nyb + 255) & ~(size_t)255;
     const size_t need = bx + by + sizeof(double) * n;
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
-    std::lock_guard<std::mutex> lk(g_rs_mu);
-    if (g_rs_used[dev] && g_rs_stream[dev] != s) DD_HIP_CHECK(hipStreamSynchronize(g_rs_stream[dev]));
-    if (g_rs_bytes[dev] < need) {
-        if (g_rs_buf[dev]) {
-            DD_HIP_CHECK(hipStreamSynchronize(g_rs_stream[dev]));
-            DD_HIP_CHECK(hipFree(g_rs_buf[dev]));
-        }
-        g_rs_buf[dev] = nullptr;
-        g_rs_bytes[dev] = 0;
-        DD_HIP_CHECK(hipMalloc((void**)&g_rs_buf[dev], need));
-        g_rs_bytes[dev] = need;
-    }
-    g_rs_stream[dev] = s;
-    g_rs_used[dev] = true;
-    double2* X = reinterpret_cast<double2*>(g_rs_buf[dev]);
-    double2* Y = reinterpret_cast<double2*>(g_rs_buf[dev] + bx);
-    double* tmp = reinterpret_cast<double*>(g_rs_buf[dev] + bx + by);      // D2Z may overwrite its input: work on a copy
+    char* base = nullptr;
+    rc = dd_scratch_get(need, s, &base);
+    if (rc != DD_OK) return rc;
+    double2* X = reinterpret_cast<double2*>(base);
+    double2* Y = reinterpret_cast<double2*>(base + bx);
+    double* tmp = reinterpret_cast<double*>(base + bx + by);               // D2Z may overwrite its input: work on a copy
     DD_HIP_CHECK(hipMemcpyAsync(tmp, in, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipfftResult r1 = hipfftExecD2Z(pf, tmp, (hipfftDoubleComplex*)X);
     const int64_t N = num < n ? num : n;
@@ -432,15 +408,16 @@ extern "C" int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needl
             return xcorr_runs(h, n, needle_host, m, vv, R, out, s);
         }
     }
-    double* v = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&v, sizeof(double) * m));
+    char* base = nullptr;
+    int rcs = dd_scratch_get(sizeof(double) * (size_t)m, s, &base);
+    if (rcs != DD_OK) return rcs;
+    double* v = reinterpret_cast<double*>(base);
     DD_HIP_CHECK(hipMemcpyAsync(v, needle_host, sizeof(double) * m, hipMemcpyHostToDevice, s));
     double vv = 0.0;
     for (int t = 0; t < m; ++t) vv += needle_host[t] * needle_host[t];
     hipLaunchKernelGGL(k_xcorr_norm, dim3(grid1(n)), dim3(256), 0, s, h, n, v, m, vv, out);
     hipError_t le = hipGetLastError();
-    hipError_t e = hipStreamSynchronize(s);
-    hipFree(v);
+    hipError_t e = hipStreamSynchronize(s);                 // the needle is the caller's host memory
     DD_HIP_CHECK(le);
     DD_HIP_CHECK(e);
     return DD_OK;

@@ -33,6 +33,12 @@ void dd_set_error(const char* fmt, ...);
 
 static inline hipStream_t dd_stream(void* s) { return (hipStream_t)s; }
 
+// Grow-only scratch buffer per device for an entry point's intermediates, reused from call to call in STREAM order: the
+// buffer belongs to the stream of the last caller, and a call on another stream first waits for that stream.  An entry
+// point that takes it neither allocates nor frees, and need not synchronise unless it reads host memory of the caller.
+int dd_scratch_get(size_t bytes, hipStream_t s, char** out);
+
+
 // Per-device one-time work (hipFuncSetAttribute and friends apply to the current device only; the C-ABI has
 // dd_set_device, so a process may drive several GPUs, from several threads).  One bit per device ordinal;
 // racing first calls on one device both do the idempotent work.

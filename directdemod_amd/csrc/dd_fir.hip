@@ -121,16 +121,13 @@ static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, in
         dd_set_error("The length of the input vector x must be greater than padlen, which is %d.", edge);
         return DD_ERR_INVALID;
     }
-    double* taps = nullptr;
-    T* y1 = nullptr;
     const int64_t N = n + 2 * (int64_t)edge;
-    DD_HIP_CHECK(hipMalloc((void**)&taps, sizeof(double) * K));
-    hipError_t e = hipMalloc((void**)&y1, sizeof(T) * N);
-    if (e != hipSuccess) {
-        hipFree(taps);
-        dd_set_error("hipMalloc: %s", hipGetErrorString(e));
-        return DD_ERR_NOMEM;
-    }
+    const size_t tb = (sizeof(double) * (size_t)K + 255) & ~(size_t)255;
+    char* base = nullptr;
+    int rcs = dd_scratch_get(tb + sizeof(T) * (size_t)N, s, &base);
+    if (rcs != DD_OK) return rcs;
+    double* taps = reinterpret_cast<double*>(base);
+    T* y1 = reinterpret_cast<T*>(base + tb);
     hipMemcpyAsync(taps, taps_host, sizeof(double) * K, hipMemcpyHostToDevice, s);
     if constexpr (sizeof(T) == 8) {
         if (dd_ff_tiled_ok(K, sizeof(T))) {
@@ -144,9 +141,7 @@ static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, in
         hipLaunchKernelGGL(k_filtfilt_bwd<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y1, out, n, edge, taps, K);
     }
     hipError_t le = hipGetLastError();
-    hipError_t se = hipStreamSynchronize(s);
-    hipFree(taps);
-    hipFree(y1);
+    hipError_t se = hipStreamSynchronize(s);               // the taps are the caller's host memory
     DD_HIP_CHECK(le);
     DD_HIP_CHECK(se);
     return DD_OK;

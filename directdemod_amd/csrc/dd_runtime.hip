@@ -88,6 +88,34 @@ extern "C" int dd_host_unregister(void* hptr) {
     if (hptr) DD_HIP_CHECK(hipHostUnregister(hptr));
     return DD_OK;
 }
+static std::mutex g_scr_mu;
+static char* g_scr_buf[64] = {nullptr};
+static size_t g_scr_bytes[64] = {0};
+static hipStream_t g_scr_stream[64] = {nullptr};
+static bool g_scr_used[64] = {false};
+int dd_scratch_get(size_t bytes, hipStream_t s, char** out) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    if (g_scr_used[dev] && g_scr_stream[dev] != s) DD_HIP_CHECK(hipStreamSynchronize(g_scr_stream[dev]));
+    if (g_scr_bytes[dev] < bytes) {
+        if (g_scr_buf[dev]) {
+            DD_HIP_CHECK(hipStreamSynchronize(g_scr_stream[dev]));
+            DD_HIP_CHECK(hipFree(g_scr_buf[dev]));
+        }
+        g_scr_buf[dev] = nullptr;
+        g_scr_bytes[dev] = 0;
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        DD_HIP_CHECK(hipMalloc((void**)&g_scr_buf[dev], want));
+        g_scr_bytes[dev] = want;
+    }
+    g_scr_stream[dev] = s;
+    g_scr_used[dev] = true;
+    *out = g_scr_buf[dev];
+    return DD_OK;
+}
+
 // Diagnostic: leave every compute unit's LDS holding `pattern` (the hardware does not clear LDS between workgroups, so a
 // kernel that reads an LDS word it never wrote sees what the previous workgroup on that CU left there).  The tests run
 // the chain kernels after a fill with NaN patterns and after a fill with zeros and demand bit-identical outputs.
