@@ -1015,10 +1015,12 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
         if (NKS == 18) {                                    // the instantiations with the in-kernel stamps (DD_STAMPS, tools only)
-            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<18, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<18>::LDS_BYTES));
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<18>::LDS_BYTES));
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
         }
@@ -1035,7 +1037,10 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
     static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
     static int launches = 0;
     const bool want_stamps_env = stamps_env != nullptr && launches++ == stamps_at;
-    const bool want_stamps = want_stamps_env && NKS == 18 && !(P.flags & DD_CHAIN_U8_INPUT);   // only these have a stamped instantiation
+    static const char* kern_env0 = getenv("DD_MFMA_KERNEL");
+    const bool ws_env = kern_env0 && strcmp(kern_env0, "ws") == 0;
+    // only these have an instantiation with the stamps compiled in: 255-tap class, complex64 input; FM output, or k_chain_mfma_ws
+    const bool want_stamps = want_stamps_env && NKS == 18 && !(P.flags & DD_CHAIN_U8_INPUT) && ((P.flags & DD_CHAIN_FM) || ws_env);
     if (want_stamps) {
         if (!stamp_buf) DD_HIP_CHECK(hipMalloc((void**)&stamp_buf, DD_STAMP_WGS * 16 * 8 * 8));
         DD_HIP_CHECK(hipMemsetAsync(stamp_buf, 0, DD_STAMP_WGS * 16 * 8 * 8, s));
@@ -1066,14 +1071,17 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
         const bool cx = !(P.flags & DD_CHAIN_FM);
         const dim3 g(grid + n_edge), b(WS_THREADS);
-        // FM output: the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
+        // the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
         static const char* kern_env = getenv("DD_MFMA_KERNEL");
-        const bool use_ab = !cx && !(kern_env && strcmp(kern_env, "ws") == 0);
+        const bool use_ab = !(kern_env && strcmp(kern_env, "ws") == 0);
+        const size_t lds_ab = (size_t)AbGeom<NKS>::LDS_BYTES;
         if (use_ab) {
-            if (u8in) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+            if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true, true>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
+            else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true, false>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
+            else if (cx) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false, true>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
             else if (NKS == 18 && t.stamps)                  // DD_STAMPS (tools): the instantiation with the in-kernel stamps compiled in
-                hipLaunchKernelGGL((k_chain_mfma_ab<18, false, true>), g, b, (size_t)AbGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
-            else hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false>), g, b, (size_t)AbGeom<NKS>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+                hipLaunchKernelGGL((k_chain_mfma_ab<18, false, false, true>), g, b, (size_t)AbGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
+            else hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false, false>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
         } else
         if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);

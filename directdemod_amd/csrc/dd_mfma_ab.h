@@ -71,7 +71,8 @@ struct AbGeom {
     static constexpr int YHCNT_OFF = YH_OFF + (AB_REG_ROWS < 16 ? 2 * YH_SET_BYTES : 0);   // [2] int: y-half buffers written (x4 waves), per set
     static constexpr int CONVCNT_OFF = YHCNT_OFF + 8;                    // [2] int: waves that have finished converting a tile into plane buffer 0 / 1
     static constexpr int WKX_OFF = (YHCNT_OFF + 16 + 15) & ~15;          // [2 sets][64 lanes][4] float2: the halo step's tile-relative phasors (kept out of the matrix waves' registers)
-    static constexpr int LDS_BYTES = WKX_OFF + 2 * 64 * 32;
+    static constexpr int SCALE_OFF = WKX_OFF + 2 * 64 * 32;              // [4] float: the power-of-two scale of tile p (complex output undoes it)
+    static constexpr int LDS_BYTES = SCALE_OFF + 16;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(MF_LDS_TILE_BYTES(NKS) <= TAPS_OFF, "the edge tile's image must not reach the tap fragments");
 };
@@ -265,7 +266,7 @@ __device__ __forceinline__ void dd_ab_unit_store(const DDChainParams& P, int b, 
 #define DD_AB_STAMP(i) if (stamp) { const unsigned long long tn = __builtin_readcyclecounter(); acc_t[i] += tn - tp; tp = tn; }
 
 // one vector-wave phase p: loads of tile p+2 | conversion of tile p | range check of tile p+1 | barrier
-template <int NKS, bool U8>
+template <int NKS, bool U8, bool CX>
 __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem, int t_begin, int n, int p,
                                              AbRaw (&rcur)[AB_VSTEPS], AbRaw (&rnext)[AB_VSTEPS], AbRaw (&rld)[AB_VSTEPS],
                                              const float2 (&wk)[AB_VSTEPS][4],
@@ -299,6 +300,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
         bool unit;
         const float scale = dd_ab_tile_scale(smem, A::RED_OFF, nu_flag, p, unit);
         if (vt == 0) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[(p + 2) & 3] = 0;   // re-arm the slot tile p+2's producers raise in phase p+1
+        if (CX && vt == 0) reinterpret_cast<float*>(smem + A::SCALE_OFF)[p & 3] = scale;
         char* planes = smem + (p & 1) * A::PLANES_BYTES;
 #ifdef AB_HALO_ON_VECTOR
         // the halo step (quads 0..XQUADS-1) on the oldest vector wave: with the vector waves at a raised priority they
@@ -347,7 +349,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
     DD_AB_STAMP(3)
 }
 
-template <int NKS, bool U8, bool ST>
+template <int NKS, bool U8, bool CX, bool ST>
 __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using A = AbGeom<NKS>;
     using Q = AbQ<NKS>;
@@ -398,9 +400,9 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
     const bool stamp = ST && taps.stamps != nullptr;       // ST: the in-kernel stamps are compiled in (tools only: ~30 scalar instructions per wave and phase)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < nph; p += 3) {                      // nph is a multiple of 6
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
-        dd_ab_vphase<NKS, U8>(P, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
+        dd_ab_vphase<NKS, U8, CX>(P, smem, t_begin, n, p, r0, r1, r2, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
+        dd_ab_vphase<NKS, U8, CX>(P, smem, t_begin, n, p + 1, r1, r2, r0, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
+        dd_ab_vphase<NKS, U8, CX>(P, smem, t_begin, n, p + 2, r2, r0, r1, wk, vt, vw, lane, stamp, acc_t, xraw, wkx);
     }
     if (stamp && lane == 0) {
         for (int q = 0; q < 4; ++q) taps.stamps[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = acc_t[q];
@@ -536,6 +538,30 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     if (mw != 0 || h != 0) out[0] = a[0];
 #pragma unroll
     for (int r = 1; r < NR; ++r) out[32 * ((r & 3) + 8 * (r >> 2))] = a[r];
+}
+
+// Complex-output flavour: the strip leaves straight from the accumulators as complex64, times the tile's start phasor
+// (the conversion rotates tile-relative) and the inverse of the power-of-two scales (tile, taps).  Row r of the lane is
+// output 32 (rowbase(r) + 4 h) + j: 256 contiguous bytes per half wave and row.  No neighbours, no boundary table.
+template <int NKS>
+__device__ __forceinline__ void dd_ab_store_cx(const DDChainParams& P, const DDMfmaTaps& taps, const char* smem, int b, int slot, int mw, int lane,
+                                               const v16f& cre, const v16f& cim) {
+    using A = AbGeom<NKS>;
+    const int j = lane & 31, h = lane >> 5;
+    const float unscale = taps.inv_tapscale / reinterpret_cast<const float*>(smem + A::SCALE_OFF)[slot & 3];
+    float2 t = make_float2(unscale, 0.f);
+    if (P.flags & DD_CHAIN_NCO) {
+        const int64_t ns = (int64_t)b * MF_ADV - 32 - MfmaGeom<NKS>::HALO;
+        const float2 ph = dd_phasor((uint64_t)(P.abs0 + ns) * P.cyc, P.nco_tbl);
+        t = make_float2(ph.x * unscale, ph.y * unscale);
+    }
+    const int64_t pw = (int64_t)b * MF_ADV - 32 + (int64_t)mw * MF_STRIP;
+    float2* out = reinterpret_cast<float2*>(P.out) + pw + j + 128 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float2 o = make_float2(fmaf(cre[r], t.x, -cim[r] * t.y), fmaf(cre[r], t.y, cim[r] * t.x));
+        if (r != 0 || mw != 0 || h != 0) out[32 * ((r & 3) + 8 * (r >> 2))] = o;   // the tile's first 32 outputs belong to the previous tile
+    }
 }
 
 // after the MFMAs: registers AB_REG_ROWS..15 (outputs 512..1023 of the strip, plus output 511 in the slack) to the set's
@@ -686,7 +712,7 @@ __device__ __forceinline__ void dd_ab_halo_convert(const DDChainParams& P, char*
 #endif
 }
 
-template <int NKS, int SET, bool U8, bool ST>
+template <int NKS, int SET, bool U8, bool CX, bool ST>
 __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
     using A = AbGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63, mw = (tid >> 6) & 3;
@@ -751,7 +777,7 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
         {   // phase pe: the rest of tile pe - 2's table, halo step of tile pe, discriminator of tile pe - 2
             const bool epi = pe >= 2 && pe - 2 < n;
 #ifdef DD_AB_DEFER
-            if (epi) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
+            if (!CX && epi) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
 #endif
             const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[pe & 3] : 0;
 #ifndef DD_AB_HALO_LATE
@@ -765,7 +791,10 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
             }
 #endif
 #ifndef DD_AB_NO_EPI
-            if (epi) dd_ab_epilogue<NKS>(P, t_begin + pe - 2, mw, lane, cre, cim, xrd);
+            if (epi) {
+                if (CX) dd_ab_store_cx<NKS>(P, taps, smem, t_begin + pe - 2, pe - 2, mw, lane, cre, cim);
+                else dd_ab_epilogue<NKS>(P, t_begin + pe - 2, mw, lane, cre, cim, xrd);
+            }
 #endif
 #ifdef DD_AB_HALO_LATE
             if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, pe, lane, xraw, wkx_lds, nu_flag);
@@ -785,9 +814,9 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
             (void)abase; (void)tb;
 #endif
 #ifndef DD_AB_DEFER
-            dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
+            if (!CX) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
 #else
-            dd_ab_publish_last(lane, cre, cim, x0);         // the rest at the start of the discriminator phase
+            if (!CX) dd_ab_publish_last(lane, cre, cim, x0);   // the rest at the start of the discriminator phase
 #endif
 #ifndef AB_YH_LATE
             if (AB_REG_ROWS < 16)
@@ -814,8 +843,8 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     }
 }
 
-// FM output only (the complex-output flavour stays on k_chain_mfma_ws).  U8: raw interleaved uint8 I,Q input.
-template <int NKS, bool U8, bool ST = false>
+// U8: raw interleaved uint8 I,Q input.  CX: complex64 output (no DD_CHAIN_FM) instead of angles.
+template <int NKS, bool U8, bool CX, bool ST = false>
 __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParams P, const DDMfmaTaps taps, int t_first, int t_last, int nwg) {
     using A = AbGeom<NKS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -844,7 +873,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_chain_mfma_ab(const DDChainParam
     }
     __syncthreads();
     const int nph = ((t_end - t_begin + 2 + 5) / 6) * 6;      // phases: a multiple of the vector loop's 3 and the matrix sets' 2
-    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0, U8, ST>(P, taps, smem, t_begin, t_end, nph);
-    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1, U8, ST>(P, taps, smem, t_begin, t_end, nph);
-    else dd_ab_vector<NKS, U8, ST>(P, taps, smem, t_begin, t_end, nph);
+    if (threadIdx.x < 256) dd_ab_matrix<NKS, 0, U8, CX, ST>(P, taps, smem, t_begin, t_end, nph);
+    else if (threadIdx.x < 512) dd_ab_matrix<NKS, 1, U8, CX, ST>(P, taps, smem, t_begin, t_end, nph);
+    else dd_ab_vector<NKS, U8, CX, ST>(P, taps, smem, t_begin, t_end, nph);
 }

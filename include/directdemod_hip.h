@@ -203,9 +203,9 @@ int dd_chain_path(const dd_chain* h);
 #define DD_KERNEL_DENSE_F32 1        /* k_chain_dense: M = 1, f32 direct form */
 #define DD_KERNEL_DECIM_TILES 2      /* k_chain_decim: M > 1, one workgroup per tile (short or unaligned chunks) */
 #define DD_KERNEL_DECIM_PERSISTENT 3 /* k_chain_decim_p: M > 1, persistent interior run + edge tiles in the same launch */
-#define DD_KERNEL_MFMA_WS 4          /* k_chain_mfma_ws: M = 1, wave-specialised MFMA kernel + edge tiles in the same launch */
+#define DD_KERNEL_MFMA_WS 4          /* k_chain_mfma_ws: M = 1, wave-specialised MFMA kernel (round 1; behind DD_MFMA_KERNEL=ws) */
 #define DD_KERNEL_MFMA_TILES 5       /* k_chain_mfma_edge: M = 1, MFMA, one workgroup per tile */
-#define DD_KERNEL_MFMA_AB 6          /* k_chain_mfma_ab: M = 1, FM output, two alternating matrix-wave sets + edge tiles in the same launch */
+#define DD_KERNEL_MFMA_AB 6          /* k_chain_mfma_ab: M = 1, FM or complex64 output, two alternating matrix-wave sets + edge tiles in the same launch */
 int dd_chain_last_kernel(const dd_chain* h);
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
 

@@ -98,12 +98,12 @@ def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8):
 
 
 def test_complex_output_chain_is_bit_reproducible(g):
-    """NCO + FIR, complex64 out: k_chain_mfma_ws."""
+    """NCO + FIR, complex64 out: k_chain_mfma_ab's complex-output flavour (and k_chain_mfma_ws behind DD_MFMA_KERNEL=ws)."""
     t = g.torch
     n = (1 << 23) + 777
     x = g.bench.make_input(t, n, 0, g.dev, 99)
     outs, kernels = _chain_runs(g, _hamming(255), 1, g.hip.DD_CHAIN_NCO, x, n, 2 * n)
-    assert set(kernels) == {g.hip.DD_KERNEL_MFMA_WS}
+    assert set(kernels) == {g.hip.DD_KERNEL_MFMA_WS if os.environ.get("DD_MFMA_KERNEL") == "ws" else g.hip.DD_KERNEL_MFMA_AB}
     _assert_identical(g, outs, 2)
 
 

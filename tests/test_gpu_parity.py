@@ -654,9 +654,9 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         no = lib.dd_chain_out_count(h, n)
         o = hip.DevArray(no, np.float32 if fm else np.complex64)
         hip.check(lib.dd_chain_process(h, d.ptr + 2 * pos, o.ptr, n, None, None))
-        # first chunk (4-byte aligned bytes): FM output runs the two-matrix-set kernel's u8 flavour, complex output the
-        # y-buffer kernel's; the second chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
-        want = (hip.DD_KERNEL_MFMA_AB if fm else hip.DD_KERNEL_MFMA_WS) if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
+        # first chunk (4-byte aligned bytes): the two-matrix-set kernel's u8 flavour (FM or complex output); the second
+        # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
+        want = hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
