@@ -293,3 +293,44 @@ def test_oracle_windows_of_the_decimated_runs(run, decim_run, where):
         (d.name, where, np.max(err[well]), np.max(err[strong]), np.median(err))
     if where == "end":
         assert k_first - 1 + len(a_ref) == d.nout                       # the window really reaches the last output
+
+
+def test_complex_output_flavour_at_full_size(run):
+    """NCO + Hamming(255), complex64 out (no FM) over the 2^26-sample input: k_chain_mfma_ab's complex-output flavour
+    against the f32 direct-form path on every output, and against the float64 oracle on windows at the stream start, a
+    tile seam and the end.  Tolerance: FIR 2e-6 of the peak (4e-6 between the two f32 kernels)."""
+    t, hip, lib = run.torch, run.hip, run.lib
+    n = run.n
+
+    def run_chain(extra):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), run.taps.ctypes.data_as(C.POINTER(C.c_double)), NTAPS,
+                                      hip.cycles_q64(F_OFF, FS), 1, hip.DD_CHAIN_NCO | extra), "dd_chain_create")
+        out = t.empty((n, 2), dtype=t.float32, device=run.dev)
+        assert run.process(h, run.x.data_ptr(), out.data_ptr(), n) == n
+        path, kern = lib.dd_chain_path(h), lib.dd_chain_last_kernel(h)
+        lib.dd_chain_destroy(h)
+        t.cuda.synchronize()
+        return out, path, kern
+
+    y, path, kern = run_chain(0)
+    assert path == 1
+    assert kern == (hip.DD_KERNEL_MFMA_WS if os.environ.get("DD_MFMA_KERNEL") == "ws" else hip.DD_KERNEL_MFMA_AB)
+    assert bool(t.isfinite(y).all())
+    peak = float(y.abs().max())
+    W = 8192
+    for w0 in (0, 4064 * 8000 - 4096, n - W):
+        h0 = max(0, w0 - (NTAPS - 1))
+        xs = run.x[h0:w0 + W].cpu().numpy().astype(np.float32)
+        xc = (xs[:, 0] + 1j * xs[:, 1]).astype(np.complex64)
+        z = O.nco(xc, F_OFF, FS, h0)
+        ref = O.FilterState(run.taps).applyOn(z) if h0 == 0 else O.lfilter_fir(run.taps, z, None)[NTAPS - 1:]
+        first = 0 if h0 == 0 else h0 + NTAPS - 1
+        got = y[first:first + len(ref)].cpu().numpy().astype(np.float64)
+        assert np.max(np.abs((got[:, 0] + 1j * got[:, 1]) - ref)) <= 2e-6 * peak, w0
+    d, path, _ = run_chain(hip.DD_CHAIN_FORCE_DIRECT)
+    assert path == 0
+    worst = 0.0
+    for s in range(0, n, 1 << 24):
+        worst = max(worst, float((y[s:s + (1 << 24)] - d[s:s + (1 << 24)]).abs().max()))
+    assert worst <= 4e-6 * peak
