@@ -352,6 +352,37 @@ def side_configs(eng, steps=10):
                     "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),
                                   "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4)}})
         lib.dd_chain_destroy(h)
+    # the headline chain on RAW u8 input (what source.IQwav reads: 2 B/sample resident instead of 8) and with complex64
+    # output (commSignal.filter without demod_fm), same kernel family
+    import torch
+    ham = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
+    x8 = (eng.xin[:n] + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+    for name, flags, src, esz, bps in (
+            ("C2 chain on raw u8 input (source.py:117-118 widened on the device), FM out", hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM | hip.DD_CHAIN_U8_INPUT, x8, 2, 6.0),
+            ("C2 front end with complex64 output (offsetFreq + Hamming 255, no demod)", hip.DD_CHAIN_NCO, eng.xin, 8, 16.0)):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), ham.ctypes.data_as(C.POINTER(C.c_double)), NTAPS, hip.cycles_q64(F_OFFSET, FS), 1, flags),
+                  "dd_chain_create")
+        got = C.c_int64(0)
+        out = torch.empty(2 * n, dtype=torch.float32, device=eng.out.device) if bps == 16.0 else eng.out
+
+        def step():
+            hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+            hip.check(lib.dd_chain_process(h, src.data_ptr(), out.data_ptr(), n, C.byref(got), eng.stream), "dd_chain_process")
+        for _ in range(100):
+            step()
+        eng.sync()
+        e0, e1 = eng.events()
+        e0.record()
+        for _ in range(10 * steps):
+            step()
+        e1.record()
+        eng.sync()
+        ms = e0.elapsed_time(e1) / (10 * steps)
+        res.append({"config": name + ", 2^26 samples, one chunk", "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
+                    "bytes_per_sample": bps, "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
+        lib.dd_chain_destroy(h)
+        del out
     return res
 
 
