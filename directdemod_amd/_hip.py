@@ -25,7 +25,7 @@ DD_ERR_NODEVICE = -5
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
 (DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
- DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB) = range(7)
+ DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS) = range(8)
 # element type of raw interleaved uint8 I,Q pairs held on the device (source.py:117-118 not yet applied): 2 B/sample
 IQ8 = np.dtype([("i", np.uint8), ("q", np.uint8)])
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "dd_host_register": (_int, [_p, _sz]),
     "dd_host_unregister": (_int, [_p]),
     "dd_debug_fill_lds": (_int, [C.c_uint32, _p]),
+    "dd_debug_fft_block": (_int, [_p, C.POINTER(C.c_double), _int, C.c_uint64, _int, _int, _p, _p]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2h": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2d": (_int, [_p, _p, _sz, _p]),

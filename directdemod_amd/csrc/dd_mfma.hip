@@ -28,6 +28,7 @@
 //   k_chain_mfma_edge  stream start/end, unaligned or u8 input, partial tiles: one tile
 //                      per 4-wave workgroup, fully predicated, same MFMA core.
 #include "dd_chain_kernels.h"
+#include "dd_fftfir.h"
 #include <stdlib.h>
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
@@ -935,6 +936,9 @@ struct DDMfmaState {
     int nks;
     v8h* frag;          // device
     float inv_tapscale;
+    std::vector<double> taps;
+    void* fft;          // overlap-save FFT form of the interior run (dd_fftfir.hip), lazy
+    int fft_tried;
 };
 
 static int mfma_nks_for(int K) {
@@ -982,6 +986,9 @@ int dd_mfma_create(void** st, const double* taps, int K) {
     s->nks = nks;
     s->frag = nullptr;
     s->inv_tapscale = (float)(1.0 / tapscale);
+    s->taps.assign(taps, taps + K);
+    s->fft = nullptr;
+    s->fft_tried = 0;
     hipError_t e = hipMalloc((void**)&s->frag, frag.size() * sizeof(_Float16));
     if (e == hipSuccess) e = hipMemcpy(s->frag, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -997,6 +1004,7 @@ int dd_mfma_create(void** st, const double* taps, int K) {
 void dd_mfma_destroy(void* st) {
     DDMfmaState* s = reinterpret_cast<DDMfmaState*>(st);
     if (!s) return;
+    if (s->fft) dd_fft_destroy(s->fft);
     hipFree(s->frag);
     delete s;
 }
@@ -1004,7 +1012,7 @@ void dd_mfma_destroy(void* st) {
 #define DD_STAMP_WGS 1024      // workgroups the DD_STAMPS diagnostic buffer holds
 
 template <int NKS>
-static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s, int* kernel_id) {
+static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* kernel_id) {
     using G = MfmaGeom<NKS>;
     const size_t lds = (size_t)MF_LDS_TILE_BYTES(NKS);
     const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
@@ -1037,7 +1045,7 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
     static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
     static int launches = 0;
     const bool want_stamps_env = stamps_env != nullptr && launches++ == stamps_at;
-    static const char* kern_env0 = getenv("DD_MFMA_KERNEL");
+    const char* kern_env0 = getenv("DD_MFMA_KERNEL");
     const bool ws_env = kern_env0 && strcmp(kern_env0, "ws") == 0;
     // only these have an instantiation with the stamps compiled in: 255-tap class, complex64 input; FM output, or k_chain_mfma_ws
     const bool want_stamps = want_stamps_env && NKS == 18 && !(P.flags & DD_CHAIN_U8_INPUT) && ((P.flags & DD_CHAIN_FM) || ws_env);
@@ -1061,6 +1069,24 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         if (hi >= lo) { t_first = (int)lo; t_last = (int)hi + 1; }
     }
     const int n_int = t_last - t_first;
+    const char* kern_env1 = getenv("DD_MFMA_KERNEL");        // read per launch: tools switch kernels inside one process
+    const bool want_fft = kern_env1 && strcmp(kern_env1, "fft") == 0;
+    if (n_int > 0 && want_fft && dd_fft_supported(st->K, 1, P.flags)) {
+        // interior run through the overlap-save FFT kernel, the tiles around it through the stand-alone edge kernel
+        if (!st->fft && !st->fft_tried) {
+            st->fft_tried = 1;
+            if (dd_fft_create(&st->fft, st->taps.data(), st->K) != DD_OK) st->fft = nullptr;
+        }
+        if (st->fft) {
+            const int n_edge = t_first + (P.nblocks - t_last);
+            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
+            DD_LAUNCH_CHECK();
+            int rc = dd_fft_launch(st->fft, P, (int64_t)t_first * MF_ADV, (int64_t)t_last * MF_ADV, s);
+            if (rc != DD_OK) return rc;
+            if (kernel_id) *kernel_id = DD_KERNEL_FFT_OS;
+            return DD_OK;
+        }
+    }
     if (n_int > 0) {
         // one 16-wave workgroup per CU (LDS bound): persistent workgroups for the interior run plus
         // one workgroup per edge tile (both sides of the run), all resident at once -- the edge
@@ -1072,7 +1098,7 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
         const bool cx = !(P.flags & DD_CHAIN_FM);
         const dim3 g(grid + n_edge), b(WS_THREADS);
         // the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
-        static const char* kern_env = getenv("DD_MFMA_KERNEL");
+        const char* kern_env = kern_env1;
         const bool use_ab = !(kern_env && strcmp(kern_env, "ws") == 0);
         const size_t lds_ab = (size_t)AbGeom<NKS>::LDS_BYTES;
         if (use_ab) {
@@ -1150,7 +1176,7 @@ static int mfma_launch_t(const DDMfmaState* st, DDChainParams& P, hipStream_t s,
 }
 
 int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s, int* kernel_id) {
-    const DDMfmaState* st = reinterpret_cast<const DDMfmaState*>(stv);
+    DDMfmaState* st = reinterpret_cast<DDMfmaState*>(stv);
     DDChainParams P = Pin;
     P.T = MF_T;
     P.nblocks = (int)((P.Ld + MF_ADV - 1) / MF_ADV);
