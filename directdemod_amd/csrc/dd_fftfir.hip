@@ -226,13 +226,30 @@ __device__ __forceinline__ void ff_load_block(const void* in, int64_t n0, int64_
 
 // FIR outputs [p_a, p_b) of the chunk (interior: every input the blocks read up to the run's last output lies inside the
 // chunk) -> FM angles out[p - s].  Persistent: workgroup g takes a contiguous run of the nblk blocks.
+// timing ablations (tools/mkvariant.sh N dd_fftfir -DFF_NO_xxx; results are wrong by construction, never shipped):
+//   FF_NO_STORE  no output stores        FF_NO_LOAD   no input loads (the first block's samples are reused)
+//   FF_NO_BARRIER no workgroup barriers  FF_NO_LDS    no exchanges at all (registers pass straight through)
+//   FF_NO_DISC   no discriminator (one component of the FIR output is stored)
+#ifdef FF_NO_BARRIER
+#define FF_SYNC() asm volatile("" ::: "memory")
+#else
+#define FF_SYNC() __syncthreads()
+#endif
+#define FF_STAMP(i)                                                                                   \
+    if (DBG == 2) {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        const unsigned long long tn = __builtin_readcyclecounter();                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        acc_t[i] += tn - tp;                                                                          \
+        tp = tn;                                                                                      \
+    }
 #define FF_DUMP(st)                                                                                   \
-    if (DBG && T.dbg_stage == (st)) {                                                                 \
+    if (DBG == 1 && T.dbg_stage == (st)) {                                                                 \
         for (int k = 0; k < 16; ++k) T.dbg[t * 16 + k] = make_float2(a[k].x, a[k].y);                 \
         return;                                                                                       \
     }
 
-template <bool U8, bool DBG = false>
+template <bool U8, int DBG = 0>
 __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams P, const DDFftTabs T, int64_t p_a, int64_t p_b, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f* const X1 = reinterpret_cast<v2f*>(smem);
@@ -270,11 +287,23 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
     const int x2w = hi * FF_S2 + lo;            // + 17 k1       thread (k0, n0) writes element k1
     const int x2r = hi * FF_S2 + lo * 17;       // + n0          thread (k0, k1) reads element n0
 
+    // every load issued so far (tables, first block) is complete before the loop: the compiler's wait-count analysis merges
+    // the loop header's state with the pre-loop state on every iteration, so a table register first used inside the loop
+    // would otherwise get a vmcnt wait there that, in the steady state, waits for the block loads issued just before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    unsigned long long acc_t[24], tp = 0;
+    if (DBG == 2) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) acc_t[i] = 0;
+        tp = __builtin_readcyclecounter();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = nx[r];
     for (int q = q_begin; q < q_end; ++q) {
         const int64_t p0 = p_a + (int64_t)FF_ADV * q;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = nx[r];
+#ifndef FF_NO_LOAD
         if (q + 1 < q_end) ff_load_block<U8>(P.in, p0 + FF_ADV - 256, nmax, t, nx);
+#endif
 
         FF_DUMP(0)
         // ---- forward pass 1 (over n2), T1, X1
@@ -282,23 +311,39 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
         FF_DUMP(1)
         ff_twiddle15<false, true>(a, tw1);
         FF_DUMP(2)
+        FF_STAMP(0)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) X1[x1w + FF_S1 * k] = a[FF_P(k)];
-        __syncthreads();
+#endif
+        FF_STAMP(1)
+        FF_SYNC();
+        FF_STAMP(2)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = X1[x1r + 16 * k];
+#endif
         FF_DUMP(3)
+        FF_STAMP(3)
         // ---- forward pass 2 (over n1), T2, X2
         ff_bfly16<false>(a);
         FF_DUMP(4)
         ff_twiddle15<false, true>(a, tw2);
         FF_DUMP(5)
+        FF_STAMP(4)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) X2[x2w + 17 * k] = a[FF_P(k)];
-        __syncthreads();
+#endif
+        FF_STAMP(5)
+        FF_SYNC();
+        FF_STAMP(6)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = X2[x2r + k];
+#endif
         FF_DUMP(6)
+        FF_STAMP(7)
         // ---- forward pass 3 (over n0), spectrum product, inverse pass 3
         ff_bfly16<false>(a);
         FF_DUMP(7)
@@ -314,23 +359,39 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
         FF_DUMP(15)
         ff_bfly16<true>(a);
         FF_DUMP(8)
+        FF_STAMP(8)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) X2[x2r + k] = a[FF_P(k)];
-        __syncthreads();
+#endif
+        FF_STAMP(9)
+        FF_SYNC();
+        FF_STAMP(10)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = X2[x2w + 17 * k];
+#endif
         FF_DUMP(9)
+        FF_STAMP(11)
         // ---- T2*, inverse pass 2
         ff_twiddle15<true, false>(a, tw2);
         FF_DUMP(10)
         ff_bfly16<true>(a);
         FF_DUMP(11)
+        FF_STAMP(12)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) X1[x1r + 16 * k] = a[FF_P(k)];
-        __syncthreads();
+#endif
+        FF_STAMP(13)
+        FF_SYNC();
+        FF_STAMP(14)
+#ifndef FF_NO_LDS
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = X1[x1w + FF_S1 * k];
+#endif
         FF_DUMP(12)
+        FF_STAMP(15)
         // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + t + 256 r]
         ff_twiddle15<true, false>(a, tw1);
         FF_DUMP(13)
@@ -344,7 +405,9 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) EDGE[wave * 16 + r] = a[FF_P(r)];
         }
-        __syncthreads();
+        FF_STAMP(16)
+        FF_SYNC();
+        FF_STAMP(17)
         {
             const int eidx = wave > 0 ? (wave - 1) * 16 : 3 * 16 - 1;
             v2f zz[16];
@@ -364,18 +427,42 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
             for (int r = 1; r < 16; ++r) zz[r] = ff_mul_lo(a[FF_P(r)], crot);
 #pragma unroll
             for (int r = 1; r < 16; ++r) zz[r] = ff_fma_hi(a[FF_P(r)], crot, zz[r]);
+            FF_STAMP(18)
             bool small = true;
 #pragma unroll
             for (int r = 1; r < 16; ++r) small = small && (fabsf(zz[r].y) <= 0.41421356f * zz[r].x);
             float ang[16];
-            if (__builtin_amdgcn_ballot_w64(!small) == 0) {        // wave-uniform: every |angle| of the wave's 960 outputs below 22.5 degrees
+#ifdef FF_NO_DISC
+#pragma unroll
+            for (int r = 1; r < 16; ++r) ang[r] = zz[r].x;
+            if (false) {
+#else
+            if (__builtin_amdgcn_ballot_w64(!small) == 0) {
+#endif        // wave-uniform: every |angle| of the wave's 960 outputs below 22.5 degrees
 #pragma unroll
                 for (int r = 1; r < 16; ++r) ang[r] = ff_atan_small(zz[r].y, zz[r].x);
             } else {
+#ifndef FF_NO_DISC
 #pragma unroll
                 for (int r = 1; r < 16; ++r) ang[r] = ff_atan2(zz[r].y, zz[r].x);
+#endif
             }
+            FF_STAMP(19)
+            // the next block's samples move into the working registers BEFORE this block's stores are issued: the wait for
+            // those loads (issued a whole block ago) then cannot include the stores -- vmcnt counts in order, and behind
+            // the branches of the store section the compiler has to assume that no younger operation covers the loads
+            // (written as volatile moves that memory operations may not cross: as plain assignments the copies are placed
+            // on the loop's back edge, behind the stores)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b64 %0, %1" : "=v"(a[r]) : "v"(nx[r]) : "memory");
+            FF_STAMP(20)
             float* const ob = outp + (p0 - P.s) + t;
+#ifdef FF_NO_STORE
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 1; r < 16; ++r) sacc += ang[r];
+            if (sacc == 1234.5f) ob[0] = sacc;
+#else
             if (p0 + FF_ADV <= p_b) {
 #pragma unroll
                 for (int r = 1; r < 16; ++r) ob[256 * (r - 1)] = ang[r];
@@ -384,7 +471,212 @@ __global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams
                 for (int r = 1; r < 16; ++r)
                     if (p0 + t + 256 * (r - 1) < p_b) ob[256 * (r - 1)] = ang[r];
             }
+#endif
         }
+        FF_STAMP(21)
+    }
+    if (DBG == 2 && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(T.dbg) + ((size_t)blockIdx.x * 4 + wave) * 24;
+#pragma unroll
+        for (int i = 0; i < 22; ++i) o[i] = acc_t[i];
+        o[23] = (unsigned long long)(q_end - q_begin);
+    }
+}
+
+// ============================================================================
+// k_chain_fft1k: the same convolution with ONE WAVE PER BLOCK -- 1024-point blocks (16 x 16 x 4), 768 outputs each.
+//
+// What the 4096-point kernel above measured: the vector pipe 47 % busy.  One wave issues a VALU
+// instruction every 4.8 cycles at best (a packed one occupies the SIMD for ~2.9), so a SIMD needs two or more waves in
+// an arithmetic phase at once; with 224 registers and 72 KB of LDS per 4-wave workgroup only two waves share a SIMD,
+// the four waves of a workgroup meet at five barriers per block and reach their load / store / exchange phases
+// together (a CU's single address unit takes ~16 cycles per 64-lane dwordx2 instruction: 16 back-to-back loads from 8
+// waves cost each wave 1000-1500 cycles).  Here a wave owns its block: both exchanges are intra-wave (no barrier at all,
+// only lgkmcnt waits), every wave runs at its own phase, 12 waves per CU (3 per SIMD, 168 registers, 10.5 KB of LDS
+// each).  1024 points cost 10 butterfly levels instead of 12, which pays for the 25 % overlap: fewer vector
+// instructions per output than the 4096-point form, for 25 % more LDS bytes and load instructions per output.
+//
+//   n = 64 n2 + 4 n1 + n0,  k = k0 + 16 k1 + 256 k2,  W = e^{-2 pi j / 1024}:
+//   W^{nk} = W16^{n2 k0} . W^{(4 n1 + n0) k0} . W16^{n1 k1} . W64^{n0 k1} . W4^{n0 k2}
+//   forward: B1 (16, over n2) | T1 = W^{lane k0} | X1 | B2 (16, over n1) | T2 = W64^{n0 k1} | X2 | B3 (4 x radix 4, over n0)
+//   lane roles: pass 1 (n1, n0) = lane; pass 2 (k0, n0), lane = 4 k0 + n0; pass 3 (k0, j), lane = 4 k0 + j, registers
+//   4 c + n0 for k1 = 4 c + j.  X1 element (k0, n1, n0) at 68 k0 + 4 n1 + n0, X2 element (k0, k1, n0) at 84 k0 + 5 k1 + n0
+//   (both conflict free for the contiguous ds_write_b64 and the strided ds_read_b64, tools/debug/lds_layout.py); the two
+//   images share one buffer: a wave's LDS operations execute in order and it has read an image completely before it
+//   writes the next.
+#define F1_N 1024
+#define F1_ADV 768                  // outputs per block: rows 4..15 of [16][64]
+#define F1_S1 68
+#define F1_S2 84
+#define F1_WAVE_BYTES (16 * F1_S2 * 8)          // 10752
+#define F1_WAVES 4
+#define F1_HP_OFF (F1_WAVES * F1_WAVE_BYTES)     // the tap spectrum as the lanes multiply it, [16][64] complex64: one copy per workgroup
+#define F1_LDS_BYTES (F1_HP_OFF + 16 * 64 * 8)
+
+struct DDFft1kTabs {
+    const float2* tw1;     // [64][16]   W1024^{lane k}
+    const float2* tw2;     // [4][16]    W64^{n0 k}
+    const float2* hp;      // [16][64]   H[k0 + 16 (4 c + j) + 256 k2] / 1024 at [4 c + k2][4 k0 + j]
+    float2 crot;
+};
+
+template <bool U8, bool CLAMP = false>
+__device__ __forceinline__ void f1_load_block(const void* in, int64_t n0, int lane, v2f (&x)[16], unsigned lim = 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned m = (unsigned)lane + 64u * r;
+        if (CLAMP) m = m < lim ? m : lim;
+        if (U8) {
+            const uchar2 u = (reinterpret_cast<const uchar2*>(in) + n0)[m];
+            x[r] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
+        } else {
+            const float2 v = (reinterpret_cast<const float2*>(in) + n0)[m];
+            x[r] = (v2f){v.x, v.y};
+        }
+    }
+}
+
+// one block: a[] holds the 1024 samples n0 .. n0+1023 (lane + 64 r) on entry; on exit, when LOADNEXT, the next block's.
+// out_row4 points at the output of row 4, lane 0.  PARTIAL: outputs at or beyond `limit` (relative to out_row4) are not stored.
+template <bool U8, bool PARTIAL, bool LOADNEXT>
+__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f* const X, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
+                                         const v2f crot, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int limit) {
+    const int hi = lane >> 2, lo = lane & 3;
+    const int x1w = lane;                    // + 68 k0
+    const int x1r = hi * F1_S1 + lo;         // + 4 n1
+    const int x2w = hi * F1_S2 + lo;         // + 5 k1
+    const int x2r = hi * F1_S2 + 5 * lo;     // + 20 c + n0      (k1 = 4 c + j)
+    // ---- forward pass 1 (over n2), T1, X1
+    ff_bfly16<false>(a);
+    ff_twiddle15<false, true>(a, tw1);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[x1w + F1_S1 * k] = a[FF_P(k)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = X[x1r + 4 * k];
+    // ---- forward pass 2 (over n1), T2, X2
+    ff_bfly16<false>(a);
+    ff_twiddle15<false, true>(a, tw2);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[x2w + 5 * k] = a[FF_P(k)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) a[4 * c + n] = X[x2r + 20 * c + n];
+    // ---- forward pass 3 (radix 4 over n0), spectrum product, inverse pass 3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ff_r4<false, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+    {
+        v2f z[16], h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = hp[64 * k];        // (this lane's column of the spectrum image in LDS)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) z[k] = ff_mul_lo(a[k], h[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = ff_fma_hi(a[k], h[k], z[k]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ff_r4<true, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) X[x2r + 20 * c + n] = a[4 * c + n];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = X[x2w + 5 * k];
+    // ---- T2*, inverse pass 2
+    ff_twiddle15<true, false>(a, tw2);
+    ff_bfly16<true>(a);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[x1r + 4 * k] = a[FF_P(k)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = X[x1w + F1_S1 * k];
+    // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + lane + 64 r]
+    ff_twiddle15<true, false>(a, tw1);
+    ff_bfly16<true>(a);
+    // ---- discriminator, rows 4..15: left-hand neighbour = lane - 1 of the same row (wave_shr:1); lane 0 takes lane 63 of
+    // the row above (wave_ror:1 of that row as the DPP's `old` operand, which a lane without a source lane keeps)
+    v2f zz[16];
+#pragma unroll
+    for (int r = 4; r < 16; ++r) {
+        const v2f cur = a[FF_P(r)], up = a[FF_P(r - 1)];
+        const int ox = __builtin_amdgcn_update_dpp(0, __float_as_int(up.x), 0x13C, 0xf, 0xf, false);
+        const int oy = __builtin_amdgcn_update_dpp(0, __float_as_int(up.y), 0x13C, 0xf, 0xf, false);
+        v2f prv;
+        prv.x = __int_as_float(__builtin_amdgcn_update_dpp(ox, __float_as_int(cur.x), 0x138, 0xf, 0xf, false));
+        prv.y = __int_as_float(__builtin_amdgcn_update_dpp(oy, __float_as_int(cur.y), 0x138, 0xf, 0xf, false));
+        zz[r] = prv;
+    }
+    {
+        v2f t[16];
+#pragma unroll
+        for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(a[FF_P(r)], zz[r]);
+#pragma unroll
+        for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hic(a[FF_P(r)], zz[r], t[r]);      // w[m] conj(w[m-1])
+#pragma unroll
+        for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(zz[r], crot);
+#pragma unroll
+        for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hi(zz[r], crot, t[r]);             // the NCO's rotation per sample
+    }
+    if (LOADNEXT) f1_load_block<U8>(in, n0_next, lane, a);      // a[] is dead: the next block's samples fly during the angles and stores
+    bool small = true;
+#pragma unroll
+    for (int r = 4; r < 16; ++r) small = small && (fabsf(zz[r].y) <= 0.41421356f * zz[r].x);
+    float ang[16];
+    if (__builtin_amdgcn_ballot_w64(!small) == 0) {        // wave-uniform: every |angle| of the block's 768 outputs below 22.5 degrees
+#pragma unroll
+        for (int r = 4; r < 16; ++r) ang[r] = ff_atan_small(zz[r].y, zz[r].x);
+    } else {
+#pragma unroll
+        for (int r = 4; r < 16; ++r) ang[r] = ff_atan2(zz[r].y, zz[r].x);
+    }
+    float* const ob = out_row4 + lane;
+#pragma unroll
+    for (int r = 4; r < 16; ++r)
+        if (!PARTIAL || lane + 64 * (r - 4) < limit) ob[64 * (r - 4)] = ang[r];
+}
+
+// FIR outputs [p_a, p_b) of the chunk -> FM angles out[p - s]; every wave takes a contiguous run of the nblk blocks
+template <bool U8>
+__global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, int64_t p_a, int64_t p_b, int nblk, int nwaves) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2f* const X = reinterpret_cast<v2f*>(smem + wave * F1_WAVE_BYTES);
+    const int gw = blockIdx.x * F1_WAVES + wave;
+    const int q_begin = (int)(((int64_t)nblk * gw) / nwaves), q_end = (int)(((int64_t)nblk * (gw + 1)) / nwaves);
+    v2f* const HP = reinterpret_cast<v2f*>(smem + F1_HP_OFF);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float2 h = T.hp[threadIdx.x + 256 * i];
+        HP[threadIdx.x + 256 * i] = (v2f){h.x, h.y};
+    }
+    __syncthreads();                           // the only barrier of the kernel, before any wave may leave
+    if (q_begin >= q_end) return;
+    const v2f* const hp = HP + lane;
+    v2f tw1[16], tw2[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float2 u = T.tw1[lane * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
+        tw1[k] = (v2f){u.x, u.y};
+        tw2[k] = (v2f){w.x, w.y};
+    }
+    const v2f crot = {T.crot.x, T.crot.y};
+    float* const outp = reinterpret_cast<float*>(P.out);
+    v2f a[16];
+    f1_load_block<U8>(P.in, p_a + (int64_t)F1_ADV * q_begin - 256, lane, a);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
+    // the run's last block may be partial; it is also the only one whose 1024 samples may reach past the chunk's end (behind
+    // the run's last output), so it is loaded on its own, with clamped indices, instead of being prefetched
+    const bool last_partial = (q_end == nblk) && (p_a + (int64_t)F1_ADV * nblk > p_b);
+    const int q_full_end = last_partial ? q_end - 1 : q_end;
+    for (int q = q_begin; q < q_full_end; ++q) {
+        const int64_t p0 = p_a + (int64_t)F1_ADV * q;
+        const int64_t n0_next = (q + 1 < q_full_end) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
+        f1_block<U8, false, true>(a, X, tw1, tw2, hp, crot, lane, P.in, n0_next, outp + (p0 - P.s), 0);
+    }
+    if (last_partial) {
+        const int64_t p0 = p_a + (int64_t)F1_ADV * (q_end - 1);
+        const int64_t room = P.L - 1 - (p0 - 256);
+        f1_load_block<U8, true>(P.in, p0 - 256, lane, a, (unsigned)(room < F1_N - 1 ? room : F1_N - 1));
+        f1_block<U8, true, false>(a, X, tw1, tw2, hp, crot, lane, P.in, 0, outp + (p0 - P.s), (int)(p_b - p0));
     }
 }
 
@@ -395,14 +687,17 @@ struct DDFftState {
     float2* tw1;
     float2* tw2;
     float2* hp;
+    float2* tw1k;       // tables of k_chain_fft1k
+    float2* tw2k;
+    float2* hp1;
     uint64_t cyc;
     int have_h;
     int nco;
 };
 
-static void fft4096(std::vector<std::complex<double>>& v) {
+static void fft_pow2(std::vector<std::complex<double>>& v) {
     // iterative radix-2, double precision (host, once per (taps, frequency))
-    const int n = FF_N;
+    const int n = (int)v.size();
     for (int i = 1, j = 0; i < n; ++i) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -430,7 +725,7 @@ int dd_fft_create(void** st, const double* taps, int K) {
     DDFftState* s = new DDFftState();
     s->K = K;
     s->taps.assign(taps, taps + K);
-    s->tw1 = s->tw2 = s->hp = nullptr;
+    s->tw1 = s->tw2 = s->hp = s->tw1k = s->tw2k = s->hp1 = nullptr;
     s->cyc = 0;
     s->have_h = 0;
     s->nco = 0;
@@ -445,7 +740,23 @@ int dd_fft_create(void** st, const double* taps, int K) {
             const double ang = -2.0 * M_PI * (double)((n0 * k) % 256) / 256.0;
             t2[n0 * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
         }
+    std::vector<float2> u1(64 * 16), u2(4 * 16);
+    for (int t = 0; t < 64; ++t)
+        for (int k = 0; k < 16; ++k) {
+            const double ang = -2.0 * M_PI * (double)((t * k) % F1_N) / (double)F1_N;
+            u1[t * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    for (int n0 = 0; n0 < 4; ++n0)
+        for (int k = 0; k < 16; ++k) {
+            const double ang = -2.0 * M_PI * (double)((n0 * k) % 64) / 64.0;
+            u2[n0 * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
+        }
     hipError_t e = hipMalloc((void**)&s->tw1, t1.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tw1k, u1.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tw2k, u2.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->hp1, 64 * 16 * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(s->tw1k, u1.data(), u1.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->tw2k, u2.data(), u2.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&s->tw2, t2.size() * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void**)&s->hp, 256 * 16 * sizeof(float2));
     if (e == hipSuccess) e = hipMemcpy(s->tw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice);
@@ -465,6 +776,9 @@ void dd_fft_destroy(void* stv) {
     if (s->tw1) (void)hipFree(s->tw1);
     if (s->tw2) (void)hipFree(s->tw2);
     if (s->hp) (void)hipFree(s->hp);
+    if (s->tw1k) (void)hipFree(s->tw1k);
+    if (s->tw2k) (void)hipFree(s->tw2k);
+    if (s->hp1) (void)hipFree(s->hp1);
     delete s;
 }
 
@@ -480,7 +794,17 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * ph;
         g[k] = std::complex<double>((double)(s->taps[k] * cosl(a)), (double)(s->taps[k] * sinl(a)));
     }
-    fft4096(g);
+    std::vector<std::complex<double>> g1(g.begin(), g.begin() + F1_N);     // the same taps, zero padded to 1024
+    fft_pow2(g);
+    fft_pow2(g1);
+    std::vector<float2> hp1(64 * 16);
+    for (int k0 = 0; k0 < 16; ++k0)
+        for (int j = 0; j < 4; ++j)
+            for (int c = 0; c < 4; ++c)
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const std::complex<double> h = g1[k0 + 16 * (4 * c + j) + 256 * k2] / (double)F1_N;
+                    hp1[(4 * c + k2) * 64 + 4 * k0 + j] = make_float2((float)h.real(), (float)h.imag());
+                }
     std::vector<float2> hp(256 * 16);
     for (int k0 = 0; k0 < 16; ++k0)
         for (int k1 = 0; k1 < 16; ++k1)
@@ -492,6 +816,7 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
     // lives until the copy has been consumed
     DD_HIP_CHECK(hipStreamSynchronize(stream));
     DD_HIP_CHECK(hipMemcpy(s->hp, hp.data(), hp.size() * sizeof(float2), hipMemcpyHostToDevice));
+    DD_HIP_CHECK(hipMemcpy(s->hp1, hp1.data(), hp1.size() * sizeof(float2), hipMemcpyHostToDevice));
     s->cyc = cyc;
     s->nco = (int)nco;
     s->have_h = 1;
@@ -521,12 +846,57 @@ int dd_fft_launch(void* stv, const DDChainParams& P, int64_t p_a, int64_t p_b, h
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * frac;
         T.crot = make_float2((float)cosl(a), (float)-sinl(a));
     }
+    const char* kern_env = getenv("DD_MFMA_KERNEL");
+    if (kern_env && strcmp(kern_env, "fft1k") == 0) {
+        static DDOncePerDevice attr1;
+        if (attr1.need()) {
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+            attr1.mark();
+        }
+        DDFft1kTabs T1;
+        T1.tw1 = s->tw1k; T1.tw2 = s->tw2k; T1.hp = s->hp1; T1.crot = T.crot;
+        const int nb1 = (int)((p_b - p_a + F1_ADV - 1) / F1_ADV);
+        static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");
+        const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
+        int grid1 = dd_cu_count() * (per_cu1 > 0 ? per_cu1 : 3);
+        if (grid1 * F1_WAVES > nb1) grid1 = (nb1 + F1_WAVES - 1) / F1_WAVES;
+        if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, p_a, p_b, nb1, grid1 * F1_WAVES);
+        else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, p_a, p_b, nb1, grid1 * F1_WAVES);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     const int64_t nblk64 = (p_b - p_a + FF_ADV - 1) / FF_ADV;
     const int nblk = (int)nblk64;
     static const char* wg_env = getenv("DD_FFT_WGS_PER_CU");
     const int per_cu = wg_env ? atoi(wg_env) : 2;
     int grid = dd_cu_count() * (per_cu > 0 ? per_cu : 2);
     if (grid > nblk) grid = nblk;
+    static const char* st_env = getenv("DD_FFT_STAMPS");
+    static int st_count = 0;
+    if (st_env && !(P.flags & DD_CHAIN_U8_INPUT) && st_count++ == atoi(st_env)) {
+        // diagnostic: per-wave cycle sums of the 19 segments of a block, averaged over waves and blocks
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
+        unsigned long long* buf = nullptr;
+        const size_t nw = (size_t)grid * 4 * 24;
+        DD_HIP_CHECK(hipMalloc((void**)&buf, nw * 8));
+        T.dbg = reinterpret_cast<float2*>(buf);
+        hipLaunchKernelGGL((k_chain_fft<false, 2>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
+        std::vector<unsigned long long> hb(nw);
+        DD_HIP_CHECK(hipMemcpy(hb.data(), buf, nw * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(buf);
+        const char* nm[22] = {"load wait + pass 1", "X1 writes", "barrier", "X1 reads", "pass 2", "X2 writes", "barrier", "X2 reads", "pass 3 + H + inverse 3",
+                              "X2' writes", "barrier", "X2' reads", "inverse 2", "X1' writes", "barrier", "X1' reads", "inverse 1 + edge", "barrier", "edge reads, z = w conj(w') c", "angles", "next block into registers", "stores"};
+        double tot = 0;
+        for (int i = 0; i < 22; ++i) {
+            double sum = 0, nb = 0;
+            for (size_t w = 0; w < (size_t)grid * 4; ++w) { sum += (double)hb[w * 24 + i]; nb += (double)hb[w * 24 + 23]; }
+            fprintf(stderr, "[fft stamps] %-26s %8.0f cycles per block\n", nm[i], sum / nb);
+            tot += sum / nb;
+        }
+        fprintf(stderr, "[fft stamps] total %.0f cycles per block and wave, %d workgroups, %d blocks\n", tot, grid, nblk);
+        return DD_OK;
+    }
     if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft<true>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
     else hipLaunchKernelGGL((k_chain_fft<false>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
     DD_LAUNCH_CHECK();
@@ -543,7 +913,7 @@ extern "C" int dd_debug_fft_block(const float* in_c64, const double* taps, int n
     hipStream_t hs = dd_stream(stream);
     rc = fft_prepare(s, nco != 0, cycles_q64, hs);
     if (rc != DD_OK) { dd_fft_destroy(st); return rc; }
-    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
+    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
     DDChainParams P;
     memset(&P, 0, sizeof(P));
     float* scratch = nullptr;
@@ -561,7 +931,7 @@ extern "C" int dd_debug_fft_block(const float* in_c64, const double* taps, int n
     T.crot = make_float2(1.f, 0.f);
     T.dbg = reinterpret_cast<float2*>(out_c64);
     T.dbg_stage = stage;
-    hipLaunchKernelGGL((k_chain_fft<false, true>), dim3(1), dim3(FF_THREADS), FF_LDS_BYTES, hs, P, T, (int64_t)256, (int64_t)(256 + FF_ADV), 1);
+    hipLaunchKernelGGL((k_chain_fft<false, 1>), dim3(1), dim3(FF_THREADS), FF_LDS_BYTES, hs, P, T, (int64_t)256, (int64_t)(256 + FF_ADV), 1);
     hipError_t e = hipStreamSynchronize(hs);
     (void)hipFree(scratch);
     dd_fft_destroy(st);

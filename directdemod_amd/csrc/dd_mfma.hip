@@ -1070,7 +1070,7 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     }
     const int n_int = t_last - t_first;
     const char* kern_env1 = getenv("DD_MFMA_KERNEL");        // read per launch: tools switch kernels inside one process
-    const bool want_fft = kern_env1 && strcmp(kern_env1, "fft") == 0;
+    const bool want_fft = kern_env1 && (strcmp(kern_env1, "fft") == 0 || strcmp(kern_env1, "fft1k") == 0);
     if (n_int > 0 && want_fft && dd_fft_supported(st->K, 1, P.flags)) {
         // interior run through the overlap-save FFT kernel, the tiles around it through the stand-alone edge kernel
         if (!st->fft && !st->fft_tried) {
