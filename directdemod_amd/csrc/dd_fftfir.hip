@@ -518,50 +518,131 @@ struct DDFft1kTabs {
     const float2* tw2;     // [4][16]    W64^{n0 k}
     const float2* hp;      // [16][64]   H[k0 + 16 (4 c + j) + 256 k2] / 1024 at [4 c + k2][4 k0 + j]
     float2 crot;
+    int stagger;           // s_sleep units (64 cycles) by which the second / third third of the grid start later
 };
 
+// A lane moves TWO consecutive samples per memory instruction (one 16-byte load, one 8-byte store of two angles): the
+// CU's address unit takes as long for a 4- or 8-byte-per-lane instruction as for a 16-byte one, and the memory
+// instructions were what the first version of this kernel waited for (ablation: without its 12 dwordx2 loads per
+// block 0.192 ms instead of 0.229; issued but never consumed 0.224 -- their cost, not their latency).  Loaded that
+// way, lane l = 32 h + i holds samples 64 (2 r + h) + 2 i + e of row pair r (e = 0, 1): both columns 2i, 2i+1 at every
+// second row.  One v_permlane32_swap per register pair exchanges the upper half of the first register with the lower
+// half of the second, after which lane l holds column t = 2 i + h at ALL rows -- the layout the first pass needs; the
+// same swap after the last pass turns it back into two consecutive outputs per lane, so the left-hand neighbour of the
+// second is in the lane's own registers.
+__device__ __forceinline__ void f1_swap(v2f& b, v2f& a) {
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(b.x), __float_as_uint(a.x), false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(b.y), __float_as_uint(a.y), false, false);
+    b = (v2f){__uint_as_float(x[0]), __uint_as_float(y[0])};
+    a = (v2f){__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+
+// row pairs [r0, r0 + n) of the block that starts at sample n0: x[2 r], x[2 r + 1] = samples n0 + 128 r + 2 lane + {0, 1}
+// (not yet swapped).  CLAMP: pair indices past `lim` (in pairs, relative to n0) read pair `lim` instead.
 template <bool U8, bool CLAMP = false>
-__device__ __forceinline__ void f1_load_block(const void* in, int64_t n0, int lane, v2f (&x)[16], unsigned lim = 0) {
+__device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int lane, v2f (&x)[16], int r0, int n, unsigned lim = 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        unsigned m = (unsigned)lane + 64u * r;
+    for (int i = 0; i < n; ++i) {
+        unsigned m = (unsigned)lane + 64u * (r0 + i);
         if (CLAMP) m = m < lim ? m : lim;
         if (U8) {
-            const uchar2 u = (reinterpret_cast<const uchar2*>(in) + n0)[m];
-            x[r] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
+            const uchar4 u = reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(in) + n0)[m];
+            x[2 * (r0 + i)] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
+            x[2 * (r0 + i) + 1] = (v2f){(float)u.z - 127.5f, (float)u.w - 127.5f};
         } else {
-            const float2 v = (reinterpret_cast<const float2*>(in) + n0)[m];
-            x[r] = (v2f){v.x, v.y};
+            const float4 v = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(in) + n0)[m];
+            x[2 * (r0 + i)] = (v2f){v.x, v.y};
+            x[2 * (r0 + i) + 1] = (v2f){v.z, v.w};
         }
     }
 }
 
-// one block: a[] holds the 1024 samples n0 .. n0+1023 (lane + 64 r) on entry; on exit, when LOADNEXT, the next block's.
-// out_row4 points at the output of row 4, lane 0.  PARTIAL: outputs at or beyond `limit` (relative to out_row4) are not stored.
+// angles of row pairs 2..7 from zz (two per lane and row pair: zz[2 r], zz[2 r + 1]), three groups of two row pairs:
+// angles | two of the next block's loads | two 8-byte stores
+template <bool U8, bool PARTIAL, bool LOADNEXT, bool FAST>
+__device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const void* in, const int64_t n0_next, const int lane, float* const ob, const int limit) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float ang[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v2f z = zz[4 + 4 * g + i];
+#ifdef FF_NO_DISC
+            ang[i] = z.x;
+#else
+            ang[i] = FAST ? ff_atan_small(z.y, z.x) : ff_atan2(z.y, z.x);
+#endif
+        }
+#ifdef FF_LOAD_NOWAIT
+        if (LOADNEXT) {                        // same loads, never consumed
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(in) + n0_next) + lane + 64 * (2 + 2 * g + i);
+                float4 junk;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(q) : "memory");
+            }
+        }
+#elif !defined(FF_NO_LOAD)
+        if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
+#endif
+#ifdef FF_NO_STORE
+        if (ang[0] + ang[1] + ang[2] + ang[3] == 1234.5f) ob[0] = ang[0];
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = 128 * (2 * g + i);                    // output of this lane's first sample of the row pair, relative to ob
+            if (!PARTIAL) {
+                *reinterpret_cast<float2*>(ob + o) = make_float2(ang[2 * i], ang[2 * i + 1]);
+            } else {
+                if (2 * lane + o < limit) ob[o] = ang[2 * i];
+                if (2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
+            }
+        }
+#endif
+    }
+}
+
+// one block.  On entry a[0..3] hold rows 0..3 of column t (the overlap kept from the previous block, or swapped by the
+// caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
+// at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
 template <bool U8, bool PARTIAL, bool LOADNEXT>
-__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f* const X, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
+__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const X, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
                                          const v2f crot, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int limit) {
     const int hi = lane >> 2, lo = lane & 3;
-    const int x1w = lane;                    // + 68 k0
-    const int x1r = hi * F1_S1 + lo;         // + 4 n1
+#pragma unroll
+    for (int r = 2; r < 8; ++r) f1_swap(a[2 * r], a[2 * r + 1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r] = a[12 + r];          // the overlap the next block starts with
+#ifdef FF_NO_COMPUTE
+    v2f zz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zz[r] = a[r];
+#else
+    // column t = 2 (lane & 31) + (lane >> 5) sits at position (t >> 1) + 34 (t & 1) of an X1 row: contiguous per half wave
+    const int x1w = (lane & 31) + 34 * (lane >> 5);                        // + 68 k0
+    const int x1r = hi * F1_S1 + (lo >> 1) + 34 * (lo & 1);                // + 2 n1     (column 4 n1 + lo)
     const int x2w = hi * F1_S2 + lo;         // + 5 k1
     const int x2r = hi * F1_S2 + 5 * lo;     // + 20 c + n0      (k1 = 4 c + j)
     // ---- forward pass 1 (over n2), T1, X1
     ff_bfly16<false>(a);
     ff_twiddle15<false, true>(a, tw1);
+#ifndef FF_NO_LDS
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[x1w + F1_S1 * k] = a[FF_P(k)];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = X[x1r + 4 * k];
+    for (int k = 0; k < 16; ++k) a[k] = X[x1r + 2 * k];
+#endif
     // ---- forward pass 2 (over n1), T2, X2
     ff_bfly16<false>(a);
     ff_twiddle15<false, true>(a, tw2);
+#ifndef FF_NO_LDS
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[x2w + 5 * k] = a[FF_P(k)];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int n = 0; n < 4; ++n) a[4 * c + n] = X[x2r + 20 * c + n];
+#endif
     // ---- forward pass 3 (radix 4 over n0), spectrum product, inverse pass 3
 #pragma unroll
     for (int c = 0; c < 4; ++c) ff_r4<false, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
@@ -576,62 +657,71 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f* const X, const v2f (
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) ff_r4<true, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+#ifndef FF_NO_LDS
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int n = 0; n < 4; ++n) X[x2r + 20 * c + n] = a[4 * c + n];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = X[x2w + 5 * k];
+#endif
     // ---- T2*, inverse pass 2
     ff_twiddle15<true, false>(a, tw2);
     ff_bfly16<true>(a);
+#ifndef FF_NO_LDS
 #pragma unroll
-    for (int k = 0; k < 16; ++k) X[x1r + 4 * k] = a[FF_P(k)];
+    for (int k = 0; k < 16; ++k) X[x1r + 2 * k] = a[FF_P(k)];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = X[x1w + F1_S1 * k];
-    // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + lane + 64 r]
+#endif
+    // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + 64 r + t]
     ff_twiddle15<true, false>(a, tw1);
     ff_bfly16<true>(a);
-    // ---- discriminator, rows 4..15: left-hand neighbour = lane - 1 of the same row (wave_shr:1); lane 0 takes lane 63 of
-    // the row above (wave_ror:1 of that row as the DPP's `old` operand, which a lane without a source lane keeps)
+    // ---- back to two consecutive outputs per lane: B[r] = w[128 r + 2 lane], A[r] = the one after it (row pairs 1..7;
+    // of pair 1 only lane 63's second value is used, as the left-hand neighbour of the block's first output)
     v2f zz[16];
-#pragma unroll
-    for (int r = 4; r < 16; ++r) {
-        const v2f cur = a[FF_P(r)], up = a[FF_P(r - 1)];
-        const int ox = __builtin_amdgcn_update_dpp(0, __float_as_int(up.x), 0x13C, 0xf, 0xf, false);
-        const int oy = __builtin_amdgcn_update_dpp(0, __float_as_int(up.y), 0x13C, 0xf, 0xf, false);
-        v2f prv;
-        prv.x = __int_as_float(__builtin_amdgcn_update_dpp(ox, __float_as_int(cur.x), 0x138, 0xf, 0xf, false));
-        prv.y = __int_as_float(__builtin_amdgcn_update_dpp(oy, __float_as_int(cur.y), 0x138, 0xf, 0xf, false));
-        zz[r] = prv;
-    }
     {
+        v2f B[8], A[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { B[r] = a[FF_P(2 * r)]; A[r] = a[FF_P(2 * r + 1)]; f1_swap(B[r], A[r]); }
+        // discriminator: the second value's neighbour is the first; the first's is the second of the lane to the left
+        // (wave_shr:1), for lane 0 that of lane 63 in the row pair above (wave_ror:1 of that register as the DPP's `old`
+        // operand, which a lane without a source lane keeps)
+        v2f pb[8];
+#pragma unroll
+        for (int r = 2; r < 8; ++r) {
+            const int ox = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].x), 0x13C, 0xf, 0xf, false);
+            const int oy = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].y), 0x13C, 0xf, 0xf, false);
+            pb[r].x = __int_as_float(__builtin_amdgcn_update_dpp(ox, __float_as_int(A[r].x), 0x138, 0xf, 0xf, false));
+            pb[r].y = __int_as_float(__builtin_amdgcn_update_dpp(oy, __float_as_int(A[r].y), 0x138, 0xf, 0xf, false));
+        }
         v2f t[16];
 #pragma unroll
-        for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(a[FF_P(r)], zz[r]);
+        for (int r = 2; r < 8; ++r) { t[2 * r] = ff_mul_lo(B[r], pb[r]); t[2 * r + 1] = ff_mul_lo(A[r], B[r]); }
 #pragma unroll
-        for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hic(a[FF_P(r)], zz[r], t[r]);      // w[m] conj(w[m-1])
+        for (int r = 2; r < 8; ++r) { zz[2 * r] = ff_fma_hic(B[r], pb[r], t[2 * r]); zz[2 * r + 1] = ff_fma_hic(A[r], B[r], t[2 * r + 1]); }   // w[m] conj(w[m-1])
 #pragma unroll
         for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(zz[r], crot);
 #pragma unroll
         for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hi(zz[r], crot, t[r]);             // the NCO's rotation per sample
     }
-    if (LOADNEXT) f1_load_block<U8>(in, n0_next, lane, a);      // a[] is dead: the next block's samples fly during the angles and stores
-    bool small = true;
+#endif
+    // a[] is dead from here: the next block's samples fly during the angles and stores.  Its first four rows are this
+    // block's last four (the 256-sample overlap), kept in `keep`: six loads per block
+#ifndef FF_NO_LOAD
+    if (LOADNEXT) {
 #pragma unroll
-    for (int r = 4; r < 16; ++r) small = small && (fabsf(zz[r].y) <= 0.41421356f * zz[r].x);
-    float ang[16];
-    if (__builtin_amdgcn_ballot_w64(!small) == 0) {        // wave-uniform: every |angle| of the block's 768 outputs below 22.5 degrees
-#pragma unroll
-        for (int r = 4; r < 16; ++r) ang[r] = ff_atan_small(zz[r].y, zz[r].x);
-    } else {
-#pragma unroll
-        for (int r = 4; r < 16; ++r) ang[r] = ff_atan2(zz[r].y, zz[r].x);
+        for (int r = 0; r < 4; ++r) a[r] = keep[r];
     }
-    float* const ob = out_row4 + lane;
+#endif
+    // wave-uniform fast path: every |angle| of the block's 768 outputs below 22.5 degrees (|im| <= tan(pi/8) re)
+    float worst = -1.0f;
 #pragma unroll
-    for (int r = 4; r < 16; ++r)
-        if (!PARTIAL || lane + 64 * (r - 4) < limit) ob[64 * (r - 4)] = ang[r];
+    for (int r = 4; r < 16; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
+    const bool fast = __builtin_amdgcn_ballot_w64(worst > 0.f) == 0;
+    float* const ob = out_row4 + 2 * lane;
+    if (fast) f1_tail<U8, PARTIAL, LOADNEXT, true>(zz, a, in, n0_next, lane, ob, limit);
+    else f1_tail<U8, PARTIAL, LOADNEXT, false>(zz, a, in, n0_next, lane, ob, limit);
 }
 
 // FIR outputs [p_a, p_b) of the chunk -> FM angles out[p - s]; every wave takes a contiguous run of the nblk blocks
@@ -651,32 +741,39 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     __syncthreads();                           // the only barrier of the kernel, before any wave may leave
     if (q_begin >= q_end) return;
     const v2f* const hp = HP + lane;
+    const int tcol = 2 * (lane & 31) + (lane >> 5);           // the column this lane transforms in passes 1 and 6
     v2f tw1[16], tw2[16];
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
-        const float2 u = T.tw1[lane * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
+        const float2 u = T.tw1[tcol * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
         tw1[k] = (v2f){u.x, u.y};
         tw2[k] = (v2f){w.x, w.y};
     }
     const v2f crot = {T.crot.x, T.crot.y};
     float* const outp = reinterpret_cast<float*>(P.out);
-    v2f a[16];
-    f1_load_block<U8>(P.in, p_a + (int64_t)F1_ADV * q_begin - 256, lane, a);
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
+    v2f a[16], keep[4];
     // the run's last block may be partial; it is also the only one whose 1024 samples may reach past the chunk's end (behind
     // the run's last output), so it is loaded on its own, with clamped indices, instead of being prefetched
     const bool last_partial = (q_end == nblk) && (p_a + (int64_t)F1_ADV * nblk > p_b);
     const int q_full_end = last_partial ? q_end - 1 : q_end;
+    if (q_begin < q_full_end) {
+        f1_load_pairs<U8>(P.in, p_a + (int64_t)F1_ADV * q_begin - 256, lane, a, 0, 8);
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
+        f1_swap(a[0], a[1]);
+        f1_swap(a[2], a[3]);
+    }
     for (int q = q_begin; q < q_full_end; ++q) {
         const int64_t p0 = p_a + (int64_t)F1_ADV * q;
         const int64_t n0_next = (q + 1 < q_full_end) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
-        f1_block<U8, false, true>(a, X, tw1, tw2, hp, crot, lane, P.in, n0_next, outp + (p0 - P.s), 0);
+        f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, lane, P.in, n0_next, outp + (p0 - P.s), 0);
     }
     if (last_partial) {
         const int64_t p0 = p_a + (int64_t)F1_ADV * (q_end - 1);
-        const int64_t room = P.L - 1 - (p0 - 256);
-        f1_load_block<U8, true>(P.in, p0 - 256, lane, a, (unsigned)(room < F1_N - 1 ? room : F1_N - 1));
-        f1_block<U8, true, false>(a, X, tw1, tw2, hp, crot, lane, P.in, 0, outp + (p0 - P.s), (int)(p_b - p0));
+        const int64_t room = (P.L - 2 - (p0 - 256)) >> 1;                                 // last whole pair of the chunk, relative to the block
+        f1_load_pairs<U8, true>(P.in, p0 - 256, lane, a, 0, 8, (unsigned)(room < F1_N / 2 - 1 ? room : F1_N / 2 - 1));
+        f1_swap(a[0], a[1]);
+        f1_swap(a[2], a[3]);
+        f1_block<U8, true, false>(a, keep, X, tw1, tw2, hp, crot, lane, P.in, 0, outp + (p0 - P.s), (int)(p_b - p0));
     }
 }
 
@@ -856,6 +953,7 @@ int dd_fft_launch(void* stv, const DDChainParams& P, int64_t p_a, int64_t p_b, h
         }
         DDFft1kTabs T1;
         T1.tw1 = s->tw1k; T1.tw2 = s->tw2k; T1.hp = s->hp1; T1.crot = T.crot;
+        { const char* e = getenv("DD_FFT_STAGGER"); T1.stagger = e ? atoi(e) : 0; }
         const int nb1 = (int)((p_b - p_a + F1_ADV - 1) / F1_ADV);
         static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");
         const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
