@@ -57,7 +57,6 @@ SIGNATURES = {
     "dd_host_register": (_int, [_p, _sz]),
     "dd_host_unregister": (_int, [_p]),
     "dd_debug_fill_lds": (_int, [C.c_uint32, _p]),
-    "dd_debug_fft_block": (_int, [_p, C.POINTER(C.c_double), _int, C.c_uint64, _int, _int, _p, _p]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2h": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2d": (_int, [_p, _p, _sz, _p]),

@@ -1,32 +1,23 @@
-// Fused hot path as an f32 overlap-save FFT convolution held in LDS (general taps, M == 1):
+// Fused hot path as an f32 overlap-save FFT convolution held in LDS (general taps up to 256, M == 1, FM output):
 //
-//     offsetFreq (NCO, commuted into the taps) -> FIR as a 4096-point circular convolution -> demod_fm
+//     offsetFreq (NCO, commuted into the taps) -> FIR as a 1024-point circular convolution -> demod_fm
 //
-// Why: the three-limb f16 Toeplitz GEMM of dd_mfma.hip spends 108 MFMAs per
-// 1024 outputs whatever the limb format (f16 x f16 limbs, exact 8-bit data x i8 tap limbs, Karatsuba forms: all 6
-// matrix instructions per 16 taps), and the chip holds only 1.57 GHz under it.  A 4096-point block FFT costs ~80
-// packed f32 instructions per block point for forward transform + spectrum product + inverse transform, independent
-// of the tap count up to 256, runs on the vector pipe alone, and takes complex taps for free -- so the NCO
+// Why: the three-limb f16 Toeplitz GEMM of dd_mfma.hip spends 108 MFMAs per 1024
+// outputs whatever the limb format (f16 x f16 limbs, exact 8-bit data x i8 tap limbs, Karatsuba forms: all 6 matrix
+// instructions per 16 taps; tools/ubench/mfma_i8_vs_f16.hip measures the bare streams: 0.148 ms of f16 MFMAs, 0.159 ms
+// of i8 MFMAs per 2^26 samples), and the chip holds only 1.57 GHz under it.  A block FFT costs ~50 packed f32
+// instructions per output for forward transform + spectrum product + inverse transform, independent of the tap count,
+// runs on the vector pipe alone at 2.2 GHz, and takes complex taps for free -- so the NCO
 //     y[p] = sum_k g[k] x[p-k] e^{-j th (p-k)} = e^{-j th p} sum_k (g[k] e^{j th k}) x[p-k] = e^{-j th p} w[p]
 // moves into the tap spectrum and the discriminator sees  y[p] conj(y[p-1]) = e^{-j th} w[p] conj(w[p-1]).
 //
-// Block geometry: N = 4096 = 16^3, 256 threads, 16 points per thread and pass.  Block q of a run covers FIR outputs
-// p0 .. p0+3839 (p0 = p_a + 3840 q); it reads the 4096 inputs n0 = p0-256 .. p0+3839, so block position m = t + 256 r
-// (thread t, register r) holds w[n0 + m]; rows r = 1..15 are the block's 3840 outputs, row 0 is the 256-sample
-// overlap (positions >= K-1 of a circular convolution are linear; K <= 256) of which only m = 255 is used, as the
-// left-hand neighbour of output 0.
+// Numerics: f32 throughout; the error of a block's outputs is relative to the largest FIR output of THAT block (3e-7 of
+// it), not to the individual output: an amplitude step of more than ~60 dB inside one 1024-sample block leaves the quiet
+// side with the loud side's rounding noise (tests/test_gpu_parity.py::test_mfma_tile_scaling_paths states the bound;
+// samples from an 8-bit source span 48 dB).  The f16-limb MFMA kernel keeps its errors within the 255-tap window.
 //
-// Index algebra (n = 256 n2 + 16 n1 + n0, k = k0 + 16 k1 + 256 k2, W = e^{-2 pi j / 4096}):
-//     W^{nk} = W16^{n2 k0} . W^{(16 n1 + n0) k0} . W16^{n1 k1} . W256^{n0 k1} . W16^{n0 k2}
-//   forward (DIF): B1 over n2 | T1 = W^{t k0} | X1 | B2 over n1 | T2 = W256^{n0 k1} | X2 | B3 over n0
-//   inverse (DIT, the transposed graph): B3^H | X2^T | T2* | B2^H | X1^T | T1* | B1^H
-// so each thread keeps ONE set of 15 + 15 twiddles for both directions, the spectrum is multiplied in the permuted
-// order in which pass 3 leaves it (thread (k0,k1), register k2: its 16 H values are loop-invariant registers), the
-// inverse exchanges write back to the very addresses the thread read in the forward exchange (no buffer hazards), and
-// the result arrives in natural order in the layout the input was loaded in.  Five workgroup barriers per block.
-//
-// LDS: X1 [16][272] and X2 [16][289] complex64 (row strides chosen so that both the 16-lane-contiguous ds_write_b64
-// and the strided ds_read_b64 of every exchange are bank-conflict free), 72 KB per workgroup, two workgroups per CU.
+// History of this file: a first version ran 4096-point blocks on 4-wave workgroups (16^3, five barriers per
+// block, 224 registers, two waves per SIMD: 0.232 ms, vector pipe 47 % busy); k_chain_fft1k below replaced it.
 #include "dd_chain_kernels.h"
 #include "dd_fftfir.h"
 #include <stdlib.h>
@@ -34,25 +25,6 @@
 #include <mutex>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-#define FF_N 4096
-#define FF_THREADS 256
-#define FF_ADV 3840                 // outputs per block = rows 1..15
-#define FF_S1 272                   // X1 row stride (complex): 2*272 mod 64 = 32
-#define FF_S2 289                   // X2 row stride (complex): 2*289 mod 64 = 2, element (k0, k1, n0) at k0*289 + k1*17 + n0
-#define FF_X1_BYTES (16 * FF_S1 * 8)
-#define FF_X2_BYTES (16 * FF_S2 * 8)
-#define FF_EDGE_OFF (FF_X1_BYTES + FF_X2_BYTES)
-#define FF_LDS_BYTES (FF_EDGE_OFF + 4 * 16 * 8)
-
-struct DDFftTabs {
-    const float2* tw1;     // [256][16]  W4096^{t k}
-    const float2* tw2;     // [16][16]   W256^{n0 k}
-    const float2* hp;      // [256][16]  H[k0 + 16 k1 + 256 k2] / 4096 at [16 k0 + k1][k2]
-    float2 crot;           // e^{-j theta}: the NCO's per-sample rotation as the discriminator sees it
-    float2* dbg;           // diagnostic instantiation only: receives the 16 registers of every thread after stage dbg_stage
-    int dbg_stage;
-};
 
 // ---- complex arithmetic on packed pairs (x = re, y = im): v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 ----
 __device__ __forceinline__ v2f ff_cmul(v2f a, v2f w) {          // a * w
@@ -201,288 +173,6 @@ __device__ __forceinline__ float ff_atan_small(float y, float x) {
     return fmaf(t, z * p, t);
 }
 
-__device__ __forceinline__ float ff_lane_left(float v) {       // wave_shr:1 (lane 0 keeps its own value; patched by the caller)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-
-template <bool U8>
-__device__ __forceinline__ void ff_load_block(const void* in, int64_t n0, int64_t nmax, int t, v2f (&x)[16]) {
-    // x[r] = sample n0 + t + 256 r (n0 is workgroup-uniform: scalar base, 32-bit lane offsets).  Only the run's last
-    // block may reach past the chunk's end -- behind the run's last output -- and clamps its indices.
-    const unsigned lim = (n0 + FF_N - 1 <= nmax) ? (unsigned)(FF_N - 1) : (unsigned)(nmax - n0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        unsigned m = (unsigned)t + 256u * r;
-        m = m < lim ? m : lim;
-        if (U8) {
-            const uchar2 u = (reinterpret_cast<const uchar2*>(in) + n0)[m];
-            x[r] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
-        } else {
-            const float2 v = (reinterpret_cast<const float2*>(in) + n0)[m];
-            x[r] = (v2f){v.x, v.y};
-        }
-    }
-}
-
-// FIR outputs [p_a, p_b) of the chunk (interior: every input the blocks read up to the run's last output lies inside the
-// chunk) -> FM angles out[p - s].  Persistent: workgroup g takes a contiguous run of the nblk blocks.
-// timing ablations (tools/mkvariant.sh N dd_fftfir -DFF_NO_xxx; results are wrong by construction, never shipped):
-//   FF_NO_STORE  no output stores        FF_NO_LOAD   no input loads (the first block's samples are reused)
-//   FF_NO_BARRIER no workgroup barriers  FF_NO_LDS    no exchanges at all (registers pass straight through)
-//   FF_NO_DISC   no discriminator (one component of the FIR output is stored)
-#ifdef FF_NO_BARRIER
-#define FF_SYNC() asm volatile("" ::: "memory")
-#else
-#define FF_SYNC() __syncthreads()
-#endif
-#define FF_STAMP(i)                                                                                   \
-    if (DBG == 2) {                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        const unsigned long long tn = __builtin_readcyclecounter();                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        acc_t[i] += tn - tp;                                                                          \
-        tp = tn;                                                                                      \
-    }
-#define FF_DUMP(st)                                                                                   \
-    if (DBG == 1 && T.dbg_stage == (st)) {                                                                 \
-        for (int k = 0; k < 16; ++k) T.dbg[t * 16 + k] = make_float2(a[k].x, a[k].y);                 \
-        return;                                                                                       \
-    }
-
-template <bool U8, int DBG = 0>
-__global__ void __launch_bounds__(FF_THREADS, 2) k_chain_fft(const DDChainParams P, const DDFftTabs T, int64_t p_a, int64_t p_b, int nblk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    v2f* const X1 = reinterpret_cast<v2f*>(smem);
-    v2f* const X2 = reinterpret_cast<v2f*>(smem + FF_X1_BYTES);
-    v2f* const EDGE = reinterpret_cast<v2f*>(smem + FF_EDGE_OFF);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int hi = t >> 4, lo = t & 15;
-
-    v2f tw1[16], tw2[16], hp[16];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const float2 a = T.tw1[t * 16 + k], b = T.tw2[lo * 16 + k];
-        tw1[k] = (v2f){a.x, a.y};
-        tw2[k] = (v2f){b.x, b.y};
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float2 h = T.hp[t * 16 + k];
-        hp[k] = (v2f){h.x, h.y};
-    }
-    const v2f crot = {T.crot.x, T.crot.y};
-
-    const int G = gridDim.x, g = blockIdx.x;
-    const int q_begin = (int)(((int64_t)nblk * g) / G), q_end = (int)(((int64_t)nblk * (g + 1)) / G);
-    if (q_begin >= q_end) return;
-    const int64_t nmax = P.L - 1;
-    float* const outp = reinterpret_cast<float*>(P.out);
-
-    v2f a[16], nx[16];
-    ff_load_block<U8>(P.in, p_a + (int64_t)FF_ADV * q_begin - 256, nmax, t, nx);
-
-    // exchange addresses (complex units)
-    const int x1w = t;                          // + 272 k0      thread (n1, n0) writes element k0
-    const int x1r = hi * FF_S1 + lo;            // + 16 n1       thread (k0, n0) reads element n1
-    const int x2w = hi * FF_S2 + lo;            // + 17 k1       thread (k0, n0) writes element k1
-    const int x2r = hi * FF_S2 + lo * 17;       // + n0          thread (k0, k1) reads element n0
-
-    // every load issued so far (tables, first block) is complete before the loop: the compiler's wait-count analysis merges
-    // the loop header's state with the pre-loop state on every iteration, so a table register first used inside the loop
-    // would otherwise get a vmcnt wait there that, in the steady state, waits for the block loads issued just before it
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
-    unsigned long long acc_t[24], tp = 0;
-    if (DBG == 2) {
-#pragma unroll
-        for (int i = 0; i < 24; ++i) acc_t[i] = 0;
-        tp = __builtin_readcyclecounter();
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = nx[r];
-    for (int q = q_begin; q < q_end; ++q) {
-        const int64_t p0 = p_a + (int64_t)FF_ADV * q;
-#ifndef FF_NO_LOAD
-        if (q + 1 < q_end) ff_load_block<U8>(P.in, p0 + FF_ADV - 256, nmax, t, nx);
-#endif
-
-        FF_DUMP(0)
-        // ---- forward pass 1 (over n2), T1, X1
-        ff_bfly16<false>(a);
-        FF_DUMP(1)
-        ff_twiddle15<false, true>(a, tw1);
-        FF_DUMP(2)
-        FF_STAMP(0)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) X1[x1w + FF_S1 * k] = a[FF_P(k)];
-#endif
-        FF_STAMP(1)
-        FF_SYNC();
-        FF_STAMP(2)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = X1[x1r + 16 * k];
-#endif
-        FF_DUMP(3)
-        FF_STAMP(3)
-        // ---- forward pass 2 (over n1), T2, X2
-        ff_bfly16<false>(a);
-        FF_DUMP(4)
-        ff_twiddle15<false, true>(a, tw2);
-        FF_DUMP(5)
-        FF_STAMP(4)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) X2[x2w + 17 * k] = a[FF_P(k)];
-#endif
-        FF_STAMP(5)
-        FF_SYNC();
-        FF_STAMP(6)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = X2[x2r + k];
-#endif
-        FF_DUMP(6)
-        FF_STAMP(7)
-        // ---- forward pass 3 (over n0), spectrum product, inverse pass 3
-        ff_bfly16<false>(a);
-        FF_DUMP(7)
-        {
-            v2f z[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) z[k] = ff_mul_lo(a[FF_P(k)], hp[k]);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) z[k] = ff_fma_hi(a[FF_P(k)], hp[k], z[k]);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = z[k];
-        }
-        FF_DUMP(15)
-        ff_bfly16<true>(a);
-        FF_DUMP(8)
-        FF_STAMP(8)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) X2[x2r + k] = a[FF_P(k)];
-#endif
-        FF_STAMP(9)
-        FF_SYNC();
-        FF_STAMP(10)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = X2[x2w + 17 * k];
-#endif
-        FF_DUMP(9)
-        FF_STAMP(11)
-        // ---- T2*, inverse pass 2
-        ff_twiddle15<true, false>(a, tw2);
-        FF_DUMP(10)
-        ff_bfly16<true>(a);
-        FF_DUMP(11)
-        FF_STAMP(12)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) X1[x1r + 16 * k] = a[FF_P(k)];
-#endif
-        FF_STAMP(13)
-        FF_SYNC();
-        FF_STAMP(14)
-#ifndef FF_NO_LDS
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = X1[x1w + FF_S1 * k];
-#endif
-        FF_DUMP(12)
-        FF_STAMP(15)
-        // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + t + 256 r]
-        ff_twiddle15<true, false>(a, tw1);
-        FF_DUMP(13)
-        ff_bfly16<true>(a);
-        FF_DUMP(14)
-
-        // ---- discriminator: rows 1..15, left-hand neighbour = lane - 1 (wave_shr:1); lane 0 takes the previous wave's
-        // lane 63 (wave 0: row r-1 of wave 3) from LDS -- the value read there is the DPP's `old` operand, which a lane
-        // without a source lane keeps
-        if (lane == 63) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) EDGE[wave * 16 + r] = a[FF_P(r)];
-        }
-        FF_STAMP(16)
-        FF_SYNC();
-        FF_STAMP(17)
-        {
-            const int eidx = wave > 0 ? (wave - 1) * 16 : 3 * 16 - 1;
-            v2f zz[16];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                const v2f e = EDGE[eidx + r];
-                const v2f cur = a[FF_P(r)];
-                v2f prv;
-                prv.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(e.x), __float_as_int(cur.x), 0x138, 0xf, 0xf, false));
-                prv.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(e.y), __float_as_int(cur.y), 0x138, 0xf, 0xf, false));
-                zz[r] = prv;
-            }
-#pragma unroll
-            for (int r = 1; r < 16; ++r) { const v2f prv = zz[r]; zz[r] = ff_mul_lo(a[FF_P(r)], prv); a[FF_P(r)] = ff_fma_hic(a[FF_P(r)], prv, zz[r]); }
-            // a[FF_P(r)] = w[m] conj(w[m-1]); the NCO's rotation per sample
-#pragma unroll
-            for (int r = 1; r < 16; ++r) zz[r] = ff_mul_lo(a[FF_P(r)], crot);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) zz[r] = ff_fma_hi(a[FF_P(r)], crot, zz[r]);
-            FF_STAMP(18)
-            bool small = true;
-#pragma unroll
-            for (int r = 1; r < 16; ++r) small = small && (fabsf(zz[r].y) <= 0.41421356f * zz[r].x);
-            float ang[16];
-#ifdef FF_NO_DISC
-#pragma unroll
-            for (int r = 1; r < 16; ++r) ang[r] = zz[r].x;
-            if (false) {
-#else
-            if (__builtin_amdgcn_ballot_w64(!small) == 0) {
-#endif        // wave-uniform: every |angle| of the wave's 960 outputs below 22.5 degrees
-#pragma unroll
-                for (int r = 1; r < 16; ++r) ang[r] = ff_atan_small(zz[r].y, zz[r].x);
-            } else {
-#ifndef FF_NO_DISC
-#pragma unroll
-                for (int r = 1; r < 16; ++r) ang[r] = ff_atan2(zz[r].y, zz[r].x);
-#endif
-            }
-            FF_STAMP(19)
-            // the next block's samples move into the working registers BEFORE this block's stores are issued: the wait for
-            // those loads (issued a whole block ago) then cannot include the stores -- vmcnt counts in order, and behind
-            // the branches of the store section the compiler has to assume that no younger operation covers the loads
-            // (written as volatile moves that memory operations may not cross: as plain assignments the copies are placed
-            // on the loop's back edge, behind the stores)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b64 %0, %1" : "=v"(a[r]) : "v"(nx[r]) : "memory");
-            FF_STAMP(20)
-            float* const ob = outp + (p0 - P.s) + t;
-#ifdef FF_NO_STORE
-            float sacc = 0.f;
-#pragma unroll
-            for (int r = 1; r < 16; ++r) sacc += ang[r];
-            if (sacc == 1234.5f) ob[0] = sacc;
-#else
-            if (p0 + FF_ADV <= p_b) {
-#pragma unroll
-                for (int r = 1; r < 16; ++r) ob[256 * (r - 1)] = ang[r];
-            } else {
-#pragma unroll
-                for (int r = 1; r < 16; ++r)
-                    if (p0 + t + 256 * (r - 1) < p_b) ob[256 * (r - 1)] = ang[r];
-            }
-#endif
-        }
-        FF_STAMP(21)
-    }
-    if (DBG == 2 && lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(T.dbg) + ((size_t)blockIdx.x * 4 + wave) * 24;
-#pragma unroll
-        for (int i = 0; i < 22; ++i) o[i] = acc_t[i];
-        o[23] = (unsigned long long)(q_end - q_begin);
-    }
-}
-
 // ============================================================================
 // k_chain_fft1k: the same convolution with ONE WAVE PER BLOCK -- 1024-point blocks (16 x 16 x 4), 768 outputs each.
 //
@@ -518,7 +208,8 @@ struct DDFft1kTabs {
     const float2* tw2;     // [4][16]    W64^{n0 k}
     const float2* hp;      // [16][64]   H[k0 + 16 (4 c + j) + 256 k2] / 1024 at [4 c + k2][4 k0 + j]
     float2 crot;
-    int stagger;           // s_sleep units (64 cycles) by which the second / third third of the grid start later
+    float theta_sub;       // != 0: |theta| is small -- the discriminator subtracts it from the angle instead of rotating every
+                           // product by crot (crot is then 1): 12 packed adds instead of 24 packed multiply-adds per block
 };
 
 // A lane moves TWO consecutive samples per memory instruction (one 16-byte load, one 8-byte store of two angles): the
@@ -557,10 +248,44 @@ __device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int la
     }
 }
 
+struct F1Edge {
+    int prev_valid;        // the value before the block's first output comes from the carried state
+    float2 prev;           //   ... un-rotated
+    int last_m;            // block position (256 + output index) of the chunk's last FIR output, or -1
+    float2 last_rot;       // e^{-j theta (abs0 + L - 1)}
+    float2* lasty_out;
+};
+__device__ __forceinline__ float2 f1_cmulf(v2f a, float2 w) {
+    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+}
+
+// sample n of the chunk as this kernel's un-rotated frame sees it: inside the chunk the input itself; before it the
+// carried history (K-1 samples AFTER the NCO, filters.py:45,69 / comm.py:77), rotated back; zeros before that; behind
+// the chunk's end a copy of its last sample (only outputs that are not stored depend on those)
+template <bool U8>
+__device__ __forceinline__ v2f f1_edge_sample(const DDChainParams& P, int64_t n) {
+    if (n < 0) {
+        const int64_t ti = n + (P.K - 1);
+        if (ti < 0) return (v2f){0.f, 0.f};
+        const float2 t = P.tail_in[ti];
+        if (!(P.flags & DD_CHAIN_NCO)) return (v2f){t.x, t.y};
+        const float2 w = dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl);     // e^{-j theta (abs0 + n)}
+        return (v2f){fmaf(t.x, w.x, t.y * w.y), fmaf(t.y, w.x, -t.x * w.y)};       // t * conj(w)
+    }
+    const int64_t nc = n < P.L ? n : P.L - 1;
+    if (U8) {
+        const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[nc];
+        return (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
+    }
+    const float2 v = reinterpret_cast<const float2*>(P.in)[nc];
+    return (v2f){v.x, v.y};
+}
+
 // angles of row pairs 2..7 from zz (two per lane and row pair: zz[2 r], zz[2 r + 1]), three groups of two row pairs:
 // angles | two of the next block's loads | two 8-byte stores
 template <bool U8, bool PARTIAL, bool LOADNEXT, bool FAST>
-__device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const void* in, const int64_t n0_next, const int lane, float* const ob, const int limit) {
+__device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const void* in, const int64_t n0_next, const int lane, float* const ob, const int lim_lo, const int limit,
+                                        const float theta_sub) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         float ang[4];
@@ -570,7 +295,16 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
 #ifdef FF_NO_DISC
             ang[i] = z.x;
 #else
-            ang[i] = FAST ? ff_atan_small(z.y, z.x) : ff_atan2(z.y, z.x);
+            // theta_sub: the NCO's per-sample rotation taken off the angle (|theta| <= 0.25, so the fast path's result stays
+            // inside (-pi, pi); the full-range form wraps)
+            if (FAST) {
+                ang[i] = ff_atan_small(z.y, z.x) - theta_sub;
+            } else {
+                float r = ff_atan2(z.y, z.x) - theta_sub;
+                r = r > 3.14159265358979f ? r - 6.28318530717959f : r;
+                r = r <= -3.14159265358979f ? r + 6.28318530717959f : r;
+                ang[i] = r;
+            }
 #endif
         }
 #ifdef FF_LOAD_NOWAIT
@@ -594,8 +328,8 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
             if (!PARTIAL) {
                 *reinterpret_cast<float2*>(ob + o) = make_float2(ang[2 * i], ang[2 * i + 1]);
             } else {
-                if (2 * lane + o < limit) ob[o] = ang[2 * i];
-                if (2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
+                if (2 * lane + o >= lim_lo && 2 * lane + o < limit) ob[o] = ang[2 * i];
+                if (2 * lane + o + 1 >= lim_lo && 2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
             }
         }
 #endif
@@ -606,9 +340,11 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
 // caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
 // at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
 template <bool U8, bool PARTIAL, bool LOADNEXT>
-__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const X, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
-                                         const v2f crot, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int limit) {
+__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
+                                         const v2f crot, const float theta_sub, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int lim_lo, const int limit,
+                                         const F1Edge* edge = nullptr) {
     const int hi = lane >> 2, lo = lane & 3;
+    v2f* const X = Xp;
 #pragma unroll
     for (int r = 2; r < 8; ++r) f1_swap(a[2 * r], a[2 * r + 1]);
 #pragma unroll
@@ -684,6 +420,19 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
         v2f B[8], A[8];
 #pragma unroll
         for (int r = 1; r < 8; ++r) { B[r] = a[FF_P(2 * r)]; A[r] = a[FF_P(2 * r + 1)]; f1_swap(B[r], A[r]); }
+        if (PARTIAL && edge) {
+            // chunk edges (cold path).  First block of a chunk that continues a stream: the FIR output before the chunk's
+            // first one is the carried state (demod_fm.py:47-49), brought into this kernel's un-rotated frame.  Last block:
+            // the chunk's last FIR output, rotated, is the next chunk's carried state.
+            if (edge->prev_valid && lane == 63) A[1] = (v2f){edge->prev.x, edge->prev.y};
+            if (edge->last_m >= 0) {
+#pragma unroll
+                for (int r = 2; r < 8; ++r) {
+                    if (128 * r + 2 * lane == edge->last_m) *edge->lasty_out = f1_cmulf(B[r], edge->last_rot);
+                    if (128 * r + 2 * lane + 1 == edge->last_m) *edge->lasty_out = f1_cmulf(A[r], edge->last_rot);
+                }
+            }
+        }
         // discriminator: the second value's neighbour is the first; the first's is the second of the lane to the left
         // (wave_shr:1), for lane 0 that of lane 63 in the row pair above (wave_ror:1 of that register as the DPP's `old`
         // operand, which a lane without a source lane keeps)
@@ -700,10 +449,12 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
         for (int r = 2; r < 8; ++r) { t[2 * r] = ff_mul_lo(B[r], pb[r]); t[2 * r + 1] = ff_mul_lo(A[r], B[r]); }
 #pragma unroll
         for (int r = 2; r < 8; ++r) { zz[2 * r] = ff_fma_hic(B[r], pb[r], t[2 * r]); zz[2 * r + 1] = ff_fma_hic(A[r], B[r], t[2 * r + 1]); }   // w[m] conj(w[m-1])
+        if (theta_sub == 0.f) {                        // (wave-uniform)
 #pragma unroll
-        for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(zz[r], crot);
+            for (int r = 4; r < 16; ++r) t[r] = ff_mul_lo(zz[r], crot);
 #pragma unroll
-        for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hi(zz[r], crot, t[r]);             // the NCO's rotation per sample
+            for (int r = 4; r < 16; ++r) zz[r] = ff_fma_hi(zz[r], crot, t[r]);         // the NCO's rotation per sample
+        }
     }
 #endif
     // a[] is dead from here: the next block's samples fly during the angles and stores.  Its first four rows are this
@@ -720,13 +471,83 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     for (int r = 4; r < 16; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
     const bool fast = __builtin_amdgcn_ballot_w64(worst > 0.f) == 0;
     float* const ob = out_row4 + 2 * lane;
-    if (fast) f1_tail<U8, PARTIAL, LOADNEXT, true>(zz, a, in, n0_next, lane, ob, limit);
-    else f1_tail<U8, PARTIAL, LOADNEXT, false>(zz, a, in, n0_next, lane, ob, limit);
+    if (fast) f1_tail<U8, PARTIAL, LOADNEXT, true>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
+    else f1_tail<U8, PARTIAL, LOADNEXT, false>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
 }
 
-// FIR outputs [p_a, p_b) of the chunk -> FM angles out[p - s]; every wave takes a contiguous run of the nblk blocks
+// one edge block (the chunk's first and / or last): samples fetched one by one through f1_edge_sample, stores
+// predicated on [s, L), carried state read and written.  Cold: two blocks per chunk.
 template <bool U8>
-__global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, int64_t p_a, int64_t p_b, int nblk, int nwaves) {
+__device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kTabs T, int q, int nblk, v2f* const X, const v2f* const hp, const int lane) {
+    // (its own copy of the twiddles: arrays handed to a function that is not inlined would live in scratch memory for
+    // the whole kernel)
+    const int tcol = 2 * (lane & 31) + (lane >> 5);
+    v2f tw1[16], tw2[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float2 u = T.tw1[tcol * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
+        tw1[k] = (v2f){u.x, u.y};
+        tw2[k] = (v2f){w.x, w.y};
+    }
+    const v2f crot = {T.crot.x, T.crot.y};
+    const int64_t p0 = (int64_t)F1_ADV * q;
+    v2f a[16], keep[4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a[2 * r] = f1_edge_sample<U8>(P, p0 - 256 + 128 * r + 2 * lane);
+        a[2 * r + 1] = f1_edge_sample<U8>(P, p0 - 256 + 128 * r + 2 * lane + 1);
+    }
+    f1_swap(a[0], a[1]);
+    f1_swap(a[2], a[3]);
+    F1Edge e;
+    e.prev_valid = 0;
+    e.prev = make_float2(0.f, 0.f);
+    e.last_m = -1;
+    e.last_rot = make_float2(1.f, 0.f);
+    e.lasty_out = P.lasty_out;
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    if (q == 0 && P.s == 0) {
+        // y[-1] = e^{-j theta (abs0 - 1)} w[-1]  ->  w[-1] = y[-1] e^{+j theta (abs0 - 1)}
+        const float2 ly = *P.lasty_in;
+        const float2 w = nco ? dd_phasor((uint64_t)(P.abs0 - 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        e.prev = make_float2(fmaf(ly.x, w.x, ly.y * w.y), fmaf(ly.y, w.x, -ly.x * w.y));
+        e.prev_valid = 1;
+    }
+    if (q == nblk - 1 && P.lasty_out) {
+        e.last_m = (int)(256 + (P.L - 1 - p0));
+        e.last_rot = nco ? dd_phasor((uint64_t)(P.abs0 + P.L - 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+    }
+    const int64_t lo64 = (int64_t)P.s - p0, hi64 = P.L - p0;
+    const int lim_lo = lo64 > 0 ? (int)lo64 : 0, lim_hi = hi64 < F1_ADV ? (int)hi64 : F1_ADV;
+    f1_block<U8, true, false>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, &e);
+    if (q == nblk - 1 && P.tail_out) {
+        // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
+        for (int i = lane; i < P.K - 1; i += 64) {
+            const int64_t n = P.L - (P.K - 1) + i;
+            float2 v;
+            if (n < 0) {
+                const int64_t ti = n + (P.K - 1);
+                v = P.tail_in[ti];                                  // (ti >= 0: i >= 0 and L >= 1)
+            } else {
+                float2 x;
+                if (U8) {
+                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
+                    x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+                } else {
+                    x = reinterpret_cast<const float2*>(P.in)[n];
+                }
+                v = nco ? dd_cmul(x, dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl)) : x;
+            }
+            P.tail_out[i] = v;
+        }
+    }
+}
+
+// The whole chunk in one launch: FIR outputs [0, L) -> FM angles out[p - s] for p >= s, carried state read (history,
+// last FIR output) and written.  Block q covers outputs [768 q, 768 q + 768); every wave takes a contiguous run of the
+// nblk blocks; block 0 and block nblk-1 are edge blocks.
+template <bool U8>
+__global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, int nblk, int nwaves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v2f* const X = reinterpret_cast<v2f*>(smem + wave * F1_WAVE_BYTES);
@@ -741,6 +562,8 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     __syncthreads();                           // the only barrier of the kernel, before any wave may leave
     if (q_begin >= q_end) return;
     const v2f* const hp = HP + lane;
+    // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
+    if (q_begin == 0) f1_edge_block<U8>(P, T, 0, nblk, X, hp, lane);
     const int tcol = 2 * (lane & 31) + (lane >> 5);           // the column this lane transforms in passes 1 and 6
     v2f tw1[16], tw2[16];
 #pragma unroll
@@ -751,42 +574,29 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     }
     const v2f crot = {T.crot.x, T.crot.y};
     float* const outp = reinterpret_cast<float*>(P.out);
-    v2f a[16], keep[4];
-    // the run's last block may be partial; it is also the only one whose 1024 samples may reach past the chunk's end (behind
-    // the run's last output), so it is loaded on its own, with clamped indices, instead of being prefetched
-    const bool last_partial = (q_end == nblk) && (p_a + (int64_t)F1_ADV * nblk > p_b);
-    const int q_full_end = last_partial ? q_end - 1 : q_end;
-    if (q_begin < q_full_end) {
-        f1_load_pairs<U8>(P.in, p_a + (int64_t)F1_ADV * q_begin - 256, lane, a, 0, 8);
+    const int q_lo = q_begin == 0 ? 1 : q_begin, q_hi = q_end == nblk ? nblk - 1 : q_end;      // interior blocks of this run
+    if (q_lo < q_hi) {
+        v2f a[16], keep[4];
+        f1_load_pairs<U8>(P.in, (int64_t)F1_ADV * q_lo - 256, lane, a, 0, 8);
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
         f1_swap(a[0], a[1]);
         f1_swap(a[2], a[3]);
+        for (int q = q_lo; q < q_hi; ++q) {
+            const int64_t p0 = (int64_t)F1_ADV * q;
+            const int64_t n0_next = (q + 1 < q_hi) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
+            f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV);
+        }
     }
-    for (int q = q_begin; q < q_full_end; ++q) {
-        const int64_t p0 = p_a + (int64_t)F1_ADV * q;
-        const int64_t n0_next = (q + 1 < q_full_end) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
-        f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, lane, P.in, n0_next, outp + (p0 - P.s), 0);
-    }
-    if (last_partial) {
-        const int64_t p0 = p_a + (int64_t)F1_ADV * (q_end - 1);
-        const int64_t room = (P.L - 2 - (p0 - 256)) >> 1;                                 // last whole pair of the chunk, relative to the block
-        f1_load_pairs<U8, true>(P.in, p0 - 256, lane, a, 0, 8, (unsigned)(room < F1_N / 2 - 1 ? room : F1_N / 2 - 1));
-        f1_swap(a[0], a[1]);
-        f1_swap(a[2], a[3]);
-        f1_block<U8, true, false>(a, keep, X, tw1, tw2, hp, crot, lane, P.in, 0, outp + (p0 - P.s), (int)(p_b - p0));
-    }
+    if (q_end == nblk && nblk > 1) f1_edge_block<U8>(P, T, nblk - 1, nblk, X, hp, lane);
 }
 
 // ============================================================================ host side
 struct DDFftState {
     int K;
     std::vector<double> taps;
-    float2* tw1;
-    float2* tw2;
-    float2* hp;
-    float2* tw1k;       // tables of k_chain_fft1k
-    float2* tw2k;
-    float2* hp1;
+    float2* tw1;        // [64][16]  W1024^{t k}
+    float2* tw2;        // [4][16]   W64^{n0 k}
+    float2* hp;         // [16][64]  the tap spectrum for the frequency in `cyc`, as pass 3 multiplies it
     uint64_t cyc;
     int have_h;
     int nco;
@@ -813,30 +623,19 @@ static void fft_pow2(std::vector<std::complex<double>>& v) {
     }
 }
 
-int dd_fft_supported(int K, int M, int flags) {
-    return (M == 1 && K >= 1 && K <= 256 && (flags & DD_CHAIN_FM)) ? 1 : 0;
+int dd_fft1k_supported(int K, int M, int flags) {
+    return (M == 1 && K >= 2 && K <= 256 && (flags & DD_CHAIN_FM)) ? 1 : 0;
 }
 
 int dd_fft_create(void** st, const double* taps, int K) {
-    if (K < 1 || K > 256) return DD_ERR_UNSUPPORTED;
+    if (K < 2 || K > 256) return DD_ERR_UNSUPPORTED;
     DDFftState* s = new DDFftState();
     s->K = K;
     s->taps.assign(taps, taps + K);
-    s->tw1 = s->tw2 = s->hp = s->tw1k = s->tw2k = s->hp1 = nullptr;
+    s->tw1 = s->tw2 = s->hp = nullptr;
     s->cyc = 0;
     s->have_h = 0;
     s->nco = 0;
-    std::vector<float2> t1(256 * 16), t2(16 * 16);
-    for (int t = 0; t < 256; ++t)
-        for (int k = 0; k < 16; ++k) {
-            const double ang = -2.0 * M_PI * (double)((t * k) % FF_N) / (double)FF_N;
-            t1[t * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
-        }
-    for (int n0 = 0; n0 < 16; ++n0)
-        for (int k = 0; k < 16; ++k) {
-            const double ang = -2.0 * M_PI * (double)((n0 * k) % 256) / 256.0;
-            t2[n0 * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
-        }
     std::vector<float2> u1(64 * 16), u2(4 * 16);
     for (int t = 0; t < 64; ++t)
         for (int k = 0; k < 16; ++k) {
@@ -848,16 +647,11 @@ int dd_fft_create(void** st, const double* taps, int K) {
             const double ang = -2.0 * M_PI * (double)((n0 * k) % 64) / 64.0;
             u2[n0 * 16 + k] = make_float2((float)cos(ang), (float)sin(ang));
         }
-    hipError_t e = hipMalloc((void**)&s->tw1, t1.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->tw1k, u1.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->tw2k, u2.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->hp1, 64 * 16 * sizeof(float2));
-    if (e == hipSuccess) e = hipMemcpy(s->tw1k, u1.data(), u1.size() * sizeof(float2), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(s->tw2k, u2.data(), u2.size() * sizeof(float2), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->tw2, t2.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->hp, 256 * 16 * sizeof(float2));
-    if (e == hipSuccess) e = hipMemcpy(s->tw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(s->tw2, t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void**)&s->tw1, u1.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tw2, u2.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->hp, 64 * 16 * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(s->tw1, u1.data(), u1.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->tw2, u2.data(), u2.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         dd_fft_destroy(s);
         dd_set_error("dd_fft_create: %s", hipGetErrorString(e));
@@ -873,17 +667,14 @@ void dd_fft_destroy(void* stv) {
     if (s->tw1) (void)hipFree(s->tw1);
     if (s->tw2) (void)hipFree(s->tw2);
     if (s->hp) (void)hipFree(s->hp);
-    if (s->tw1k) (void)hipFree(s->tw1k);
-    if (s->tw2k) (void)hipFree(s->tw2k);
-    if (s->hp1) (void)hipFree(s->hp1);
     delete s;
 }
 
-// tap spectrum for the NCO frequency of this launch (frac(f/fs) = cyc / 2^64), permuted for pass 3
+// tap spectrum for the NCO frequency of this launch (frac(f/fs) = cyc / 2^64), in the order pass 3 multiplies it
 static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream) {
     if (s->have_h && s->cyc == cyc && s->nco == (int)nco) return DD_OK;
     const long double frac = nco ? (long double)cyc / 18446744073709551616.0L : 0.0L;      // [0, 1)
-    std::vector<std::complex<double>> g(FF_N, std::complex<double>(0.0, 0.0));
+    std::vector<std::complex<double>> g(F1_N, std::complex<double>(0.0, 0.0));
     for (int k = 0; k < s->K; ++k) {
         // e^{+j 2 pi frac k}, argument reduced exactly before the call
         long double ph = frac * (long double)k;
@@ -891,148 +682,59 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * ph;
         g[k] = std::complex<double>((double)(s->taps[k] * cosl(a)), (double)(s->taps[k] * sinl(a)));
     }
-    std::vector<std::complex<double>> g1(g.begin(), g.begin() + F1_N);     // the same taps, zero padded to 1024
     fft_pow2(g);
-    fft_pow2(g1);
-    std::vector<float2> hp1(64 * 16);
+    std::vector<float2> hp(64 * 16);
     for (int k0 = 0; k0 < 16; ++k0)
         for (int j = 0; j < 4; ++j)
             for (int c = 0; c < 4; ++c)
                 for (int k2 = 0; k2 < 4; ++k2) {
-                    const std::complex<double> h = g1[k0 + 16 * (4 * c + j) + 256 * k2] / (double)F1_N;
-                    hp1[(4 * c + k2) * 64 + 4 * k0 + j] = make_float2((float)h.real(), (float)h.imag());
+                    const std::complex<double> h = g[k0 + 16 * (4 * c + j) + 256 * k2] / (double)F1_N;
+                    hp[(4 * c + k2) * 64 + 4 * k0 + j] = make_float2((float)h.real(), (float)h.imag());
                 }
-    std::vector<float2> hp(256 * 16);
-    for (int k0 = 0; k0 < 16; ++k0)
-        for (int k1 = 0; k1 < 16; ++k1)
-            for (int k2 = 0; k2 < 16; ++k2) {
-                const std::complex<double> h = g[k0 + 16 * k1 + 256 * k2] / (double)FF_N;
-                hp[(16 * k0 + k1) * 16 + k2] = make_float2((float)h.real(), (float)h.imag());
-            }
-    // the table may still be read by an earlier launch on this stream: stream-ordered copy from a staging vector that
-    // lives until the copy has been consumed
+    // an earlier launch on this stream may still read the table (a chain changes its frequency rarely: once per handle)
     DD_HIP_CHECK(hipStreamSynchronize(stream));
     DD_HIP_CHECK(hipMemcpy(s->hp, hp.data(), hp.size() * sizeof(float2), hipMemcpyHostToDevice));
-    DD_HIP_CHECK(hipMemcpy(s->hp1, hp1.data(), hp1.size() * sizeof(float2), hipMemcpyHostToDevice));
     s->cyc = cyc;
     s->nco = (int)nco;
     s->have_h = 1;
     return DD_OK;
 }
 
-int dd_fft_launch(void* stv, const DDChainParams& P, int64_t p_a, int64_t p_b, hipStream_t stream) {
+// the whole chunk through k_chain_fft1k (one launch, carried state included)
+int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     DDFftState* s = reinterpret_cast<DDFftState*>(stv);
-    if (p_b <= p_a) return DD_OK;
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
     int rc = fft_prepare(s, nco, P.cyc, stream);
     if (rc != DD_OK) return rc;
-    static DDOncePerDevice attr_set;
-    if (attr_set.need()) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        attr_set.mark();
+    static DDOncePerDevice attr1;
+    if (attr1.need()) {
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        attr1.mark();
     }
-    DDFftTabs T;
-    T.tw1 = s->tw1;
-    T.tw2 = s->tw2;
-    T.hp = s->hp;
-    T.dbg = nullptr;
-    T.dbg_stage = 0;
+    DDFft1kTabs T1;
+    T1.tw1 = s->tw1; T1.tw2 = s->tw2; T1.hp = s->hp;
     {
         const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * frac;
-        T.crot = make_float2((float)cosl(a), (float)-sinl(a));
-    }
-    const char* kern_env = getenv("DD_MFMA_KERNEL");
-    if (kern_env && strcmp(kern_env, "fft1k") == 0) {
-        static DDOncePerDevice attr1;
-        if (attr1.need()) {
-            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
-            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
-            attr1.mark();
+        // theta in (-pi, pi]; small -> subtracted from the angle, else applied as a rotation of every product
+        const long double th = a > 3.14159265358979323846264338327950288L ? a - 2.0L * 3.14159265358979323846264338327950288L : a;
+        static const char* rot_env = getenv("DD_FFT_ROTATE");          // tools: force the rotation form
+        if (fabsl(th) <= 0.25L && th != 0.0L && !(rot_env && atoi(rot_env))) {
+            T1.theta_sub = (float)th;
+            T1.crot = make_float2(1.f, 0.f);
+        } else {
+            T1.theta_sub = 0.f;
+            T1.crot = make_float2((float)cosl(a), (float)-sinl(a));
         }
-        DDFft1kTabs T1;
-        T1.tw1 = s->tw1k; T1.tw2 = s->tw2k; T1.hp = s->hp1; T1.crot = T.crot;
-        { const char* e = getenv("DD_FFT_STAGGER"); T1.stagger = e ? atoi(e) : 0; }
-        const int nb1 = (int)((p_b - p_a + F1_ADV - 1) / F1_ADV);
-        static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");
-        const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
-        int grid1 = dd_cu_count() * (per_cu1 > 0 ? per_cu1 : 3);
-        if (grid1 * F1_WAVES > nb1) grid1 = (nb1 + F1_WAVES - 1) / F1_WAVES;
-        if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, p_a, p_b, nb1, grid1 * F1_WAVES);
-        else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, p_a, p_b, nb1, grid1 * F1_WAVES);
-        DD_LAUNCH_CHECK();
-        return DD_OK;
     }
-    const int64_t nblk64 = (p_b - p_a + FF_ADV - 1) / FF_ADV;
-    const int nblk = (int)nblk64;
-    static const char* wg_env = getenv("DD_FFT_WGS_PER_CU");
-    const int per_cu = wg_env ? atoi(wg_env) : 2;
-    int grid = dd_cu_count() * (per_cu > 0 ? per_cu : 2);
-    if (grid > nblk) grid = nblk;
-    static const char* st_env = getenv("DD_FFT_STAMPS");
-    static int st_count = 0;
-    if (st_env && !(P.flags & DD_CHAIN_U8_INPUT) && st_count++ == atoi(st_env)) {
-        // diagnostic: per-wave cycle sums of the 19 segments of a block, averaged over waves and blocks
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        unsigned long long* buf = nullptr;
-        const size_t nw = (size_t)grid * 4 * 24;
-        DD_HIP_CHECK(hipMalloc((void**)&buf, nw * 8));
-        T.dbg = reinterpret_cast<float2*>(buf);
-        hipLaunchKernelGGL((k_chain_fft<false, 2>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
-        std::vector<unsigned long long> hb(nw);
-        DD_HIP_CHECK(hipMemcpy(hb.data(), buf, nw * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(buf);
-        const char* nm[22] = {"load wait + pass 1", "X1 writes", "barrier", "X1 reads", "pass 2", "X2 writes", "barrier", "X2 reads", "pass 3 + H + inverse 3",
-                              "X2' writes", "barrier", "X2' reads", "inverse 2", "X1' writes", "barrier", "X1' reads", "inverse 1 + edge", "barrier", "edge reads, z = w conj(w') c", "angles", "next block into registers", "stores"};
-        double tot = 0;
-        for (int i = 0; i < 22; ++i) {
-            double sum = 0, nb = 0;
-            for (size_t w = 0; w < (size_t)grid * 4; ++w) { sum += (double)hb[w * 24 + i]; nb += (double)hb[w * 24 + 23]; }
-            fprintf(stderr, "[fft stamps] %-26s %8.0f cycles per block\n", nm[i], sum / nb);
-            tot += sum / nb;
-        }
-        fprintf(stderr, "[fft stamps] total %.0f cycles per block and wave, %d workgroups, %d blocks\n", tot, grid, nblk);
-        return DD_OK;
-    }
-    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft<true>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
-    else hipLaunchKernelGGL((k_chain_fft<false>), dim3(grid), dim3(FF_THREADS), FF_LDS_BYTES, stream, P, T, p_a, p_b, nblk);
+    const int nb1 = (int)((P.L + F1_ADV - 1) / F1_ADV);
+    static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");           // tools: occupancy experiments
+    const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
+    int grid1 = dd_cu_count() * (per_cu1 > 0 ? per_cu1 : 3);
+    if (grid1 * F1_WAVES > nb1) grid1 = (nb1 + F1_WAVES - 1) / F1_WAVES;
+    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, nb1, grid1 * F1_WAVES);
+    else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, nb1, grid1 * F1_WAVES);
     DD_LAUNCH_CHECK();
-    return DD_OK;
-}
-
-// diagnostic: one block (4096 complex64 samples at `in`, device) through the kernel up to `stage`; out receives the
-// 256 x 16 register image after that stage (tests/tools compare it with a NumPy model of the same data flow)
-extern "C" int dd_debug_fft_block(const float* in_c64, const double* taps, int ntaps, uint64_t cycles_q64, int nco, int stage, float* out_c64, void* stream) {
-    void* st = nullptr;
-    int rc = dd_fft_create(&st, taps, ntaps);
-    if (rc != DD_OK) return rc;
-    DDFftState* s = reinterpret_cast<DDFftState*>(st);
-    hipStream_t hs = dd_stream(stream);
-    rc = fft_prepare(s, nco != 0, cycles_q64, hs);
-    if (rc != DD_OK) { dd_fft_destroy(st); return rc; }
-    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-    DDChainParams P;
-    memset(&P, 0, sizeof(P));
-    float* scratch = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&scratch, FF_N * sizeof(float)));
-    P.in = in_c64;
-    P.out = scratch;
-    P.L = FF_N;
-    P.Ld = FF_N;
-    P.K = ntaps;
-    P.M = 1;
-    P.flags = DD_CHAIN_FM | (nco ? DD_CHAIN_NCO : 0);
-    P.cyc = cycles_q64;
-    DDFftTabs T;
-    T.tw1 = s->tw1; T.tw2 = s->tw2; T.hp = s->hp;
-    T.crot = make_float2(1.f, 0.f);
-    T.dbg = reinterpret_cast<float2*>(out_c64);
-    T.dbg_stage = stage;
-    hipLaunchKernelGGL((k_chain_fft<false, 1>), dim3(1), dim3(FF_THREADS), FF_LDS_BYTES, hs, P, T, (int64_t)256, (int64_t)(256 + FF_ADV), 1);
-    hipError_t e = hipStreamSynchronize(hs);
-    (void)hipFree(scratch);
-    dd_fft_destroy(st);
-    if (e != hipSuccess) { dd_set_error("dd_debug_fft_block: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
     return DD_OK;
 }

@@ -1069,19 +1069,21 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
         if (hi >= lo) { t_first = (int)lo; t_last = (int)hi + 1; }
     }
     const int n_int = t_last - t_first;
-    const char* kern_env1 = getenv("DD_MFMA_KERNEL");        // read per launch: tools switch kernels inside one process
-    const bool want_fft = kern_env1 && (strcmp(kern_env1, "fft") == 0 || strcmp(kern_env1, "fft1k") == 0);
-    if (n_int > 0 && want_fft && dd_fft_supported(st->K, 1, P.flags)) {
-        // interior run through the overlap-save FFT kernel, the tiles around it through the stand-alone edge kernel
+    // DD_MFMA_KERNEL (read per launch: tools and tests switch kernels inside one process): "ab" / "ws" force the MFMA
+    // kernels, "fft1k" the overlap-save FFT kernel wherever it applies; unset = by tap class
+    const char* kern_env1 = getenv("DD_MFMA_KERNEL");
+    const bool force_fft1k = kern_env1 && strcmp(kern_env1, "fft1k") == 0;
+    const bool force_mfma = kern_env1 && (strcmp(kern_env1, "ab") == 0 || strcmp(kern_env1, "ws") == 0);
+    // The FFT kernel's time does not depend on the tap count (0.221 ms per 2^26 samples, 0.207 from raw u8); the MFMA
+    // kernel's does: 0.227 ms in the 162..257-tap class, 0.20 below.  FM output only.
+    const bool fft_class = NKS == 18;
+    if ((force_fft1k || (fft_class && !force_mfma)) && dd_fft1k_supported(st->K, 1, P.flags) && aligned) {
         if (!st->fft && !st->fft_tried) {
             st->fft_tried = 1;
             if (dd_fft_create(&st->fft, st->taps.data(), st->K) != DD_OK) st->fft = nullptr;
         }
         if (st->fft) {
-            const int n_edge = t_first + (P.nblocks - t_last);
-            hipLaunchKernelGGL(k_chain_mfma_edge<NKS>, dim3(n_edge), dim3(MF_THREADS), lds, s, P, t, t_first, t_last);
-            DD_LAUNCH_CHECK();
-            int rc = dd_fft_launch(st->fft, P, (int64_t)t_first * MF_ADV, (int64_t)t_last * MF_ADV, s);
+            int rc = dd_fft1k_launch(st->fft, P, s);
             if (rc != DD_OK) return rc;
             if (kernel_id) *kernel_id = DD_KERNEL_FFT_OS;
             return DD_OK;

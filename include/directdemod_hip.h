@@ -68,11 +68,6 @@ int  dd_host_unregister(void* hptr);
 /* diagnostic: fill the LDS of every compute unit with `pattern` (LDS is not cleared between workgroups).  The parity
  * suite runs the chain kernels after a NaN fill and after a zero fill and requires bit-identical outputs. */
 int  dd_debug_fill_lds(uint32_t pattern, void* stream);
-/* diagnostic: one 4096-sample block (complex64, device) through the overlap-save FFT kernel (dd_fftfir.hip) up to
- * `stage`; out_c64 (device, 256 x 16 complex64) receives every thread's 16 registers after that stage.
- * tests/test_gpu_fft.py checks each stage against a NumPy model of the same data flow. */
-int  dd_debug_fft_block(const float* in_c64, const double* taps, int ntaps, uint64_t cycles_q64, int nco, int stage,
-                        float* out_c64, void* stream);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
@@ -211,7 +206,7 @@ int dd_chain_path(const dd_chain* h);
 #define DD_KERNEL_MFMA_WS 4          /* k_chain_mfma_ws: M = 1, wave-specialised MFMA kernel (round 1; behind DD_MFMA_KERNEL=ws) */
 #define DD_KERNEL_MFMA_TILES 5       /* k_chain_mfma_edge: M = 1, MFMA, one workgroup per tile */
 #define DD_KERNEL_MFMA_AB 6          /* k_chain_mfma_ab: M = 1, FM or complex64 output, two alternating matrix-wave sets + edge tiles in the same launch */
-#define DD_KERNEL_FFT_OS 7           /* k_chain_fft: M = 1, FM output, f32 overlap-save FFT convolution in LDS (NCO commuted into the tap spectrum) + edge tiles */
+#define DD_KERNEL_FFT_OS 7           /* k_chain_fft1k: M = 1, FM output, 162..256 taps: f32 overlap-save FFT convolution, one wave per 1024-point block, NCO commuted into the tap spectrum, whole chunk in one launch */
 int dd_chain_last_kernel(const dd_chain* h);
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
 

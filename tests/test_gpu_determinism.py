@@ -83,8 +83,16 @@ def _hamming(K):
 
 @pytest.mark.parametrize("ntaps", [255, 151, 127, 63])
 @pytest.mark.parametrize("u8", [False, True])
-def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8):
-    """NCO + FIR + FM at M = 1: k_chain_mfma_ab (every tap class) with the edge tiles riding along."""
+@pytest.mark.parametrize("kernel", ["auto", "ab", "fft1k"])
+def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, monkeypatch):
+    """NCO + FIR + FM at M = 1: k_chain_fft1k (the 162..256-tap class by default, every class when forced: no atomics, one
+    wave per block, LDS image rewritten completely before it is read) and k_chain_mfma_ab (every tap class) with the edge
+    tiles riding along."""
+    if kernel == "auto":
+        monkeypatch.delenv("DD_MFMA_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("DD_MFMA_KERNEL", kernel)
+    want = g.hip.DD_KERNEL_FFT_OS if (kernel == "fft1k" or (kernel == "auto" and ntaps > 161)) else g.hip.DD_KERNEL_MFMA_AB
     t = g.torch
     n = (1 << 23) + 12345
     x = g.bench.make_input(t, n, 0, g.dev, 5 + ntaps)
@@ -93,7 +101,7 @@ def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8):
         x = (x + 127.5).round().clamp(0, 255).to(t.uint8).contiguous()
         flags |= g.hip.DD_CHAIN_U8_INPUT
     outs, kernels = _chain_runs(g, _hamming(ntaps), 1, flags, x, n, n)
-    assert set(kernels) == {g.hip.DD_KERNEL_MFMA_AB}
+    assert set(kernels) == {want}
     _assert_identical(g, outs, 1)
 
 

@@ -15,7 +15,7 @@ stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ntaps = 255
 taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1)))
 outs = {}
-for kern in ("ab", "fft"):
+for kern in ("ab", "fft1k"):
     os.environ["DD_MFMA_KERNEL"] = kern
     out = torch.zeros(n, dtype=torch.float32, device=dev)
     h = C.c_void_p()
@@ -27,7 +27,7 @@ for kern in ("ab", "fft"):
     torch.cuda.synchronize()
     outs[kern] = out.cpu().numpy()[:got.value]
     lib.dd_chain_destroy(h)
-a, f = outs["ab"], outs["fft"]
+a, f = outs["ab"], outs["fft1k"]
 d = np.abs((f - a + np.pi) % (2 * np.pi) - np.pi)
 pa = 4064 - 1
 nb = (len(d) - pa) // 3840 - 2

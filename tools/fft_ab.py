@@ -17,7 +17,7 @@ if U8:
     x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 names = {v: k for k, v in vars(_hip).items() if k.startswith("DD_KERNEL_")}
-kernels = os.environ.get("KERNELS", "ab,fft").split(",")
+kernels = os.environ.get("KERNELS", "ab,fft1k").split(",")
 reps = int(os.environ.get("REPS", "200"))
 for ntaps in [int(v) for v in os.environ.get("NTAPS", "255").split(",")]:
     taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1)))
