@@ -663,7 +663,8 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         hip.check(lib.dd_chain_process(h, d.ptr + 2 * pos, o.ptr, n, None, None))
         # first chunk (4-byte aligned bytes): the two-matrix-set kernel's u8 flavour (FM or complex output); the second
         # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
-        want = hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
+        # (FM output with 255 taps: the overlap-save FFT kernel takes the aligned chunk, whole)
+        want = (hip.DD_KERNEL_FFT_OS if fm else hip.DD_KERNEL_MFMA_AB) if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
