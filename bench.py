@@ -10,8 +10,9 @@ roofline.  Workload = BASELINE.json configs[1] ("C2"):
 A "step" = one pass of the fused hot path over the GPU's shard.  With --gpus N>1 the
 stream is N shards of 2^26 samples, one rank per GPU: rank r re-filters the 256 samples
 before its shard as a lead-in of the same launch (absolute-index state, no halo exchange)
-and no collective sits on the data path (weak scaling).  `--gather` additionally times an
-RCCL all_gather of the decoded output and reports it in "extra" (never in `value`).
+and no collective sits on the data path (weak scaling).  With more than one rank the run ALSO assembles the decoded
+stream and times an RCCL all_gather of the decoded output per step (BASELINE north_star: "trivial RCCL/xGMI gather of
+decoded output"), reported in "extra" (never in `value`); `--no-gather` skips that leg.
 
 Launching.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank.  Started
 plainly with --gpus N>1 it is the *launcher*: it builds the extension once (in a child
@@ -158,6 +159,18 @@ def launch(n_gpus, argv):
     that has initialised the GPU must not fork/exec the ranks)."""
     import subprocess
     if not os.environ.get("DD_BENCH_STUB"):
+        if not os.environ.get("DD_BENCH_ONE_DEVICE"):
+            # how many GPUs does this node show?  Asked in a throw-away child (the launcher itself stays clear of torch
+            # and HIP); a short node gets one clear line instead of a stack trace per rank
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               capture_output=True, text=True)
+            try:
+                seen = int((r.stdout or "").strip().splitlines()[-1])
+            except (ValueError, IndexError):
+                seen = -1
+            if seen < n_gpus:
+                sys.stderr.write("bench.py: --gpus %d asked for, %s GPU(s) visible on this node\n" % (n_gpus, seen if seen >= 0 else "no"))
+                return 2
         r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], stdout=subprocess.DEVNULL)
         if r.returncode != 0:
             raise SystemExit("bench.py: building the HIP extension failed (exit %d)" % r.returncode)
@@ -242,12 +255,14 @@ class HipStep:
         return self.out[self.first:self.first + self.n], cnt
 
     def path(self):
+        if self.lib.dd_chain_last_kernel(self.h) == 7:
+            return "fft-f32-overlap-save"
         return {0: "direct-f32", 1: "mfma-f16x3"}.get(self.lib.dd_chain_path(self.h), str(self.lib.dd_chain_path(self.h)))
 
     def kernel(self):
         """the kernel the last step launched (one launch per step)"""
         return {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
-                6: "k_chain_mfma_ab"}.get(self.lib.dd_chain_last_kernel(self.h), "?")
+                6: "k_chain_mfma_ab", 7: "k_chain_fft1k"}.get(self.lib.dd_chain_last_kernel(self.h), "?")
 
     def close(self):
         self.lib.dd_chain_destroy(self.h)
@@ -403,6 +418,12 @@ def run_rank(args):
         local_rank = 0
     if args.simulate_rank is not None:
         rank = args.simulate_rank
+    if not stub and not one_device and world > 1 and torch.cuda.device_count() < world:
+        # started directly under torch.distributed.run on a node with fewer GPUs than ranks (device_count() does not
+        # initialise the GPU): one line from rank 0, every rank leaves with the same code
+        if rank == 0:
+            sys.stderr.write("bench.py: %d ranks, %d GPU(s) visible on this node\n" % (world, torch.cuda.device_count()))
+        raise SystemExit(2)
     if not stub:
         build_once_per_node()                      # before any rendezvous: ranks never race on the build
     if world > 1:
@@ -478,7 +499,10 @@ def run_rank(args):
     dt_max, kern_ms_max, long_ms_max, cold_ms_max = (float(v) for v in tmax)
 
     extra = {}
-    if args.gather and world > 1:
+    if world > 1:
+        extra["backend"] = dist.get_backend()
+        extra["world_size_seen"] = dist.get_world_size()
+    if world > 1 and not args.no_gather:
         from directdemod_amd import shard
         shard_out, cnt = eng.shard_output()                 # this rank's outputs (a view) and how many are valid
         if one_device:
@@ -575,7 +599,8 @@ def parse_args(argv=None):
                     help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
                          "chip holds under sustained load (a cold MI355X runs its first ~10 ms of kernels 15-20 %% slower)")
     ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the decoded output")
+    ap.add_argument("--gather", action="store_true", help="(default with more than one rank; kept for old command lines)")
+    ap.add_argument("--no-gather", action="store_true", help="more than one rank: skip the RCCL all_gather leg of the decoded output")
     ap.add_argument("--force-direct", action="store_true", help="f32 direct-form kernel instead of the MFMA path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the C3/C4 side lines (extra.side)")

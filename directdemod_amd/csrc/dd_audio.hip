@@ -5,7 +5,6 @@
 // peak pick uses device sort / stream compaction (hipCUB) + a tiny sequential grouping.
 #include "dd_common.h"
 #include <hipfft/hipfft.h>
-#include <hipcub/hipcub.hpp>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -332,9 +331,6 @@ struct DDRuns {
     int start[DD_XCORR_MAX_RUNS + 1];
     double val[DD_XCORR_MAX_RUNS];
 };
-struct SqOp {
-    __host__ __device__ double operator()(const double& x) const { return x * x; }
-};
 
 __global__ void __launch_bounds__(256) k_xcorr_runs(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                     const DDRuns R, double vv, double* __restrict__ out) {
@@ -354,32 +350,29 @@ __global__ void __launch_bounds__(256) k_xcorr_runs(const double* __restrict__ P
     out[i] = c / sqrt(e * vv);
 }
 
+// (defined with the batched accurate-sync chain further down: prefix sums of h and h^2 over tiles of 2048 samples)
+#define DD_SCAN_TILE 2048
+__global__ void k_scan_part(const double* __restrict__ h, int64_t n, int tiles, double2* __restrict__ part);
+__global__ void k_scan_final(const double* __restrict__ h, int64_t n, int tiles, const double2* __restrict__ part, double* __restrict__ P, double* __restrict__ Q);
+
 static int xcorr_runs(const double* h, int64_t n, const double* needle_host, int m, double vv, const DDRuns& R, double* out, hipStream_t s) {
-    double *P = nullptr, *Q = nullptr;
-    void* tmp = nullptr;
-    size_t tb1 = 0, tb2 = 0;
-    hipcub::TransformInputIterator<double, SqOp, const double*> h2(h, SqOp());
-    DD_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb1, h, P, (int)n, s));
-    DD_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, h2, Q, (int)n, s));
-    const size_t tb = tb1 > tb2 ? tb1 : tb2;
+    // P[i] = sum h[0..i), Q[i] = sum h^2[0..i): the two-launch tile scan of the batched chain, batch of one
+    const int tiles = (int)((n + DD_SCAN_TILE - 1) / DD_SCAN_TILE);
     std::lock_guard<std::mutex> lk(g_sync_mu);
     char* base = nullptr;
     const size_t pq_bytes = (sizeof(double) * (2 * (n + 1)) + 255) & ~(size_t)255;
-    int rc = sync_scratch(pq_bytes + (tb ? tb : 16), &base);
+    int rc = sync_scratch(pq_bytes + sizeof(double2) * (size_t)tiles, &base);
     if (rc != DD_OK) return rc;
-    P = (double*)base;
-    Q = P + (n + 1);
-    tmp = base + pq_bytes;
-    hipError_t e1 = hipMemsetAsync(P, 0, sizeof(double), s);
-    hipError_t e2 = hipMemsetAsync(Q, 0, sizeof(double), s);
-    size_t t1 = tb, t2 = tb;
-    hipError_t e3 = hipcub::DeviceScan::InclusiveSum(tmp, t1, h, P + 1, (int)n, s);
-    hipError_t e4 = hipcub::DeviceScan::InclusiveSum(tmp, t2, h2, Q + 1, (int)n, s);
+    double* P = (double*)base;
+    double* Q = P + (n + 1);
+    double2* part = (double2*)(base + pq_bytes);
+    hipLaunchKernelGGL(k_scan_part, dim3(tiles, 1), dim3(256), 0, s, h, n, tiles, part);
+    hipLaunchKernelGGL(k_scan_final, dim3(tiles, 1), dim3(256), 0, s, h, n, tiles, part, P, Q);
     hipLaunchKernelGGL(k_xcorr_runs, dim3(grid1(n)), dim3(256), 0, s, P, Q, n, m, R, vv, out);
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(s);
     (void)needle_host;
-    DD_HIP_CHECK(e1); DD_HIP_CHECK(e2); DD_HIP_CHECK(e3); DD_HIP_CHECK(e4); DD_HIP_CHECK(le); DD_HIP_CHECK(se);
+    DD_HIP_CHECK(le); DD_HIP_CHECK(se);
     return DD_OK;
 }
 
@@ -424,15 +417,134 @@ extern "C" int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needl
 }
 
 // ---------------------------------------------------------------- X2: peak pick (decode_noaa.py:713-751)
-struct GtThr {
-    const double* cor;
-    double thr;
-    __host__ __device__ bool operator()(const int64_t& i) const { return cor[i] > thr; }
+// The reference takes the means of the K largest and K smallest correlation values with np.argpartition (:717-723; K is
+// two per second of signal) and then every index whose value exceeds a threshold between them (:726).  No sort of the
+// whole array is needed for that: a radix SELECT finds the K-th largest and K-th smallest value exactly -- eight
+// passes over the data, one byte of the order-preserving 64-bit key per pass, histograms in LDS (16 interleaved copies,
+// so that the many samples of one bin do not serialise on one address), a one-workgroup kernel between passes that
+// picks the bin and narrows the prefix -- and the values beyond them (fewer than K each) are appended to a small
+// buffer; the host sorts those 2K values and sums them in ascending order.  Candidates: per-tile counts, a scan of the
+// counts, a second pass that writes the indices in ascending order.
+__device__ __forceinline__ unsigned long long dd_key_f64(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);          // ascending in x, total order (-0 < +0, NaNs at the ends)
+}
+struct DDSelState {
+    unsigned long long prefix[2];      // selected high bytes so far: [0] K-th largest, [1] K-th smallest
+    unsigned int remaining[2];         // rank still to find inside the prefix
+    unsigned int beyond[2];            // values strictly beyond the final key (above / below)
+    unsigned int hist[2][256];
+    unsigned int n_out[2];             // appended values
 };
-
-__global__ void __launch_bounds__(256) k_gather_f64(const double* __restrict__ src, const int64_t* __restrict__ idx, int n, double* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
+__global__ void __launch_bounds__(256) k_sel_hist(const double* __restrict__ x, int64_t n, int pass, DDSelState* __restrict__ st) {
+    __shared__ unsigned int h[2][16][256];
+    for (int i = threadIdx.x; i < 2 * 16 * 256; i += 256) (&h[0][0][0])[i] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const unsigned long long p0 = st->prefix[0], p1 = st->prefix[1];
+    const int copy = threadIdx.x & 15;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long k = dd_key_f64(x[i]);
+        const unsigned long long hi = pass ? (k >> (shift + 8)) : 0;
+        const unsigned int d = (unsigned int)(k >> shift) & 255u;
+        if (hi == p0) atomicAdd(&h[0][copy][d], 1u);
+        if (hi == p1) atomicAdd(&h[1][copy][d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        unsigned int c = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += h[i >> 8][k][i & 255];
+        if (c) atomicAdd(&st->hist[i >> 8][i & 255], c);
+    }
+}
+// one wave: pick the byte of this pass for both selections, clear the histograms
+__global__ void __launch_bounds__(64) k_sel_pick(DDSelState* __restrict__ st) {
+    if (threadIdx.x == 0) {
+        unsigned int r = st->remaining[0], c = 0;
+        int d = 255;
+        for (; d > 0; --d) { if (c + st->hist[0][d] >= r) break; c += st->hist[0][d]; }      // from the top
+        st->prefix[0] = (st->prefix[0] << 8) | (unsigned long long)d;
+        st->remaining[0] = r - c;
+        st->beyond[0] += c;
+    }
+    if (threadIdx.x == 1) {
+        unsigned int r = st->remaining[1], c = 0;
+        int d = 0;
+        for (; d < 255; ++d) { if (c + st->hist[1][d] >= r) break; c += st->hist[1][d]; }      // from the bottom
+        st->prefix[1] = (st->prefix[1] << 8) | (unsigned long long)d;
+        st->remaining[1] = r - c;
+        st->beyond[1] += c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 64) st->hist[i >> 8][i & 255] = 0;
+}
+// values strictly above the K-th largest / strictly below the K-th smallest (fewer than K each), any order
+__global__ void __launch_bounds__(256) k_sel_collect(const double* __restrict__ x, int64_t n, DDSelState* __restrict__ st, double* __restrict__ above,
+                                                     double* __restrict__ below, unsigned int cap) {
+    const unsigned long long khi = st->prefix[0], klo = st->prefix[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = x[i];
+        const unsigned long long k = dd_key_f64(v);
+        if (k > khi) { const unsigned int o = atomicAdd(&st->n_out[0], 1u); if (o < cap) above[o] = v; }
+        if (k < klo) { const unsigned int o = atomicAdd(&st->n_out[1], 1u); if (o < cap) below[o] = v; }
+    }
+}
+// candidates cor > thr: per tile of 2048 values the count ...
+#define DD_CAND_TILE 2048
+__global__ void __launch_bounds__(256) k_cand_count(const double* __restrict__ cor, int64_t n, double thr, unsigned int* __restrict__ cnt) {
+    __shared__ unsigned int sw[4];
+    const int64_t i0 = (int64_t)blockIdx.x * DD_CAND_TILE + 8 * threadIdx.x;
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += (i0 + j < n && cor[i0 + j] > thr) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+// ... exclusive scan of the tile counts (one workgroup; cnt[tiles] receives the total) ...
+__global__ void __launch_bounds__(256) k_cand_scan(unsigned int* __restrict__ cnt, int tiles) {
+    __shared__ unsigned int carry, sw[4];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b = 0; b < tiles; b += 256) {
+        const int i = b + threadIdx.x;
+        const unsigned int v = i < tiles ? cnt[i] : 0u;
+        unsigned int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((threadIdx.x & 63) >= d) incl += u; }
+        if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned int off = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += sw[w];
+        if (i < tiles) cnt[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[tiles] = carry;
+}
+// ... and the indices (with their heights), ascending
+__global__ void __launch_bounds__(256) k_cand_write(const double* __restrict__ cor, int64_t n, double thr, const unsigned int* __restrict__ off,
+                                                    int64_t* __restrict__ idx, double* __restrict__ val) {
+    __shared__ unsigned int sw[4];
+    const int64_t i0 = (int64_t)blockIdx.x * DD_CAND_TILE + 8 * threadIdx.x;
+    unsigned int c = 0;
+    bool f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { f[j] = i0 + j < n && cor[i0 + j] > thr; c += f[j] ? 1u : 0u; }
+    unsigned int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((threadIdx.x & 63) >= d) incl += u; }
+    if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned int o = off[blockIdx.x] + incl - c;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) o += sw[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (f[j]) { idx[o] = i0 + j; val[o] = cor[i0 + j]; ++o; }
 }
 
 extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate, int needle_len,
@@ -441,53 +553,70 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
     hipStream_t s = dd_stream(stream);
     const int K = (int)(2 * ((double)n / samp_rate)) + 2;                 // expectedPeaks (:714)
     DD_REQUIRE(K <= n, "signal shorter than the expected peak count");
-    // ---- all intermediates from the scratch arena: [sorted n f64 | cand n i64 | gathered heights n f64 | count | library temp]
-    size_t sort_tmp = 0, sel_tmp = 0;
-    {
-        double* nul = nullptr;
-        int64_t* nuli = nullptr;
-        int* nulc = nullptr;
-        hipcub::CountingInputIterator<int64_t> idx0(0);
-        GtThr pred0{cor, 0.0};
-        DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, cor, nul, (int)n, 0, 64, s));
-        DD_HIP_CHECK(hipcub::DeviceSelect::If(nullptr, sel_tmp, idx0, nuli, nulc, (int)n, pred0, s));
-    }
+    // ---- all intermediates from the scratch arena: [select state | above K | below K | tile counts | cand idx n | cand val n]
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_cand = al(sizeof(double) * n), o_cv = o_cand + al(sizeof(int64_t) * n), o_cnt = o_cv + al(sizeof(double) * n);
-    const size_t o_tmp = o_cnt + 256, tmp_bytes = sort_tmp > sel_tmp ? sort_tmp : sel_tmp;
+    const int tiles = (int)((n + DD_CAND_TILE - 1) / DD_CAND_TILE);
+    const size_t o_above = al(sizeof(DDSelState)), o_below = o_above + al(sizeof(double) * K), o_cnt = o_below + al(sizeof(double) * K);
+    const size_t o_cand = o_cnt + al(sizeof(unsigned int) * (tiles + 1)), o_cv = o_cand + al(sizeof(int64_t) * n);
     std::lock_guard<std::mutex> lk(g_sync_mu);
     char* base = nullptr;
-    int rc = sync_scratch(o_tmp + tmp_bytes + 256, &base);
+    int rc = sync_scratch(o_cv + al(sizeof(double) * n), &base);
     if (rc != DD_OK) return rc;
-    double* sorted = (double*)base;
+    DDSelState* st = (DDSelState*)base;
+    double* d_above = (double*)(base + o_above);
+    double* d_below = (double*)(base + o_below);
+    unsigned int* d_cnt = (unsigned int*)(base + o_cnt);
     int64_t* cand = (int64_t*)(base + o_cand);
     double* d_cv = (double*)(base + o_cv);
-    int* d_count = (int*)(base + o_cnt);
-    void* tmp = base + o_tmp;
-    // ---- mean of the K largest and K smallest values (argpartition, :717-723): device sort
-    size_t tb = tmp_bytes;
-    DD_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, cor, sorted, (int)n, 0, 64, s));
-    std::vector<double> lo(K), hi(K);
-    DD_HIP_CHECK(hipMemcpyAsync(lo.data(), sorted, sizeof(double) * K, hipMemcpyDeviceToHost, s));
-    DD_HIP_CHECK(hipMemcpyAsync(hi.data(), sorted + (n - K), sizeof(double) * K, hipMemcpyDeviceToHost, s));
+    // ---- mean of the K largest and K smallest values (argpartition, :717-723): radix select
+    DDSelState h0;
+    memset(&h0, 0, sizeof(h0));
+    h0.remaining[0] = h0.remaining[1] = (unsigned int)K;
+    DD_HIP_CHECK(hipMemcpyAsync(st, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
+    const unsigned int sel_grid = (unsigned int)(grid1(n) < 1024 ? grid1(n) : 1024);
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid), dim3(256), 0, s, cor, n, pass, st);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, s, st);
+    }
+    hipLaunchKernelGGL(k_sel_collect, dim3(sel_grid), dim3(256), 0, s, cor, n, st, d_above, d_below, (unsigned int)K);
+    DD_LAUNCH_CHECK();
+    DDSelState h1;
+    std::vector<double> hi(K), lo(K);
+    DD_HIP_CHECK(hipMemcpyAsync(&h1, st, sizeof(h1), hipMemcpyDeviceToHost, s));
+    DD_HIP_CHECK(hipMemcpyAsync(hi.data(), d_above, sizeof(double) * K, hipMemcpyDeviceToHost, s));
+    DD_HIP_CHECK(hipMemcpyAsync(lo.data(), d_below, sizeof(double) * K, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    auto unkey = [](unsigned long long k) {
+        const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double d;
+        memcpy(&d, &u, sizeof(d));
+        return d;
+    };
+    DD_REQUIRE(h1.n_out[0] == h1.beyond[0] && h1.n_out[1] == h1.beyond[1] && h1.n_out[0] < (unsigned int)K && h1.n_out[1] < (unsigned int)K,
+               "dd_find_peaks_f64: selection bookkeeping (internal)");
+    {
+        const double vhi = unkey(h1.prefix[0]), vlo = unkey(h1.prefix[1]);
+        for (unsigned int i = h1.n_out[0]; i < (unsigned int)K; ++i) hi[i] = vhi;     // the K-th largest itself and its ties
+        for (unsigned int i = h1.n_out[1]; i < (unsigned int)K; ++i) lo[i] = vlo;
+        std::sort(hi.begin(), hi.end());
+        std::sort(lo.begin(), lo.end());
+    }
     double sum_hi = 0.0, sum_lo = 0.0;
-    for (int i = 0; i < K; ++i) { sum_hi += hi[i]; sum_lo += lo[i]; }
+    for (int i = 0; i < K; ++i) { sum_hi += hi[i]; sum_lo += lo[i]; }     // ascending, like the sums over the sorted array they replace
     double avgpk = sum_hi / K;
     avgpk -= 0.25 * (avgpk - sum_lo / K);                                 // NOAA_PEAKHEIGHTWIGGLE (:723)
-    // ---- candidates cor > threshold, ascending index (:726): device stream compaction
-    hipcub::CountingInputIterator<int64_t> idx(0);
-    GtThr pred{cor, avgpk};
-    tb = tmp_bytes;
-    DD_HIP_CHECK(hipcub::DeviceSelect::If(tmp, tb, idx, cand, d_count, (int)n, pred, s));
-    int count = 0;
-    DD_HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    // ---- candidates cor > threshold, ascending index (:726), with their heights
+    hipLaunchKernelGGL(k_cand_count, dim3(tiles), dim3(256), 0, s, cor, n, avgpk, d_cnt);
+    hipLaunchKernelGGL(k_cand_scan, dim3(1), dim3(256), 0, s, d_cnt, tiles);
+    hipLaunchKernelGGL(k_cand_write, dim3(tiles), dim3(256), 0, s, cor, n, avgpk, d_cnt, cand, d_cv);
+    DD_LAUNCH_CHECK();
+    unsigned int ucount = 0;
+    DD_HIP_CHECK(hipMemcpyAsync(&ucount, d_cnt + tiles, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    const int count = (int)ucount;
     std::vector<int64_t> ci(count);
     std::vector<double> cv(count);
     if (count > 0) {
-        // candidate heights gathered on the device: two downloads whatever the number of candidate runs
-        hipLaunchKernelGGL(k_gather_f64, dim3(grid1(count)), dim3(256), 0, s, cor, cand, count, d_cv);
         DD_HIP_CHECK(hipMemcpyAsync(ci.data(), cand, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
         DD_HIP_CHECK(hipMemcpyAsync(cv.data(), d_cv, sizeof(double) * count, hipMemcpyDeviceToHost, s));
         DD_HIP_CHECK(hipStreamSynchronize(s));
@@ -531,7 +660,7 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
 // The windows are independent and equally long, so the whole chain runs once over [windows][samples]
 // arrays: a dozen launches per batch instead of ~40 launches, ~25 allocations and 8 host round trips per
 // window.  Each stage is the arithmetic of the per-window entry points (same kernels or the same
-// device functions); only the prefix sums (own scan instead of hipcub) and the batched FFT plan may
+// device functions); only the prefix sums and the batched FFT plan may
 // round differently, at the 1e-13 level of the correlation.
 #include "dd_chain_kernels.h"
 #include "dd_filtfilt_kernels.h"
@@ -562,7 +691,6 @@ __global__ void __launch_bounds__(256) k_sync_fm(const float2* __restrict__ Y, i
 
 // P[b][i] = sum h[b][0..i), Q likewise of h^2, in two launches over tiles of 2048 samples: tile sums, then each
 // tile adds the sums of the tiles before it (ascending) to its own scan -- every tile of every window in parallel
-#define DD_SCAN_TILE 2048
 __device__ __forceinline__ void dd_scan_tile_load(const double* __restrict__ h, int64_t n, int64_t i0, double (&p)[8], double (&q)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -30,7 +30,7 @@ def _run(extra_args, env_extra=None, timeout=240):
 
 @pytest.mark.timeout(300)
 def test_gpus_2_launches_two_ranks_and_prints_one_line():
-    r, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--ramp-ms", "2", "--gather"])
+    r, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--ramp-ms", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
@@ -40,8 +40,33 @@ def test_gpus_2_launches_two_ranks_and_prints_one_line():
     assert len(j["extra"]["kernel_ms_per_rank"]) == 2
     # gather leg: rank 0 of the stream contributes n-1 outputs (quirk Q3), every other rank n
     assert j["extra"]["gathered_outputs"] == 2 * j["config"]["samples_per_gpu"] - 1
-    assert "with_all_gather_MSamples_per_s" in j["extra"]
+    assert "with_all_gather_MSamples_per_s" in j["extra"] and "all_gather_ms_per_step" in j["extra"]      # without --gather
+    assert j["extra"]["world_size_seen"] == 2 and j["extra"]["backend"] == "gloo"
     assert "cpu_baseline" not in j                      # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(300)
+def test_no_gather_skips_the_collective_leg():
+    r, lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-ms", "2", "--no-gather"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert "with_all_gather_MSamples_per_s" not in j["extra"] and j["extra"]["world_size_seen"] == 2
+
+
+@pytest.mark.timeout(120)
+def test_short_node_gets_one_clear_line():
+    """--gpus 4 on a node that shows fewer GPUs (this container shows none): the launcher probes the device count in a
+    throw-away child and leaves with one line and a non-zero code, before building or starting any rank"""
+    env = dict(os.environ)
+    for k in ("DD_BENCH_STUB", "DD_BENCH_ONE_DEVICE", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=100, cwd=ROOT)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    msg = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py:")]
+    assert len(msg) == 1 and "--gpus 4" in msg[0] and "visible" in msg[0], r.stderr[-500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.timeout(120)
@@ -63,7 +88,7 @@ def test_launcher_does_not_import_torch_or_hip():
         "    stdout=[]\n"
         "    def wait(self): return 0\n"
         "subprocess.Popen=lambda cmd, **k: (calls.append(cmd), P())[1]\n"
-        "subprocess.run=lambda cmd, **k: type('R',(),{'returncode':0})()\n"
+        "subprocess.run=lambda cmd, **k: type('R',(),{'returncode':0,'stdout':'8\\n'})()\n"
         "try:\n"
         "    bench.main()\n"
         "except SystemExit as e:\n"

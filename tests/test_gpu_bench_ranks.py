@@ -23,15 +23,18 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
         env.pop(k, None)
     env["DD_BENCH_ONE_DEVICE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "22", "--steps", "3",
-                        "--warmup", "1", "--ramp-ms", "5", "--gather"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
+                        "--warmup", "1", "--ramp-ms", "5"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     n = 1 << 22
     assert j["n_gpus"] == 2 and j["config"]["samples_per_gpu"] == n and j["scaling"] == "weak"
-    assert j["config"]["kernel_path"] == "mfma-f16x3" and j["data"].startswith("synthetic")
+    assert j["config"]["kernel"] == "k_chain_fft1k" and j["data"].startswith("synthetic")
     assert len(j["extra"]["kernel_ms_per_rank"]) == 2 and all(t > 0 for t in j["extra"]["kernel_ms_per_rank"])
+    # the gather leg runs without being asked for
     assert j["extra"]["gathered_outputs"] == 2 * n - 1
+    assert j["extra"]["with_all_gather_MSamples_per_s"] > 0 and j["extra"]["all_gather_ms_per_step"] > 0
+    assert j["extra"]["world_size_seen"] == 2 and j["extra"]["backend"] == "gloo"     # (one-device check: gloo; nccl on a real node)
     assert 0.005 < j["extra"]["output_rms_rad"] < 0.02            # the demodulated 1 kHz tone (deviation 5 rad)
     assert "cpu_baseline" not in j and "side" not in j["extra"]

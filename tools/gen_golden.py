@@ -109,7 +109,33 @@ def gen_afsk(O, filters):
           int(np.sum(cap["sign"] < 0)))
 
 
+def gen_c4_60s():
+    """config 4 at BENCH duration ("duration 8 s (smoke) and 60 s (bench) ... Pass = identical index
+    lists"): the reference's own getCrudeSync + getAccurateSync (decode_noaa.py:769-880) over a 60 s synthetic APT
+    recording (seed 1); only the index lists (a few KB) are stored.  ~10 minutes of the reference's time (its accurate
+    sync is ~2 s per window), so it has its own switch:  gen_golden.py --c4-60s"""
+    install_shim()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    from directdemod import decode_noaa
+    from oracle import dd_oracle as O
+    dur = 60.0
+    raw = O.synth_apt_iq(dur, 2048000, seed=1)
+    src = ArraySource(raw, 2048000)
+    nobj = decode_noaa.decode_noaa(src, 30000.0)
+    sa, sb = nobj.getCrudeSync()
+    g = {"dur": np.float64(dur), "seed": np.int64(1), "useful": np.int64(nobj.useful),
+         "crude_syncA": np.asarray(sa, dtype=np.int64), "crude_syncB": np.asarray(sb, dtype=np.int64)}
+    acc = nobj.getAccurateSync()
+    g["acc_syncA"] = np.asarray(acc[0], dtype=np.int64)
+    g["acc_syncB"] = np.asarray(acc[4], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "noaa_c4_60s.npz"), **g)
+    print("noaa_c4_60s: crude A %d B %d, accurate A %d B %d, useful %d" % (len(sa), len(sb), len(acc[0]), len(acc[4]), nobj.useful))
+
+
 def main():
+    if "--c4-60s" in sys.argv:
+        return gen_c4_60s()
     only_afsk = "--afsk-only" in sys.argv
     install_shim()
     sys.path.insert(0, REF)
