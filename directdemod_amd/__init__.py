@@ -14,5 +14,6 @@ is no CPU fallback: without the library or without a GPU the compute calls raise
 """
 from . import constants  # noqa: F401
 
-__all__ = ["comm", "filters", "demod_fm", "demod_am", "chunker", "constants", "source", "pipeline"]
+# `from directdemod_amd import *` brings in the drop-in modules (imported lazily: nothing here loads the HIP library)
+__all__ = ["comm", "filters", "demod_fm", "demod_am", "chunker", "constants", "source", "resample", "afsk", "noaa_sync", "shard", "stream"]
 __version__ = "0.1.0"

@@ -273,7 +273,13 @@ def register_stream(s):
     v = _sval(s)
     if v:
         with _pool_lock:
+            first = not _streams
             _streams[v] = _streams.get(v, 0) + 1
+        if first and _lib is not None:
+            # buffers freed while only the null stream was in use were parked without a fence (null-stream work may
+            # still be pending on them); from now on a parked buffer can be handed to a non-blocking stream, so let
+            # that work finish once
+            _lib.dd_stream_sync(None)
 
 
 def unregister_stream(s):
@@ -293,16 +299,21 @@ def _fence_events():
         return []
     evs = []
     L = lib()
-    for sv in [0] + live:
+    try:
+        for sv in [0] + live:
+            with _pool_lock:
+                e = _event_spare.pop() if _event_spare else None
+            if e is None:
+                e = C.c_void_p()
+                if L.dd_event_create(C.byref(e)) != DD_OK:
+                    raise HipError("dd_event_create: " + last_error())
+            evs.append(e)
+            if L.dd_event_record(e, C.c_void_p(sv) if sv else None) != DD_OK:
+                raise HipError("dd_event_record: " + last_error())
+    except Exception:
         with _pool_lock:
-            e = _event_spare.pop() if _event_spare else None
-        if e is None:
-            e = C.c_void_p()
-            if L.dd_event_create(C.byref(e)) != DD_OK:
-                raise HipError("dd_event_create: " + last_error())
-        if L.dd_event_record(e, C.c_void_p(sv) if sv else None) != DD_OK:
-            raise HipError("dd_event_record: " + last_error())
-        evs.append(e)
+            _event_spare.extend(evs)            # (the events made so far go back to the spare list, not lost)
+        raise
     return evs
 
 

@@ -20,16 +20,20 @@
     } while (0)
 
 // ---------------------------------------------------------------- plan cache
+// (a plan is bound to the stream it is used on -- hipfftSetStream -- and owns a work area: one plan per stream, so two
+// host threads on two streams never re-bind or share one)
 struct PlanKey {
     int dev;
     int type;
     int64_t n;
     int batch;
+    hipStream_t stream;
     bool operator<(const PlanKey& o) const {
         if (dev != o.dev) return dev < o.dev;
         if (type != o.type) return type < o.type;
         if (n != o.n) return n < o.n;
-        return batch < o.batch;
+        if (batch != o.batch) return batch < o.batch;
+        return stream < o.stream;
     }
 };
 static std::mutex g_plan_mu;
@@ -40,14 +44,14 @@ static int get_plan(hipfftHandle* out, hipfftType type, int64_t n, int batch, hi
     DD_HIP_CHECK(hipGetDevice(&dev));
     DD_REQUIRE(n >= 1 && n < (1ll << 31), "FFT length");
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    PlanKey k{dev, (int)type, n, batch};
+    PlanKey k{dev, (int)type, n, batch, s};
     auto it = g_plans.find(k);
     if (it == g_plans.end()) {
         hipfftHandle h;
         DD_FFT_CHECK(hipfftPlan1d(&h, (int)n, type, batch));
+        DD_FFT_CHECK(hipfftSetStream(h, s));
         it = g_plans.emplace(k, h).first;
     }
-    DD_FFT_CHECK(hipfftSetStream(it->second, s));
     *out = it->second;
     return DD_OK;
 }
@@ -104,8 +108,9 @@ extern "C" int dd_am_envelope_f64(const double* in, double* out, int64_t n, int6
     const int64_t rem = n - nfull * block;                  // 1 .. block
     const int GB = 16;                                       // full blocks per batched transform
     const int64_t wlen = nfull ? (nfull < GB ? nfull : GB) * block : 0;
-    char* base = nullptr;
-    int rc = dd_scratch_get(sizeof(double2) * (size_t)(wlen > rem ? wlen : rem), s, &base);
+    DDScratchLock scr;                      // held until this entry point has enqueued everything
+    int rc = scr.get(sizeof(double2) * (size_t)(wlen > rem ? wlen : rem), s);
+    char* base = scr.ptr;
     if (rc != DD_OK) return rc;
     double2* work = reinterpret_cast<double2*>(base);
     for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) {
@@ -242,7 +247,7 @@ extern "C" int dd_rpoly_process(dd_rpoly* r, const double* in, int64_t n, int fl
     return DD_OK;
 }
 
-// The FFT resampler's intermediates come from dd_scratch_get: the call neither allocates, frees nor synchronises (in the
+// The FFT resampler's intermediates come from the per-stream scratch (DDScratchLock): the call neither allocates, frees nor synchronises (in the
 // C3 chunk loop -- one call per 2^22-sample chunk -- those were 88 of the 140 us a chunk cost the host).
 extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream) {
     DD_REQUIRE(n >= 1 && num >= 1, "n/num");
@@ -257,7 +262,9 @@ extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int
     const size_t bx = (sizeof(double2) * nxb + 255) & ~(size_t)255, by = (sizeof(double2) * nyb + 255) & ~(size_t)255;
     const size_t need = bx + by + sizeof(double) * n;
     char* base = nullptr;
-    rc = dd_scratch_get(need, s, &base);
+    DDScratchLock scr;                      // held until this entry point has enqueued everything
+    rc = scr.get(need, s);
+    base = scr.ptr;
     if (rc != DD_OK) return rc;
     double2* X = reinterpret_cast<double2*>(base);
     double2* Y = reinterpret_cast<double2*>(base + bx);
@@ -401,8 +408,9 @@ extern "C" int dd_xcorr_norm_f64(const double* h, int64_t n, const double* needl
             return xcorr_runs(h, n, needle_host, m, vv, R, out, s);
         }
     }
-    char* base = nullptr;
-    int rcs = dd_scratch_get(sizeof(double) * (size_t)m, s, &base);
+    DDScratchLock scr;                      // held until this entry point has enqueued everything
+    int rcs = scr.get(sizeof(double) * (size_t)m, s);
+    char* base = scr.ptr;
     if (rcs != DD_OK) return rcs;
     double* v = reinterpret_cast<double*>(base);
     DD_HIP_CHECK(hipMemcpyAsync(v, needle_host, sizeof(double) * m, hipMemcpyHostToDevice, s));

@@ -33,10 +33,21 @@ void dd_set_error(const char* fmt, ...);
 
 static inline hipStream_t dd_stream(void* s) { return (hipStream_t)s; }
 
-// Grow-only scratch buffer per device for an entry point's intermediates, reused from call to call in STREAM order: the
-// buffer belongs to the stream of the last caller, and a call on another stream first waits for that stream.  An entry
-// point that takes it neither allocates nor frees, and need not synchronise unless it reads host memory of the caller.
-int dd_scratch_get(size_t bytes, hipStream_t s, char** out);
+// Grow-only scratch buffer per (device, stream) for an entry point's intermediates.  An entry point takes the lock,
+// enqueues its copies and kernels on that stream and drops the lock when it returns: the buffer is then protected by
+// stream order (a later call on the same stream is enqueued behind this one; a call on another stream has a buffer of
+// its own), and two host threads that use the same stream take turns enqueuing.  Neither allocates nor synchronises in
+// the steady state.
+struct DDScratchLock {
+    void* entry = nullptr;
+    char* ptr = nullptr;
+    int get(size_t bytes, hipStream_t s);      // DD_OK or an error code; ptr is valid until this object dies
+    ~DDScratchLock();
+    DDScratchLock() = default;
+    DDScratchLock(const DDScratchLock&) = delete;
+    DDScratchLock& operator=(const DDScratchLock&) = delete;
+};
+void dd_scratch_forget_stream(hipStream_t s);  // the stream is about to be destroyed: free its buffers
 
 
 // Per-device one-time work (hipFuncSetAttribute and friends apply to the current device only; the C-ABI has

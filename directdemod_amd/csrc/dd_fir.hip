@@ -123,8 +123,9 @@ static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, in
     }
     const int64_t N = n + 2 * (int64_t)edge;
     const size_t tb = (sizeof(double) * (size_t)K + 255) & ~(size_t)255;
-    char* base = nullptr;
-    int rcs = dd_scratch_get(tb + sizeof(T) * (size_t)N, s, &base);
+    DDScratchLock scr;                      // held until this entry point has enqueued everything
+    int rcs = scr.get(tb + sizeof(T) * (size_t)N, s);
+    char* base = scr.ptr;
     if (rcs != DD_OK) return rcs;
     double* taps = reinterpret_cast<double*>(base);
     T* y1 = reinterpret_cast<T*>(base + tb);
@@ -510,6 +511,9 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
     for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * 2 + c) * IIR_S + k] : 0.0;
     const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;            // samples of this chain's block
     const int nsteps = lb / IIR_W_CH;
+    // the counted waits of the write pass assume that every step issues all 16 of its (predicated) stores: true for a
+    // workgroup whose 32 blocks all exist and are whole; the last workgroup of a call waits for everything instead
+    const bool partial = (b0 + IIR_W_BLOCKS > nb) || ((b0 + IIR_W_BLOCKS) * (int64_t)lb > n);
     // sample this lane moves in a DMA / a store of pair r: lanes 0..31 the first block of the pair, 32..63 the second
     const int half = lane >> 5, l32 = lane & 31;
     auto issue = [&](int step) {
@@ -530,7 +534,9 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
         // step st must have landed.  Younger than its DMAs: the DMA batches of the steps after it and (write pass) the
         // store batches of the iterations since -- 16 instructions each
         const int ahead = nsteps - 1 - st < IIR_W_NB - 1 ? nsteps - 1 - st : IIR_W_NB - 1;       // DMA batches in flight behind step st
-        if (WRITE) {
+        if (WRITE && partial) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // fewer than 16 stores per step may have issued: nothing to count on
+        } else if (WRITE) {
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");             // 2 x 16 DMAs + 2 x 16 stores = 64: one more than the counter holds
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

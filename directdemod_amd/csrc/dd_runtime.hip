@@ -2,6 +2,8 @@
 // hot path: S1 (u8 ingest), N1 (NCO), R1 (decimation gather), D1 (FM
 // discriminator).  gfx950 only.
 #include "dd_common.h"
+#include <vector>
+#include <mutex>
 #include <stdarg.h>
 #include <mutex>
 
@@ -88,32 +90,85 @@ extern "C" int dd_host_unregister(void* hptr) {
     if (hptr) DD_HIP_CHECK(hipHostUnregister(hptr));
     return DD_OK;
 }
-static std::mutex g_scr_mu;
-static char* g_scr_buf[64] = {nullptr};
-static size_t g_scr_bytes[64] = {0};
-static hipStream_t g_scr_stream[64] = {nullptr};
-static bool g_scr_used[64] = {false};
-int dd_scratch_get(size_t bytes, hipStream_t s, char** out) {
+// ---- scratch buffers keyed by (device, stream) (dd_common.h, DDScratchLock)
+struct DDScratchEntry {
+    std::mutex mu;
+    int dev;
+    hipStream_t stream;
+    char* buf = nullptr;
+    size_t bytes = 0;
+    unsigned long long last_use = 0;
+};
+static std::mutex g_scr_mu;                                   // the table only; never held while an entry is in use
+static std::vector<DDScratchEntry*> g_scr;
+static unsigned long long g_scr_clock = 0;
+#define DD_SCRATCH_MAX_ENTRIES 16
+
+int DDScratchLock::get(size_t bytes, hipStream_t s) {
     int dev = 0;
     DD_HIP_CHECK(hipGetDevice(&dev));
-    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
-    std::lock_guard<std::mutex> lk(g_scr_mu);
-    if (g_scr_used[dev] && g_scr_stream[dev] != s) DD_HIP_CHECK(hipStreamSynchronize(g_scr_stream[dev]));
-    if (g_scr_bytes[dev] < bytes) {
-        if (g_scr_buf[dev]) {
-            DD_HIP_CHECK(hipStreamSynchronize(g_scr_stream[dev]));
-            DD_HIP_CHECK(hipFree(g_scr_buf[dev]));
+    DDScratchEntry* e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_scr_mu);
+        for (DDScratchEntry* c : g_scr)
+            if (c->dev == dev && c->stream == s) { e = c; break; }
+        if (!e) {
+            if (g_scr.size() >= DD_SCRATCH_MAX_ENTRIES) {
+                // streams come and go (a caller may destroy one without telling us): drop the least recently used
+                // entry nobody holds; its stream may be dead, so nothing is synchronised -- hipFree waits for the device
+                size_t victim = g_scr.size();
+                for (size_t i = 0; i < g_scr.size(); ++i)
+                    if ((victim == g_scr.size() || g_scr[i]->last_use < g_scr[victim]->last_use) && g_scr[i]->mu.try_lock()) {
+                        if (victim != g_scr.size()) g_scr[victim]->mu.unlock();
+                        victim = i;
+                    }
+                if (victim != g_scr.size()) {
+                    DDScratchEntry* v = g_scr[victim];
+                    if (v->buf) (void)hipFree(v->buf);
+                    v->mu.unlock();
+                    delete v;
+                    g_scr.erase(g_scr.begin() + (long)victim);
+                }
+            }
+            e = new DDScratchEntry();
+            e->dev = dev;
+            e->stream = s;
+            g_scr.push_back(e);
         }
-        g_scr_buf[dev] = nullptr;
-        g_scr_bytes[dev] = 0;
-        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-        DD_HIP_CHECK(hipMalloc((void**)&g_scr_buf[dev], want));
-        g_scr_bytes[dev] = want;
+        e->last_use = ++g_scr_clock;
     }
-    g_scr_stream[dev] = s;
-    g_scr_used[dev] = true;
-    *out = g_scr_buf[dev];
+    e->mu.lock();
+    entry = e;
+    if (e->bytes < bytes) {
+        if (e->buf) {
+            const hipError_t fe = hipFree(e->buf);              // (waits for the device: earlier users of the buffer are done)
+            e->buf = nullptr;
+            e->bytes = 0;
+            DD_HIP_CHECK(fe);
+        }
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        DD_HIP_CHECK(hipMalloc((void**)&e->buf, want));
+        e->bytes = want;
+    }
+    ptr = e->buf;
     return DD_OK;
+}
+DDScratchLock::~DDScratchLock() {
+    if (entry) reinterpret_cast<DDScratchEntry*>(entry)->mu.unlock();
+}
+void dd_scratch_forget_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    for (size_t i = 0; i < g_scr.size();) {
+        DDScratchEntry* c = g_scr[i];
+        if (c->stream == s && c->mu.try_lock()) {
+            if (c->buf) (void)hipFree(c->buf);
+            c->mu.unlock();
+            delete c;
+            g_scr.erase(g_scr.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
 }
 
 // Diagnostic: leave every compute unit's LDS holding `pattern` (the hardware does not clear LDS between workgroups, so a
@@ -158,7 +213,11 @@ extern "C" int dd_stream_create(void** stream) {
     return DD_OK;
 }
 extern "C" int dd_stream_destroy(void* stream) {
-    if (stream) DD_HIP_CHECK(hipStreamDestroy(dd_stream(stream)));
+    if (stream) {
+        DD_HIP_CHECK(hipStreamSynchronize(dd_stream(stream)));
+        dd_scratch_forget_stream(dd_stream(stream));
+        DD_HIP_CHECK(hipStreamDestroy(dd_stream(stream)));
+    }
     return DD_OK;
 }
 extern "C" int dd_stream_sync(void* stream) {

@@ -10,7 +10,7 @@ samples for 1 s in 10 chunks).
 
     rs = resample.polyResampler(200000, 11025)            # once, outside the chunk loop (like a filter)
     for ...: audio.extend(sig.filter(...).bwLim(200000).funcApply(fm.demod).resamplePoly(rs))
-    audio.extend(rs.flush(11025))                          # the tail (the filter's look-ahead)
+    audio.extend(rs.flush())                          # the tail (the filter's look-ahead)
 """
 import ctypes as C
 import math

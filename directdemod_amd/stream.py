@@ -16,6 +16,8 @@ inside the loop (only when the ring wraps onto a slot still being copied from).
 import ctypes as C
 from concurrent.futures import ThreadPoolExecutor
 
+import mmap
+
 import numpy as np
 
 from . import _hip, chunker, constants
@@ -94,6 +96,10 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
     register = direct and staging == "registered" and 2 * min(b - a for a, b in chunks) >= 65536
     registered = [None] * depth                     # host address pinned for the chunk in slot k (page aligned)
     reg_hi = 0                                      # end of the last pinned range
+    buf_end = 0                                     # end of the recording in host memory (pinned ranges stop at its last page)
+    if direct and register and chunks:
+        vall = src.raw_view(chunks[0][0], chunks[-1][1])
+        buf_end = vall.ctypes.data + vall.nbytes
     ring = PinnedRing(2 * maxlen, depth, pinned=not direct)
     total_out = max(1, len(range(0, src.length, decim)))
     out = DevArray(total_out, np.float32)
@@ -118,19 +124,25 @@ def stream_fm_chain(src, taps, freq_hz, decim, chunk_size=constants.PROC_CHUNKSI
                         registered[k] = None
                     # pinned ranges tile the recording in whole pages without overlap (a page can be registered once):
                     # this chunk's range starts where the previous one ended
-                    lo = max(v.ctypes.data & ~4095, reg_hi)
-                    hi = (v.ctypes.data + 2 * n + 4095) & ~4095
-                    split = 0                                                                 # bytes of this chunk that lie in the previous range
+                    pg = mmap.PAGESIZE
+                    lo = max(v.ctypes.data & ~(pg - 1), reg_hi)
+                    hi = (v.ctypes.data + 2 * n + pg - 1) & ~(pg - 1)
+                    if buf_end:
+                        hi = min(hi, (buf_end + pg - 1) & ~(pg - 1))                        # never past the page that holds the recording's last byte
+                    # bytes of this chunk that lie in the previous chunk's (still pinned) range: copied on their own,
+                    # pinned or not -- a copy may not start inside one registration and run on into other memory
+                    split = max(0, min(2 * n, reg_hi - v.ctypes.data)) if reg_hi else 0
                     if hi > lo:
                         if L.dd_host_register(lo, hi - lo) == _hip.DD_OK:
                             registered[k] = lo
-                            split = max(0, min(2 * n, lo - v.ctypes.data)) if reg_hi else 0
                             reg_hi = hi
                         else:
-                            register = False                                                  # cannot pin this memory: plain "direct" from here on
-                    if split:                                                                 # one copy per pinned range (a copy may not span two registrations)
+                            register = False                                                  # cannot pin this memory: plain "direct" from the next chunk on
+                            reg_hi = 0
+                    if split:
                         check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, split, ring.copy_stream), "h2d")
-                        check(L.dd_memcpy_h2d(ring.dev[k].ptr + split, v.ctypes.data + split, 2 * n - split, ring.copy_stream), "h2d")
+                        if 2 * n > split:
+                            check(L.dd_memcpy_h2d(ring.dev[k].ptr + split, v.ctypes.data + split, 2 * n - split, ring.copy_stream), "h2d")
                     else:
                         check(L.dd_memcpy_h2d(ring.dev[k].ptr, v.ctypes.data, 2 * n, ring.copy_stream), "h2d")
                 else:

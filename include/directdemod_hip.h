@@ -230,7 +230,10 @@ int64_t dd_rpoly_out_count(const dd_rpoly* h, int64_t n, int flush);
 int dd_rpoly_process(dd_rpoly* h, const double* in, int64_t n, int flush, double* out, int64_t* n_out, void* stream);
 
 /* ---- A1: demod_am.demod = abs(hilbert(x)) (demod_am.py:18-29) in fixed blocks
- *      (decode_noaa.py:647-653: 240 000-sample blocks, chunker rule) ----------- */
+ *      (decode_noaa.py:647-653: 240 000-sample blocks, chunker rule).  Asynchronous on `stream` like
+ *      dd_resample_fft_f64: intermediates come from a grow-only buffer the library keeps per (device, stream) -- no
+ *      allocation and no synchronisation in the steady state; callers on different streams never share a buffer,
+ *      two host threads on one stream take turns enqueuing ----------- */
 int dd_am_envelope_f64(const double* in, double* out, int64_t n, int64_t block, void* stream);
 
 /* ---- X1: decode_noaa.__correlate (decode_noaa.py:659-675) --------------------- */

@@ -137,6 +137,28 @@ def test_c4_crude_and_accurate_sync_indices_golden(dd, noaa_inputs):
     assert np.max(np.abs(np.array(ta) - g["acc_syncA_time"])) < 1e-4
 
 
+@pytest.mark.timeout(900)
+def test_c4_at_bench_duration_index_lists_golden(dd, golden_dir):
+    """config 4 at BENCH duration (60 s, "Pass = identical index lists"): crude and accurate sync over a 60 s
+    synthetic APT recording resident in HBM, every index equal to the reference's own getCrudeSync / getAccurateSync run
+    (tests/golden/noaa_c4_60s.npz, tools/gen_golden.py --c4-60s; decode_noaa.py:769-880)."""
+    g = _load(golden_dir, "noaa_c4_60s.npz")
+    raw = O.synth_apt_iq(float(g["dur"]), 2048000, seed=int(g["seed"]))
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    sa, sb = ns.getCrudeSync()
+    assert ns.useful == int(g["useful"]) == 1
+    assert np.array_equal(sa, g["crude_syncA"]) and np.array_equal(sb, g["crude_syncB"])
+    assert len(sa) == 120 and len(sb) == 120
+    (ia, pa, ta), (ib, pb, tb) = ns.getAccurateSync()              # batched windows, recording resident (uploaded by the crude pass)
+    assert np.array_equal(ia, g["acc_syncA"]) and np.array_equal(ib, g["acc_syncB"])
+    # and once more through a fresh object over the now-resident recording (what bench.py's side line times)
+    ns2 = dd.noaa.noaa_sync(src, 30000.0)
+    sa2, sb2 = ns2.getCrudeSync()
+    (ia2, _, _), (ib2, _, _) = ns2.getAccurateSync()
+    assert np.array_equal(sa2, sa) and np.array_equal(sb2, sb) and np.array_equal(ia2, ia) and np.array_equal(ib2, ib)
+
+
 def test_c4_audio_stage_vs_golden(dd, noaa_inputs):
     g, raw = noaa_inputs
     src = dd.source.IQarray(raw, 2048000)
@@ -145,7 +167,7 @@ def test_c4_audio_stage_vs_golden(dd, noaa_inputs):
     assert aud.sampRate == 60235
     a = aud.signal
     d = np.abs(np.angle(np.exp(1j * (a[:20000] - g["audio_3s_head"]))))
-    assert np.max(d) < 1e-4 and np.median(d) < 2e-6
+    assert np.max(d) < 2e-5 and np.median(d) < 2e-6
 
 
 def test_c3_chain_golden(dd, golden_dir):
@@ -211,7 +233,7 @@ def test_streaming_ring_feeder_equals_one_shot(dd):
             got = out.to_host().astype(np.float64)
             assert rate == r2 and got.shape == ref.shape, (M, staging)
             d = np.abs(np.angle(np.exp(1j * (got - ref))))
-            assert np.max(d) < 1e-4 and np.median(d) < 2e-6, (M, staging, np.max(d))
+            assert np.max(d) < 2e-5 and np.median(d) < 2e-6, (M, staging, np.max(d))
 
 
 def test_iir_butter_golden(dd, ops):
@@ -320,6 +342,21 @@ def test_iir_block_parallel_long_inputs(dd, cplx):
         # stateless form
         f0 = dd.filters.butter(*args, storeState=False, **kw)
         assert rel_err(f0.applyOn(x[:100000]), ss.lfilter(b, a, x[:100000])) < tol
+
+
+@pytest.mark.parametrize("tail_blocks", [1, 5, 14, 31])
+def test_iir_wave_kernel_partial_last_workgroup(dd, tail_blocks):
+    """complex128 input takes the one-wave LDS-DMA block passes (32 blocks per workgroup); its write pass counts on 16
+    stores per step, which the last workgroup does not issue when it owns fewer than 32 blocks or a ragged last block:
+    nb % 32 in {1, 5, 14, 31} with a partial last block, against scipy.signal.lfilter"""
+    import scipy.signal as ss
+    rng = np.random.default_rng(40 + tail_blocks)
+    n = 256 * (32 * 40 + tail_blocks) - 100
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex128)
+    f = dd.filters.butter(2400000, 100000.0, storeState=False)
+    y = f.applyOn(dd.hip.DevArray.from_host(x))
+    ref = ss.lfilter(np.asarray(f.getB), np.asarray(f.getA), x)
+    assert rel_err(y.to_host(), ref) < 1e-9
 
 
 def test_iir_block_parallel_complex64_iq(dd):

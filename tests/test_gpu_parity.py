@@ -349,6 +349,7 @@ def test_short_first_chunks(dd):
         off = 0
         idx = 0
         refs = []
+        mags = []
         for i in range(len(cuts) - 1):
             a, b = cuts[i], cuts[i + 1]
             s = dd.comm.commSignal(1000000, x[a:b], ck).offsetFreq(10000.0).filter(flt)
@@ -361,12 +362,15 @@ def test_short_first_chunks(dd):
                 continue            # the reference's demod raises IndexError on an empty chunk
             s.funcApply(fm.demod)
             out.extend(s)
+            prv = last
             r, last = O.fm_demod(y, last)
             refs.append(r)
+            yy = y if prv is None else np.concatenate([[prv], y])
+            mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
         ref = np.concatenate(refs)
         assert out.length == len(ref)
-        d = np.abs(np.angle(np.exp(1j * (out.signal - ref))))
-        assert np.max(d) < 1e-3 and np.median(d) < FM_MED
+        # the two-tier mask of fm_check: 1e-4 rad wherever the product is not vanishing, 2e-5 on well-conditioned outputs
+        fm_check(out.signal, ref, np.concatenate(mags))
 
 
 # ----------------------------------------------------------------------------- raw C-ABI
@@ -527,7 +531,7 @@ def test_mfma_tile_scaling_paths(dd, profile, monkeypatch):
         mask &= prod > 0
         d = np.abs(np.angle(np.exp(1j * (np.asarray(a, dtype=np.float64) - a_ref))))
         assert len(a) == L - 1
-        assert np.max(d[mask]) <= 2e-4, (profile, kernel, float(np.max(d[mask])))
+        assert np.max(d[mask]) <= 5e-5, (profile, kernel, float(np.max(d[mask])))
 
 
 def test_seek_with_lead_in_equals_primed_shard(dd):

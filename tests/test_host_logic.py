@@ -196,3 +196,18 @@ def test_iqwav_walks_riff_chunks_to_data(tmp_path):
     write_iq_wav(mono, raw, 8000, channels=1)
     with pytest.raises(TypeError):
         source.IQwav(str(mono))
+
+
+def test_bench_apt_generator_equals_the_test_suites():
+    """bench.py's C4 side line and tests/test_gpu_audio.py's 60 s golden test must run over the same recording"""
+    import bench
+    from oracle import dd_oracle as O
+    assert np.array_equal(bench.synth_apt_iq(1.3, 2048000, seed=1), O.synth_apt_iq(1.3, 2048000, seed=1))
+
+
+def test_star_import_brings_the_drop_in_modules():
+    ns = {}
+    exec("from directdemod_amd import *", ns)
+    for m in ("comm", "filters", "demod_fm", "demod_am", "chunker", "constants", "source"):
+        assert m in ns and hasattr(ns[m], "__name__"), m
+    assert hasattr(ns["comm"], "commSignal") and hasattr(ns["filters"], "hamming") and hasattr(ns["chunker"], "chunker")
