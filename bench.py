@@ -343,6 +343,14 @@ def side_configs(eng, steps=10):
                           "dd_chain_process")
                 o += got.value
             return o
+        cb = (C.c_int64 * (len(bounds) + 1))(*([a for a, _ in bounds] + [n]))
+        cn = (C.c_int64 * len(bounds))()
+
+        def one_pass_chunk_list():
+            # the same chunk list in ONE call (dd_chain_process_chunks: one launch, outputs bit-identical to the loop's)
+            hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+            hip.check(lib.dd_chain_process_chunks(h, xin.data_ptr(), out.data_ptr(), cb, len(bounds), cn, eng.stream), "dd_chain_process_chunks")
+            return int(sum(cn))
         def timed(fn):
             for _ in range(3):
                 r = fn()
@@ -354,17 +362,22 @@ def side_configs(eng, steps=10):
             e1.record()
             eng.sync()
             return e0.elapsed_time(e1) / steps, r
-        ms, n_out = timed(one_pass)
-        # the same 2^26 samples as ONE chunk (one launch): what the kernel does without the chunk loop's launch seams
+        ms_loop, n_out = timed(one_pass)
+        ms, n_out_list = timed(one_pass_chunk_list)
+        assert n_out_list == n_out
+        # the same 2^26 samples as ONE chunk (one launch): what the kernel does without any chunk seam
         chunked_bounds = bounds
         bounds = [(0, n)]
         ms1, n_out1 = timed(one_pass)
         bounds = chunked_bounds
         assert n_out1 == n_out
         bps = 8.0 + 4.0 / M
-        res.append({"config": name, "launches_per_pass": len(bounds), "ms_per_pass": round(ms, 4), "outputs": n_out,
+        res.append({"config": name, "chunks": len(bounds), "launches_per_pass": 1, "ms_per_pass": round(ms, 4), "outputs": n_out,
                     "GS_per_s": round(n / ms / 1e6, 1), "bytes_per_sample": round(bps, 3),
                     "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4),
+                    "how": "dd_chain_process_chunks: the whole chunk list in one launch, carried state handed over inside it",
+                    "chunk_loop": {"launches_per_pass": len(bounds), "ms": round(ms_loop, 4), "GS_per_s": round(n / ms_loop / 1e6, 1),
+                                   "frac_of_8TBs": round(n * bps / (ms_loop * 1e-3) / 8e12, 4)},
                     "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),
                                   "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4)}})
         lib.dd_chain_destroy(h)

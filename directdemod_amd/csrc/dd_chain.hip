@@ -176,6 +176,36 @@ __global__ void __launch_bounds__(DD_DENSE_THREADS) k_chain_dense(const DDChainP
 // (device function: the stand-alone kernel k_chain_decim below runs it for every tile of a chunk without
 // an interior run; k_chain_decim_p runs it in its trailing workgroups for the tiles around the interior run,
 // so a chunk is ONE launch either way)
+// in-launch hand-over of the carried state between the chunks of dd_chain_process_chunks (cdna_hip_programming.md,
+// Guideline 16): the producer's stores are drained by every wave, the workgroup meets, one lane releases at agent scope
+// and sets the flag with an agent-scope atomic; the consumer polls that one word relaxed from one lane, acquires once,
+// the workgroup meets, then everybody reads with plain loads.  The flags are zeroed by a memset ahead of every launch.
+// Producers have lower workgroup indices than their consumers and only two workgroups per chunk ever wait, so a
+// waiting workgroup cannot keep its producer off the device; the spin is bounded all the same.
+__device__ __forceinline__ void dd_seam_wait(unsigned int* flag) {
+    if (threadIdx.x == 0) {
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        gu32* f = (gu32*)flag;
+        for (unsigned spins = 0; spins < (1u << 24); ++spins) {
+            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void dd_seam_post(unsigned int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (ROCm 7.2 may drop the fence's own wait)
+        __hip_atomic_store((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const int bid, char* smem) {
     const int K = P.K, M = P.M, T = P.T;
     const int S = (T - 1) * M + K + (M - 1);
@@ -194,6 +224,7 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
     const int64_t pfirst = dd_tile_pfirst(P, b);
     const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
     const bool fm = (P.flags & DD_CHAIN_FM) != 0;
+    if (P.seam_wait && (ns < 0 || pfirst < 0)) dd_seam_wait(P.seam_wait);      // this tile reads the previous chunk's state
 
     const int ngroups = (S + 63) / 64;
     // interior tile (whole span inside the chunk, complex64 input): the WHOLE tile is requested at
@@ -366,11 +397,13 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
         }
     }
     const int64_t p = pfirst + t;
+    const bool posts = P.seam_post && b == P.nblocks - 1;       // the tile that writes the state the next chunk of this launch reads
     if (!fm) {
         if (t < T && p < P.Ld) {
             reinterpret_cast<float2*>(P.out)[p] = acc;
             if (P.lasty_out && p == P.Ld - 1) *P.lasty_out = acc;
         }
+        if (posts) dd_seam_post(P.seam_post);
         return;
     }
     if (p == -1) acc = *P.lasty_in;
@@ -382,6 +415,7 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
         }
         if (p == P.Ld - 1) *P.lasty_out = acc;
     }
+    if (posts) dd_seam_post(P.seam_post);
 }
 
 __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainParams P) {
@@ -455,7 +489,7 @@ __device__ __forceinline__ void dd_decim_stage_u8(const DDChainParams& P, int nq
 }
 
 template <bool U8>
-__device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int b_next, int nq, int t, dd_v4f_a8 (&v)[DD_DECIM_NV],
+__device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, const DDChainParams& Pn, int b_next, int nq, int t, dd_v4f_a8 (&v)[DD_DECIM_NV],
                                               dd_v4u_a4 (&v8)[DD_DECIM_NV8], const float2 (&w18)[8],
                                               float2* sx, const float2* w2, float2* yblk, const float* gl, float2 w1a, float2 w1b) {
     const int K = P.K, M = P.M, T = P.T;
@@ -468,7 +502,7 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int
     }
     if (U8) {
         dd_decim_stage_u8(P, nq, t, v8, sx, w2, w18);      // (nq counts octets here)
-        if (b_next >= 0) dd_decim_issue_u8(P, b_next, nq, t, v8);
+        if (b_next >= 0) dd_decim_issue_u8(Pn, b_next, nq, t, v8);
     } else {
         float2 g[DD_DECIM_NV];
         if (nco) {
@@ -490,7 +524,7 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, int
                 *reinterpret_cast<float4*>(sx + 2 * q) = make_float4(xa.x, xa.y, xb.x, xb.y);
             }
         }
-        if (b_next >= 0) dd_decim_issue(P, b_next, nq, t, v);  // next tile: in flight from here to the next staging
+        if (b_next >= 0) dd_decim_issue(Pn, b_next, nq, t, v); // next tile (of this chunk or, in a multi-chunk launch, the next): in flight from here to the next staging
     }
     __syncthreads();
     float2 acc = make_float2(0.f, 0.f);
@@ -581,7 +615,86 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
     for (int k = 0; k < 8; ++k)
         w18[k] = (U8 && (P.flags & DD_CHAIN_NCO)) ? dd_phasor((uint64_t)(((8 * t) & 63) + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
     __syncthreads();
-    for (int b = begin; b < end; ++b) dd_decim_tile<U8>(P, b, b + 1 < end ? b + 1 : -1, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
+    for (int b = begin; b < end; ++b) dd_decim_tile<U8>(P, b, P, b + 1 < end ? b + 1 : -1, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
+}
+
+// ---- several chunks, ONE launch (dd_chain_process_chunks) -------------------------------------------------------------
+// The reference's chunk loops (decode_fm.py:54-70: 2^22-sample chunks; decode_noaa.py:614-624) make one call per chunk;
+// a launch per chunk costs ~7 us of kernel boundary, fill and drain around ~15 us of work (C3).  Here the persistent
+// workgroups walk the CONCATENATED list of every chunk's interior tiles, and every chunk's edge tiles (its first, with
+// the carried history, and its last, which writes the new state) ride along as trailing workgroups.  Each tile is
+// computed exactly as in the chunk's own launch -- same tile grid per chunk, same tile-relative constants -- so the
+// outputs are bit-identical to the loop's; the state a chunk hands to the next travels through device memory behind
+// the seam flags above.  Per chunk: its full parameter block (edge tiles) and the few fields an interior tile needs.
+struct DDSeg {
+    const void* in;
+    void* out;
+    int64_t abs0;
+    int off, s, lo, pad;
+};
+template <bool U8>
+__global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_multi(const DDChainParams* __restrict__ Pc, const DDSeg* __restrict__ seg,
+                                                                           const int* __restrict__ ipre, const int* __restrict__ epre, int nchunks, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= nwg) {
+        const int e = (int)blockIdx.x - nwg;
+        int c = 0;
+        while (c + 1 < nchunks && e >= epre[c + 1]) ++c;               // (uniform)
+        const DDChainParams P = Pc[c];
+        dd_decim_edge_tile(P, e - epre[c], smem);
+        return;
+    }
+    DDChainParams P = Pc[0];                                           // K, M, T, flags, cyc, taps and tables are the same for every chunk
+    const int K = P.K, M = P.M, T = P.T;
+    const int S = U8 ? (((T - 1) * M + K + (M - 1) + 7) & ~7) : (((T - 1) * M + K + (M - 1) + 1) & ~1);
+    const int nq = U8 ? S / 8 : S / 2;
+    float2* sx = reinterpret_cast<float2*>(smem);
+    float2* w2 = sx + S + 4;
+    float2* yblk = w2 + (S / 64 + 2);
+    float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)S + 4 + (S / 64 + 2) + DD_DECIM_THREADS) + 15) & ~(size_t)15));
+    const int t = threadIdx.x;
+    const int n = ipre[nchunks];
+    const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int begin = (int)(((int64_t)wg * n) / nwg), end = (int)(((int64_t)(wg + 1) * n) / nwg);      // global interior tile indices
+    if (begin >= end) return;
+    int c = 0;
+    while (begin >= ipre[c + 1]) ++c;
+    auto load_seg = [&](DDChainParams& Q, int cc) {
+        const DDSeg g = seg[cc];
+        Q.in = g.in; Q.out = g.out; Q.abs0 = g.abs0; Q.off = g.off; Q.s = g.s;
+        return g.lo;
+    };
+    int lo = load_seg(P, c);
+    DDChainParams Pn = P;
+    dd_v4f_a8 v[DD_DECIM_NV];
+    dd_v4u_a4 v8[DD_DECIM_NV8];
+    if (U8) dd_decim_issue_u8(P, lo + (begin - ipre[c]), nq, t, v8);
+    else dd_decim_issue(P, lo + (begin - ipre[c]), nq, t, v);
+    for (int j = t; j < ((K + 7) & ~7); j += DD_DECIM_THREADS) gl[j] = j < K ? P.taps_rev[(DD_DENSE_R - 1) + j] : 0.f;
+    float2 w1a = make_float2(1.f, 0.f), w1b = make_float2(1.f, 0.f);
+    if (P.flags & DD_CHAIN_NCO) {
+        for (int g = t; g < S / 64 + 1; g += DD_DECIM_THREADS) w2[g] = dd_phasor((uint64_t)g * 64 * P.cyc, P.nco_tbl);
+        w1a = dd_phasor((uint64_t)((2 * t) & 63) * P.cyc, P.nco_tbl);
+        w1b = dd_phasor((uint64_t)(((2 * t) & 63) + 1) * P.cyc, P.nco_tbl);
+    }
+    float2 w18[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        w18[k] = (U8 && (P.flags & DD_CHAIN_NCO)) ? dd_phasor((uint64_t)(((8 * t) & 63) + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+    __syncthreads();
+    for (int g = begin; g < end; ++g) {
+        const int b = lo + (g - ipre[c]);
+        int b_next = -1, cn = c, lon = lo;
+        if (g + 1 < end) {
+            if (g + 1 >= ipre[c + 1]) {                               // the next tile opens the next chunk with an interior run
+                do { ++cn; } while (g + 1 >= ipre[cn + 1]);
+                lon = load_seg(Pn, cn);
+            }
+            b_next = lon + (g + 1 - ipre[cn]);
+        }
+        dd_decim_tile<U8>(P, b, Pn, b_next, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
+        if (cn != c) { P = Pn; c = cn; lo = lon; }
+    }
 }
 
 // rare path (chunk without a kept sample) and shard priming: new tail only
@@ -747,6 +860,80 @@ int64_t dd_fused_out_count(const dd_fm* fm, int64_t n, int M, int off) {
     return no > 0 ? no : 0;
 }
 
+// geometry of one chunk through the decimating kernels (M > 1): tile size, tile count, LDS, and -- when the chunk has an
+// interior run worth a persistent grid -- that run [lo, hi) (P.skip_lo / skip_hi) and the workgroups a CU holds
+struct DDDecimPlan {
+    size_t lds, lds_p;
+    bool persistent;
+    int lo, hi, per_cu;
+};
+static int decim_plan(DDChainParams& P, DDDecimPlan& pl) {
+    const bool isfm = (P.flags & DD_CHAIN_FM) != 0;
+    int T = (DD_DECIM_SPAN_MAX - P.K - (P.M - 1)) / P.M + 1;
+    if (T > DD_DECIM_THREADS) T = DD_DECIM_THREADS;
+    if (T < 2) T = 2;
+    P.T = T;
+    P.nblocks = isfm ? (int)((P.Ld - P.s + (P.T - 2)) / (P.T - 1)) : (int)((P.Ld + P.T - 1) / P.T);
+    if (P.nblocks < 1) P.nblocks = 1;
+    const int S = (T - 1) * P.M + P.K + (P.M - 1);
+    const int SP = S + 4;
+    const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
+    DD_REQUIRE(lds <= 160 * 1024, "filter/decimation too large for the decimating kernel's LDS tile");
+    if (lds > 64 * 1024)
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    pl.lds = lds;
+    pl.lds_p = lds;
+    pl.persistent = false;
+    pl.per_cu = 1;
+    // interior tiles [b_lo, b_hi): span (rounded up to a sample pair) inside the chunk, all T outputs valid,
+    // complex64 input, not the chunk's last tile (that one writes the carried state)
+    P.skip_lo = P.skip_hi = P.nblocks;
+    pl.lo = pl.hi = P.nblocks;
+    const bool u8in = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+    const int S2 = u8in ? ((S + 7) & ~7) : ((S + 1) & ~1);
+    if (S2 <= DD_DECIM_SPAN_MAX && (reinterpret_cast<uintptr_t>(P.in) & (u8in ? 3 : 7)) == 0) {
+        const int64_t adv = isfm ? (P.T - 1) : P.T;                  // outputs a tile advances by
+        const int64_t pf0 = isfm ? (int64_t)P.s - 1 : 0;             // pfirst of tile 0
+        // ns(b) = off + (pf0 + b adv) M - (K-1) >= 0 ;  ns(b) + S2 <= L ;  pf0 + b adv >= 0 ;  pf0 + b adv + T <= Ld
+        int64_t lo = 0;
+        while (lo < P.nblocks && ((int64_t)P.off + (pf0 + lo * adv) * P.M - (P.K - 1) < 0 || pf0 + lo * adv < 0)) ++lo;
+        int64_t hi = P.nblocks - 1;                                  // exclusive bound candidates, walk down
+        while (hi > lo && ((int64_t)P.off + (pf0 + (hi - 1) * adv) * P.M - (P.K - 1) + S2 > P.L || pf0 + (hi - 1) * adv + P.T > P.Ld)) --hi;
+        if (hi - lo >= 64) {
+            P.skip_lo = (int)lo;
+            P.skip_hi = (int)hi;
+            pl.lo = (int)lo;
+            pl.hi = (int)hi;
+            pl.persistent = true;
+            const size_t lds_p0 = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
+            pl.lds_p = lds_p0 > lds ? lds_p0 : lds;                  // the edge workgroups of the same launch need `lds`
+            static DDOncePerDevice attr_p;
+            if (attr_p.need()) {
+                DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_p.mark();
+            }
+            // every workgroup must be resident from the start (a persistent grid with queued workgroups
+            // runs in rounds): ask the runtime how many fit (LDS and registers)
+            static std::mutex occ_mu;
+            static size_t occ_lds[2] = {0, 0};          // the answer depends on (flavour, LDS size) only: asked once per change
+            static int occ_val[2] = {0, 0};
+            std::lock_guard<std::mutex> lk(occ_mu);
+            int per_cu = occ_val[u8in];
+            if (occ_lds[u8in] != pl.lds_p || per_cu < 1) {
+                if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, pl.lds_p)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, pl.lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
+                occ_lds[u8in] = pl.lds_p;
+                occ_val[u8in] = per_cu;
+            }
+            pl.per_cu = per_cu;
+        }
+    }
+    return DD_OK;
+}
+
 int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out, hipStream_t s) {
     DD_REQUIRE(fir && a.n >= 0 && a.M >= 1 && a.off >= 0 && a.off < a.M, "fused arguments");
     DDChainParams P;
@@ -817,75 +1004,25 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         DD_LAUNCH_CHECK();
         fir->last_kernel = DD_KERNEL_DENSE_F32;
     } else {
-        int T = (DD_DECIM_SPAN_MAX - P.K - (P.M - 1)) / P.M + 1;
-        if (T > DD_DECIM_THREADS) T = DD_DECIM_THREADS;
-        if (T < 2) T = 2;
-        P.T = T;
-        P.nblocks = isfm ? (int)((P.Ld - P.s + (P.T - 2)) / (P.T - 1)) : (int)((P.Ld + P.T - 1) / P.T);
-        if (P.nblocks < 1) P.nblocks = 1;
-        const int S = (T - 1) * P.M + P.K + (P.M - 1);
-        const int SP = S + 4;
-        const size_t lds = sizeof(float2) * ((size_t)SP + (S + 63) / 64 + 1 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
-        DD_REQUIRE(lds <= 160 * 1024, "filter/decimation too large for the decimating kernel's LDS tile");
-        if (lds > 64 * 1024)
-            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // interior tiles [b_lo, b_hi): span (rounded up to a sample pair) inside the chunk, all T outputs valid,
-        // complex64 input, not the chunk's last tile (that one writes the carried state)
-        P.skip_lo = P.skip_hi = P.nblocks;
+        DDDecimPlan pl;
+        int rc = decim_plan(P, pl);
+        if (rc != DD_OK) return rc;
         const bool u8in = (P.flags & DD_CHAIN_U8_INPUT) != 0;
-        const int S2 = u8in ? ((S + 7) & ~7) : ((S + 1) & ~1);
-        if (S2 <= DD_DECIM_SPAN_MAX && (reinterpret_cast<uintptr_t>(P.in) & (u8in ? 3 : 7)) == 0) {
-            const int64_t adv = isfm ? (P.T - 1) : P.T;                  // outputs a tile advances by
-            const int64_t pf0 = isfm ? (int64_t)P.s - 1 : 0;             // pfirst of tile 0
-            // ns(b) = off + (pf0 + b adv) M - (K-1) >= 0 ;  ns(b) + S2 <= L ;  pf0 + b adv >= 0 ;  pf0 + b adv + T <= Ld
-            int64_t lo = 0;
-            while (lo < P.nblocks && ((int64_t)P.off + (pf0 + lo * adv) * P.M - (P.K - 1) < 0 || pf0 + lo * adv < 0)) ++lo;
-            int64_t hi = P.nblocks - 1;                                  // exclusive bound candidates, walk down
-            while (hi > lo && ((int64_t)P.off + (pf0 + (hi - 1) * adv) * P.M - (P.K - 1) + S2 > P.L || pf0 + (hi - 1) * adv + P.T > P.Ld)) --hi;
-            if (hi - lo >= 64) {
-                P.skip_lo = (int)lo;
-                P.skip_hi = (int)hi;
-                const size_t lds_p0 = sizeof(float2) * ((size_t)S2 + 4 + S2 / 64 + 2 + DD_DECIM_THREADS) + sizeof(float) * ((P.K + 7) & ~7) + 16;
-                const size_t lds_p = lds_p0 > lds ? lds_p0 : lds;       // the edge workgroups of the same launch need `lds`
-                static DDOncePerDevice attr_p;
-                if (attr_p.need()) {
-                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr_p.mark();
-                }
-                const int ncu = dd_cu_count();
-                // every workgroup must be resident from the start (a persistent grid with queued workgroups
-                // runs in rounds): ask the runtime how many fit (LDS and registers)
-                static std::mutex occ_mu;
-                static size_t occ_lds[2] = {0, 0};          // the answer depends on (flavour, LDS size) only: asked once per change
-                static int occ_val[2] = {0, 0};
-                int per_cu;
-                {
-                    std::lock_guard<std::mutex> lk(occ_mu);
-                    per_cu = occ_val[u8in];
-                    if (occ_lds[u8in] != lds_p || per_cu < 1) {
-                        if ((u8in ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<true>, DD_DECIM_THREADS, lds_p)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_decim_p<false>, DD_DECIM_THREADS, lds_p)) != hipSuccess || per_cu < 1) per_cu = 1;
-                        occ_lds[u8in] = lds_p;
-                        occ_val[u8in] = per_cu;
-                    }
-                }
-                // the tiles around the interior run ride along as trailing workgroups of the same launch; the
-                // persistent grid leaves them their slots
-                const int n_rest = P.nblocks - (int)(hi - lo);
-                const int slots = ncu * per_cu;
-                int grid = n_rest < slots / 2 ? slots - n_rest : slots / 2;
-                if (grid > hi - lo) grid = (int)(hi - lo);
-                if (grid >= 8) grid &= ~7;
-                if (u8in) hipLaunchKernelGGL(k_chain_decim_p<true>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi, grid);
-                else hipLaunchKernelGGL(k_chain_decim_p<false>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), lds_p, s, P, (int)lo, (int)hi, grid);
-                DD_LAUNCH_CHECK();
-                fir->last_kernel = DD_KERNEL_DECIM_PERSISTENT;
-            }
-        }
-        if (P.skip_hi == P.skip_lo) {
+        if (pl.persistent) {
+            // the tiles around the interior run ride along as trailing workgroups of the same launch; the
+            // persistent grid leaves them their slots
+            const int n_rest = P.nblocks - (pl.hi - pl.lo);
+            const int slots = dd_cu_count() * pl.per_cu;
+            int grid = n_rest < slots / 2 ? slots - n_rest : slots / 2;
+            if (grid > pl.hi - pl.lo) grid = pl.hi - pl.lo;
+            if (grid >= 8) grid &= ~7;
+            if (u8in) hipLaunchKernelGGL(k_chain_decim_p<true>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), pl.lds_p, s, P, pl.lo, pl.hi, grid);
+            else hipLaunchKernelGGL(k_chain_decim_p<false>, dim3(grid + n_rest), dim3(DD_DECIM_THREADS), pl.lds_p, s, P, pl.lo, pl.hi, grid);
+            DD_LAUNCH_CHECK();
+            fir->last_kernel = DD_KERNEL_DECIM_PERSISTENT;
+        } else {
             // no interior run (short chunk, unaligned input): every tile through the stand-alone edge kernel
-            hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), lds, s, P);
+            hipLaunchKernelGGL(k_chain_decim, dim3(P.nblocks), dim3(DD_DECIM_THREADS), pl.lds, s, P);
             DD_LAUNCH_CHECK();
             fir->last_kernel = DD_KERNEL_DECIM_TILES;
         }
@@ -981,6 +1118,8 @@ struct dd_chain {
     int64_t abs_index;
     void* scratch;          // discarded outputs of dd_chain_prime
     size_t scratch_bytes;
+    char* multi;            // dd_chain_process_chunks: seam flags, per-chunk parameter blocks, prefix tables, seam state
+    size_t multi_bytes;
 };
 
 extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles_q64,
@@ -996,6 +1135,8 @@ extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint
     c->abs_index = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->multi = nullptr;
+    c->multi_bytes = 0;
     int rc = dd_fir_create(&c->fir, taps, ntaps);
     if (rc == DD_OK && (flags & DD_CHAIN_FM)) rc = dd_fm_create(&c->fm);
     if (rc != DD_OK) {
@@ -1011,6 +1152,7 @@ extern "C" int dd_chain_destroy(dd_chain* c) {
     dd_fir_destroy(c->fir);
     dd_fm_destroy(c->fm);
     hipFree(c->scratch);
+    hipFree(c->multi);
     delete c;
     return DD_OK;
 }
@@ -1063,6 +1205,139 @@ extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t 
     int rc = dd_fused_launch(c->fir, c->fm, a, n_out, dd_stream(stream));
     if (rc == DD_OK) c->abs_index += n;
     return rc;
+}
+
+// The chunks [bounds[i], bounds[i+1]) of `in` (sample offsets, ascending, nchunks + 1 of them) as dd_chain_process would
+// take them one after the other -- same outputs, bit for bit, concatenated at `out`, same state afterwards -- in ONE
+// launch when the chain decimates (M > 1) and every chunk keeps at least one sample; otherwise the loop itself.
+extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                                       int64_t* n_out_host, void* stream) {
+    DD_REQUIRE(c && bounds_host && nchunks >= 0, "arguments");
+    hipStream_t s = dd_stream(stream);
+    const bool isfm = c->fm != nullptr;
+    const bool u8 = (c->flags & DD_CHAIN_U8_INPUT) != 0;
+    const size_t isz = u8 ? 2 : sizeof(float2), osz = isfm ? sizeof(float) : sizeof(float2);
+    for (int i = 0; i < nchunks; ++i) DD_REQUIRE(bounds_host[i + 1] >= bounds_host[i], "bounds must ascend");
+    // plan every chunk with the state the loop would give it
+    std::vector<DDChainParams> Pv;
+    std::vector<DDDecimPlan> plv;
+    std::vector<int64_t> nout(nchunks > 0 ? nchunks : 1, 0);
+    bool one_launch = c->M > 1 && nchunks >= 2 && !(c->flags & DD_CHAIN_FORCE_DIRECT) && c->fir->K >= 2;
+    if (one_launch) {
+        int64_t abs_index = c->abs_index, opos = 0;
+        int has_last = isfm ? c->fm->has_last : 0;
+        for (int i = 0; i < nchunks && one_launch; ++i) {
+            const int64_t n = bounds_host[i + 1] - bounds_host[i];
+            DDChainParams P;
+            memset(&P, 0, sizeof(P));
+            P.in = reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[i];
+            P.out = reinterpret_cast<char*>(out) + osz * (size_t)opos;
+            P.taps_rev = c->fir->taps_rev;
+            P.nco_tbl = dd_nco_table();
+            P.cyc = c->cyc;
+            P.abs0 = abs_index;
+            P.L = n;
+            P.K = c->fir->K;
+            P.M = c->M;
+            P.off = (int)((c->M - abs_index % c->M) % c->M);
+            P.Ld = kept_count(n, P.off, c->M);
+            P.flags = (c->flags & (DD_CHAIN_NCO | DD_CHAIN_U8_INPUT)) | (isfm ? DD_CHAIN_FM : 0);
+            P.s = (isfm && !has_last) ? 1 : 0;
+            if (n == 0 || P.Ld == 0 || (isfm && P.Ld - P.s <= 0 && false)) { one_launch = false; break; }
+            DDDecimPlan pl;
+            int rc = decim_plan(P, pl);
+            if (rc != DD_OK) return rc;
+            nout[i] = isfm ? P.Ld - P.s : P.Ld;
+            if (nout[i] < 0) nout[i] = 0;
+            Pv.push_back(P);
+            plv.push_back(pl);
+            opos += nout[i];
+            abs_index += n;
+            if (isfm) has_last = 1;
+        }
+    }
+    if (!one_launch) {
+        int64_t opos = 0;
+        for (int i = 0; i < nchunks; ++i) {
+            int64_t got = 0;
+            int rc = dd_chain_process(c, reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[i],
+                                      reinterpret_cast<char*>(out) + osz * (size_t)opos, bounds_host[i + 1] - bounds_host[i], &got, stream);
+            if (rc != DD_OK) return rc;
+            if (n_out_host) n_out_host[i] = got;
+            opos += got;
+        }
+        return DD_OK;
+    }
+    // device image: [flags, 16-byte padded][parameter blocks][segments][interior prefix][edge prefix][seam tails][seam last samples]
+    const int K1 = c->fir->K - 1;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_par = al(sizeof(unsigned int) * nchunks), o_seg = o_par + al(sizeof(DDChainParams) * nchunks);
+    const size_t o_ipre = o_seg + al(sizeof(DDSeg) * nchunks), o_epre = o_ipre + al(sizeof(int) * (nchunks + 1));
+    const size_t o_tail = o_epre + al(sizeof(int) * (nchunks + 1)), o_last = o_tail + al(sizeof(float2) * (size_t)K1 * nchunks);
+    const size_t total = o_last + al(sizeof(float2) * nchunks);
+    if (total > c->multi_bytes) {
+        DD_HIP_CHECK(hipStreamSynchronize(s));
+        hipFree(c->multi);
+        c->multi = nullptr;
+        c->multi_bytes = 0;
+        DD_HIP_CHECK(hipMalloc((void**)&c->multi, total));
+        c->multi_bytes = total;
+    }
+    unsigned int* flags = reinterpret_cast<unsigned int*>(c->multi);
+    float2* seam_tail = reinterpret_cast<float2*>(c->multi + o_tail);
+    float2* seam_last = reinterpret_cast<float2*>(c->multi + o_last);
+    dd_fir* fir = c->fir;
+    std::vector<char> img(o_tail - o_par, 0);
+    DDChainParams* hP = reinterpret_cast<DDChainParams*>(img.data());
+    DDSeg* hS = reinterpret_cast<DDSeg*>(img.data() + (o_seg - o_par));
+    int* hI = reinterpret_cast<int*>(img.data() + (o_ipre - o_par));
+    int* hE = reinterpret_cast<int*>(img.data() + (o_epre - o_par));
+    hI[0] = hE[0] = 0;
+    size_t lds_p = 0;
+    int per_cu = 0;
+    for (int i = 0; i < nchunks; ++i) {
+        DDChainParams& P = Pv[i];
+        P.tail_in = i == 0 ? (fir->tail_override ? fir->tail_override : fir->tail[fir->parity]) : seam_tail + (size_t)K1 * (i - 1);
+        P.tail_out = i == nchunks - 1 ? fir->tail[fir->parity ^ 1] : seam_tail + (size_t)K1 * i;
+        if (isfm) {
+            P.lasty_in = i == 0 ? c->fm->last + c->fm->parity : seam_last + (i - 1);
+            P.lasty_out = i == nchunks - 1 ? c->fm->last + (c->fm->parity ^ 1) : seam_last + i;
+        }
+        P.seam_wait = i > 0 ? flags + (i - 1) : nullptr;
+        P.seam_post = i < nchunks - 1 ? flags + i : nullptr;
+        hP[i] = P;
+        hS[i].in = P.in; hS[i].out = P.out; hS[i].abs0 = P.abs0; hS[i].off = P.off; hS[i].s = P.s; hS[i].lo = plv[i].lo; hS[i].pad = 0;
+        hI[i + 1] = hI[i] + (plv[i].hi - plv[i].lo);
+        hE[i + 1] = hE[i] + (P.nblocks - (plv[i].hi - plv[i].lo));
+        if (plv[i].lds_p > lds_p) lds_p = plv[i].lds_p;
+        if (plv[i].persistent && (per_cu == 0 || plv[i].per_cu < per_cu)) per_cu = plv[i].per_cu;
+    }
+    const int n_int = hI[nchunks], n_edge = hE[nchunks];
+    if (per_cu < 1) per_cu = 1;
+    DD_HIP_CHECK(hipMemsetAsync(flags, 0, o_par, s));
+    DD_HIP_CHECK(hipMemcpyAsync(c->multi + o_par, img.data(), img.size(), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    const int slots = dd_cu_count() * per_cu;
+    int grid = n_edge < slots / 2 ? slots - n_edge : slots / 2;
+    if (grid > n_int) grid = n_int;
+    if (grid >= 8) grid &= ~7;
+    if (grid < 0) grid = 0;
+    const DDChainParams* dP = reinterpret_cast<const DDChainParams*>(c->multi + o_par);
+    const DDSeg* dS = reinterpret_cast<const DDSeg*>(c->multi + o_seg);
+    const int* dI = reinterpret_cast<const int*>(c->multi + o_ipre);
+    const int* dE = reinterpret_cast<const int*>(c->multi + o_epre);
+    if (u8) hipLaunchKernelGGL(k_chain_decim_multi<true>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
+    else hipLaunchKernelGGL(k_chain_decim_multi<false>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
+    DD_LAUNCH_CHECK();
+    fir->last_kernel = DD_KERNEL_DECIM_MULTI;
+    fir->parity ^= 1;
+    fir->tail_override = nullptr;
+    if (isfm) {
+        c->fm->parity ^= 1;
+        c->fm->has_last = 1;
+    }
+    c->abs_index += bounds_host[nchunks] - bounds_host[0];
+    if (n_out_host) for (int i = 0; i < nchunks; ++i) n_out_host[i] = nout[i];
+    return DD_OK;
 }
 
 extern "C" int dd_chain_seek(dd_chain* c, int64_t abs_index, void* stream) {

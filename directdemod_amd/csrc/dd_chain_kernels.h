@@ -68,6 +68,11 @@ struct DDChainParams {
     int T;                     // FIR outputs computed per block
     int nblocks;
     int skip_lo, skip_hi;      // tiles [skip_lo, skip_hi) belong to another launch (persistent interior kernel); equal = none
+    // several chunks in ONE launch (dd_chain_process_chunks): the carried state of chunk c-1 reaches chunk c through
+    // device memory inside the launch.  seam_wait: polled (then acquired) before this chunk's tiles read tail_in /
+    // lasty_in; seam_post: set, behind an agent-scope release, by the tile that has written tail_out / lasty_out.
+    unsigned int* seam_wait;
+    unsigned int* seam_post;
 };
 
 // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the

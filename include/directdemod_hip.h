@@ -195,6 +195,14 @@ int64_t dd_chain_out_count(const dd_chain* h, int64_t n);
 /* process one chunk of n input samples (complex64, or u8 pairs with DD_CHAIN_U8_INPUT).
  * out: float32 radians when DD_CHAIN_FM, else complex64. */
 int dd_chain_process(dd_chain* h, const void* in, void* out, int64_t n, int64_t* n_out, void* stream);
+/* Several chunks in one call: chunk i is the samples [bounds_host[i], bounds_host[i+1]) of `in` (nchunks + 1 ascending
+ * offsets).  Same outputs, bit for bit, as nchunks dd_chain_process calls in that order -- concatenated at `out`, counts
+ * per chunk in n_out_host (may be NULL) -- and the same carried state afterwards; for a decimating chain (the reference's
+ * chunk loops: decode_fm.py:54-70 with 2^22-sample chunks, decode_noaa.py:614-624) ONE kernel launch instead of one per
+ * chunk (persistent workgroups walk every chunk's tiles, the state a chunk hands to the next travels through device
+ * memory inside the launch).  bench.py: C3's sixteen chunks 0.23 ms as a loop, 0.12 ms here. */
+int dd_chain_process_chunks(dd_chain* h, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                            int64_t* n_out_host, void* stream);
 /* which kernel the chain dispatches to: 0 = f32 direct form, 1 = f16-split MFMA Toeplitz */
 int dd_chain_path(const dd_chain* h);
 /* the kernel the last dd_chain_process call launched (one launch per call): lets tests and benchmarks assert
@@ -207,6 +215,7 @@ int dd_chain_path(const dd_chain* h);
 #define DD_KERNEL_MFMA_TILES 5       /* k_chain_mfma_edge: M = 1, MFMA, one workgroup per tile */
 #define DD_KERNEL_MFMA_AB 6          /* k_chain_mfma_ab: M = 1, FM or complex64 output, two alternating matrix-wave sets + edge tiles in the same launch */
 #define DD_KERNEL_FFT_OS 7           /* k_chain_fft1k: M = 1, FM output, 162..256 taps: f32 overlap-save FFT convolution, one wave per 1024-point block, NCO commuted into the tap spectrum, whole chunk in one launch */
+#define DD_KERNEL_DECIM_MULTI 8      /* k_chain_decim_multi: M > 1, every chunk of a dd_chain_process_chunks call in one launch */
 int dd_chain_last_kernel(const dd_chain* h);
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */
 

@@ -132,6 +132,74 @@ def test_decimating_chain_is_bit_reproducible(g, M, ntaps, fm, u8):
     _assert_identical(g, outs, per)
 
 
+@pytest.mark.parametrize("shape", ["C3", "C4", "ragged", "tiny_chunks"])
+@pytest.mark.parametrize("fm", [True, False])
+@pytest.mark.parametrize("u8", [False, True])
+def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm, u8):
+    """dd_chain_process_chunks: every chunk of a decimating chunk loop in ONE launch (k_chain_decim_multi; the carried
+    state crosses the chunk seams through device memory inside the launch).  Outputs, per-chunk counts and the state left
+    behind (checked by one more chunk afterwards) must equal those of the dd_chain_process loop as integers; also after
+    LDS fills, and with the seam flags' buffer reused from call to call."""
+    t, lib, hip = g.torch, g.lib, g.hip
+    if shape == "C3":
+        M, taps, n, cuts = 50, _hamming(127), 1 << 23, [i << 21 for i in range(5)]
+    elif shape == "C4":
+        M, taps, n, cuts = 34, _hamming(151), (1 << 23) + 999, [0, 3000000, 6000000, (1 << 23) + 999]
+    elif shape == "ragged":
+        M, taps, n, cuts = 8, _hamming(255), (1 << 22) + 77, [0, 1000001, 1000001 + 70003, 3000000, (1 << 22) + 77]
+    else:
+        M, taps, n, cuts = 5, _hamming(63), 200000, list(range(0, 200001, 20000))      # chunks without an interior run
+    tail = 50000                                                                      # one more chunk through the plain entry afterwards
+    x = g.bench.make_input(t, n + tail, 0, g.dev, 4242 + M)
+    flags = hip.DD_CHAIN_NCO | (hip.DD_CHAIN_FM if fm else 0)
+    isz = 8
+    if u8:
+        x = (x + 127.5).round().clamp(0, 255).to(t.uint8).contiguous()
+        flags |= hip.DD_CHAIN_U8_INPUT
+        isz = 2
+    per = 1 if fm else 2
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+
+    def make():
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps), hip.cycles_q64(25000.0, FS), M, flags), "create")
+        return h
+    nfl = per * ((n + tail) // M + 8)
+    # the loop
+    h = make()
+    ref = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
+    counts, pos = [], 0
+    got = C.c_int64(0)
+    for a, b in zip(cuts[:-1] + [n], cuts[1:] + [n + tail]):
+        hip.check(lib.dd_chain_process(h, x.data_ptr() + isz * a, ref.data_ptr() + 4 * per * pos, b - a, C.byref(got), g.stream), "process")
+        counts.append(got.value)
+        pos += got.value
+    assert lib.dd_chain_last_kernel(h) != hip.DD_KERNEL_NONE
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    # one launch (twice on the same handle after a reset, once after an LDS fill)
+    h = make()
+    bounds = (C.c_int64 * len(cuts))(*cuts)
+    nout = (C.c_int64 * (len(cuts) - 1))()
+    for rep, pat in enumerate((None, 0xFFFFFFFF, 0x00000000)):
+        if pat is not None:
+            hip.check(lib.dd_debug_fill_lds(pat, g.stream), "fill")
+        lib.dd_chain_reset(h, g.stream)
+        out = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
+        hip.check(lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), bounds, len(cuts) - 1, nout, g.stream), "chunks")
+        assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_MULTI
+        assert list(nout) == counts[:-1]
+        p2 = sum(nout)
+        hip.check(lib.dd_chain_process(h, x.data_ptr() + isz * n, out.data_ptr() + 4 * per * p2, tail, C.byref(got), g.stream), "process")
+        assert got.value == counts[-1]
+        t.cuda.synchronize()
+        tot = per * (p2 + got.value)
+        assert bool(t.isfinite(ref[:tot]).all())
+        diff = int((out[:tot].view(t.int32) != ref[:tot].view(t.int32)).sum())
+        assert diff == 0, "%d of %d output words differ from the chunk loop (rep %d)" % (diff, tot, rep)
+    lib.dd_chain_destroy(h)
+
+
 @pytest.mark.parametrize("n", [300, 5000, 70000])
 def test_short_chunks_are_bit_reproducible(g, n):
     """chunks too short for the persistent kernels (dense / tiled kernels only)."""
