@@ -412,11 +412,60 @@ def side_configs(eng, steps=10):
                     "bytes_per_sample": bps, "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
         lib.dd_chain_destroy(h)
         del out
+    res.append(side_c3_end_to_end(eng, steps))
     res.append(side_c4_end_to_end())
     return res
 
 
 # ----------------------------------------------------------------------------- one rank
+def side_c3_end_to_end(eng, steps=10):
+    """config 3 end to end (decode_fm.py:54-70): 2^26 samples @10 MS/s in sixteen chunks of 2^22, each chunk offsetFreq
+    250 kHz + remez127 + bwLim /50 + FM (state carried) and then bwLim(11025, strict) = scipy.signal.resample of ITS outputs
+    (comm.py:110-116: 83886 or 83887 samples -> 4624).  Two calls: dd_chain_process_chunks (one launch) and
+    dd_resample_fft_chunks (batched plans per length group)."""
+    import scipy.signal as ss
+    import torch
+    hip, lib = eng._hip, eng.lib
+    n, chunk, M, fs, f = eng.n, 1 << 22, 50, 10000000, 250000.0
+    rz = np.ascontiguousarray(ss.remez(127, [0, 100e3, 150e3, 4999999], [1, 0], fs=1e7), dtype=np.float64)
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), rz.ctypes.data_as(C.POINTER(C.c_double)), len(rz), hip.cycles_q64(f, fs), M,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "dd_chain_create")
+    nch = n // chunk
+    cb = (C.c_int64 * (nch + 1))(*[i * chunk for i in range(nch + 1)])
+    cn = (C.c_int64 * nch)()
+    audio = torch.empty(nch * 4700, dtype=torch.float64, device=eng.out.device)
+    A = C.c_int64 * nch
+    state = {}
+
+    def one_pass():
+        hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+        hip.check(lib.dd_chain_process_chunks(h, eng.xin.data_ptr(), eng.out.data_ptr(), cb, nch, cn, eng.stream), "dd_chain_process_chunks")
+        lens = list(cn)
+        if "args" not in state:                      # chunk lengths are host arithmetic: the same every pass
+            nums = [int(11025 * v / (fs // M)) for v in lens]
+            ioff = [sum(lens[:i]) for i in range(nch)]
+            ooff = [sum(nums[:i]) for i in range(nch)]
+            state["args"] = (A(*ioff), A(*lens), A(*ooff), A(*nums), sum(nums), sorted(set(lens)))
+        ioff, ln, ooff, nm, tot, _ = state["args"]
+        hip.check(lib.dd_resample_fft_chunks(eng.out.data_ptr(), 1, ioff, ln, audio.data_ptr(), ooff, nm, nch, eng.stream), "dd_resample_fft_chunks")
+        return tot
+    for _ in range(3):
+        tot = one_pass()
+    eng.sync()
+    e0, e1 = eng.events()
+    e0.record()
+    for _ in range(steps):
+        one_pass()
+    e1.record()
+    eng.sync()
+    ms = e0.elapsed_time(e1) / steps
+    lib.dd_chain_destroy(h)
+    return {"config": "C3 end to end (front end + FFT resample to 11 025 S/s), 2^26 samples @10 MS/s in 16 chunks of 2^22",
+            "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1), "audio_samples": int(tot), "chunk_output_lengths": state["args"][5],
+            "how": "dd_chain_process_chunks + dd_resample_fft_chunks: 1 chain launch, batched hipFFT plans per chunk-length group"}
+
+
 def synth_apt_iq(duration_s, fs=2048000, seed=1, f_offset=30000.0, dev=17000.0, amp=60.0, sigma=4.0):
     """The C4 workload: synthetic NOAA-APT-shaped IQ on the u8 grid -- 2 lines/s x 2080 words at 4160 words/s,
     sync A at words 0-39 and sync B at 1040-1079 mapped (bit*233+11)/255, AM on a 2400 Hz subcarrier, FM (dev Hz) at

@@ -101,6 +101,7 @@ SIGNATURES = {
     "dd_chain_path": (_int, [_p]),
     "dd_chain_last_kernel": (_int, [_p]),
     "dd_resample_fft_f64": (_int, [_p, _p, _i64, _i64, _p]),
+    "dd_resample_fft_chunks": (_int, [_p, _int, _pi64, _pi64, _p, _pi64, _pi64, _int, _p]),
     "dd_rpoly_create": (_int, [_pp, C.POINTER(C.c_double), _int, _int, _int, _i64]),
     "dd_rpoly_destroy": (_int, [_p]),
     "dd_rpoly_reset": (_int, [_p]),

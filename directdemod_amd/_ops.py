@@ -79,6 +79,25 @@ def resample_fft(x, num):
     return out
 
 
+def resample_fft_chunks(x, in_offsets, lengths, nums):
+    """R2 for a chunk list in one call (dd_resample_fft_chunks): chunk i = x[in_offsets[i] : in_offsets[i] + lengths[i]]
+    (float32 or float64 device array) resampled to nums[i] samples; returns the concatenated float64 device array and
+    the output offsets"""
+    import ctypes as C
+    if x.dtype not in (_F32, _F64):
+        raise NotImplementedError("strict bwLim (FFT resample) is implemented for real signals")
+    k = len(lengths)
+    out_off = [0] * k
+    for i in range(1, k):
+        out_off[i] = out_off[i - 1] + int(nums[i - 1])
+    total = (out_off[-1] + int(nums[-1])) if k else 0
+    out = DevArray(max(total, 1), _F64)
+    A = C.c_int64 * max(k, 1)
+    check(lib().dd_resample_fft_chunks(x.ptr, 1 if x.dtype == _F32 else 0, A(*[int(v) for v in in_offsets]), A(*[int(v) for v in lengths]), out.ptr,
+                                       A(*out_off), A(*[int(v) for v in nums]), k, None), "dd_resample_fft_chunks")
+    return out.view(0, total), out_off
+
+
 def am_envelope(x, block=None):
     """A1 (demod_am.py:18-29)"""
     if x.dtype == _F32:

@@ -283,6 +283,85 @@ extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int
     return DD_OK;
 }
 
+// ---- R2 over a chunk list: the per-chunk FFT resample of a chunk loop (decode_fm.py:54-70: every 2^22-sample chunk ends
+// in bwLim(strict) = scipy.signal.resample of ITS outputs) for all chunks at once.  Chunks of equal (length, target
+// length) share a batched plan: gather (f32 or f64 -> f64) | batched D2Z | spectrum bins | batched Z2D | scale + scatter.
+struct DDRsJob { int64_t in_off, out_off; };
+template <typename T>
+__global__ void __launch_bounds__(256) k_rs_gather(const T* __restrict__ in, const DDRsJob* __restrict__ jobs, int64_t n, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[(int64_t)blockIdx.y * n + i] = (double)in[jobs[blockIdx.y].in_off + i];
+}
+__global__ void __launch_bounds__(256) k_rs_bins_b(const double2* __restrict__ X, double2* __restrict__ Y, int64_t nx_bins, int64_t ny_bins, int64_t N, int64_t num, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ny_bins) return;
+    X += (int64_t)blockIdx.y * nx_bins;
+    Y += (int64_t)blockIdx.y * ny_bins;
+    // scipy.signal.resample for real input (rfft route): keep the first N/2+1 bins; the Nyquist bin of the SHORTER length is
+    // halved when downsampling / doubled... same rule as k_resample_bins
+    double2 v = make_double2(0.0, 0.0);
+    const int64_t nyq = N / 2;
+    if (k < nx_bins && k <= nyq) {
+        v = X[k];
+        if (N % 2 == 0 && k == nyq) {
+            if (num < n) { v.x *= 2.0; v.y *= 2.0; }      // downsampling: the kept Nyquist bin collects both halves
+            else if (num > n) { v.x *= 0.5; v.y *= 0.5; }
+        }
+    }
+    Y[k] = v;
+}
+__global__ void __launch_bounds__(256) k_rs_scatter(const double* __restrict__ src, const DDRsJob* __restrict__ jobs, int64_t num, double scale, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < num) out[jobs[blockIdx.y].out_off + i] = src[(int64_t)blockIdx.y * num + i] * scale;
+}
+
+extern "C" int dd_resample_fft_chunks(const void* in, int in_is_f32, const int64_t* in_off_host, const int64_t* n_host, double* out,
+                                      const int64_t* out_off_host, const int64_t* num_host, int count, void* stream) {
+    DD_REQUIRE(in && out && in_off_host && n_host && out_off_host && num_host && count >= 0, "arguments");
+    hipStream_t s = dd_stream(stream);
+    std::vector<char> done(count, 0);
+    for (int first = 0; first < count; ++first) {
+        if (done[first]) continue;
+        const int64_t n = n_host[first], num = num_host[first];
+        DD_REQUIRE(n >= 1 && num >= 1, "n/num");
+        std::vector<DDRsJob> jobs;
+        for (int j = first; j < count; ++j)
+            if (!done[j] && n_host[j] == n && num_host[j] == num) { jobs.push_back({in_off_host[j], out_off_host[j]}); done[j] = 1; }
+        const int B = (int)jobs.size();
+        hipfftHandle pf, pb;
+        int rc = get_plan(&pf, HIPFFT_D2Z, n, B, s);
+        if (rc != DD_OK) return rc;
+        rc = get_plan(&pb, HIPFFT_Z2D, num, B, s);
+        if (rc != DD_OK) return rc;
+        const int64_t nxb = n / 2 + 1, nyb = num / 2 + 1;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_x = al(sizeof(DDRsJob) * B), o_y = o_x + al(sizeof(double2) * nxb * B), o_t = o_y + al(sizeof(double2) * nyb * B);
+        const size_t o_r = o_t + al(sizeof(double) * n * B), need = o_r + al(sizeof(double) * num * B);
+        DDScratchLock scr;
+        rc = scr.get(need, s);
+        if (rc != DD_OK) return rc;
+        DDRsJob* dj = reinterpret_cast<DDRsJob*>(scr.ptr);
+        double2* X = reinterpret_cast<double2*>(scr.ptr + o_x);
+        double2* Y = reinterpret_cast<double2*>(scr.ptr + o_y);
+        double* tmp = reinterpret_cast<double*>(scr.ptr + o_t);
+        double* res = reinterpret_cast<double*>(scr.ptr + o_r);
+        DD_HIP_CHECK(hipMemcpyAsync(dj, jobs.data(), sizeof(DDRsJob) * B, hipMemcpyHostToDevice, s));     // (pageable source: staged before the call returns)
+        if (in_is_f32) hipLaunchKernelGGL(k_rs_gather<float>, dim3(grid1(n), B), dim3(256), 0, s, (const float*)in, dj, n, tmp);
+        else hipLaunchKernelGGL(k_rs_gather<double>, dim3(grid1(n), B), dim3(256), 0, s, (const double*)in, dj, n, tmp);
+        hipfftResult r1 = hipfftExecD2Z(pf, tmp, (hipfftDoubleComplex*)X);
+        const int64_t N = num < n ? num : n;
+        hipLaunchKernelGGL(k_rs_bins_b, dim3(grid1(nyb), B), dim3(256), 0, s, X, Y, nxb, nyb, N, num, n);
+        hipfftResult r2 = hipfftExecZ2D(pb, (hipfftDoubleComplex*)Y, res);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(grid1(num), B), dim3(256), 0, s, res, dj, num, 1.0 / (double)n, out);
+        if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) {
+            dd_set_error("hipfft exec failed (%d, %d)", (int)r1, (int)r2);
+            return DD_ERR_HIP;
+        }
+        DD_LAUNCH_CHECK();
+    }
+    return DD_OK;
+}
+
 // grow-only scratch per device for the audio-rate entry points' intermediates (no allocation in the steady state:
 // a hipMalloc/hipFree pair costs 50-100 us, a dozen of them were half of a correlate + peak-pick call)
 static std::mutex g_sync_mu;

@@ -223,6 +223,12 @@ int dd_chain_last_kernel(const dd_chain* h);
 /* Fourier-domain resample of one chunk, float64 real: n -> num samples.  Asynchronous on `stream`; the intermediates
  * live in a grow-only buffer kept by the library (no allocation, no synchronisation in the steady state). */
 int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream);
+/* The same per-chunk resample for a whole chunk list in one call (a chunk loop ends every chunk in bwLim(strict):
+ * decode_fm.py:54-70): chunk i is the n_host[i] samples at in + in_off_host[i] (float32 when in_is_f32 -- the FM output of
+ * dd_chain_process_chunks -- else float64) and becomes num_host[i] float64 samples at out + out_off_host[i]; offsets in
+ * elements.  Chunks of equal (n, num) share batched hipFFT plans: two transforms per group instead of two per chunk. */
+int dd_resample_fft_chunks(const void* in, int in_is_f32, const int64_t* in_off_host, const int64_t* n_host, double* out,
+                           const int64_t* out_off_host, const int64_t* num_host, int count, void* stream);
 
 /* ---- polyphase rational resampler (BASELINE north_star, config 3 "polyphase resample to 11.025 kS/s").
  * The reference has NO counterpart (its only resampler is the FFT one above, comm.py:110-116): a build-defined

@@ -137,6 +137,26 @@ def test_c4_crude_and_accurate_sync_indices_golden(dd, noaa_inputs):
     assert np.max(np.abs(np.array(ta) - g["acc_syncA_time"])) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_resample_chunk_list_equals_per_chunk_resample(dd, dtype):
+    """dd_resample_fft_chunks (batched plans per (length, target) group) against the per-chunk entry and the oracle's
+    scipy.signal.resample restatement: the C3 shape (chunks of 83886 / 83887 samples -> 4624) and mixed lengths"""
+    rng = np.random.default_rng(8)
+    lengths = [83887, 83886, 83886, 83887, 83886, 5000, 83887, 5001, 5000]
+    nums = [int(11025 * n / 200000) for n in lengths]
+    x = rng.standard_normal(sum(lengths)).astype(dtype)
+    offs = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    d = dd.hip.DevArray.from_host(x)
+    out, out_off = dd.ops.resample_fft_chunks(d, offs, lengths, nums)
+    got = out.to_host()
+    assert got.shape == (sum(nums),)
+    for i, (o, n, m) in enumerate(zip(offs, lengths, nums)):
+        piece = x[o:o + n].astype(np.float64)
+        one = dd.ops.resample_fft(dd.hip.DevArray.from_host(piece), m).to_host()
+        assert rel_err(got[out_off[i]:out_off[i] + m], one) < 1e-12, i
+        assert rel_err(got[out_off[i]:out_off[i] + m], O.resample_fft(piece, m)) < 1e-9, i
+
+
 @pytest.mark.timeout(900)
 def test_c4_at_bench_duration_index_lists_golden(dd, golden_dir):
     """config 4 at BENCH duration (60 s, "Pass = identical index lists"): crude and accurate sync over a 60 s
