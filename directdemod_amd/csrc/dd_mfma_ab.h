@@ -24,13 +24,8 @@
 
 #define AB_VWAVES 8
 #define AB_VTHREADS (64 * AB_VWAVES)
-#ifndef AB_REG_ROWS
-#define AB_REG_ROWS 16        // accumulator registers (of 16) whose outputs the owning matrix wave turns into angles itself.  With 8,
-                              // the rest (outputs 512..1023 of the strip) go through LDS to the vector waves so that the three
-                              // vector-issuing waves of a SIMD carry equal shares -- measured SLOWER (0.2393 ms against 0.2340):
-                              // the 34 extra LDS stores sit behind the last MFMA of the matrix wave's phase and the LDS is
-                              // already 50 % busy with fragment reads.  Kept selectable (-DAB_REG_ROWS=8) for the record.
-#endif
+#define AB_REG_ROWS 16        // accumulator registers (of 16) whose outputs the owning matrix wave turns into angles itself (with 8
+                              // the other half go through LDS to the vector waves: measured slower, 0.2393 ms against 0.2340)
 #define AB_RED_ENTRIES 12     // range-check slots per tile: 8 vector waves, the halo step (entry 8), padding to 16 bytes
 #ifndef DD_AB_EPI_PRIO
 #define DD_AB_EPI_PRIO 0
@@ -38,13 +33,9 @@
 #ifndef DD_AB_VEC_PRIO
 #define DD_AB_VEC_PRIO 0
 #endif
-// measured alternatives, correct and parity-tested, none faster (DESIGN.md 4.2b "round 2, second pass"); off by default:
-//   DD_AB_DEFER     all but one entry of a strip's boundary table written at the START of the discriminator phase instead
-//                   of between the last MFMA and the barrier (MFMA phase 4250 -> 3900 cycles, launch time unchanged)
-//   DD_AB_PREFETCH  the fragments of the first k-step requested before the barrier, behind a per-tile count of the
-//                   converting waves (needs 24 more live registers across the barrier: spills, slower)
-//   DD_AB_TINY      discriminator from the ratio im / re with a two-coefficient polynomial below 9 degrees (7 instead
-//                   of 9.5 instructions per row; the discriminator wave is no faster for it)
+// The round-2 experiments that were built, parity-tested, measured and found no faster (boundary table
+// deferred, first k-step prefetched across the barrier, ratio-form discriminator, grouped fragment reads, the halo step
+// on a vector wave) are no longer switches of this header: tools/variants/mfma_ab_switches.patch puts them back.
 // timing ablations (tools/mkvariant.sh ... -DDD_AB_NO_xxx; results are wrong by construction, never shipped):
 //   DD_AB_NO_EPI      matrix waves skip the discriminator      DD_AB_NO_MFMA   matrix waves skip the MFMAs
 //   DD_AB_NO_CONVERT  vector waves skip the rotation / split   DD_AB_NO_LOAD   vector waves skip the tile loads
@@ -165,9 +156,6 @@ __device__ __forceinline__ void dd_ab_convert_quad(const AbRaw& raw, char* plane
     dd_ab_split2(x2.y, x3.y, ih.y, il.y);
     const int e = 4 * q;
     const int off = 2 * e + 16 * (e >> 5);                 // 8-byte aligned: a quad never straddles a 32-sample pad
-#ifdef DD_AB_NO_DSWRITE
-    if (scale != 12345.f) return;                          // (ablation: the limbs are computed, never written)
-#endif
     *reinterpret_cast<uint2*>(planes + off) = rh;
     *reinterpret_cast<uint2*>(planes + G::PLANE + off) = rl;
     *reinterpret_cast<uint2*>(planes + 2 * G::PLANE + off) = ih;
@@ -209,18 +197,8 @@ __device__ __forceinline__ float dd_ab_tile_scale(const char* smem, int red_off,
 // executes a wave's operations in order, so whoever sees the count sees the stores).  The matrix set that computes
 // tile t next phase reads the count at the end of its discriminator phase; with all AB_CONV_WAVES shares in, it
 // requests its first two k-steps of fragments BEFORE the barrier and its MFMAs start the moment the barrier opens.
-#ifdef AB_HALO_ON_VECTOR
-#define AB_CONV_WAVES AB_VWAVES
-#else
 #define AB_CONV_WAVES (AB_VWAVES + 1)
-#endif
 __device__ __forceinline__ void dd_ab_conv_done(char* smem, int cnt_off, int t, int lane) {
-#ifdef DD_AB_PREFETCH
-    if (lane == 0) {
-        const unsigned addr = (unsigned)(uintptr_t)(smem + cnt_off) + 4u * (unsigned)(t & 1);
-        asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1) : "memory");
-    }
-#endif
 }
 
 // one 256-output unit of the vector waves' share: outputs 512 + 256 u + 4 lane + {0..3} of strip s, tile b
@@ -291,7 +269,7 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
     AbUnit ud;
     ud.r4 = ud.i4 = make_float4(1.f, 0.f, 0.f, 0.f);
     ud.ym = make_float2(1.f, 0.f);
-#if !defined(DD_AB_NO_EPI) && !defined(AB_YH_LATE)
+#ifndef DD_AB_NO_EPI
     if (do_unit) ud = dd_ab_unit_read<NKS>(reinterpret_cast<const float*>(smem + A::YH_OFF + ((p - 1) & 1) * A::YH_SET_BYTES), vw, lane);
 #endif
     DD_AB_STAMP(0)
@@ -302,14 +280,6 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
         if (vt == 0) reinterpret_cast<int*>(smem + A::NONUNIT_OFF)[(p + 2) & 3] = 0;   // re-arm the slot tile p+2's producers raise in phase p+1
         if (CX && vt == 0) reinterpret_cast<float*>(smem + A::SCALE_OFF)[p & 3] = scale;
         char* planes = smem + (p & 1) * A::PLANES_BYTES;
-#ifdef AB_HALO_ON_VECTOR
-        // the halo step (quads 0..XQUADS-1) on the oldest vector wave: with the vector waves at a raised priority they
-        // finish long before the matrix waves, and the wave-step that does not divide among eight waves costs nothing
-        if (vw == 0 && (Q::XQUADS == 64 || lane < Q::XQUADS)) {
-            if (unit) dd_ab_convert_quad<NKS, true>(xraw, planes, lane, wkx, scale);
-            else dd_ab_convert_quad<NKS, false>(xraw, planes, lane, wkx, scale);
-        }
-#endif
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) {
             if (unit) dd_ab_convert_quad<NKS, true>(rcur[st], planes, Q::XQUADS + vt + AB_VTHREADS * st, wk[st], scale);
@@ -318,30 +288,14 @@ __device__ __forceinline__ void dd_ab_vphase(const DDChainParams& P, char* smem,
         dd_ab_conv_done(smem, A::CONVCNT_OFF, p, lane);
     }
 #endif
-#if defined(AB_HALO_ON_VECTOR) && !defined(DD_AB_NO_LOAD)
-    if (vw == 0)                                            // the next tile's halo (one phase ahead: used at the end of this phase and in the next)
-        xraw = dd_ab_load_quad<NKS, U8>(P, t_begin + (p + 1 < n ? p + 1 : n - 1), lane < Q::XQUADS ? lane : Q::XQUADS - 1);
-#endif
     DD_AB_STAMP(1)
 #ifndef DD_AB_NO_EPI
-#ifdef AB_YH_LATE
-    if (do_unit) {
-        // the owning set writes its y-half at the START of this phase (not behind its MFMAs): wait for its four waves
-        const int* cnt = reinterpret_cast<const int*>(smem + A::YHCNT_OFF) + ((p - 1) & 1);
-        const int want = 4 * (((p - 2) >> 1) + 1);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
-        ud = dd_ab_unit_read<NKS>(reinterpret_cast<const float*>(smem + A::YH_OFF + ((p - 1) & 1) * A::YH_SET_BYTES), vw, lane);
-    }
-#endif
     if (do_unit) dd_ab_unit_store(P, t_begin + p - 2, vw, lane, ud);
 #endif
     if (p + 1 < n) {                                        // does tile p+1 fit the f16 limbs unscaled?
         float m = 0.f;
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(rnext[st], m);
-#ifdef AB_HALO_ON_VECTOR
-        if (vw == 0) m = dd_ab_absmax(xraw, m);             // tile p+1's halo, requested above
-#endif
         dd_ab_publish_range(m, smem, A::RED_OFF, A::NONUNIT_OFF, p + 1, vw, lane);
     }
     DD_AB_STAMP(2)
@@ -376,22 +330,10 @@ __device__ __forceinline__ void dd_ab_vector(const DDChainParams& P, const DDMfm
     xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) wkx[k] = make_float2(1.f, 0.f);
-#ifdef AB_HALO_ON_VECTOR
-    if (vw == 0) {
-        xraw = dd_ab_load_quad<NKS, U8>(P, t_begin, lane < Q::XQUADS ? lane : Q::XQUADS - 1);
-        if (P.flags & DD_CHAIN_NCO) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wkx[k] = dd_phasor((uint64_t)(4 * lane + k) * P.cyc, P.nco_tbl);
-        }
-    }
-#endif
     {   // range of tile 0 (what phase p-1 does for tile p); its non-unit flag is preset: the true maximum is read
         float m = 0.f;
 #pragma unroll
         for (int st = 0; st < AB_VSTEPS; ++st) m = dd_ab_absmax(r0[st], m);
-#ifdef AB_HALO_ON_VECTOR
-        if (vw == 0) m = dd_ab_absmax(xraw, m);
-#endif
         m = dd_wave_max(m);
         if (lane == 63) reinterpret_cast<float*>(smem + A::RED_OFF)[vw] = m;
     }
@@ -463,42 +405,6 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
     for (int r = 0; r < NR; ++r) bv[r] = xrd[r];
     // 2. z = y[n] conj(y[n-1]); y[n-1] is the same register one lane to the left: DPP row_shr:1, which leaves the
     //    first lane of each 16-lane row (no source lane) at the old value of the destination = its table entry
-#ifdef DD_AB_TINY
-    // 3. t = im / re for every row (every path starts from it; im is not kept), then wave-uniform fast paths: the
-    //    strip's largest |t| and smallest re pick the polynomial.  |t| <= 0.16 (9 degrees: an oversampled FM signal
-    //    always is): two coefficients, 1.0e-8 rad.  |t| <= tan 22.5 degrees: four.  Anything else -- re <= 0, a NaN --
-    //    the full-range form.  7 instructions per row on the first path (9.5 with a separate range test per row).
-    float re[NR], t[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const float pre = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].x), __float_as_int(cre[r]), 0x111, 0xf, 0xf, false));
-        const float pim = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[r].y), __float_as_int(cim[r]), 0x111, 0xf, 0xf, false));
-        re[r] = fmaf(cre[r], pre, cim[r] * pim);
-        t[r] = fmaf(cim[r], pre, -cre[r] * pim) * __builtin_amdgcn_rcpf(re[r]);
-    }
-    float mx = fabsf(t[0]), mnre = re[0];
-#pragma unroll
-    for (int r = 1; r + 1 < NR; r += 2) {                    // v_max3_f32 / v_min3_f32: two rows per instruction
-        mx = fmaxf(fmaxf(mx, fabsf(t[r])), fabsf(t[r + 1]));
-        mnre = fminf(fminf(mnre, re[r]), re[r + 1]);
-    }
-    if ((NR & 1) == 0) { mx = fmaxf(mx, fabsf(t[NR - 1])); mnre = fminf(mnre, re[NR - 1]); }
-    const bool re_pos = mnre > 0.f;
-    float a[NR];
-    if (__builtin_amdgcn_ballot_w64(!(re_pos && mx <= 0.16f)) == 0) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const float z = t[r] * t[r];
-            a[r] = fmaf(t[r] * z, fmaf(1.946828067e-01f, z, -3.332866728e-01f), t[r]);
-        }
-    } else if (__builtin_amdgcn_ballot_w64(!(re_pos && mx <= 0.41421354f)) == 0) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) a[r] = dd_atan_ratio_small(t[r]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) a[r] = dd_atan_ratio_full(t[r], re[r]);
-    }
-#else
     float re[NR], im[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -523,7 +429,6 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
 #pragma unroll
         for (int r = 0; r < NR; ++r) a[r] = dd_fast_atan2(im[r], re[r]);
     }
-#endif
     // 4. row r of the lane is output 32 (rowbase(r) + 4 h) + j: 128 contiguous bytes per half wave and row.
     //    The tile's first 32 outputs (strip 0, row 0) belong to the previous tile.
 #ifdef DD_AB_NO_STORE
@@ -616,9 +521,6 @@ __device__ __forceinline__ void dd_ab_publish(int lane, int mw, const v16f& cre,
         // (two 4-byte stores per entry: an 8-byte store wants re and im in adjacent registers, 32 v_mov per strip)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-#ifdef DD_AB_DEFER
-            if (q == 15 && g == 3) continue;                // written by dd_ab_publish_last in the MFMA phase
-#endif
             float* d = reinterpret_cast<float*>(((q & 3) != 3 ? pa : pb) + q);
             d[0] = cre[q];
             d[1] = cim[q];
@@ -643,47 +545,18 @@ __device__ __forceinline__ void dd_ab_mfma_strip(const char* abase, const v8h* t
     for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
     if (!have_head) dd_ab_frag_head<NKS, 0, AB_HEAD_KSTEPS>(abase, tb, f);
     dd_ab_frag_head<NKS, AB_HEAD_KSTEPS, 2>(abase, tb, f);
-#ifdef DD_AB_GROUPED_READS
-    // the six fragment reads of k-step ks+2 issued together in front of the six MFMAs of k-step ks, waits left to
-    // the compiler (tools/ubench/mfma_lds_stream.hip: 32.3 cycles per MFMA alone on the CU, against 33.6 for one
-    // pinned read per MFMA gap)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int b = ks % 3;
-        if (ks + 2 < NKS) { DD_WS_LOADF((ks + 2) % 3, ks + 2) }
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][0], f[b][4], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][2], f[b][4], cim, 0, 0, 0);
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][1], f[b][4], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][3], f[b][4], cim, 0, 0, 0);
-        cre = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][0], f[b][5], cre, 0, 0, 0);
-        cim = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b][2], f[b][5], cim, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
 #pragma unroll
     for (int ks = 0; ks < NKS - 1; ++ks) {
         DD_WS_STEP(ks % 3, (ks + 2) % 3, (ks + 2 < NKS ? ks + 2 : ks), (ks + 2 < NKS))
     }
     DD_WS_STEP((NKS - 1) % 3, (NKS + 1) % 3, NKS - 1, false)
-#endif
 }
 
 // End of a set's discriminator phase: if every converting wave has reported tile t = qnext - 1 (the set's next MFMA
 // tile) complete, request the fragments of its first two k-steps now; they land while the wave waits at the barrier.
 template <int NKS>
 __device__ __forceinline__ bool dd_ab_try_head(const char* smem, int n, int qnext, int aoff, const v8h* tb, v8h (&f)[3][6]) {
-#ifndef DD_AB_PREFETCH
     return false;
-#else
-    using A = AbGeom<NKS>;
-    if (qnext < 1 || qnext > n) return false;
-    const int t = qnext - 1;
-    const int c = *reinterpret_cast<const volatile int*>(smem + A::CONVCNT_OFF + 4 * (t & 1));
-    if (__builtin_amdgcn_readfirstlane(c) < AB_CONV_WAVES * ((t >> 1) + 1)) return false;
-    asm volatile("" ::: "memory");                          // the plane reads stay behind the count
-    dd_ab_frag_head<NKS, 0, AB_HEAD_KSTEPS>(smem + (t & 1) * A::PLANES_BYTES + aoff, tb, f);
-    return true;
-#endif
 }
 
 // the halo step (quads 0..63 of a tile) on the matrix wave of strip 0, set SET: conversion in the set's discriminator
@@ -729,11 +602,7 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
     const int lg = lane >> 4;
     const float2* xrd = lg == 0 ? x0 : (lg == 1 ? xa : (lg == 2 ? x1 : xb));
     // halo step: set 1 owns the even tiles' (its discriminator phases are the even ones), set 0 the odd tiles'
-#ifdef AB_HALO_ON_VECTOR
-    const bool halo = false;                                // the oldest vector wave takes the halo step (see dd_ab_vphase)
-#else
     const bool halo = mw == 0;
-#endif
     AbRaw xraw;
     xraw.a = xraw.b = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* wkx_lds = reinterpret_cast<float4*>(smem + A::WKX_OFF) + (SET * 64 + lane) * 2;     // written and read by this lane only
@@ -776,28 +645,13 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
         const int qm = pe + 1;                              // this set's MFMA phase of the pair (tile pe)
         {   // phase pe: the rest of tile pe - 2's table, halo step of tile pe, discriminator of tile pe - 2
             const bool epi = pe >= 2 && pe - 2 < n;
-#ifdef DD_AB_DEFER
-            if (!CX && epi) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
-#endif
             const int nu_flag = halo ? reinterpret_cast<const int*>(smem + A::NONUNIT_OFF)[pe & 3] : 0;
-#ifndef DD_AB_HALO_LATE
             if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, pe, lane, xraw, wkx_lds, nu_flag);
-#endif
-#if defined(AB_YH_LATE) && !defined(DD_AB_NO_EPI)
-            if (AB_REG_ROWS < 16 && epi) {
-                dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
-                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores have landed
-                if (lane == 0) atomicAdd(reinterpret_cast<int*>(smem + A::YHCNT_OFF) + SET, 1);
-            }
-#endif
 #ifndef DD_AB_NO_EPI
             if (epi) {
                 if (CX) dd_ab_store_cx<NKS>(P, taps, smem, t_begin + pe - 2, pe - 2, mw, lane, cre, cim);
                 else dd_ab_epilogue<NKS>(P, t_begin + pe - 2, mw, lane, cre, cim, xrd);
             }
-#endif
-#ifdef DD_AB_HALO_LATE
-            if (halo) dd_ab_halo_convert<NKS, U8>(P, smem, t_begin, n, pe, lane, xraw, wkx_lds, nu_flag);
 #endif
             head = dd_ab_try_head<NKS>(smem, n, qm, aoff, tb, f);
             DD_AB_STAMP(1)
@@ -813,15 +667,9 @@ __device__ __forceinline__ void dd_ab_matrix(const DDChainParams& P, const DDMfm
 #else
             (void)abase; (void)tb;
 #endif
-#ifndef DD_AB_DEFER
             if (!CX) dd_ab_publish(lane, mw, cre, cim, reinterpret_cast<float2*>(smem + A::BCOL_OFF + SET * A::BCOL_SET_BYTES), x0, xa, x1, xb);
-#else
-            if (!CX) dd_ab_publish_last(lane, cre, cim, x0);   // the rest at the start of the discriminator phase
-#endif
-#ifndef AB_YH_LATE
             if (AB_REG_ROWS < 16)
                 dd_ab_write_yhalf(lane, cre, cim, reinterpret_cast<float*>(smem + A::YH_OFF + SET * A::YH_SET_BYTES) + mw * A::YH_STRIDE, 4 * A::YH_STRIDE);
-#endif
             __builtin_amdgcn_s_setprio(DD_AB_EPI_PRIO);
         }
         // range of the halo the set converts in its next discriminator phase (tile qm + 1, requested a phase ago)
