@@ -677,8 +677,8 @@ def run_rank(args):
                 tj = json.load(open(tf))
                 traffic = tj.get("bytes_per_launch_log2n_%d" % args.log2n)
                 traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                  "tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
-                                  % (tj.get("kernel", "k_chain_mfma_ws"), tj.get("git", "2ba8115")))
+                                  "tools/profile_r03.sh / tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
+                                  % (tj.get("kernel", "?"), tj.get("git", "?")))
             except Exception:
                 traffic = None
         if world == 1 and not stub and not args.no_side:

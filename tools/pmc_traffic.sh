@@ -17,7 +17,7 @@ import collections, os, subprocess
 def mean(path, counter):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "k_chain_mfma_" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and "k_chain_" in r["Kernel_Name"]:
             by[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     k = max(by, key=lambda n: len(by[n]))                   # the headline launch (most dispatches)
     return sum(by[k]) / len(by[k]), len(by[k]), k
