@@ -1182,6 +1182,11 @@ extern "C" int dd_chain_path(const dd_chain* c) {
     return (dd_mfma_supported(c->fir->K, c->M, fl) && (c->fir->mfma || !c->fir->mfma_tried)) ? 1 : 0;
 }
 
+extern "C" int dd_fir_last_kernel(const dd_fir* f) {
+    if (!f) return DD_ERR_INVALID;
+    return f->last_kernel;
+}
+
 extern "C" int dd_chain_last_kernel(const dd_chain* c) {
     if (!c) return DD_ERR_INVALID;
     return c->fir->last_kernel;

@@ -273,6 +273,45 @@ def test_chain_c2_golden(dd, ops):
     fm_check(s.signal, g["chain_c2"], np.abs(yo[1:] * np.conj(yo[:-1])))
 
 
+@pytest.mark.parametrize("K", [162, 200, 255, 256])
+@pytest.mark.parametrize("f_off", [25000.0, -31000.0, 0.0, 700000.0])
+def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, monkeypatch):
+    """k_chain_fft1k (the default M = 1 FM kernel for 162..256 taps; forced here): 768-output blocks, the chunk's first and
+    last block are edge blocks (carried history rotated back into the un-rotated frame, y[-1] from the carried last output,
+    predicated stores, new state).  Chunks of 1, 2, K-2, 767, 768, 769, 1535, 1536 ... samples with state carried, the
+    angle-subtraction form of the NCO step (|theta| <= 0.25 rad), the rotation form (700 kHz at 2.4 MS/s: theta = 1.83 rad),
+    a negative offset, no offset; against the float64 oracle."""
+    monkeypatch.setenv("DD_MFMA_KERNEL", "fft1k")
+    fs = 2400000
+    cuts = np.cumsum([0, 1, 2, K - 2, 767, 768, 769, 1535, 1536, 5000, 3, 40000, 777])
+    L = int(cuts[-1])
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 900 + K, f_carrier=f_off if f_off else 1000.0, f_mod=700.0, dev=4.0))
+    taps = O.win_hamming(K)
+    flt = dd.filters.hamming(K)
+    fm = dd.demod_fm.demod_fm()
+    ck = dd.chunker.chunker(_Src(L))
+    out = dd.comm.commSignal(fs)
+    fo = O.FilterState(taps)
+    last, idx, refs, mags = None, 0, [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        s = dd.comm.commSignal(fs, x[a:b], ck)
+        if f_off:
+            s.offsetFreq(f_off)
+        s.filter(flt).funcApply(fm.demod)
+        out.extend(s)
+        y = fo.applyOn(O.nco(x[a:b], f_off, fs, idx) if f_off else x[a:b])
+        idx += b - a
+        prv = last
+        r, last = O.fm_demod(y, last)
+        refs.append(r)
+        yy = y if prv is None else np.concatenate([[prv], y])
+        mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
+    ref = np.concatenate(refs)
+    assert out.length == len(ref) == L - 1
+    assert flt._last_kernel() == dd.hip.DD_KERNEL_FFT_OS
+    fm_check(out.signal, ref, np.concatenate(mags))
+
+
 def test_fused_equals_unfused_stages(dd):
     """The fused kernel and the stage-by-stage kernels are the same arithmetic."""
     L = 30000
