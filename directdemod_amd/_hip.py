@@ -98,6 +98,7 @@ SIGNATURES = {
     "dd_chain_out_count": (_i64, [_p, _i64]),
     "dd_chain_process": (_int, [_p, _p, _p, _i64, _pi64, _p]),
     "dd_fir_last_kernel": (_int, [_p]),
+    "dd_fused_process_chunks": (_int, [_p, _p, _p, _p, _pi64, _int, _int, C.c_uint64, _i64, _int, _int, _int, _pi64, _p]),
     "dd_chain_process_chunks": (_int, [_p, _p, _p, _pi64, _int, _pi64, _p]),
     "dd_chain_path": (_int, [_p]),
     "dd_chain_last_kernel": (_int, [_p]),

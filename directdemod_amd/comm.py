@@ -32,10 +32,133 @@ _pending = []
 
 
 def flush_all():
-    """Execute every recorded operation, oldest signal first."""
+    """Execute every recorded operation, oldest signal first.  A run of pending signals that are the chunks of ONE chunk
+    loop over a device-resident recording -- consecutive views of one buffer through the same filter / demodulator with
+    the chunker variables following on -- executes as one chunk-list call (dd_fused_process_chunks: one launch,
+    bit-identical to chunk by chunk; the strict bwLim that may end each chunk as one dd_resample_fft_chunks)."""
     while _pending:
-        s = _pending.pop(0)
-        s._run_ops()
+        k = _batch_len()
+        if k >= 2:
+            batch = _pending[:k]
+            del _pending[:k]
+            _run_batch(batch)
+        else:
+            s = _pending.pop(0)
+            s._run_ops()
+
+
+def _chunk_pattern(s):
+    """(nco op or None, filter, (M, off), fm or None, resample num or None) when the recorded operations of `s` are exactly
+    [offsetFreq] filter bwLim [demod_fm] [bwLim strict] on device-resident IQ samples; None otherwise"""
+    ops = s._ops
+    if s._dev is None or s._dev.dtype not in (_C64, _IQ8) or s._dev.n == 0:
+        return None
+    i = 0
+    nco = None
+    if i < len(ops) and ops[i][0] == "nco":
+        nco = ops[i]
+        i += 1
+    if not (i < len(ops) and ops[i][0] == "fir"):
+        return None
+    filt = ops[i][1]
+    i += 1
+    if not (i < len(ops) and ops[i][0] == "decim" and ops[i][1] > 1):
+        return None
+    decim = (ops[i][1], ops[i][2])
+    i += 1
+    fm = None
+    if i < len(ops) and ops[i][0] == "fm":
+        fm = ops[i][1]
+        i += 1
+    rs = None
+    if i < len(ops) and ops[i][0] == "resample":
+        rs = ops[i][1]
+        i += 1
+    if i != len(ops) or not filt._carries() or (fm is not None and not fm._carries()):
+        return None
+    return nco, filt, decim, fm, rs
+
+
+def _batch_len():
+    first = _chunk_pattern(_pending[0])
+    if first is None:
+        return 1
+    nco0, filt, (M, off), fm, rs0 = first
+    k = 1
+    prev = _pending[0]
+    nco_prev, off_prev = nco0, off
+    while k < len(_pending):
+        cur = _pending[k]
+        pat = _chunk_pattern(cur)
+        if pat is None:
+            break
+        nco, f2, (M2, off2), fm2, rs = pat
+        n_prev = prev._dev.n
+        if f2 is not filt or fm2 is not fm or M2 != M or (rs is None) != (rs0 is None) or (nco is None) != (nco0 is None):
+            break
+        if cur._dev.dtype != prev._dev.dtype or cur._dev.ptr != prev._dev.ptr + n_prev * prev._dev.dtype.itemsize:
+            break                                              # not the next samples of the same buffer
+        if nco is not None and (nco[1] != nco_prev[1] or nco[2] != nco_prev[2] + n_prev):
+            break                                              # "freqoffset" does not follow on (comm.py:75-76)
+        if off2 != (M - (n_prev - off_prev) % M) % M:
+            break                                              # "bwlim" phase does not follow on (comm.py:123-125)
+        prev, nco_prev, off_prev = cur, nco, off2
+        k += 1
+    return k
+
+
+def _run_batch(sigs):
+    import ctypes as C
+    from . import _ops
+    nco0, filt, (M, off0), fm, rs0 = _chunk_pattern(sigs[0])
+    k = len(sigs)
+    fir_h = filt._handle()
+    filt._prepare_call()
+    fm_h = None
+    has_last = True
+    if fm is not None:
+        fm_h = fm._handle()
+        fm._prepare_call()
+        has_last = fm._dev_has_last()
+    lens = [s._dev.n for s in sigs]
+    bounds = [0]
+    for n in lens:
+        bounds.append(bounds[-1] + n)
+    # expected outputs per chunk (the same arithmetic _ops.fused asserts per call)
+    expect, off = [], off0
+    for i, n in enumerate(lens):
+        kept = len(range(off, n, M))
+        e = kept
+        if fm is not None:
+            e = max(0, kept - (0 if has_last else 1))
+            has_last = True
+        expect.append(e)
+        off = (M - (n - off) % M) % M
+    x0 = sigs[0]._dev
+    out = DevArray(max(1, sum(expect)), _F32 if fm is not None else _C64)
+    flags = (_hip.DD_CHAIN_FORCE_DIRECT if _ops.FORCE_DIRECT else 0) | (_hip.DD_CHAIN_U8_INPUT if x0.dtype == _IQ8 else 0)
+    nout = (C.c_int64 * k)()
+    _hip.check(_hip.lib().dd_fused_process_chunks(fir_h, fm_h, x0.ptr, out.ptr, (C.c_int64 * (k + 1))(*bounds), k,
+                                                  1 if nco0 is not None else 0, nco0[1] if nco0 is not None else 0,
+                                                  nco0[2] if nco0 is not None else 0, M, off0, flags, nout, None),
+               "dd_fused_process_chunks")
+    assert list(nout) == expect, (list(nout), expect)
+    if fm is not None:
+        fm._after_call()
+    offs = [0]
+    for e in expect:
+        offs.append(offs[-1] + e)
+    if rs0 is not None:
+        nums = [_chunk_pattern(s)[4] for s in sigs]
+        res, ooff = _ops.resample_fft_chunks(out, offs[:-1], expect, nums)
+        pieces = [res.view(ooff[i], nums[i]) for i in range(k)]
+    else:
+        pieces = [out.view(offs[i], expect[i]) for i in range(k)]
+    for s, piece in zip(sigs, pieces):
+        s._ops = []
+        s._dev = piece
+        s._host = None
+        s._cap = None
 
 
 class commSignal:
@@ -60,6 +183,8 @@ class commSignal:
         self._host = None
         self._dev = None
         self._cap = None            # growable device buffer used by extend()
+        self._lazy = []             # signals extend()ed while their own operations were still pending (appended at materialise)
+        self._into = None           # the container this signal has been lazily extend()ed into
         self._store(sig, copy=True)
 
     # ------------------------------------------------------------------ storage
@@ -75,6 +200,7 @@ class commSignal:
             self._dev = None
         self._cap = None
         self._ops = []
+        self._lazy = []
 
     def _device(self, want=None):
         """Device copy of the stored array.  Complex -> complex64, real -> float64
@@ -125,11 +251,23 @@ class commSignal:
         return self._device()
 
     def _materialise(self):
-        if self._ops:
+        if self._ops or self._lazy:
             flush_all()
+            lazies, self._lazy = self._lazy, []
+            for sig in lazies:
+                sig._into = None
+                self._append(sig)
+
+    def _settle(self):
+        """before this signal changes: if it sits in a container's lazy list, let the container take its samples first"""
+        if self._into is not None:
+            self._into._materialise()
 
     # ------------------------------------------------------------------ hot path (recorded)
     def _record(self, op):
+        self._settle()
+        if self._lazy:
+            self._materialise()
         if not self._ops:
             _pending.append(self)
         self._ops.append(op)
@@ -173,8 +311,11 @@ class commSignal:
             # Fourier-domain resample of the whole chunk == scipy.signal.resample (comm.py:110-116)
             from . import _ops
             num = int(tsampRate * self.length / self.sampRate)
-            self._materialise()
-            self._store(_ops.resample_fft(self._device(), num), copy=False)
+            if self._ops and self._ops[-1][0] == "fm":
+                self._record(("resample", num))               # real (FM) data: runs with the chain, batched over a chunk list
+            else:
+                self._materialise()
+                self._store(_ops.resample_fft(self._device(), num), copy=False)
             self.__sampRate = tsampRate
             self.__len = num
         else:
@@ -229,14 +370,39 @@ class commSignal:
             self.__sampRate = sig.sampRate
         if not self.__sampRate == sig.sampRate:
             raise TypeError("Signals must have same sampling rate to be extended")
-        self._materialise()
-        sig._materialise()
+        self._settle()
         if sig.length == 0:
             return self
+        if sig._ops and sig._into is None and sig is not self and sig._dev is not None and sig._dev._base is not None:
+            # the other signal is a slice of a device-resident recording whose operations are still pending: take its samples
+            # when somebody needs ours (its chunk loop may then run as one chunk-list call).  All bookkeeping is done now.
+            # (Chunks uploaded one by one are taken at once, so their buffers do not pile up.)
+            if self.__len == 0 and not self._lazy and not self._ops:
+                self._host = None
+                self._dev = None
+                self._cap = None
+            self._lazy.append(sig)
+            sig._into = self
+            self.__len += sig.length
+            return self
+        self._materialise()
+        sig._materialise()
+        self._append(sig)
+        self.__len = self._phys_len()
+        return self
+
+    def _phys_len(self):
+        if self._dev is not None:
+            return self._dev.n
+        return len(self._host) if self._host is not None else 0
+
+    def _append(self, sig):
+        """append the (materialised) samples of sig to the device buffer; lengths are the caller's business"""
         other = sig._device()
         if other.dtype == _IQ8:
             other = _convert(other, _C64)
-        if self.__len == 0:
+        have = self._phys_len()
+        if have == 0:
             mine_dt = other.dtype
         else:
             mine_dt = self._device().dtype
@@ -249,21 +415,20 @@ class commSignal:
                     mine_dt = wide
                 if other.dtype != wide:
                     other = _convert(other, wide)
-        need = self.__len + other.n
+        need = have + other.n
         if self._cap is None or self._cap.n < need or self._cap.dtype != mine_dt:
             cap = DevArray(max(need * 2, 1024), mine_dt)
-            if self.__len:
-                _hip.check(_hip.lib().dd_memcpy_d2d(cap.ptr, self._device().ptr, self.__len * mine_dt.itemsize, None), "d2d")
+            if have:
+                _hip.check(_hip.lib().dd_memcpy_d2d(cap.ptr, self._device().ptr, have * mine_dt.itemsize, None), "d2d")
             self._cap = cap
-        _hip.check(_hip.lib().dd_memcpy_d2d(self._cap.ptr + self.__len * mine_dt.itemsize, other.ptr,
+        _hip.check(_hip.lib().dd_memcpy_d2d(self._cap.ptr + have * mine_dt.itemsize, other.ptr,
                                             other.n * mine_dt.itemsize, None), "d2d")
-        self.__len = need
         self._dev = self._cap.view(0, need)
         self._host = None
-        return self
 
     def updateSignal(self, sig):
         ''' Updates the signal (comm.py:166-181); copies host arrays like the reference'''
+        self._settle()
         self._materialise()
         if isinstance(sig, DevArray):
             self._store(sig, copy=False)
@@ -315,6 +480,8 @@ class commSignal:
                 x = _ops.decimate(x, ops[i][1], ops[i][2])
             elif kind == "fm":
                 x = ops[i][1]._demod_device(x)
+            elif kind == "resample":
+                x = _ops.resample_fft(x, ops[i][1])
             i += 1
         self._dev = x
         self._host = None

@@ -745,6 +745,8 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->hpar = 0;
     f->hist_mode = DD_HIST_ONES;
     f->last_kernel = DD_KERNEL_NONE;
+    f->multi = nullptr;
+    f->multi_bytes = 0;
     const int R = DD_DENSE_R;
     const int K = ntaps;
     // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
@@ -783,6 +785,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
 extern "C" int dd_fir_destroy(dd_fir* f) {
     if (!f) return DD_OK;
     if (f->mfma) dd_mfma_destroy(f->mfma);
+    hipFree(f->multi);
     hipFree(f->taps_rev);
     hipFree(f->tail[0]);
     hipFree(f->tail[1]);
@@ -1118,8 +1121,6 @@ struct dd_chain {
     int64_t abs_index;
     void* scratch;          // discarded outputs of dd_chain_prime
     size_t scratch_bytes;
-    char* multi;            // dd_chain_process_chunks: seam flags, per-chunk parameter blocks, prefix tables, seam state
-    size_t multi_bytes;
 };
 
 extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint64_t cycles_q64,
@@ -1135,8 +1136,6 @@ extern "C" int dd_chain_create(dd_chain** h, const double* taps, int ntaps, uint
     c->abs_index = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
-    c->multi = nullptr;
-    c->multi_bytes = 0;
     int rc = dd_fir_create(&c->fir, taps, ntaps);
     if (rc == DD_OK && (flags & DD_CHAIN_FM)) rc = dd_fm_create(&c->fm);
     if (rc != DD_OK) {
@@ -1152,7 +1151,6 @@ extern "C" int dd_chain_destroy(dd_chain* c) {
     dd_fir_destroy(c->fir);
     dd_fm_destroy(c->fm);
     hipFree(c->scratch);
-    hipFree(c->multi);
     delete c;
     return DD_OK;
 }
@@ -1212,86 +1210,69 @@ extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t 
     return rc;
 }
 
-// The chunks [bounds[i], bounds[i+1]) of `in` (sample offsets, ascending, nchunks + 1 of them) as dd_chain_process would
-// take them one after the other -- same outputs, bit for bit, concatenated at `out`, same state afterwards -- in ONE
-// launch when the chain decimates (M > 1) and every chunk keeps at least one sample; otherwise the loop itself.
-extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, const int64_t* bounds_host, int nchunks,
-                                       int64_t* n_out_host, void* stream) {
-    DD_REQUIRE(c && bounds_host && nchunks >= 0, "arguments");
-    hipStream_t s = dd_stream(stream);
-    const bool isfm = c->fm != nullptr;
-    const bool u8 = (c->flags & DD_CHAIN_U8_INPUT) != 0;
+// Core of the chunk-list entry points: the chunks [bounds[i], bounds[i+1]) of `in` through (fir, fm) exactly as the
+// per-chunk loop would take them -- chunk i starts at absolute index start_index + (bounds[i] - bounds[0]) with the
+// decimation phase the previous chunk left (comm.py:123-125) -- in ONE launch when the chain decimates (M > 1) and every
+// chunk keeps at least one sample.  Returns 1 when it has done so (state committed), 0 when the caller must loop, < 0 on error.
+static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                                   int nco, uint64_t cyc, int64_t start_index, int M, int off0, int flags, int64_t* n_out_host, hipStream_t s) {
+    const bool isfm = fm != nullptr;
+    const bool u8 = (flags & DD_CHAIN_U8_INPUT) != 0;
     const size_t isz = u8 ? 2 : sizeof(float2), osz = isfm ? sizeof(float) : sizeof(float2);
-    for (int i = 0; i < nchunks; ++i) DD_REQUIRE(bounds_host[i + 1] >= bounds_host[i], "bounds must ascend");
-    // plan every chunk with the state the loop would give it
+    if (!(M > 1 && nchunks >= 2 && !(flags & DD_CHAIN_FORCE_DIRECT) && fir->K >= 2)) return 0;
     std::vector<DDChainParams> Pv;
     std::vector<DDDecimPlan> plv;
-    std::vector<int64_t> nout(nchunks > 0 ? nchunks : 1, 0);
-    bool one_launch = c->M > 1 && nchunks >= 2 && !(c->flags & DD_CHAIN_FORCE_DIRECT) && c->fir->K >= 2;
-    if (one_launch) {
-        int64_t abs_index = c->abs_index, opos = 0;
-        int has_last = isfm ? c->fm->has_last : 0;
-        for (int i = 0; i < nchunks && one_launch; ++i) {
-            const int64_t n = bounds_host[i + 1] - bounds_host[i];
-            DDChainParams P;
-            memset(&P, 0, sizeof(P));
-            P.in = reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[i];
-            P.out = reinterpret_cast<char*>(out) + osz * (size_t)opos;
-            P.taps_rev = c->fir->taps_rev;
-            P.nco_tbl = dd_nco_table();
-            P.cyc = c->cyc;
-            P.abs0 = abs_index;
-            P.L = n;
-            P.K = c->fir->K;
-            P.M = c->M;
-            P.off = (int)((c->M - abs_index % c->M) % c->M);
-            P.Ld = kept_count(n, P.off, c->M);
-            P.flags = (c->flags & (DD_CHAIN_NCO | DD_CHAIN_U8_INPUT)) | (isfm ? DD_CHAIN_FM : 0);
-            P.s = (isfm && !has_last) ? 1 : 0;
-            if (n == 0 || P.Ld == 0 || (isfm && P.Ld - P.s <= 0 && false)) { one_launch = false; break; }
-            DDDecimPlan pl;
-            int rc = decim_plan(P, pl);
-            if (rc != DD_OK) return rc;
-            nout[i] = isfm ? P.Ld - P.s : P.Ld;
-            if (nout[i] < 0) nout[i] = 0;
-            Pv.push_back(P);
-            plv.push_back(pl);
-            opos += nout[i];
-            abs_index += n;
-            if (isfm) has_last = 1;
-        }
-    }
-    if (!one_launch) {
-        int64_t opos = 0;
-        for (int i = 0; i < nchunks; ++i) {
-            int64_t got = 0;
-            int rc = dd_chain_process(c, reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[i],
-                                      reinterpret_cast<char*>(out) + osz * (size_t)opos, bounds_host[i + 1] - bounds_host[i], &got, stream);
-            if (rc != DD_OK) return rc;
-            if (n_out_host) n_out_host[i] = got;
-            opos += got;
-        }
-        return DD_OK;
+    std::vector<int64_t> nout(nchunks, 0);
+    int64_t abs_index = start_index, opos = 0;
+    int has_last = isfm ? fm->has_last : 0, off = off0;
+    for (int i = 0; i < nchunks; ++i) {
+        const int64_t n = bounds_host[i + 1] - bounds_host[i];
+        DDChainParams P;
+        memset(&P, 0, sizeof(P));
+        P.in = reinterpret_cast<const char*>(in) + isz * (size_t)(bounds_host[i] - bounds_host[0]);
+        P.out = reinterpret_cast<char*>(out) + osz * (size_t)opos;
+        P.taps_rev = fir->taps_rev;
+        P.nco_tbl = dd_nco_table();
+        P.cyc = cyc;
+        P.abs0 = abs_index;
+        P.L = n;
+        P.K = fir->K;
+        P.M = M;
+        P.off = off;
+        P.Ld = kept_count(n, off, M);
+        P.flags = (nco ? DD_CHAIN_NCO : 0) | (u8 ? DD_CHAIN_U8_INPUT : 0) | (isfm ? DD_CHAIN_FM : 0);
+        P.s = (isfm && !has_last) ? 1 : 0;
+        if (n == 0 || P.Ld == 0) return 0;
+        DDDecimPlan pl;
+        int rc = decim_plan(P, pl);
+        if (rc != DD_OK) return rc;
+        nout[i] = isfm ? P.Ld - P.s : P.Ld;
+        if (nout[i] < 0) nout[i] = 0;
+        Pv.push_back(P);
+        plv.push_back(pl);
+        opos += nout[i];
+        abs_index += n;
+        off = (int)((M - (n - off) % M) % M);                    // nextOff of comm.py:124
+        if (isfm) has_last = 1;
     }
     // device image: [flags, 16-byte padded][parameter blocks][segments][interior prefix][edge prefix][seam tails][seam last samples]
-    const int K1 = c->fir->K - 1;
+    const int K1 = fir->K - 1;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_par = al(sizeof(unsigned int) * nchunks), o_seg = o_par + al(sizeof(DDChainParams) * nchunks);
     const size_t o_ipre = o_seg + al(sizeof(DDSeg) * nchunks), o_epre = o_ipre + al(sizeof(int) * (nchunks + 1));
     const size_t o_tail = o_epre + al(sizeof(int) * (nchunks + 1)), o_last = o_tail + al(sizeof(float2) * (size_t)K1 * nchunks);
     const size_t total = o_last + al(sizeof(float2) * nchunks);
-    if (total > c->multi_bytes) {
+    if (total > fir->multi_bytes) {
         DD_HIP_CHECK(hipStreamSynchronize(s));
-        hipFree(c->multi);
-        c->multi = nullptr;
-        c->multi_bytes = 0;
-        DD_HIP_CHECK(hipMalloc((void**)&c->multi, total));
-        c->multi_bytes = total;
+        hipFree(fir->multi);
+        fir->multi = nullptr;
+        fir->multi_bytes = 0;
+        DD_HIP_CHECK(hipMalloc((void**)&fir->multi, total));
+        fir->multi_bytes = total;
     }
-    unsigned int* flags = reinterpret_cast<unsigned int*>(c->multi);
-    float2* seam_tail = reinterpret_cast<float2*>(c->multi + o_tail);
-    float2* seam_last = reinterpret_cast<float2*>(c->multi + o_last);
-    dd_fir* fir = c->fir;
+    unsigned int* seam_flags = reinterpret_cast<unsigned int*>(fir->multi);
+    float2* seam_tail = reinterpret_cast<float2*>(fir->multi + o_tail);
+    float2* seam_last = reinterpret_cast<float2*>(fir->multi + o_last);
     std::vector<char> img(o_tail - o_par, 0);
     DDChainParams* hP = reinterpret_cast<DDChainParams*>(img.data());
     DDSeg* hS = reinterpret_cast<DDSeg*>(img.data() + (o_seg - o_par));
@@ -1305,11 +1286,11 @@ extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, c
         P.tail_in = i == 0 ? (fir->tail_override ? fir->tail_override : fir->tail[fir->parity]) : seam_tail + (size_t)K1 * (i - 1);
         P.tail_out = i == nchunks - 1 ? fir->tail[fir->parity ^ 1] : seam_tail + (size_t)K1 * i;
         if (isfm) {
-            P.lasty_in = i == 0 ? c->fm->last + c->fm->parity : seam_last + (i - 1);
-            P.lasty_out = i == nchunks - 1 ? c->fm->last + (c->fm->parity ^ 1) : seam_last + i;
+            P.lasty_in = i == 0 ? fm->last + fm->parity : seam_last + (i - 1);
+            P.lasty_out = i == nchunks - 1 ? fm->last + (fm->parity ^ 1) : seam_last + i;
         }
-        P.seam_wait = i > 0 ? flags + (i - 1) : nullptr;
-        P.seam_post = i < nchunks - 1 ? flags + i : nullptr;
+        P.seam_wait = i > 0 ? seam_flags + (i - 1) : nullptr;
+        P.seam_post = i < nchunks - 1 ? seam_flags + i : nullptr;
         hP[i] = P;
         hS[i].in = P.in; hS[i].out = P.out; hS[i].abs0 = P.abs0; hS[i].off = P.off; hS[i].s = P.s; hS[i].lo = plv[i].lo; hS[i].pad = 0;
         hI[i + 1] = hI[i] + (plv[i].hi - plv[i].lo);
@@ -1319,17 +1300,17 @@ extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, c
     }
     const int n_int = hI[nchunks], n_edge = hE[nchunks];
     if (per_cu < 1) per_cu = 1;
-    DD_HIP_CHECK(hipMemsetAsync(flags, 0, o_par, s));
-    DD_HIP_CHECK(hipMemcpyAsync(c->multi + o_par, img.data(), img.size(), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    DD_HIP_CHECK(hipMemsetAsync(seam_flags, 0, o_par, s));
+    DD_HIP_CHECK(hipMemcpyAsync(fir->multi + o_par, img.data(), img.size(), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
     const int slots = dd_cu_count() * per_cu;
     int grid = n_edge < slots / 2 ? slots - n_edge : slots / 2;
     if (grid > n_int) grid = n_int;
     if (grid >= 8) grid &= ~7;
     if (grid < 0) grid = 0;
-    const DDChainParams* dP = reinterpret_cast<const DDChainParams*>(c->multi + o_par);
-    const DDSeg* dS = reinterpret_cast<const DDSeg*>(c->multi + o_seg);
-    const int* dI = reinterpret_cast<const int*>(c->multi + o_ipre);
-    const int* dE = reinterpret_cast<const int*>(c->multi + o_epre);
+    const DDChainParams* dP = reinterpret_cast<const DDChainParams*>(fir->multi + o_par);
+    const DDSeg* dS = reinterpret_cast<const DDSeg*>(fir->multi + o_seg);
+    const int* dI = reinterpret_cast<const int*>(fir->multi + o_ipre);
+    const int* dE = reinterpret_cast<const int*>(fir->multi + o_epre);
     if (u8) hipLaunchKernelGGL(k_chain_decim_multi<true>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
     else hipLaunchKernelGGL(k_chain_decim_multi<false>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
     DD_LAUNCH_CHECK();
@@ -1337,11 +1318,72 @@ extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, c
     fir->parity ^= 1;
     fir->tail_override = nullptr;
     if (isfm) {
-        c->fm->parity ^= 1;
-        c->fm->has_last = 1;
+        fm->parity ^= 1;
+        fm->has_last = 1;
     }
-    c->abs_index += bounds_host[nchunks] - bounds_host[0];
     if (n_out_host) for (int i = 0; i < nchunks; ++i) n_out_host[i] = nout[i];
+    return 1;
+}
+
+// The chunks [bounds[i], bounds[i+1]) of `in` (sample offsets, ascending, nchunks + 1 of them) as dd_chain_process would
+// take them one after the other -- same outputs, bit for bit, concatenated at `out`, same state afterwards.
+extern "C" int dd_chain_process_chunks(dd_chain* c, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                                       int64_t* n_out_host, void* stream) {
+    DD_REQUIRE(c && bounds_host && nchunks >= 0, "arguments");
+    hipStream_t s = dd_stream(stream);
+    const bool isfm = c->fm != nullptr;
+    const bool u8 = (c->flags & DD_CHAIN_U8_INPUT) != 0;
+    const size_t isz = u8 ? 2 : sizeof(float2), osz = isfm ? sizeof(float) : sizeof(float2);
+    for (int i = 0; i < nchunks; ++i) DD_REQUIRE(bounds_host[i + 1] >= bounds_host[i], "bounds must ascend");
+    if (nchunks == 0) return DD_OK;
+    const char* in0 = reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[0];
+    int rc = fused_chunks_one_launch(c->fir, c->fm, in0, out, bounds_host, nchunks, (c->flags & DD_CHAIN_NCO) ? 1 : 0, c->cyc, c->abs_index,
+                                     c->M, chain_off(c), c->flags & (DD_CHAIN_U8_INPUT | DD_CHAIN_FORCE_DIRECT), n_out_host, s);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        c->abs_index += bounds_host[nchunks] - bounds_host[0];
+        return DD_OK;
+    }
+    int64_t opos = 0;
+    for (int i = 0; i < nchunks; ++i) {
+        int64_t got = 0;
+        rc = dd_chain_process(c, reinterpret_cast<const char*>(in) + isz * (size_t)bounds_host[i],
+                              reinterpret_cast<char*>(out) + osz * (size_t)opos, bounds_host[i + 1] - bounds_host[i], &got, stream);
+        if (rc != DD_OK) return rc;
+        if (n_out_host) n_out_host[i] = got;
+        opos += got;
+    }
+    return DD_OK;
+}
+
+// The same for the object-model form (dd_fused_process): chunk i of `in` (which points at the first chunk's first sample)
+// is bounds[i+1] - bounds[i] samples long; start_index / offset are the chunker variables of the FIRST chunk, the later
+// chunks' follow by the reference's own carry rules (comm.py:75-76, 123-125).  carry must be 1 (storeState).
+extern "C" int dd_fused_process_chunks(dd_fir* fir, dd_fm* fm, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                                       int nco, uint64_t cycles_q64, int64_t start_index, int decim, int offset, int flags,
+                                       int64_t* n_out_host, void* stream) {
+    DD_REQUIRE(fir && bounds_host && nchunks >= 0 && decim >= 1 && offset >= 0 && offset < decim, "arguments");
+    hipStream_t s = dd_stream(stream);
+    const bool u8 = (flags & DD_CHAIN_U8_INPUT) != 0;
+    const size_t isz = u8 ? 2 : sizeof(float2), osz = fm ? sizeof(float) : sizeof(float2);
+    for (int i = 0; i < nchunks; ++i) DD_REQUIRE(bounds_host[i + 1] >= bounds_host[i], "bounds must ascend");
+    if (nchunks == 0) return DD_OK;
+    int rc = fused_chunks_one_launch(fir, fm, in, out, bounds_host, nchunks, nco, cycles_q64, start_index, decim, offset,
+                                     flags & (DD_CHAIN_U8_INPUT | DD_CHAIN_FORCE_DIRECT), n_out_host, s);
+    if (rc != 0) return rc < 0 ? rc : DD_OK;
+    int64_t opos = 0, abs_index = start_index;
+    int off = offset;
+    for (int i = 0; i < nchunks; ++i) {
+        const int64_t n = bounds_host[i + 1] - bounds_host[i];
+        int64_t got = 0;
+        rc = dd_fused_process(fir, fm, reinterpret_cast<const char*>(in) + isz * (size_t)(bounds_host[i] - bounds_host[0]),
+                              reinterpret_cast<char*>(out) + osz * (size_t)opos, n, nco, cycles_q64, abs_index, decim, off, flags, 1, &got, stream);
+        if (rc != DD_OK) return rc;
+        if (n_out_host) n_out_host[i] = got;
+        opos += got;
+        abs_index += n;
+        off = (int)((decim - (n - off) % decim) % decim);
+    }
     return DD_OK;
 }
 

@@ -22,6 +22,8 @@ struct dd_fir {
     int hpar;
     int hist_mode;
     int last_kernel;        // DD_KERNEL_* of the last fused launch through this filter
+    char* multi;            // chunk-list launches: seam flags, per-chunk parameter blocks, prefix tables, seam state (grow-only)
+    size_t multi_bytes;
 };
 // demod_fm object: carried last sample (demod_fm.py:43-49)
 struct dd_fm {

@@ -61,6 +61,9 @@ class demod_fm():
             check(lib().dd_fm_reset(self._handle()), "dd_fm_reset")
             self.__dev_has_last = False
 
+    def _carries(self):
+        return bool(self.__storeState)
+
     def _dev_has_last(self):
         return self.__dev_has_last
 

@@ -58,6 +58,10 @@ class filter:
     def _fusable(self):
         return self.__isFIR and not self.__zeroPhase
 
+    def _carries(self):
+        """storeState: the history moves on from call to call (what a chunk-list launch needs)"""
+        return bool(self.__storeState)
+
     def _last_kernel(self):
         """DD_KERNEL_* of the last fused launch through this filter (tests assert the intended kernel ran)"""
         return int(lib().dd_fir_last_kernel(self._handle()))

@@ -170,6 +170,16 @@ int dd_fused_process(dd_fir* fir, dd_fm* fm, const void* in, void* out, int64_t 
                      int nco, uint64_t cycles_q64, int64_t start_index, int decim, int offset,
                      int flags, int carry, int64_t* n_out, void* stream);
 
+/* A chunk LIST through the object-model form: `in` points at the first chunk's first sample, chunk i is
+ * bounds_host[i+1] - bounds_host[i] samples long (nchunks + 1 ascending offsets), start_index / offset are the chunker
+ * variables of the FIRST chunk (the later chunks' follow by the reference's carry rules, comm.py:75-76, 123-125), the
+ * filter and the demodulator carry their state (storeState) exactly as over nchunks dd_fused_process calls: outputs
+ * concatenated at `out`, bit-identical to that loop, counts in n_out_host; ONE launch for a decimating chain.  The drop-in
+ * classes use it when a chunk loop's chunks are consecutive views of one device-resident recording (comm.py). */
+int dd_fused_process_chunks(dd_fir* fir, dd_fm* fm, const void* in, void* out, const int64_t* bounds_host, int nchunks,
+                            int nco, uint64_t cycles_q64, int64_t start_index, int decim, int offset, int flags,
+                            int64_t* n_out_host, void* stream);
+
 /* Convenience handle bundling one filter, one FM demodulator and the chunker
  * variables of one stream (used by bench.py and the sharded multi-GPU driver). */
 typedef struct dd_chain dd_chain;

@@ -213,6 +213,110 @@ def test_c3_chain_golden(dd, golden_dir):
     assert np.max(np.abs(out.signal - g["chain_c3"])) < 2e-5
 
 
+def _class_chunk_loop(dd, rate, L, chunk, get, taps, M, f_off, fm_on, strict_rate, out_rate):
+    """the reference's chunk loop (decode scripts: chunker -> commSignal(...).offsetFreq.filter.bwLim.funcApply.bwLim -> extend)"""
+    class _Src:
+        length = L
+    ck = dd.chunker.chunker(_Src(), chunk)
+    out = dd.comm.commSignal(out_rate)
+    filt = dd.filters.filter(taps, 1, storeState=True)
+    fm = dd.demod_fm.demod_fm()
+    for a, b in ck.getChunks:
+        s = dd.comm.commSignal(rate, get(a, b), ck)
+        if f_off is not None:
+            s.offsetFreq(f_off)
+        s.filter(filt).bwLim(rate // M, uniq="First")
+        if fm_on:
+            s.funcApply(fm.demod)
+        if strict_rate:
+            s.bwLim(strict_rate, True)
+        out.extend(s)
+    return out, filt
+
+
+@pytest.mark.parametrize("case", ["c3_c64", "c3_u8", "c4_u8_no_resample", "iq_out", "ragged_last"])
+def test_class_chunk_loop_over_a_resident_recording_is_one_launch(dd, case):
+    """The drop-in classes on a device-resident recording: the chunk loop's per-chunk operations are recorded, and run as
+    ONE chunk-list launch (+ one batched resample) when the output is first needed -- bit for bit what the same loop
+    gives chunk by chunk."""
+    rate, L, chunk, M, f_off, fm_on, strict, out_rate, K = {
+        "c3_c64": (10000000, 1 << 20, 83887, 50, 250000.0, True, 11025, 11025, 127),
+        "c3_u8": (10000000, 1 << 20, 83887, 50, 250000.0, True, 11025, 11025, 127),
+        "c4_u8_no_resample": (2048000, 1 << 21, 250000, 34, None, True, None, 2048000 // 34, 151),
+        "iq_out": (2048000, 1 << 20, 131072, 8, 30000.0, False, None, 256000, 65),
+        "ragged_last": (2048000, (1 << 20) + 12345, 100003, 34, 30000.0, True, 40960, 40960, 151),
+    }[case]
+    raw = O.synth_iq_fm(L, rate, 5, f_carrier=f_off or 0.0, f_mod=1e3, dev=5.0)
+    taps = O.win_blackmanharris(K)
+    u8 = "u8" in case or case == "ragged_last"
+    if u8:
+        res = dd.hip.DevArray.from_host(np.ascontiguousarray(raw).reshape(-1), dtype=np.uint8)
+        res = dd.hip.DevArray(L, dd.hip.IQ8, ptr=res.ptr, base=res)
+        one = lambda a, b: _own(dd, res.view(a, b - a))
+    else:
+        x = O.grid_c64(raw)
+        res = dd.hip.DevArray.from_host(x, dtype=np.complex64)
+        one = lambda a, b: x[a:b]
+    got, filt = _class_chunk_loop(dd, rate, L, chunk, lambda a, b: res.view(a, b - a), taps, M, f_off, fm_on, strict, out_rate)
+    assert len(dd.comm._pending) > 1                       # nothing has run yet
+    g = got.signal
+    assert filt._last_kernel() == dd.hip.DD_KERNEL_DECIM_MULTI
+    ref, f2 = _class_chunk_loop(dd, rate, L, chunk, one, taps, M, f_off, fm_on, strict, out_rate)
+    r = ref.signal
+    assert f2._last_kernel() != dd.hip.DD_KERNEL_DECIM_MULTI
+    assert got.length == ref.length == len(g) == len(r) and got.sampRate == ref.sampRate
+    assert g.dtype == r.dtype and np.array_equal(g, r)
+
+
+def _own(dd, view):
+    """a private device copy of a view (not a slice of a larger buffer: the classes then run it at once)"""
+    d = dd.hip.DevArray(view.n, view.dtype)
+    dd.hip.check(dd.hip.lib().dd_memcpy_d2d(d.ptr, view.ptr, view.n * view.dtype.itemsize, None), "d2d")
+    return d
+
+
+def test_class_chunk_loop_deferred_extend_keeps_the_reference_order_of_events(dd):
+    """what the lazily extended container must not get wrong: a chunk signal changed after extend() contributes the samples
+    it had AT extend(); reading the container in the middle of the loop, mixing in a chunk that cannot join the list, and
+    extending with host signals in between all give the sequential result"""
+    rate, L, chunk, M = 2048000, 600000, 100000, 34
+    raw = O.synth_iq_fm(L, rate, 9, f_carrier=30000.0, f_mod=1e3, dev=5.0)
+    x = O.grid_c64(raw)
+    res = dd.hip.DevArray.from_host(x, dtype=np.complex64)
+    taps = O.win_blackmanharris(151)
+
+    def loop(get, meddle):
+        class _Src:
+            length = L
+        ck = dd.chunker.chunker(_Src(), chunk)
+        out = dd.comm.commSignal(rate // M)
+        filt = dd.filters.filter(taps, 1, storeState=True)
+        fm = dd.demod_fm.demod_fm()
+        lens = []
+        for i, (a, b) in enumerate(ck.getChunks):
+            s = dd.comm.commSignal(rate, get(a, b), ck).offsetFreq(30000.0).filter(filt).bwLim(rate // M, uniq="First")
+            s.funcApply(fm.demod)
+            out.extend(s)
+            if meddle:
+                if i == 1:
+                    s.updateSignal(np.zeros(5))                      # the container already has this chunk's samples
+                if i == 2:
+                    lens.append(float(np.sum(out.signal)))           # read in the middle of the loop
+                if i == 3:
+                    out.extend(dd.comm.commSignal(rate // M, np.arange(7.0)))      # a host signal in between
+            else:
+                if i == 2:
+                    lens.append(float(np.sum(out.signal)))
+                if i == 3:
+                    out.extend(dd.comm.commSignal(rate // M, np.arange(7.0)))
+        return out, lens
+
+    got, gl = loop(lambda a, b: res.view(a, b - a), True)
+    ref, rl = loop(lambda a, b: x[a:b], False)
+    assert got.length == ref.length and gl == rl
+    assert np.array_equal(got.signal, ref.signal)
+
+
 def test_source_readers(dd, tmp_path):
     raw = O.synth_iq_noise(5000, 8)
     f = tmp_path / "x.dat"
