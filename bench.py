@@ -203,6 +203,10 @@ def build_once_per_node():
 
 
 # ----------------------------------------------------------------------------- engines
+KERNEL_NAMES = {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
+                6: "k_chain_mfma_ab", 7: "k_chain_fft1k", 8: "k_chain_decim_multi"}
+
+
 class HipStep:
     """One rank's shard of the C2 workload through the C-ABI chain (dd_chain_*): the product path."""
 
@@ -262,8 +266,7 @@ class HipStep:
 
     def kernel(self):
         """the kernel the last step launched (one launch per step)"""
-        return {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
-                6: "k_chain_mfma_ab", 7: "k_chain_fft1k"}.get(self.lib.dd_chain_last_kernel(self.h), "?")
+        return KERNEL_NAMES.get(self.lib.dd_chain_last_kernel(self.h), "?")
 
     def close(self):
         self.lib.dd_chain_destroy(self.h)
@@ -413,6 +416,7 @@ def side_configs(eng, steps=10):
         lib.dd_chain_destroy(h)
         del out
     res.append(side_c3_end_to_end(eng, steps))
+    res.append(side_c3_through_classes(eng, steps))
     res.append(side_c4_end_to_end())
     return res
 
@@ -464,6 +468,49 @@ def side_c3_end_to_end(eng, steps=10):
     return {"config": "C3 end to end (front end + FFT resample to 11 025 S/s), 2^26 samples @10 MS/s in 16 chunks of 2^22",
             "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1), "audio_samples": int(tot), "chunk_output_lengths": state["args"][5],
             "how": "dd_chain_process_chunks + dd_resample_fft_chunks: 1 chain launch, batched hipFFT plans per chunk-length group"}
+
+
+def side_c3_through_classes(eng, steps=10):
+    """The same C3 job written as the reference writes it (decode_fm.py:54-70) against the drop-in classes -- chunker,
+    commSignal(...).offsetFreq.filter.bwLim.funcApply(fm.demod).bwLim(strict), extend -- on slices of the device-resident
+    input.  Wall clock per pass (the Python of sixteen chunks included), the result read on the device at the end."""
+    import time
+    import scipy.signal as ss
+    from directdemod_amd import comm, filters, demod_fm, chunker, _hip
+    n, chunk, fs = eng.n, 1 << 22, 10000000
+    res = _hip.DevArray(n, np.complex64, ptr=eng.xin.data_ptr(), base=eng.xin)
+    taps = np.ascontiguousarray(ss.remez(127, [0, 100e3, 150e3, 4999999], [1, 0], fs=1e7))
+    objs = {}
+
+    class _Src:
+        length = n
+
+    def one_pass(fresh):
+        if fresh or not objs:
+            objs["rz"], objs["fm"] = filters.filter(taps, 1, storeState=True), demod_fm.demod_fm()
+        rz, fm = objs["rz"], objs["fm"]
+        ck = chunker.chunker(_Src(), chunk)
+        out = comm.commSignal(11025)
+        for a, b in ck.getChunks:
+            out.extend(comm.commSignal(fs, res.view(a, b - a), ck).offsetFreq(250000.0).filter(rz)
+                       .bwLim(200000, uniq="First").funcApply(fm.demod).bwLim(11025, True))
+        return out.length, out.device_signal
+
+    def timed(fresh):
+        for _ in range(3):
+            tot, _d = one_pass(fresh)
+        _hip.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tot, _d = one_pass(fresh)
+        _hip.sync()
+        return (time.perf_counter() - t0) * 1e3 / steps, tot
+    ms_fresh, tot = timed(True)
+    ms, _ = timed(False)
+    rz = objs["rz"]
+    return {"config": "C3 end to end through the drop-in classes (chunker / commSignal / filter / demod_fm, 16 chunks of 2^22, device-resident input)",
+            "ms_per_pass_wall": round(ms, 4), "ms_per_pass_wall_new_filter_and_demod_objects_each_pass": round(ms_fresh, 4),
+            "GS_per_s": round(n / ms / 1e6, 1), "audio_samples": int(tot), "kernel": KERNEL_NAMES.get(rz._last_kernel(), "?"), "how": "recorded chunk loop -> dd_fused_process_chunks + dd_resample_fft_chunks when the output is read"}
 
 
 def synth_apt_iq(duration_s, fs=2048000, seed=1, f_offset=30000.0, dev=17000.0, amp=60.0, sigma=4.0):
