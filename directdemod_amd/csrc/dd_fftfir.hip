@@ -241,12 +241,27 @@ __device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int la
             x[2 * (r0 + i)] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
             x[2 * (r0 + i) + 1] = (v2f){(float)u.z - 127.5f, (float)u.w - 127.5f};
         } else {
+#ifdef FF_NT_LOAD
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            const v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(reinterpret_cast<const float2*>(in) + n0) + m);
+#else
             const float4 v = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(in) + n0)[m];
+#endif
             x[2 * (r0 + i)] = (v2f){v.x, v.y};
             x[2 * (r0 + i) + 1] = (v2f){v.z, v.w};
         }
     }
 }
+
+#ifdef FF_TRACE
+// tools/debug/fft_trace.py: cycles per phase of f1_block (s_memtime stamps; every stamp drains the wave's LDS / scalar counter),
+// summed per wave over its interior blocks
+#define FF_NPH 14
+__device__ unsigned long long g_ff_trace[4096 * (FF_NPH + 2)];
+#define FF_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FF_T(i) do { } while (0)
+#endif
 
 struct F1Edge {
     int prev_valid;        // the value before the block's first output comes from the carried state
@@ -298,7 +313,7 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
             // theta_sub: the NCO's per-sample rotation taken off the angle (|theta| <= 0.25, so the fast path's result stays
             // inside (-pi, pi); the full-range form wraps)
             if (FAST) {
-                ang[i] = ff_atan_small(z.y, z.x) - theta_sub;
+                ang[i] = ff_atan_small(z.y, z.x) - theta_sub;          // (the compiler pairs these into packed instructions)
             } else {
                 float r = ff_atan2(z.y, z.x) - theta_sub;
                 r = r > 3.14159265358979f ? r - 6.28318530717959f : r;
@@ -326,7 +341,11 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
         for (int i = 0; i < 2; ++i) {
             const int o = 128 * (2 * g + i);                    // output of this lane's first sample of the row pair, relative to ob
             if (!PARTIAL) {
+#ifdef FF_NT_STORE
+                __builtin_nontemporal_store((v2f){ang[2 * i], ang[2 * i + 1]}, reinterpret_cast<v2f*>(ob + o));
+#else
                 *reinterpret_cast<float2*>(ob + o) = make_float2(ang[2 * i], ang[2 * i + 1]);
+#endif
             } else {
                 if (2 * lane + o >= lim_lo && 2 * lane + o < limit) ob[o] = ang[2 * i];
                 if (2 * lane + o + 1 >= lim_lo && 2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
@@ -342,9 +361,18 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
 template <bool U8, bool PARTIAL, bool LOADNEXT>
 __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
                                          const v2f crot, const float theta_sub, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int lim_lo, const int limit,
-                                         const F1Edge* edge = nullptr) {
+                                         const F1Edge* edge = nullptr
+#ifdef FF_TRACE
+                                         , unsigned* tr = nullptr
+#endif
+                                         ) {
     const int hi = lane >> 2, lo = lane & 3;
     v2f* const X = Xp;
+#ifdef FF_TRACE
+    unsigned tdummy[FF_NPH];
+    if (!tr) tr = tdummy;
+    unsigned tprev = (unsigned)__builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int r = 2; r < 8; ++r) f1_swap(a[2 * r], a[2 * r + 1]);
 #pragma unroll
@@ -361,7 +389,9 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     const int x2r = hi * F1_S2 + 5 * lo;     // + 20 c + n0      (k1 = 4 c + j)
     // ---- forward pass 1 (over n2), T1, X1
     ff_bfly16<false>(a);
+    FF_T(0);
     ff_twiddle15<false, true>(a, tw1);
+    FF_T(1);
 #ifndef FF_NO_LDS
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[x1w + F1_S1 * k] = a[FF_P(k)];
@@ -369,8 +399,11 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     for (int k = 0; k < 16; ++k) a[k] = X[x1r + 2 * k];
 #endif
     // ---- forward pass 2 (over n1), T2, X2
+    FF_T(2);
     ff_bfly16<false>(a);
+    FF_T(3);
     ff_twiddle15<false, true>(a, tw2);
+    FF_T(4);
 #ifndef FF_NO_LDS
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[x2w + 5 * k] = a[FF_P(k)];
@@ -380,6 +413,7 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
         for (int n = 0; n < 4; ++n) a[4 * c + n] = X[x2r + 20 * c + n];
 #endif
     // ---- forward pass 3 (radix 4 over n0), spectrum product, inverse pass 3
+    FF_T(5);
 #pragma unroll
     for (int c = 0; c < 4; ++c) ff_r4<false, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
     {
@@ -393,6 +427,7 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) ff_r4<true, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+    FF_T(6);
 #ifndef FF_NO_LDS
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -402,8 +437,10 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     for (int k = 0; k < 16; ++k) a[k] = X[x2w + 5 * k];
 #endif
     // ---- T2*, inverse pass 2
+    FF_T(7);
     ff_twiddle15<true, false>(a, tw2);
     ff_bfly16<true>(a);
+    FF_T(8);
 #ifndef FF_NO_LDS
 #pragma unroll
     for (int k = 0; k < 16; ++k) X[x1r + 2 * k] = a[FF_P(k)];
@@ -411,8 +448,10 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
     for (int k = 0; k < 16; ++k) a[k] = X[x1w + F1_S1 * k];
 #endif
     // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + 64 r + t]
+    FF_T(9);
     ff_twiddle15<true, false>(a, tw1);
     ff_bfly16<true>(a);
+    FF_T(10);
     // ---- back to two consecutive outputs per lane: B[r] = w[128 r + 2 lane], A[r] = the one after it (row pairs 1..7;
     // of pair 1 only lane 63's second value is used, as the left-hand neighbour of the block's first output)
     v2f zz[16];
@@ -470,9 +509,11 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #pragma unroll
     for (int r = 4; r < 16; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
     const bool fast = __builtin_amdgcn_ballot_w64(worst > 0.f) == 0;
+    FF_T(11);
     float* const ob = out_row4 + 2 * lane;
     if (fast) f1_tail<U8, PARTIAL, LOADNEXT, true>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
     else f1_tail<U8, PARTIAL, LOADNEXT, false>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
+    FF_T(12);
 }
 
 // one edge block (the chunk's first and / or last): samples fetched one by one through f1_edge_sample, stores
@@ -581,11 +622,29 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
         f1_swap(a[0], a[1]);
         f1_swap(a[2], a[3]);
+#ifdef FF_TRACE
+        unsigned tr[FF_NPH];
+#pragma unroll
+        for (int i = 0; i < FF_NPH; ++i) tr[i] = 0;
+        const unsigned tloop = (unsigned)__builtin_readcyclecounter();
+#endif
         for (int q = q_lo; q < q_hi; ++q) {
             const int64_t p0 = (int64_t)F1_ADV * q;
             const int64_t n0_next = (q + 1 < q_hi) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
+#ifdef FF_TRACE
+            f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, nullptr, tr);
+#else
             f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV);
+#endif
         }
+#ifdef FF_TRACE
+        tr[13] = (unsigned)__builtin_readcyclecounter() - tloop;
+        if (gw < 4096 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < FF_NPH; ++i) g_ff_trace[gw * (FF_NPH + 2) + i] = tr[i];
+            g_ff_trace[gw * (FF_NPH + 2) + FF_NPH] = (unsigned long long)(q_hi - q_lo);
+        }
+#endif
     }
     if (q_end == nblk && nblk > 1) f1_edge_block<U8>(P, T, nblk - 1, nblk, X, hp, lane);
 }
@@ -699,6 +758,14 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
     s->have_h = 1;
     return DD_OK;
 }
+
+#ifdef FF_TRACE
+extern "C" int dd_debug_fft_trace(unsigned long long* out, int nwaves) {
+    DD_HIP_CHECK(hipDeviceSynchronize());
+    DD_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_trace), sizeof(unsigned long long) * (size_t)nwaves * (FF_NPH + 2)));
+    return DD_OK;
+}
+#endif
 
 // the whole chunk through k_chain_fft1k (one launch, carried state included)
 int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
