@@ -95,51 +95,103 @@ __device__ __forceinline__ void ff_twiddle15(v2f (&a)[16], const v2f (&w)[16]) {
     for (int k = 1; k < 16; ++k) a[PERM ? FF_P(k) : k] = CONJ ? ff_fma_hic(a[PERM ? FF_P(k) : k], w[k], t[k]) : ff_fma_hi(a[PERM ? FF_P(k) : k], w[k], t[k]);
 }
 
-// 4-point DFT, forward W4 = -j, inverse +j; ROT2: input x2 still carries a factor -j (forward) / +j (inverse)
-template <bool INV, bool ROT2>
-__device__ __forceinline__ void ff_r4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
-    v2f s0, s1;
-    if (ROT2) {
-        s0 = INV ? ff_addpj(x0, x2) : ff_addmj(x0, x2);
-        s1 = INV ? ff_addmj(x0, x2) : ff_addpj(x0, x2);
-    } else {
-        s0 = x0 + x2;
-        s1 = x0 - x2;
-    }
-    const v2f s2 = x1 + x3, d = x1 - x3;
-    x0 = s0 + s2;
-    x2 = s0 - s2;
-    x1 = INV ? ff_addpj(s1, d) : ff_addmj(s1, d);
-    x3 = INV ? ff_addmj(s1, d) : ff_addpj(s1, d);
+// c + (a.x w.x, a.y w.x): first half of c + a * w (second half: ff_fma_hi / ff_fma_hic)
+template <bool SC>
+__device__ __forceinline__ v2f ff_fma_lo(v2f a, v2f w, v2f c) {
+    v2f r;
+    if (SC) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(w), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
+template <bool SC>
+__device__ __forceinline__ v2f ff_mul_lo_t(v2f a, v2f w) { return SC ? ff_mul_lo_s(a, w) : ff_mul_lo(a, w); }
+template <bool CONJ, bool SC>
+__device__ __forceinline__ v2f ff_fma_hi_t(v2f a, v2f w, v2f t) {
+    return SC ? ff_fma_hi_s<CONJ>(a, w, t) : (CONJ ? ff_fma_hic(a, w, t) : ff_fma_hi(a, w, t));
+}
+__device__ __forceinline__ v2f ff_2u_minus_s(v2f u, v2f s, v2f two) {          // 2 u - s   (two = (2, 2) in a scalar register pair)
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(u), "s"(two), "v"(s));
+    return r;
 }
 
-// 16-point DFT in registers, 4 x 4: a[4p + q] in, output k = c + 4d in a[4c + d] = a[FF_P(k)]
+// One stage of four 4-point DFTs (forward W4 = -j, inverse +j) over a[B + S i], i = 0..3, for the four bases B of the
+// stage (S = 4: B = 0..3; S = 1: B = 0, 4, 8, 12), whose inputs carry factors: bit e of MASK set = a[e] is to be
+// multiplied by w[e] (conj(w[e]) if CONJ) first; bit e of ROT set (only inputs i = 2) = by -j (forward) / +j (inverse).
+// The factors are folded into the first additions: x + w y as two packed FMAs, x - w y = 2 x - (x + w y) as a third --
+// three instructions where a product and two additions take four (inputs 1 and 0 are multiplied out: two instructions
+// each).  Written step by step across the four butterflies so that no instruction reads the result of the one before it
+// (a packed result may not be read by the next instruction: the compiler would pad with s_nop).
+template <bool INV, bool CONJ, int S, unsigned MASK, unsigned ROT, bool SC>
+__device__ __forceinline__ void ff_stage(v2f (&a)[16], const v2f (&w)[16]) {
+    const v2f two = {2.0f, 2.0f};
+    v2f t0[4], t1[4], u0[4], u1[4], ta[4], tb[4], s0[4], s1[4], s2[4], d[4];
+#define FF_E(g, i) ((S == 4 ? (g) : 4 * (g)) + S * (i))
+#define FF_M(g, i) ((MASK >> FF_E(g, i)) & 1u)
+#define FF_R(g) ((ROT >> FF_E(g, 2)) & 1u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (FF_M(g, 0)) t0[g] = ff_mul_lo_t<SC>(a[FF_E(g, 0)], w[FF_E(g, 0)]);
+        if (FF_M(g, 1)) t1[g] = ff_mul_lo_t<SC>(a[FF_E(g, 1)], w[FF_E(g, 1)]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u0[g] = FF_M(g, 0) ? ff_fma_hi_t<CONJ, SC>(a[FF_E(g, 0)], w[FF_E(g, 0)], t0[g]) : a[FF_E(g, 0)];
+        u1[g] = FF_M(g, 1) ? ff_fma_hi_t<CONJ, SC>(a[FF_E(g, 1)], w[FF_E(g, 1)], t1[g]) : a[FF_E(g, 1)];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (FF_M(g, 2)) ta[g] = ff_fma_lo<SC>(a[FF_E(g, 2)], w[FF_E(g, 2)], u0[g]);
+        if (FF_M(g, 3)) tb[g] = ff_fma_lo<SC>(a[FF_E(g, 3)], w[FF_E(g, 3)], u1[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (FF_M(g, 2)) s0[g] = ff_fma_hi_t<CONJ, SC>(a[FF_E(g, 2)], w[FF_E(g, 2)], ta[g]);
+        else if (FF_R(g)) s0[g] = INV ? ff_addpj(u0[g], a[FF_E(g, 2)]) : ff_addmj(u0[g], a[FF_E(g, 2)]);
+        else s0[g] = u0[g] + a[FF_E(g, 2)];
+        s2[g] = FF_M(g, 3) ? ff_fma_hi_t<CONJ, SC>(a[FF_E(g, 3)], w[FF_E(g, 3)], tb[g]) : u1[g] + a[FF_E(g, 3)];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (FF_M(g, 2)) s1[g] = ff_2u_minus_s(u0[g], s0[g], two);
+        else if (FF_R(g)) s1[g] = INV ? ff_addmj(u0[g], a[FF_E(g, 2)]) : ff_addpj(u0[g], a[FF_E(g, 2)]);
+        else s1[g] = u0[g] - a[FF_E(g, 2)];
+        d[g] = FF_M(g, 3) ? ff_2u_minus_s(u1[g], s2[g], two) : u1[g] - a[FF_E(g, 3)];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        a[FF_E(g, 0)] = s0[g] + s2[g];
+        a[FF_E(g, 2)] = s0[g] - s2[g];
+        a[FF_E(g, 1)] = INV ? ff_addpj(s1[g], d[g]) : ff_addmj(s1[g], d[g]);
+        a[FF_E(g, 3)] = INV ? ff_addmj(s1[g], d[g]) : ff_addpj(s1[g], d[g]);
+    }
+#undef FF_E
+#undef FF_M
+#undef FF_R
+}
+
+// 16-point DFT in registers, 4 x 4: a[4p + q] in, output k = c + 4d in a[4c + d] = a[FF_P(k)].  PRE: input a[k] carries the
+// factor w[k] (conj(w[k]) for the inverse), k = 1..15 -- the twiddles of the transposed (inverse) graph, folded into the first stage.
+template <bool INV, bool PRE>
+__device__ __forceinline__ void ff_bfly16(v2f (&a)[16], const v2f (&w)[16]) {
+    ff_stage<INV, INV, 4, PRE ? 0xFFFEu : 0u, 0u, false>(a, w);
+    // a[4c + q] = u[q][c];  u[q][c] *= W16^{q c} (conjugated for the inverse), constants in scalar register pairs; W16^4 = -j by
+    // swapped additions
+    v2f cw[16];
+    cw[5] = (v2f){0.92387953251128674f, -0.38268343236508977f};
+    cw[6] = (v2f){0.70710678118654752f, -0.70710678118654752f};
+    cw[7] = (v2f){0.38268343236508977f, -0.92387953251128674f};
+    cw[9] = cw[6];
+    cw[11] = (v2f){-0.70710678118654752f, -0.70710678118654752f};
+    cw[13] = cw[7];
+    cw[14] = cw[11];
+    cw[15] = (v2f){-0.92387953251128674f, 0.38268343236508977f};
+    ff_stage<INV, INV, 1, 0xEAE0u, 0x0400u, true>(a, cw);
+}
 template <bool INV>
 __device__ __forceinline__ void ff_bfly16(v2f (&a)[16]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ff_r4<INV, false>(a[q], a[4 + q], a[8 + q], a[12 + q]);
-    // a[4c + q] = u[q][c];  u[q][c] *= W16^{q c} (conjugated for the inverse); constants in scalar register pairs
-    const v2f w1 = {0.92387953251128674f, -0.38268343236508977f};
-    const v2f w2 = {0.70710678118654752f, -0.70710678118654752f};
-    const v2f w3 = {0.38268343236508977f, -0.92387953251128674f};
-    const v2f w6 = {-0.70710678118654752f, -0.70710678118654752f};
-    const v2f w9 = {-0.92387953251128674f, 0.38268343236508977f};
-    const v2f t5 = ff_mul_lo_s(a[5], w1), t6 = ff_mul_lo_s(a[6], w2), t7 = ff_mul_lo_s(a[7], w3), t9 = ff_mul_lo_s(a[9], w2);
-    const v2f t11 = ff_mul_lo_s(a[11], w6), t13 = ff_mul_lo_s(a[13], w3), t14 = ff_mul_lo_s(a[14], w6), t15 = ff_mul_lo_s(a[15], w9);
-    a[5] = ff_fma_hi_s<INV>(a[5], w1, t5);
-    a[6] = ff_fma_hi_s<INV>(a[6], w2, t6);
-    a[7] = ff_fma_hi_s<INV>(a[7], w3, t7);
-    a[9] = ff_fma_hi_s<INV>(a[9], w2, t9);
-    a[11] = ff_fma_hi_s<INV>(a[11], w6, t11);
-    a[13] = ff_fma_hi_s<INV>(a[13], w3, t13);
-    a[14] = ff_fma_hi_s<INV>(a[14], w6, t14);
-    a[15] = ff_fma_hi_s<INV>(a[15], w9, t15);
-    // u[2][2] *= W16^4 = -j: folded into the additions of the second stage (ROT2)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (c == 2) ff_r4<INV, true>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
-        else ff_r4<INV, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
-    }
+    v2f none[16];
+    ff_bfly16<INV, false>(a, none);
 }
 
 __device__ __forceinline__ float ff_atan2(float y, float x) {
@@ -359,7 +411,7 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
 // caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
 // at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
 template <bool U8, bool PARTIAL, bool LOADNEXT>
-__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw2)[16], const v2f* const hp,
+__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw3)[16], const v2f* const hp,
                                          const v2f crot, const float theta_sub, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int lim_lo, const int limit,
                                          const F1Edge* edge = nullptr
 #ifdef FF_TRACE
@@ -398,11 +450,10 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = X[x1r + 2 * k];
 #endif
-    // ---- forward pass 2 (over n1), T2, X2
+    // ---- forward pass 2 (over n1), X2
     FF_T(2);
     ff_bfly16<false>(a);
     FF_T(3);
-    ff_twiddle15<false, true>(a, tw2);
     FF_T(4);
 #ifndef FF_NO_LDS
 #pragma unroll
@@ -412,21 +463,22 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #pragma unroll
         for (int n = 0; n < 4; ++n) a[4 * c + n] = X[x2r + 20 * c + n];
 #endif
-    // ---- forward pass 3 (radix 4 over n0), spectrum product, inverse pass 3
+    // ---- T2 folded into forward pass 3 (radix 4 over n0); the spectrum product folded into inverse pass 3; T2*
     FF_T(5);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ff_r4<false, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+    ff_stage<false, false, 1, 0xEEEEu, 0u, false>(a, tw3);
     {
-        v2f z[16], h[16];
+        v2f h[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) h[k] = hp[64 * k];        // (this lane's column of the spectrum image in LDS)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) z[k] = ff_mul_lo(a[k], h[k]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = ff_fma_hi(a[k], h[k], z[k]);
+        ff_stage<true, false, 1, 0xFFFFu, 0u, false>(a, h);
     }
+    {
+        v2f z[16];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ff_r4<true, false>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+        for (int k = 0; k < 16; ++k) if (k & 3) z[k] = ff_mul_lo(a[k], tw3[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k & 3) a[k] = ff_fma_hic(a[k], tw3[k], z[k]);
+    }
     FF_T(6);
 #ifndef FF_NO_LDS
 #pragma unroll
@@ -436,9 +488,8 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = X[x2w + 5 * k];
 #endif
-    // ---- T2*, inverse pass 2
+    // ---- inverse pass 2
     FF_T(7);
-    ff_twiddle15<true, false>(a, tw2);
     ff_bfly16<true>(a);
     FF_T(8);
 #ifndef FF_NO_LDS
@@ -447,10 +498,9 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = X[x1w + F1_S1 * k];
 #endif
-    // ---- T1*, inverse pass 1: a[FF_P(r)] = w[n0 + 64 r + t]
+    // ---- T1* folded into inverse pass 1: a[FF_P(r)] = w[n0 + 64 r + t]
     FF_T(9);
-    ff_twiddle15<true, false>(a, tw1);
-    ff_bfly16<true>(a);
+    ff_bfly16<true, true>(a, tw1);
     FF_T(10);
     // ---- back to two consecutive outputs per lane: B[r] = w[128 r + 2 lane], A[r] = the one after it (row pairs 1..7;
     // of pair 1 only lane 63's second value is used, as the left-hand neighbour of the block's first output)
@@ -478,8 +528,9 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
         v2f pb[8];
 #pragma unroll
         for (int r = 2; r < 8; ++r) {
-            const int ox = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].x), 0x13C, 0xf, 0xf, false);
-            const int oy = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].y), 0x13C, 0xf, 0xf, false);
+            // (every lane of a wave_ror has a source lane: bound_ctrl set, so that no `old` value has to be materialised)
+            const int ox = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].x), 0x13C, 0xf, 0xf, true);
+            const int oy = __builtin_amdgcn_update_dpp(0, __float_as_int(A[r - 1].y), 0x13C, 0xf, 0xf, true);
             pb[r].x = __int_as_float(__builtin_amdgcn_update_dpp(ox, __float_as_int(A[r].x), 0x138, 0xf, 0xf, false));
             pb[r].y = __int_as_float(__builtin_amdgcn_update_dpp(oy, __float_as_int(A[r].y), 0x138, 0xf, 0xf, false));
         }
@@ -523,12 +574,15 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
     // (its own copy of the twiddles: arrays handed to a function that is not inlined would live in scratch memory for
     // the whole kernel)
     const int tcol = 2 * (lane & 31) + (lane >> 5);
-    v2f tw1[16], tw2[16];
+    v2f tw1[16], tw3[16];
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
-        const float2 u = T.tw1[tcol * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
+        const float2 u = T.tw1[tcol * 16 + k];
         tw1[k] = (v2f){u.x, u.y};
-        tw2[k] = (v2f){w.x, w.y};
+        if (k & 3) {                                               // pass-3 layout: register 4 c + n0 of lane j holds k1 = 4 c + j
+            const float2 w = T.tw2[(k & 3) * 16 + (k & 12) + (lane & 3)];
+            tw3[k] = (v2f){w.x, w.y};
+        }
     }
     const v2f crot = {T.crot.x, T.crot.y};
     const int64_t p0 = (int64_t)F1_ADV * q;
@@ -560,7 +614,7 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
     }
     const int64_t lo64 = (int64_t)P.s - p0, hi64 = P.L - p0;
     const int lim_lo = lo64 > 0 ? (int)lo64 : 0, lim_hi = hi64 < F1_ADV ? (int)hi64 : F1_ADV;
-    f1_block<U8, true, false>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, &e);
+    f1_block<U8, true, false>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, &e);
     if (q == nblk - 1 && P.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < P.K - 1; i += 64) {
@@ -606,12 +660,15 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
     if (q_begin == 0) f1_edge_block<U8>(P, T, 0, nblk, X, hp, lane);
     const int tcol = 2 * (lane & 31) + (lane >> 5);           // the column this lane transforms in passes 1 and 6
-    v2f tw1[16], tw2[16];
+    v2f tw1[16], tw3[16];
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
-        const float2 u = T.tw1[tcol * 16 + k], w = T.tw2[(lane & 3) * 16 + k];
+        const float2 u = T.tw1[tcol * 16 + k];
         tw1[k] = (v2f){u.x, u.y};
-        tw2[k] = (v2f){w.x, w.y};
+        if (k & 3) {                                               // pass-3 layout: register 4 c + n0 of lane j holds k1 = 4 c + j
+            const float2 w = T.tw2[(k & 3) * 16 + (k & 12) + (lane & 3)];
+            tw3[k] = (v2f){w.x, w.y};
+        }
     }
     const v2f crot = {T.crot.x, T.crot.y};
     float* const outp = reinterpret_cast<float*>(P.out);
@@ -632,9 +689,9 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
             const int64_t p0 = (int64_t)F1_ADV * q;
             const int64_t n0_next = (q + 1 < q_hi) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
 #ifdef FF_TRACE
-            f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, nullptr, tr);
+            f1_block<U8, false, true>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, nullptr, tr);
 #else
-            f1_block<U8, false, true>(a, keep, X, tw1, tw2, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV);
+            f1_block<U8, false, true>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV);
 #endif
         }
 #ifdef FF_TRACE
