@@ -31,7 +31,8 @@ for ntaps in [int(v) for v in os.environ.get("NTAPS", "255").split(",")]:
                                            _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_U8_INPUT if U8 else 0)), "create")
             got = C.c_int64(0)
             def step():
-                lib.dd_chain_reset(h, stream)
+                if not os.environ.get("NORESET"):          # NORESET=1: the stream continues (carried state: the output is not shifted by one)
+                    lib.dd_chain_reset(h, stream)
                 _hip.check(lib.dd_chain_process(h, x.data_ptr(), out.data_ptr(), n, C.byref(got), stream), "process")
             for _ in range(reps):
                 step()
