@@ -195,7 +195,7 @@ extern "C" int dd_rpoly_create(dd_rpoly** h, const double* taps_host, int ntaps,
     if (e == hipSuccess) e = hipMalloc((void**)&r->hist[0], sizeof(double) * (r->q > 0 ? r->q : 1));
     if (e == hipSuccess) e = hipMalloc((void**)&r->hist[1], sizeof(double) * (r->q > 0 ? r->q : 1));
     if (e != hipSuccess) {
-        hipFree(r->taps); hipFree(r->hist[0]); hipFree(r->hist[1]);
+        (void)hipFree(r->taps); (void)hipFree(r->hist[0]); (void)hipFree(r->hist[1]);
         delete r;
         dd_set_error("dd_rpoly_create: %s", hipGetErrorString(e));
         return e == hipErrorNoDevice ? DD_ERR_NODEVICE : DD_ERR_HIP;
@@ -204,7 +204,7 @@ extern "C" int dd_rpoly_create(dd_rpoly** h, const double* taps_host, int ntaps,
     return DD_OK;
 }
 extern "C" int dd_rpoly_destroy(dd_rpoly* r) {
-    if (r) { hipFree(r->taps); hipFree(r->hist[0]); hipFree(r->hist[1]); delete r; }
+    if (r) { (void)hipFree(r->taps); (void)hipFree(r->hist[0]); (void)hipFree(r->hist[1]); delete r; }
     return DD_OK;
 }
 extern "C" int dd_rpoly_reset(dd_rpoly* r) {
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(256) k_cand_scan(unsigned int* __restrict__ cn
         const unsigned int v = i < tiles ? cnt[i] : 0u;
         unsigned int incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((threadIdx.x & 63) >= d) incl += u; }
+        for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += u; }
         if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = incl;
         __syncthreads();
         unsigned int off = carry;
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(256) k_cand_write(const double* __restrict__ c
     for (int j = 0; j < 8; ++j) { f[j] = i0 + j < n && cor[i0 + j] > thr; c += f[j] ? 1u : 0u; }
     unsigned int incl = c;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((threadIdx.x & 63) >= d) incl += u; }
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += u; }
     if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = incl;
     __syncthreads();
     unsigned int o = off[blockIdx.x] + incl - c;
@@ -1019,14 +1019,14 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
     DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * nb));
     hipfftHandle pm;
     int rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
-    if (rc != DD_OK) { hipFree(buf); hipFree(HH); return rc; }
+    if (rc != DD_OK) { (void)hipFree(buf); (void)hipFree(HH); return rc; }
     hipError_t e0 = hipMemcpyAsync(buf, host.data(), sizeof(double) * M, hipMemcpyHostToDevice, s);
     hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
     hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
     hipError_t e = hipStreamSynchronize(s);
-    hipFree(buf);
+    (void)hipFree(buf);
     if (e0 != hipSuccess || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
-        hipFree(HH);
+        (void)hipFree(HH);
         dd_set_error("Hilbert kernel spectrum: hipfft %d, hip %s", (int)r2, hipGetErrorString(e0 != hipSuccess ? e0 : e));
         return DD_ERR_HIP;
     }

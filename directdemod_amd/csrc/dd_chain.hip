@@ -785,15 +785,15 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
 extern "C" int dd_fir_destroy(dd_fir* f) {
     if (!f) return DD_OK;
     if (f->mfma) dd_mfma_destroy(f->mfma);
-    hipFree(f->multi);
-    hipFree(f->taps_rev);
-    hipFree(f->tail[0]);
-    hipFree(f->tail[1]);
-    hipFree(f->tail_const[0]);
-    hipFree(f->tail_const[1]);
-    hipFree(f->taps_dev);
-    hipFree(f->hist[0]);
-    hipFree(f->hist[1]);
+    (void)hipFree(f->multi);
+    (void)hipFree(f->taps_rev);
+    (void)hipFree(f->tail[0]);
+    (void)hipFree(f->tail[1]);
+    (void)hipFree(f->tail_const[0]);
+    (void)hipFree(f->tail_const[1]);
+    (void)hipFree(f->taps_dev);
+    (void)hipFree(f->hist[0]);
+    (void)hipFree(f->hist[1]);
     delete f;
     return DD_OK;
 }
@@ -840,7 +840,7 @@ extern "C" int dd_fm_create(dd_fm** h) {
 }
 extern "C" int dd_fm_destroy(dd_fm* h) {
     if (h) {
-        hipFree(h->last);
+        (void)hipFree(h->last);
         delete h;
     }
     return DD_OK;
@@ -1150,7 +1150,7 @@ extern "C" int dd_chain_destroy(dd_chain* c) {
     if (!c) return DD_OK;
     dd_fir_destroy(c->fir);
     dd_fm_destroy(c->fm);
-    hipFree(c->scratch);
+    (void)hipFree(c->scratch);
     delete c;
     return DD_OK;
 }
@@ -1264,7 +1264,7 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     const size_t total = o_last + al(sizeof(float2) * nchunks);
     if (total > fir->multi_bytes) {
         DD_HIP_CHECK(hipStreamSynchronize(s));
-        hipFree(fir->multi);
+        (void)hipFree(fir->multi);
         fir->multi = nullptr;
         fir->multi_bytes = 0;
         DD_HIP_CHECK(hipMalloc((void**)&fir->multi, total));
@@ -1415,7 +1415,7 @@ extern "C" int dd_chain_prime(dd_chain* c, const void* halo_in, int64_t n_halo, 
     const size_t ob = (size_t)(no > 0 ? no : 1) * ((c->flags & DD_CHAIN_FM) ? sizeof(float) : sizeof(float2));
     if (ob > c->scratch_bytes) {
         DD_HIP_CHECK(hipStreamSynchronize(s));
-        hipFree(c->scratch);
+        (void)hipFree(c->scratch);
         c->scratch = nullptr;
         c->scratch_bytes = 0;
         DD_HIP_CHECK(hipMalloc(&c->scratch, ob));

@@ -129,7 +129,7 @@ static int filtfilt_impl(const double* taps_host, int K, const T* in, T* out, in
     if (rcs != DD_OK) return rcs;
     double* taps = reinterpret_cast<double*>(base);
     T* y1 = reinterpret_cast<T*>(base + tb);
-    hipMemcpyAsync(taps, taps_host, sizeof(double) * K, hipMemcpyHostToDevice, s);
+    DD_HIP_CHECK(hipMemcpyAsync(taps, taps_host, sizeof(double) * K, hipMemcpyHostToDevice, s));
     if constexpr (sizeof(T) == 8) {
         if (dd_ff_tiled_ok(K, sizeof(T))) {
             dd_filtfilt_launch<T>(in, n, y1, out, n, n, K, taps, 1, s);
@@ -262,7 +262,7 @@ extern "C" int dd_iir_create(dd_iir** h, const double* b, const double* a, int n
     }
     int rc = iir_set_state(f, nullptr);
     if (rc != DD_OK) {
-        hipFree(f->state);
+        (void)hipFree(f->state);
         delete f;
         return rc;
     }
@@ -272,10 +272,10 @@ extern "C" int dd_iir_create(dd_iir** h, const double* b, const double* a, int n
 
 extern "C" int dd_iir_destroy(dd_iir* h) {
     if (h) {
-        hipFree(h->state);
-        if (h->mats) hipFree(h->mats);
-        if (h->mats_long) hipFree(h->mats_long);
-        if (h->scratch) hipFree(h->scratch);
+        (void)hipFree(h->state);
+        if (h->mats) (void)hipFree(h->mats);
+        if (h->mats_long) (void)hipFree(h->mats_long);
+        if (h->scratch) (void)hipFree(h->scratch);
         delete h;
     }
     return DD_OK;
@@ -753,7 +753,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     case SS: {                                                                                                       \
         static DDOncePerDevice attr_set;                                                                             \
         if (attr_set.need()) {                                                                                       \
-            hipFuncSetAttribute((const void*)k_iir_blocks_t<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); \
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_iir_blocks_t<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t)); \
             attr_set.mark();                                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL((k_iir_blocks_t<SS, WR>), dim3(gbt), dim3(256), lds_t, s, in, out, n, ncomp, C, blk, nb, h->state, SAVE, lb); \
@@ -775,7 +775,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     case SS: {                                                                                                       \
         static DDOncePerDevice attr_w;                                                                               \
         if (attr_w.need()) {                                                                                         \
-            hipFuncSetAttribute((const void*)k_iir_blocks_w<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_iir_blocks_w<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
             attr_w.mark();                                                                                           \
         }                                                                                                            \
         hipLaunchKernelGGL((k_iir_blocks_w<SS, WR>), dim3(gbw), dim3(64), lds_w, s, reinterpret_cast<const double2*>(in), \
@@ -863,7 +863,7 @@ extern "C" int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int
     DD_HIP_CHECK(hipMalloc((void**)&ext, sizeof(double) * N * nc));
     hipError_t e = hipMalloc((void**)&y1, sizeof(double) * N * nc);
     if (e != hipSuccess) {
-        hipFree(ext);
+        (void)hipFree(ext);
         dd_set_error("hipMalloc: %s", hipGetErrorString(e));
         return DD_ERR_NOMEM;
     }
@@ -877,8 +877,8 @@ extern "C" int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int
     hipError_t le = hipGetLastError();
     hipError_t ce = hipMemcpyAsync(out, ext + (int64_t)edge * nc, sizeof(double) * n * nc, hipMemcpyDeviceToDevice, s);
     hipError_t se = hipStreamSynchronize(s);
-    hipFree(ext);
-    hipFree(y1);
+    (void)hipFree(ext);
+    (void)hipFree(y1);
     DD_HIP_CHECK(le);
     DD_HIP_CHECK(ce);
     DD_HIP_CHECK(se);

@@ -728,7 +728,6 @@ __device__ __forceinline__ void dd_ws_vphase(const DDChainParams& P, const DDMfm
 
 template <int NKS, bool U8, bool CX, bool ST>
 __device__ __forceinline__ void dd_ws_vector(const DDChainParams& P, const DDMfmaTaps& taps, char* smem, int t_begin, int t_end, int nph) {
-    using G = MfmaGeom<NKS>;
     using W = WsGeom<NKS>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int vt = tid - 64 * WS_MWAVES, vw = vt >> 6;
@@ -992,7 +991,7 @@ int dd_mfma_create(void** st, const double* taps, int K) {
     hipError_t e = hipMalloc((void**)&s->frag, frag.size() * sizeof(_Float16));
     if (e == hipSuccess) e = hipMemcpy(s->frag, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (s->frag) hipFree(s->frag);
+        if (s->frag) (void)hipFree(s->frag);
         delete s;
         dd_set_error("dd_mfma_create: %s", hipGetErrorString(e));
         return DD_ERR_HIP;
@@ -1005,7 +1004,7 @@ void dd_mfma_destroy(void* st) {
     DDMfmaState* s = reinterpret_cast<DDMfmaState*>(st);
     if (!s) return;
     if (s->fft) dd_fft_destroy(s->fft);
-    hipFree(s->frag);
+    (void)hipFree(s->frag);
     delete s;
 }
 

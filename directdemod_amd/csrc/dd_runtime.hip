@@ -277,7 +277,7 @@ const float2* dd_nco_table(void) {
         if (hipMalloc((void**)&p, sizeof(float2) * DD_NCO_TSIZE) != hipSuccess) return nullptr;
         hipLaunchKernelGGL(k_fill_nco_table, dim3(DD_NCO_TSIZE / 256), dim3(256), 0, 0, p);
         if (hipDeviceSynchronize() != hipSuccess) {
-            hipFree(p);
+            (void)hipFree(p);
             return nullptr;
         }
         g_tbl[dev] = p;
