@@ -213,7 +213,7 @@ def test_c3_chain_golden(dd, golden_dir):
     assert np.max(np.abs(out.signal - g["chain_c3"])) < 2e-5
 
 
-def _class_chunk_loop(dd, rate, L, chunk, get, taps, M, f_off, fm_on, strict_rate, out_rate):
+def _class_chunk_loop(dd, rate, L, chunk, get, taps, M, f_off, fm_on, strict_rate, out_rate, one_by_one=False):
     """the reference's chunk loop (decode scripts: chunker -> commSignal(...).offsetFreq.filter.bwLim.funcApply.bwLim -> extend)"""
     class _Src:
         length = L
@@ -231,6 +231,8 @@ def _class_chunk_loop(dd, rate, L, chunk, get, taps, M, f_off, fm_on, strict_rat
         if strict_rate:
             s.bwLim(strict_rate, True)
         out.extend(s)
+        if one_by_one:
+            dd.comm.flush_all()                            # every chunk executes on its own: the chunk-by-chunk route on the same slices
     return out, filt
 
 
@@ -315,6 +317,56 @@ def test_class_chunk_loop_deferred_extend_keeps_the_reference_order_of_events(dd
     ref, rl = loop(lambda a, b: x[a:b], False)
     assert got.length == ref.length and gl == rl
     assert np.array_equal(got.signal, ref.signal)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_class_chunk_loop_random_shapes_three_ways(dd, seed):
+    """seeded random chunk loops (length, chunk size, taps, decimation, NCO on/off, FM on/off, strict resample on/off, u8 or
+    complex64): the loop over slices of the resident recording run as one chunk-list launch == the same slices chunk by chunk,
+    bit for bit; private copies of the chunks agree to rounding (a copy is aligned where a slice at an odd sample offset is not,
+    which selects between the persistent and the plain decimating kernel: their NCO phasors round differently, found by seed 2);
+    all agree with the oracle's chunk loop (float64) to the float32 chain's tolerance"""
+    rng = np.random.default_rng(1000 + seed)
+    rate = int(rng.choice([2048000, 2400000, 10000000]))
+    M = int(rng.choice([2, 3, 8, 34, 50, 100]))
+    K = int(rng.choice([2, 15, 64, 127, 151, 255, 300]))
+    L = int(rng.integers(40000, 900000))
+    chunk = int(rng.integers(max(3 * K, 5000), max(3 * K, 5000) + L // 2))
+    use_nco = bool(rng.integers(0, 2))
+    fm_on = bool(rng.integers(0, 4) > 0)
+    strict = int(rng.choice([0, 11025, 40960])) if fm_on and rate // M > 41000 else 0
+    u8 = bool(rng.integers(0, 2))
+    f_off = float(rng.choice([25000.0, -30000.0, 250000.0])) if use_nco else None
+    raw = O.synth_iq_fm(L, rate, 50 + seed, f_carrier=f_off or 10000.0, f_mod=1e3, dev=5.0)
+    taps = O.firwin_lowpass(K, 0.4 / M) if K > 2 else np.array([0.5, 0.5])
+    x = O.grid_c64(raw)
+    if u8:
+        base = dd.hip.DevArray.from_host(np.ascontiguousarray(raw).reshape(-1), dtype=np.uint8)
+        res = dd.hip.DevArray(L, dd.hip.IQ8, ptr=base.ptr, base=base)
+        private = lambda a, b: _own(dd, res.view(a, b - a))
+    else:
+        res = dd.hip.DevArray.from_host(x, dtype=np.complex64)
+        private = lambda a, b: x[a:b]
+    out_rate = strict if strict else rate // M
+    got, f1 = _class_chunk_loop(dd, rate, L, chunk, lambda a, b: res.view(a, b - a), taps, M, f_off, fm_on, strict, out_rate)
+    ref, f2 = _class_chunk_loop(dd, rate, L, chunk, lambda a, b: res.view(a, b - a), taps, M, f_off, fm_on, strict, out_rate, one_by_one=True)
+    prv, f3 = _class_chunk_loop(dd, rate, L, chunk, private, taps, M, f_off, fm_on, strict, out_rate)
+    g, r, pv = got.signal, ref.signal, prv.signal
+    nchunks = len(O.chunk_list(L, chunk))
+    case = dict(seed=seed, rate=rate, M=M, K=K, L=L, chunk=chunk, nco=f_off, fm=fm_on, strict=strict, u8=u8, nchunks=nchunks)
+    if nchunks >= 2:
+        assert f1._last_kernel() == dd.hip.DD_KERNEL_DECIM_MULTI and f2._last_kernel() != dd.hip.DD_KERNEL_DECIM_MULTI, case
+    assert got.length == ref.length == len(g) and g.dtype == r.dtype and np.array_equal(g, r), case
+    assert len(pv) == len(g) and np.max(np.abs(pv - g)) < (1e-5 if fm_on else 1e-4 * np.max(np.abs(g))), case
+    if fm_on:
+        want, want_rate = O.audio_chain(lambda a, b: x[a:b], L, rate, f_off or 0.0, taps, rate // M, strict or None, bool(strict),
+                                        chunk_size=chunk, use_nco=use_nco)
+        assert want_rate == got.sampRate and len(want) == len(g), case
+        if strict:
+            assert np.max(np.abs(g - want)) < 5e-5, case           # the resample spreads the discriminator's float32 error
+        else:
+            d = np.abs(np.angle(np.exp(1j * (g - want))))
+            assert np.max(d) < 2e-4 and np.median(d) < 5e-6, (case, float(np.max(d)))
 
 
 def test_source_readers(dd, tmp_path):
