@@ -312,6 +312,59 @@ def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, monkeypatch):
     fm_check(out.signal, ref, np.concatenate(mags))
 
 
+@pytest.mark.parametrize("kern", ["fft1k", "ab"])
+@pytest.mark.parametrize("seed", range(8))
+def test_m1_fm_chain_random_taps_and_cuts(dd, kern, seed, monkeypatch):
+    """both M = 1 FM kernels on seeded random cases: taps that are no window (a low-pass design with random perturbations and sign
+    changes, random length), random chunk cuts (lengths 1 .. 60 000, state carried), a random NCO frequency (either sign, up to
+    fs/2) or none, raw u8 or complex64 chunks; against the float64 oracle chunk by chunk"""
+    monkeypatch.setenv("DD_MFMA_KERNEL", kern)
+    rng = np.random.default_rng(7000 + seed)
+    fs = int(rng.choice([2400000, 2048000, 10000000]))
+    K = int(rng.integers(2, 257)) if kern == "fft1k" else int(rng.integers(16, 288))
+    f_off = float(rng.uniform(-0.5, 0.5) * fs) if rng.integers(0, 4) else 0.0
+    u8 = bool(rng.integers(0, 2))
+    taps = O.firwin_lowpass(K, float(rng.uniform(0.02, 0.4))) if K > 3 else rng.standard_normal(K)
+    taps = taps * (1.0 + 0.3 * rng.standard_normal(K)) * float(rng.choice([1.0, -1.0, 37.0]))
+    ncuts = int(rng.integers(3, 9))
+    lens = np.concatenate([rng.integers(1, 60000, size=ncuts), [1, int(rng.integers(1, 3 * K + 3)), 768 * int(rng.integers(1, 40))]])
+    rng.shuffle(lens)
+    cuts = np.concatenate([[0], np.cumsum(lens)])
+    L = int(cuts[-1])
+    raw = O.synth_iq_fm(L, fs, 300 + seed, f_carrier=f_off if abs(f_off) > 1 else 5000.0, f_mod=900.0, dev=3.0)
+    x = O.grid_c64(raw)
+    flt = dd.filters.filter(taps, 1, storeState=True)
+    fm = dd.demod_fm.demod_fm()
+    ck = dd.chunker.chunker(_Src(L))
+    out = dd.comm.commSignal(fs)
+    fo = O.FilterState(taps)
+    last, idx, refs, mags, kernels = None, 0, [], [], set()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        a, b = int(a), int(b)
+        chunk = dd.hip.DevArray.from_host(np.ascontiguousarray(raw[a:b]).reshape(-1).view(dd.hip.IQ8)) if u8 else x[a:b]
+        s = dd.comm.commSignal(fs, chunk, ck)
+        if f_off:
+            s.offsetFreq(f_off)
+        s.filter(flt).funcApply(fm.demod)
+        out.extend(s)
+        _ = out.length
+        dd.comm.flush_all()
+        kernels.add(flt._last_kernel())
+        y = fo.applyOn(O.nco(x[a:b], f_off, fs, idx) if f_off else x[a:b])
+        idx += b - a
+        prv = last
+        r, last = O.fm_demod(y, last)
+        refs.append(r)
+        yy = y if prv is None else np.concatenate([[prv], y])
+        mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
+    ref = np.concatenate(refs)
+    case = dict(kern=kern, seed=seed, fs=fs, K=K, f_off=f_off, u8=u8, L=L, cuts=lens.tolist())
+    assert out.length == len(ref) == L - 1, case
+    if kern == "fft1k":
+        assert dd.hip.DD_KERNEL_FFT_OS in kernels, (case, kernels)
+    fm_check(out.signal, ref, np.concatenate(mags))
+
+
 def test_fused_equals_unfused_stages(dd):
     """The fused kernel and the stage-by-stage kernels are the same arithmetic."""
     L = 30000
