@@ -24,8 +24,8 @@ Timing.  `value` and `ms_per_step` are wall clock around the K timed steps (barr
 device sync on both sides, max over ranks).  `roofline.kernel_ms` is HIP-event time on the
 launch stream around the same K launches / K (one kernel launch per step).  20 steps are
 only ~4 ms of device time, so the same step is also run for >= 100 ms right after the
-timed region (`extra.steady_check`); a cold run (first 20 steps of the process, before the
-clock pre-roll) is reported in `extra.cold_ms_per_step`.
+timed region (`extra.steady_check`); the process's first step (one-off costs) and the 19 after it,
+before the pre-roll, are reported in `extra.first_step_ms` / `extra.cold_ms_per_step`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -622,15 +622,20 @@ def run_rank(args):
             dist.barrier()
         eng.sync()
 
-    # cold figure: the first steps this process runs, before any pre-roll (HIP events on the launch stream)
+    # cold figures: the first step this process runs (one-off costs: code object load, the taps' spectrum, tables) and the 19
+    # steps after it, before any pre-roll (HIP events on the launch stream).  tools/debug/cold_steps.py shows the profile: launch 1
+    # ~8 ms, launches 2-6 at the steady time, then 15-35 % slower for ~80 launches while the power controller settles
     cold_steps = 20
-    c0, c1 = eng.events()
+    f0, c0, c1 = eng.events() + (eng.events()[0],)
+    f0.record()
+    step()
     c0.record()
-    for _ in range(cold_steps):
+    for _ in range(cold_steps - 1):
         step()
     c1.record()
     eng.sync()
-    cold_ms = c0.elapsed_time(c1) / cold_steps
+    first_ms = f0.elapsed_time(c0)
+    cold_ms = c0.elapsed_time(c1) / (cold_steps - 1)
 
     ramp_steps = 0
     t_ramp = time.perf_counter()
@@ -665,14 +670,14 @@ def run_rank(args):
     barrier()
     long_ms = l0.elapsed_time(l1) / long_steps
 
-    tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms, first_ms], dtype=torch.float64, device=cdev)
     per_rank = None
     if world > 1:
         allk = [torch.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(allk, tmax)
         per_rank = [round(float(t[1]), 4) for t in allk]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max, kern_ms_max, long_ms_max, cold_ms_max = (float(v) for v in tmax)
+    dt_max, kern_ms_max, long_ms_max, cold_ms_max, first_ms_max = (float(v) for v in tmax)
 
     extra = {}
     if world > 1:
@@ -708,7 +713,8 @@ def run_rank(args):
         chk = eng.out[eng.first + 1000:eng.first + 1000 + 4096].double().cpu().numpy()
         extra["output_rms_rad"] = float(np.sqrt(np.mean(chk ** 2)))
     extra["clock_preroll"] = {"ms": args.ramp_ms, "steps": ramp_steps}
-    extra["cold_ms_per_step"] = round(cold_ms_max, 4)
+    extra["first_step_ms"] = round(first_ms_max, 4)             # one-off: code object load, tap spectrum, tables
+    extra["cold_ms_per_step"] = round(cold_ms_max, 4)          # steps 2..20 of the process
     extra["steady_check"] = {"steps": long_steps, "kernel_ms": round(long_ms_max, 4)}
     if per_rank is not None:
         extra["kernel_ms_per_rank"] = per_rank
@@ -773,7 +779,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ramp-ms", type=float, default=250.0,
                     help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
-                         "chip holds under sustained load (a cold MI355X runs its first ~10 ms of kernels 15-20 %% slower)")
+                         "chip holds under sustained load (the board's power controller takes ~20 ms to settle on it; "
+                         "in between the kernel runs 15-35 %% slower)")
     ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
     ap.add_argument("--gather", action="store_true", help="(default with more than one rank; kept for old command lines)")
     ap.add_argument("--no-gather", action="store_true", help="more than one rank: skip the RCCL all_gather leg of the decoded output")
