@@ -325,7 +325,8 @@ class commSignal:
                 offset = self.__chunker.get(constants.CHUNK_BWLIM + uniq, 0)
                 nextOff = (jumpIndex - (self.length - offset) % jumpIndex) % jumpIndex
                 self.__chunker.set(constants.CHUNK_BWLIM + uniq, nextOff)
-            self._record(("decim", jumpIndex, int(offset)))
+            if jumpIndex != 1 or offset != 0:                  # x[0::1] is x: nothing to run (and a chunk list stays a chunk list)
+                self._record(("decim", jumpIndex, int(offset)))
             self.__sampRate = int(self.sampRate / jumpIndex)
             self.__len = len(range(offset, self.__len, jumpIndex))
         return self
