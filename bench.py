@@ -426,7 +426,7 @@ def side_c3_end_to_end(eng, steps=10):
     """config 3 end to end (decode_fm.py:54-70): 2^26 samples @10 MS/s in sixteen chunks of 2^22, each chunk offsetFreq
     250 kHz + remez127 + bwLim /50 + FM (state carried) and then bwLim(11025, strict) = scipy.signal.resample of ITS outputs
     (comm.py:110-116: 83886 or 83887 samples -> 4624).  Two calls: dd_chain_process_chunks (one launch) and
-    dd_resample_fft_chunks (batched plans per length group)."""
+    dd_resample_fft_chunks (one chirp-z batch: these lengths have large prime factors)."""
     import scipy.signal as ss
     import torch
     hip, lib = eng._hip, eng.lib
@@ -467,7 +467,7 @@ def side_c3_end_to_end(eng, steps=10):
     lib.dd_chain_destroy(h)
     return {"config": "C3 end to end (front end + FFT resample to 11 025 S/s), 2^26 samples @10 MS/s in 16 chunks of 2^22",
             "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1), "audio_samples": int(tot), "chunk_output_lengths": state["args"][5],
-            "how": "dd_chain_process_chunks + dd_resample_fft_chunks: 1 chain launch, batched hipFFT plans per chunk-length group"}
+            "how": "dd_chain_process_chunks + dd_resample_fft_chunks: 1 chain launch; the 16 resamples as ONE chirp-z batch for the 2313 bins kept (3.2^15-point convolutions, chunk lengths mixed)"}
 
 
 def side_c3_through_classes(eng, steps=10):

@@ -249,10 +249,209 @@ extern "C" int dd_rpoly_process(dd_rpoly* r, const double* in, int64_t n, int fl
 
 // The FFT resampler's intermediates come from the per-stream scratch (DDScratchLock): the call neither allocates, frees nor synchronises (in the
 // C3 chunk loop -- one call per 2^22-sample chunk -- those were 88 of the 140 us a chunk cost the host).
+// ---- R2 when the chunk length has a large prime factor (C3: 83 886 = 2.3.11.31.41, 83 887 = 149.563): the library's length-n
+// transform is then Bluestein's chirp-z at >= 2n - 1 points (175 616 for these) in some 26 launches.  Downsampling needs only
+// the K = num/2 + 1 lowest bins, and a chirp-z for K bins needs a cyclic convolution of only n + K - 1 points:
+//   X[k] = w[k] . sum_m (x[m] w[m]) conj(w[k - m]),   w[m] = exp(-i pi m^2 / n)   (m^2 reduced mod 2n in integers: exact phase)
+// = pre-multiply | forward transform of length L (7-smooth, >= n + K - 1) | times the chirp's spectrum | inverse | post-multiply,
+// and the chirp tables depend on (n, K) only, so chunks of DIFFERENT lengths share one batch (the chunk loop of config 3
+// alternates 83 886 / 83 887): five launches + two library transforms for the whole chunk list.
+struct DDCztKey {
+    int dev;
+    hipStream_t s;
+    int64_t n, K, L;
+    bool operator<(const DDCztKey& o) const {
+        if (dev != o.dev) return dev < o.dev;
+        if (s != o.s) return s < o.s;
+        if (n != o.n) return n < o.n;
+        if (K != o.K) return K < o.K;
+        return L < o.L;
+    }
+};
+struct DDCztTab { double2* w; double2* bspec; };
+static std::mutex g_czt_mu;
+static std::map<DDCztKey, DDCztTab> g_czt;
+
+__global__ void __launch_bounds__(256) k_czt_tables(double2* __restrict__ w, double2* __restrict__ bt, int64_t n, int64_t K, int64_t L) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int64_t r = (i * i) % (2 * n);
+        double sn, cs;
+        sincospi((double)r / (double)n, &sn, &cs);
+        w[i] = make_double2(cs, -sn);
+    }
+    if (i < L) {
+        // conj(w[m]) at m = i (0 <= m < K) and at m = i - L (-(n-1) <= m < 0); zero in between (L >= n + K - 1)
+        const int64_t m = i < K ? i : (i > L - n ? L - i : -1);
+        double2 v = make_double2(0.0, 0.0);
+        if (m >= 0) {
+            const int64_t r = (m * m) % (2 * n);
+            double sn, cs;
+            sincospi((double)r / (double)n, &sn, &cs);
+            v = make_double2(cs, sn);
+        }
+        bt[i] = v;
+    }
+}
+
+static int64_t largest_prime_factor(int64_t n) {
+    int64_t best = 1;
+    for (int64_t p = 2; p * p <= n; ++p)
+        while (n % p == 0) { best = p; n /= p; }
+    return n > 1 ? n : best;
+}
+// the chirp-z route pays when the library would run Bluestein itself (radices up to 17 are native) and few bins are kept
+static bool czt_wanted(int64_t n, int64_t num) {
+    static const char* env = getenv("DD_RESAMPLE_CZT");    // tools / tests: 0 = never, 1 = whenever downsampling
+    if (env && atoi(env) == 0) return false;
+    if (!(num < n && n >= 256)) return false;
+    if (env && atoi(env) == 1) return true;
+    return largest_prime_factor(n) > 17 && 4 * (num / 2 + 1) <= n;
+}
+
+static int czt_tables(int64_t n, int64_t K, int64_t L, hipStream_t s, DDCztTab* out) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_czt_mu);
+    const DDCztKey key{dev, s, n, K, L};
+    auto it = g_czt.find(key);
+    if (it == g_czt.end()) {
+        if (g_czt.size() >= 64) {                          // (a chunk loop has one or two lengths; this is a leak guard)
+            DD_HIP_CHECK(hipDeviceSynchronize());
+            for (auto& e : g_czt) { (void)hipFree(e.second.w); (void)hipFree(e.second.bspec); }
+            g_czt.clear();
+        }
+        DDCztTab t{nullptr, nullptr};
+        DD_HIP_CHECK(hipMalloc((void**)&t.w, sizeof(double2) * (size_t)n));
+        hipError_t e = hipMalloc((void**)&t.bspec, sizeof(double2) * (size_t)L);
+        if (e != hipSuccess) { (void)hipFree(t.w); DD_HIP_CHECK(e); }
+        hipfftHandle pl;
+        int rc = get_plan(&pl, HIPFFT_Z2Z, L, 1, s);
+        if (rc != DD_OK) { (void)hipFree(t.w); (void)hipFree(t.bspec); return rc; }
+        hipLaunchKernelGGL(k_czt_tables, dim3(grid1(n > L ? n : L)), dim3(256), 0, s, t.w, t.bspec, n, K, L);
+        if (hipfftExecZ2Z(pl, (hipfftDoubleComplex*)t.bspec, (hipfftDoubleComplex*)t.bspec, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+            (void)hipFree(t.w); (void)hipFree(t.bspec);
+            dd_set_error("hipfft exec failed (chirp spectrum)");
+            return DD_ERR_HIP;
+        }
+        it = g_czt.emplace(key, t).first;
+    }
+    *out = it->second;
+    return DD_OK;
+}
+
+struct DDCztJob {
+    int64_t in_off, out_off, n;
+    const double2* w;
+    const double2* bspec;
+    double scale;                                          // 1 / n
+};
+#define DD_CZT_MAXB 16
+struct DDCztJobs { DDCztJob j[DD_CZT_MAXB]; };             // passed by value: no upload per call
+template <typename T>
+__global__ void __launch_bounds__(256) k_czt_pre(const T* __restrict__ in, const DDCztJobs jobs, int64_t L, double2* __restrict__ A) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= L) return;
+    const DDCztJob& j = jobs.j[blockIdx.y];
+    double2 v = make_double2(0.0, 0.0);
+    if (m < j.n) {
+        const double x = (double)in[j.in_off + m];
+        const double2 w = j.w[m];
+        v = make_double2(x * w.x, x * w.y);
+    }
+    A[(int64_t)blockIdx.y * L + m] = v;
+}
+__global__ void __launch_bounds__(256) k_czt_mul(double2* __restrict__ A, const DDCztJobs jobs, int64_t L) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= L) return;
+    const double2 b = jobs.j[blockIdx.y].bspec[m];
+    double2* p = A + (int64_t)blockIdx.y * L + m;
+    const double2 a = *p;
+    *p = make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// bins 0 .. num/2 of the length-n transform -> the half spectrum the length-num inverse takes (scipy.signal.resample, real
+// input, downsampling: the kept Nyquist bin of an even num collects both halves; same rule as k_rs_bins_b)
+__global__ void __launch_bounds__(256) k_czt_bins(const double2* __restrict__ A, const DDCztJobs jobs, int64_t L, double2* __restrict__ Y, int64_t ny_bins,
+                                                  int64_t num) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ny_bins) return;
+    const DDCztJob& j = jobs.j[blockIdx.y];
+    const double2 c = A[(int64_t)blockIdx.y * L + k];
+    const double2 w = j.w[k];
+    const double il = 1.0 / (double)L;
+    double2 v = make_double2((c.x * w.x - c.y * w.y) * il, (c.x * w.y + c.y * w.x) * il);
+    if ((num & 1) == 0 && k == num / 2) { v.x *= 2.0; v.y *= 2.0; }
+    Y[(int64_t)blockIdx.y * ny_bins + k] = v;
+}
+__global__ void __launch_bounds__(256) k_czt_scatter(const double* __restrict__ src, const DDCztJobs jobs, int64_t num, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < num) out[jobs.j[blockIdx.y].out_off + i] = src[(int64_t)blockIdx.y * num + i] * jobs.j[blockIdx.y].scale;
+}
+
+// chunks idx[0..B) (all with target length num, every one wanted by czt_wanted), at most DD_CZT_MAXB per batch
+static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_off, const int64_t* n_host, double* out, const int64_t* out_off,
+                              int64_t num, const std::vector<int>& idx_all, hipStream_t s) {
+    const int64_t K = num / 2 + 1;
+    int64_t nmax = 0;
+    for (int j : idx_all) nmax = n_host[j] > nmax ? n_host[j] : nmax;
+    // convolution length: the smaller of the next 2^a and 3.2^a (measured for config 3, need 86 199, ms per 16 chunks: 98 304 =
+    // 3.2^15 0.103, 131 072 0.112, 114 688 = 7.2^14 0.116, 86 400 = the smallest 7-smooth multiple of 16 0.140, 90 112 = 11.2^13
+    // 0.147: the library's power-of-two passes beat less data).  DD_CZT_LEN=<n> (tools) forces a length
+    static const char* lenv = getenv("DD_CZT_LEN");
+    int64_t L = 1;
+    while (L < nmax + K - 1) L <<= 1;
+    if (L >= 4 && 3 * (L / 4) >= nmax + K - 1) L = 3 * (L / 4);
+    if (lenv && atoll(lenv) >= nmax + K - 1) L = atoll(lenv);
+    for (size_t at = 0; at < idx_all.size(); at += DD_CZT_MAXB) {
+        const int B = (int)std::min<size_t>(DD_CZT_MAXB, idx_all.size() - at);
+        DDCztJobs jobs;
+        memset(&jobs, 0, sizeof(jobs));
+        for (int b = 0; b < B; ++b) {
+            const int j = idx_all[at + b];
+            DDCztTab t;
+            int rc = czt_tables(n_host[j], K, L, s, &t);
+            if (rc != DD_OK) return rc;
+            jobs.j[b] = DDCztJob{in_off[j], out_off[j], n_host[j], t.w, t.bspec, 1.0 / (double)n_host[j]};
+        }
+        hipfftHandle pz, pb;
+        int rc = get_plan(&pz, HIPFFT_Z2Z, L, B, s);
+        if (rc != DD_OK) return rc;
+        rc = get_plan(&pb, HIPFFT_Z2D, num, B, s);
+        if (rc != DD_OK) return rc;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_y = al(sizeof(double2) * (size_t)L * B), o_r = o_y + al(sizeof(double2) * (size_t)K * B);
+        const size_t need = o_r + al(sizeof(double) * (size_t)num * B);
+        DDScratchLock scr;
+        rc = scr.get(need, s);
+        if (rc != DD_OK) return rc;
+        double2* A = reinterpret_cast<double2*>(scr.ptr);
+        double2* Y = reinterpret_cast<double2*>(scr.ptr + o_y);
+        double* res = reinterpret_cast<double*>(scr.ptr + o_r);
+        if (in_is_f32) hipLaunchKernelGGL(k_czt_pre<float>, dim3(grid1(L), B), dim3(256), 0, s, (const float*)in, jobs, L, A);
+        else hipLaunchKernelGGL(k_czt_pre<double>, dim3(grid1(L), B), dim3(256), 0, s, (const double*)in, jobs, L, A);
+        const hipfftResult r1 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_FORWARD);
+        hipLaunchKernelGGL(k_czt_mul, dim3(grid1(L), B), dim3(256), 0, s, A, jobs, L);
+        const hipfftResult r2 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_BACKWARD);
+        hipLaunchKernelGGL(k_czt_bins, dim3(grid1(K), B), dim3(256), 0, s, A, jobs, L, Y, K, num);
+        const hipfftResult r3 = hipfftExecZ2D(pb, (hipfftDoubleComplex*)Y, res);
+        hipLaunchKernelGGL(k_czt_scatter, dim3(grid1(num), B), dim3(256), 0, s, res, jobs, num, out);
+        if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || r3 != HIPFFT_SUCCESS) {
+            dd_set_error("hipfft exec failed (%d, %d, %d)", (int)r1, (int)r2, (int)r3);
+            return DD_ERR_HIP;
+        }
+        DD_LAUNCH_CHECK();
+    }
+    return DD_OK;
+}
+
 extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int64_t num, void* stream) {
     DD_REQUIRE(n >= 1 && num >= 1, "n/num");
     DD_REQUIRE(in && out, "null buffer");
     hipStream_t s = dd_stream(stream);
+    if (czt_wanted(n, num)) {
+        const int64_t zero = 0;
+        return resample_czt_batch(in, 0, &zero, &n, out, &zero, num, std::vector<int>{0}, s);
+    }
     hipfftHandle pf, pb;
     int rc = get_plan(&pf, HIPFFT_D2Z, n, 1, s);
     if (rc != DD_OK) return rc;
@@ -320,10 +519,19 @@ extern "C" int dd_resample_fft_chunks(const void* in, int in_is_f32, const int64
     DD_REQUIRE(in && out && in_off_host && n_host && out_off_host && num_host && count >= 0, "arguments");
     hipStream_t s = dd_stream(stream);
     std::vector<char> done(count, 0);
+    for (int j = 0; j < count; ++j) DD_REQUIRE(n_host[j] >= 1 && num_host[j] >= 1, "n/num");
+    // chunks whose length the library would transform by Bluestein: one chirp-z batch per target length, whatever the lengths
+    for (int first = 0; first < count; ++first) {
+        if (done[first] || !czt_wanted(n_host[first], num_host[first])) continue;
+        std::vector<int> idx;
+        for (int j = first; j < count; ++j)
+            if (!done[j] && num_host[j] == num_host[first] && czt_wanted(n_host[j], num_host[j])) { idx.push_back(j); done[j] = 1; }
+        int rc = resample_czt_batch(in, in_is_f32, in_off_host, n_host, out, out_off_host, num_host[first], idx, s);
+        if (rc != DD_OK) return rc;
+    }
     for (int first = 0; first < count; ++first) {
         if (done[first]) continue;
         const int64_t n = n_host[first], num = num_host[first];
-        DD_REQUIRE(n >= 1 && num >= 1, "n/num");
         std::vector<DDRsJob> jobs;
         for (int j = first; j < count; ++j)
             if (!done[j] && n_host[j] == n && num_host[j] == num) { jobs.push_back({in_off_host[j], out_off_host[j]}); done[j] = 1; }
