@@ -5,9 +5,10 @@
 // Why: the three-limb f16 Toeplitz GEMM of dd_mfma.hip spends 108 MFMAs per 1024
 // outputs whatever the limb format (f16 x f16 limbs, exact 8-bit data x i8 tap limbs, Karatsuba forms: all 6 matrix
 // instructions per 16 taps; tools/ubench/mfma_i8_vs_f16.hip measures the bare streams: 0.148 ms of f16 MFMAs, 0.159 ms
-// of i8 MFMAs per 2^26 samples), and the chip holds only 1.57 GHz under it.  A block FFT costs ~50 packed f32
-// instructions per output for forward transform + spectrum product + inverse transform, independent of the tap count,
-// runs on the vector pipe alone at 2.2 GHz, and takes complex taps for free -- so the NCO
+// of i8 MFMAs per 2^26 samples), and the chip holds only 1.54 GHz under it at the board's 1400 W cap.  A block FFT costs ~44
+// packed f32 instructions per output for forward transform + spectrum product + inverse transform (+ 12 for the discriminator),
+// independent of the tap count, runs on the vector pipe alone at 2.08 GHz under the same cap, and takes complex taps for
+// free -- so the NCO
 //     y[p] = sum_k g[k] x[p-k] e^{-j th (p-k)} = e^{-j th p} sum_k (g[k] e^{j th k}) x[p-k] = e^{-j th p} w[p]
 // moves into the tap spectrum and the discriminator sees  y[p] conj(y[p-1]) = e^{-j th} w[p] conj(w[p-1]).
 //
@@ -27,26 +28,16 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---- complex arithmetic on packed pairs (x = re, y = im): v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 ----
-__device__ __forceinline__ v2f ff_cmul(v2f a, v2f w) {          // a * w
-    const v2f t = a * w.xx;
-    return __builtin_elementwise_fma(a.yx, (v2f){-w.y, w.y}, t);
-}
-__device__ __forceinline__ v2f ff_cmulc(v2f a, v2f w) {         // a * conj(w)
-    const v2f t = a * w.xx;
-    return __builtin_elementwise_fma(a.yx, (v2f){w.y, -w.y}, t);
-}
-template <bool INV>
-__device__ __forceinline__ v2f ff_tw(v2f a, v2f w) { return INV ? ff_cmulc(a, w) : ff_cmul(a, w); }
 // register that holds output k of ff_bfly16
 #define FF_P(k) (4 * ((k) & 3) + ((k) >> 2))
 
-// the same with a loop-invariant factor held in a register pair: written as the two instructions with their operand
-// selects and sign modifiers spelt out.  Left to the compiler, the splat (w.x, w.x) and the signed swizzles (-w.y, w.y),
-// (w.y, -w.y) of all 46 factors are hoisted out of the block loop as registers of their own -- 6 registers per factor.
-// On gfx950 a packed-f32 result may not be read by the very next VALU instruction (one wait state; the compiler pads
-// with s_nop where it cannot find an independent instruction, and it does not look inside asm statements), so the two
-// halves of a product are issued as separate statements and the callers keep a dependent pair at least one
-// instruction apart: all first halves of a group, then all second halves.
+// A complex product a * w with a loop-invariant factor w held in a register pair, written as its two instructions with their
+// operand selects and sign modifiers spelt out.  Left to the compiler (a * w.xx + a.yx * (-w.y, w.y)), the splat and the signed
+// swizzles of all the factors are hoisted out of the block loop as registers of their own -- 6 registers per factor.
+// On gfx950 a packed-f32 result may not be read by the very next VALU instruction (one wait state: the compiler pads with
+// s_nop where it cannot find an independent instruction, and it does not reorder asm statements to find one), so the two
+// halves of a product are separate statements and the callers keep a dependent pair at least one instruction apart: all
+// first halves of a group, then all second halves.
 __device__ __forceinline__ v2f ff_mul_lo(v2f a, v2f w) {        // (a.x w.x, a.y w.x)
     v2f t;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
