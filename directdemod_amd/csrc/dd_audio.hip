@@ -316,11 +316,9 @@ static int czt_tables(int64_t n, int64_t K, int64_t L, hipStream_t s, DDCztTab* 
     const DDCztKey key{dev, s, n, K, L};
     auto it = g_czt.find(key);
     if (it == g_czt.end()) {
-        if (g_czt.size() >= 64) {                          // (a chunk loop has one or two lengths; this is a leak guard)
-            DD_HIP_CHECK(hipDeviceSynchronize());
-            for (auto& e : g_czt) { (void)hipFree(e.second.w); (void)hipFree(e.second.bspec); }
-            g_czt.clear();
-        }
+        // a chunk loop has one or two lengths.  Tables are never freed (another thread may be using them): past 64 of them the
+        // caller takes the library's own transform instead
+        if (g_czt.size() >= 64) return 1;
         DDCztTab t{nullptr, nullptr};
         DD_HIP_CHECK(hipMalloc((void**)&t.w, sizeof(double2) * (size_t)n));
         hipError_t e = hipMalloc((void**)&t.bspec, sizeof(double2) * (size_t)L);
@@ -402,6 +400,11 @@ static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_o
     while (L < nmax + K - 1) L <<= 1;
     if (L >= 4 && 3 * (L / 4) >= nmax + K - 1) L = 3 * (L / 4);
     if (lenv && atoll(lenv) >= nmax + K - 1) L = atoll(lenv);
+    for (int j : idx_all) {                                  // every table first: 1 = not taken, nothing enqueued yet
+        DDCztTab t;
+        const int rc = czt_tables(n_host[j], K, L, s, &t);
+        if (rc != DD_OK) return rc;
+    }
     for (size_t at = 0; at < idx_all.size(); at += DD_CZT_MAXB) {
         const int B = (int)std::min<size_t>(DD_CZT_MAXB, idx_all.size() - at);
         DDCztJobs jobs;
@@ -450,7 +453,8 @@ extern "C" int dd_resample_fft_f64(const double* in, double* out, int64_t n, int
     hipStream_t s = dd_stream(stream);
     if (czt_wanted(n, num)) {
         const int64_t zero = 0;
-        return resample_czt_batch(in, 0, &zero, &n, out, &zero, num, std::vector<int>{0}, s);
+        const int rc = resample_czt_batch(in, 0, &zero, &n, out, &zero, num, std::vector<int>{0}, s);
+        if (rc != 1) return rc;
     }
     hipfftHandle pf, pb;
     int rc = get_plan(&pf, HIPFFT_D2Z, n, 1, s);
@@ -525,9 +529,11 @@ extern "C" int dd_resample_fft_chunks(const void* in, int in_is_f32, const int64
         if (done[first] || !czt_wanted(n_host[first], num_host[first])) continue;
         std::vector<int> idx;
         for (int j = first; j < count; ++j)
-            if (!done[j] && num_host[j] == num_host[first] && czt_wanted(n_host[j], num_host[j])) { idx.push_back(j); done[j] = 1; }
-        int rc = resample_czt_batch(in, in_is_f32, in_off_host, n_host, out, out_off_host, num_host[first], idx, s);
+            if (!done[j] && num_host[j] == num_host[first] && czt_wanted(n_host[j], num_host[j])) idx.push_back(j);
+        const int rc = resample_czt_batch(in, in_is_f32, in_off_host, n_host, out, out_off_host, num_host[first], idx, s);
+        if (rc == 1) break;                                  // table cache full: the groups below take everything that is left
         if (rc != DD_OK) return rc;
+        for (int j : idx) done[j] = 1;
     }
     for (int first = 0; first < count; ++first) {
         if (done[first]) continue;
