@@ -245,6 +245,24 @@ __device__ __forceinline__ float ff_atan_small(float y, float x) {
 #define F1_WAVES 4
 #define F1_HP_OFF (F1_WAVES * F1_WAVE_BYTES)     // the tap spectrum as the lanes multiply it, [16][64] complex64: one copy per workgroup
 #define F1_LDS_BYTES (F1_HP_OFF + 16 * 64 * 8)
+#ifndef F1_RUN_BLOCKS
+#define F1_RUN_BLOCKS 4            // blocks per contiguous run of a wave (DDFft1kMap)
+#endif
+
+// Which interior blocks a wave takes (blocks 1 .. nblk-2; NI of them, NW waves).  Wave w owns B_w = b or b + 1 blocks (the
+// balanced split floor(NI (w+1) / NW) - floor(NI w / NW)) and walks them in K rounds: in round k every wave takes a short
+// contiguous run (r0[k] blocks for a wave that owns b, r1[k] for one that owns b + 1) and the runs of a round tile one
+// window of the stream in wave order -- so at any time the device works on ONE moving window of ~NW * R * 9 KB instead of NW
+// streams 175 KB apart.  tools/ubench/stream_2to1.hip (profiles/r04_stream_2to1.txt): the same 8 B in / 4 B out traffic
+// moves at 5.0 TB/s with one contiguous run per wave (K = 1, the round-3 kernel) and at 5.5-6.0 as a moving window
+// (6.2 / 7.2 TB/s with non-temporal loads and stores).  Inside a run the 256-sample overlap stays in registers (six
+// loads per block); the first block of a run loads all eight row pairs.
+#define F1_MAXK 32
+struct DDFft1kMap {
+    int K, b;
+    int r0[F1_MAXK], r1[F1_MAXK];     // run lengths in round k
+    int wstart[F1_MAXK];              // interior blocks before round k's window
+};
 
 struct DDFft1kTabs {
     const float2* tw1;     // [64][16]   W1024^{lane k}
@@ -253,6 +271,10 @@ struct DDFft1kTabs {
     float2 crot;
     float theta_sub;       // != 0: |theta| is small -- the discriminator subtracts it from the angle instead of rotating every
                            // product by crot (crot is then 1): 12 packed adds instead of 24 packed multiply-adds per block
+    int base;              // block b covers FIR outputs [768 b + base, 768 b + base + 768), base in [s - 15, s]: chosen on the host so
+                           // that every interior store instruction writes whole 64-byte lines of `out` (a stream START drops one
+                           // angle, demod_fm.py:43-49, which put every 512-byte store 4 bytes ahead of a line boundary: PMC WRITE_SIZE
+                           // 1.12 x the output; and a chunk loop's `out` pointer need not be aligned at all)
 };
 
 // A lane moves TWO consecutive samples per memory instruction (one 16-byte load, one 8-byte store of two angles): the
@@ -273,8 +295,8 @@ __device__ __forceinline__ void f1_swap(v2f& b, v2f& a) {
 
 // row pairs [r0, r0 + n) of the block that starts at sample n0: x[2 r], x[2 r + 1] = samples n0 + 128 r + 2 lane + {0, 1}
 // (not yet swapped).  CLAMP: pair indices past `lim` (in pairs, relative to n0) read pair `lim` instead.
-template <bool U8, bool CLAMP = false>
-__device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int lane, v2f (&x)[16], int r0, int n, unsigned lim = 0) {
+template <bool U8, bool CLAMP = false, int NX = 16>
+__device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int lane, v2f (&x)[NX], int r0, int n, unsigned lim = 0) {
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         unsigned m = (unsigned)lane + 64u * (r0 + i);
@@ -307,7 +329,8 @@ __device__ unsigned long long g_ff_trace[4096 * (FF_NPH + 2)];
 #endif
 
 struct F1Edge {
-    int prev_valid;        // the value before the block's first output comes from the carried state
+    int prev_m;            // block position (256 + output index) of the FIR output before the chunk's first one, which comes from the
+                           // carried state (255 = just before the block's first output), or -1
     float2 prev;           //   ... un-rotated
     int last_m;            // block position (256 + output index) of the chunk's last FIR output, or -1
     float2 last_rot;       // e^{-j theta (abs0 + L - 1)}
@@ -402,9 +425,9 @@ __device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const
 // caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
 // at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
 template <bool U8, bool PARTIAL, bool LOADNEXT>
-__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw3)[16], const v2f* const hp,
+__device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw3)[16], const v2f* const hp,
                                          const v2f crot, const float theta_sub, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int lim_lo, const int limit,
-                                         const F1Edge* edge = nullptr
+                                         const bool jump = false, const F1Edge* edge = nullptr
 #ifdef FF_TRACE
                                          , unsigned* tr = nullptr
 #endif
@@ -504,7 +527,13 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
             // chunk edges (cold path).  First block of a chunk that continues a stream: the FIR output before the chunk's
             // first one is the carried state (demod_fm.py:47-49), brought into this kernel's un-rotated frame.  Last block:
             // the chunk's last FIR output, rotated, is the next chunk's carried state.
-            if (edge->prev_valid && lane == 63) A[1] = (v2f){edge->prev.x, edge->prev.y};
+            if (edge->prev_m >= 0) {
+#pragma unroll
+                for (int r = 1; r < 8; ++r) {
+                    if (128 * r + 2 * lane == edge->prev_m) B[r] = (v2f){edge->prev.x, edge->prev.y};
+                    if (128 * r + 2 * lane + 1 == edge->prev_m) A[r] = (v2f){edge->prev.x, edge->prev.y};
+                }
+            }
             if (edge->last_m >= 0) {
 #pragma unroll
                 for (int r = 2; r < 8; ++r) {
@@ -540,11 +569,11 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f* cons
 #endif
     // a[] is dead from here: the next block's samples fly during the angles and stores.  Its first four rows are this
     // block's last four (the 256-sample overlap), kept in `keep`: six loads per block
+    // (jump, wave-uniform: the next block is not this one's successor -- its first two row pairs are loaded as well, into
+    // registers of their own: the caller swaps them into a[0..3] at the top of the next block, where the wave waits for that
+    // block's samples anyway; otherwise the caller copies `keep`)
 #ifndef FF_NO_LOAD
-    if (LOADNEXT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = keep[r];
-    }
+    if (LOADNEXT && jump) f1_load_pairs<U8, false, 4>(in, n0_next, lane, jl, 0, 2);
 #endif
     // wave-uniform fast path: every |angle| of the block's 768 outputs below 22.5 degrees (|im| <= tan(pi/8) re)
     float worst = -1.0f;
@@ -576,8 +605,8 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
         }
     }
     const v2f crot = {T.crot.x, T.crot.y};
-    const int64_t p0 = (int64_t)F1_ADV * q;
-    v2f a[16], keep[4];
+    const int64_t p0 = (int64_t)F1_ADV * q + T.base;
+    v2f a[16], keep[4], jl[4];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         a[2 * r] = f1_edge_sample<U8>(P, p0 - 256 + 128 * r + 2 * lane);
@@ -586,7 +615,7 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
     f1_swap(a[0], a[1]);
     f1_swap(a[2], a[3]);
     F1Edge e;
-    e.prev_valid = 0;
+    e.prev_m = -1;
     e.prev = make_float2(0.f, 0.f);
     e.last_m = -1;
     e.last_rot = make_float2(1.f, 0.f);
@@ -597,7 +626,7 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
         const float2 ly = *P.lasty_in;
         const float2 w = nco ? dd_phasor((uint64_t)(P.abs0 - 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
         e.prev = make_float2(fmaf(ly.x, w.x, ly.y * w.y), fmaf(ly.y, w.x, -ly.x * w.y));
-        e.prev_valid = 1;
+        e.prev_m = (int)(255 - p0);                    // (p0 = base <= 0 here)
     }
     if (q == nblk - 1 && P.lasty_out) {
         e.last_m = (int)(256 + (P.L - 1 - p0));
@@ -605,7 +634,7 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
     }
     const int64_t lo64 = (int64_t)P.s - p0, hi64 = P.L - p0;
     const int lim_lo = lo64 > 0 ? (int)lo64 : 0, lim_hi = hi64 < F1_ADV ? (int)hi64 : F1_ADV;
-    f1_block<U8, true, false>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, &e);
+    f1_block<U8, true, false>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, false, &e);
     if (q == nblk - 1 && P.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < P.K - 1; i += 64) {
@@ -630,15 +659,14 @@ __device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kT
 }
 
 // The whole chunk in one launch: FIR outputs [0, L) -> FM angles out[p - s] for p >= s, carried state read (history,
-// last FIR output) and written.  Block q covers outputs [768 q, 768 q + 768); every wave takes a contiguous run of the
-// nblk blocks; block 0 and block nblk-1 are edge blocks.
+// last FIR output) and written.  Block q covers outputs [768 q + base, 768 q + base + 768), base <= s (DDFft1kTabs); every wave
+// takes a contiguous run of the nblk blocks; block 0 and block nblk-1 are edge blocks.
 template <bool U8>
-__global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, int nblk, int nwaves) {
+__global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, const DDFft1kMap M, int nblk, int nwaves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v2f* const X = reinterpret_cast<v2f*>(smem + wave * F1_WAVE_BYTES);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform by construction: the
+    v2f* const X = reinterpret_cast<v2f*>(smem + wave * F1_WAVE_BYTES);                             //  block map below is scalar code)
     const int gw = blockIdx.x * F1_WAVES + wave;
-    const int q_begin = (int)(((int64_t)nblk * gw) / nwaves), q_end = (int)(((int64_t)nblk * (gw + 1)) / nwaves);
     v2f* const HP = reinterpret_cast<v2f*>(smem + F1_HP_OFF);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -646,28 +674,37 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
         HP[threadIdx.x + 256 * i] = (v2f){h.x, h.y};
     }
     __syncthreads();                           // the only barrier of the kernel, before any wave may leave
-    if (q_begin >= q_end) return;
     const v2f* const hp = HP + lane;
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
-    if (q_begin == 0) f1_edge_block<U8>(P, T, 0, nblk, X, hp, lane);
-    const int tcol = 2 * (lane & 31) + (lane >> 5);           // the column this lane transforms in passes 1 and 6
-    v2f tw1[16], tw3[16];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const float2 u = T.tw1[tcol * 16 + k];
-        tw1[k] = (v2f){u.x, u.y};
-        if (k & 3) {                                               // pass-3 layout: register 4 c + n0 of lane j holds k1 = 4 c + j
-            const float2 w = T.tw2[(k & 3) * 16 + (k & 12) + (lane & 3)];
-            tw3[k] = (v2f){w.x, w.y};
-        }
+    if (gw == 0) f1_edge_block<U8>(P, T, 0, nblk, X, hp, lane);
+    // this wave's interior blocks: run k = [1 + start_k, 1 + start_k + len_k)
+    const int ni = nblk - 2;
+    const int w0 = ni > 0 ? (int)(((int64_t)ni * gw) / nwaves) : 0, w1 = ni > 0 ? (int)(((int64_t)ni * (gw + 1)) / nwaves) : 0;
+    const bool big = (w1 - w0) > M.b;
+    const int cbig = w0 - M.b * gw;                 // waves before this one that own b + 1 blocks
+#define F1_RUN(k, st, ln) do { const int r0_ = M.r0[k], r1_ = M.r1[k]; st = 1 + M.wstart[k] + gw * r0_ + cbig * (r1_ - r0_); ln = big ? r1_ : r0_; } while (0)
+    int k = 0, q = 0, rem = 0;
+    for (; k < M.K; ++k) {
+        F1_RUN(k, q, rem);
+        if (rem > 0) break;
     }
-    const v2f crot = {T.crot.x, T.crot.y};
-    float* const outp = reinterpret_cast<float*>(P.out);
-    const int q_lo = q_begin == 0 ? 1 : q_begin, q_hi = q_end == nblk ? nblk - 1 : q_end;      // interior blocks of this run
-    if (q_lo < q_hi) {
-        v2f a[16], keep[4];
-        f1_load_pairs<U8>(P.in, (int64_t)F1_ADV * q_lo - 256, lane, a, 0, 8);
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): see k_chain_fft
+    if (w1 > w0 && k < M.K) {
+        const int tcol = 2 * (lane & 31) + (lane >> 5);           // the column this lane transforms in passes 1 and 6
+        v2f tw1[16], tw3[16];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+            const float2 u = T.tw1[tcol * 16 + i];
+            tw1[i] = (v2f){u.x, u.y};
+            if (i & 3) {                                               // pass-3 layout: register 4 c + n0 of lane j holds k1 = 4 c + j
+                const float2 w = T.tw2[(i & 3) * 16 + (i & 12) + (lane & 3)];
+                tw3[i] = (v2f){w.x, w.y};
+            }
+        }
+        const v2f crot = {T.crot.x, T.crot.y};
+        float* const outp = reinterpret_cast<float*>(P.out);
+        v2f a[16], keep[4], jl[4];
+        f1_load_pairs<U8>(P.in, (int64_t)F1_ADV * q + T.base - 256, lane, a, 0, 8);
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
         f1_swap(a[0], a[1]);
         f1_swap(a[2], a[3]);
 #ifdef FF_TRACE
@@ -676,25 +713,48 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
         for (int i = 0; i < FF_NPH; ++i) tr[i] = 0;
         const unsigned tloop = (unsigned)__builtin_readcyclecounter();
 #endif
-        for (int q = q_lo; q < q_hi; ++q) {
-            const int64_t p0 = (int64_t)F1_ADV * q;
-            const int64_t n0_next = (q + 1 < q_hi) ? p0 + F1_ADV - 256 : p0 - 256;     // (the last one re-reads itself: no branch in the block)
+        for (;;) {
+            int qn = q + 1;
+            bool jump = false, done = false;
+            if (--rem <= 0) {                      // (wave-uniform) the run ends with this block: where is the next one?
+                int st = 0, ln = 0;
+                for (++k; k < M.K; ++k) {
+                    F1_RUN(k, st, ln);
+                    if (ln > 0) break;
+                }
+                if (k < M.K) { qn = st; rem = ln; jump = true; }
+                else { qn = q; done = true; }        // (the last one re-reads itself: no branch in the block)
+            }
+            const int64_t p0 = (int64_t)F1_ADV * q + T.base;
+            const int64_t n0_next = (int64_t)F1_ADV * qn + T.base - 256;
 #ifdef FF_TRACE
-            f1_block<U8, false, true>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, nullptr, tr);
+            f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump, nullptr, tr);
 #else
-            f1_block<U8, false, true>(a, keep, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV);
+            f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump);
 #endif
+            if (done) break;
+            if (jump) {
+                f1_swap(jl[0], jl[1]);
+                f1_swap(jl[2], jl[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = jl[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = keep[r];
+            }
+            q = qn;
         }
 #ifdef FF_TRACE
         tr[13] = (unsigned)__builtin_readcyclecounter() - tloop;
         if (gw < 4096 && lane == 0) {
 #pragma unroll
             for (int i = 0; i < FF_NPH; ++i) g_ff_trace[gw * (FF_NPH + 2) + i] = tr[i];
-            g_ff_trace[gw * (FF_NPH + 2) + FF_NPH] = (unsigned long long)(q_hi - q_lo);
+            g_ff_trace[gw * (FF_NPH + 2) + FF_NPH] = (unsigned long long)(w1 - w0);
         }
 #endif
     }
-    if (q_end == nblk && nblk > 1) f1_edge_block<U8>(P, T, nblk - 1, nblk, X, hp, lane);
+#undef F1_RUN
+    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8>(P, T, nblk - 1, nblk, X, hp, lane);
 }
 
 // ============================================================================ host side
@@ -843,13 +903,45 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
             T1.crot = make_float2((float)cosl(a), (float)-sinl(a));
         }
     }
-    const int nb1 = (int)((P.L + F1_ADV - 1) / F1_ADV);
+    // the block grid is laid so that block b's first angle, out[768 b + base - s], starts a 64-byte line of `out`
+    // (DD_FFT_FRAME=0, tools: the grid starts at output 0 whatever the alignment, as before round 4)
+    static const char* frame_env = getenv("DD_FFT_FRAME");
+    {
+        const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
+        T1.base = (frame_env && atoi(frame_env) == 0) ? 0 : P.s - a16;
+        while (T1.base > P.L - 1) T1.base -= 16;                 // (a chunk of one sample: the last block must hold output L - 1)
+    }
+    const int nb1 = (int)((P.L - T1.base + F1_ADV - 1) / F1_ADV);
     static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");           // tools: occupancy experiments
     const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
     int grid1 = dd_cu_count() * (per_cu1 > 0 ? per_cu1 : 3);
     if (grid1 * F1_WAVES > nb1) grid1 = (nb1 + F1_WAVES - 1) / F1_WAVES;
-    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, nb1, grid1 * F1_WAVES);
-    else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, nb1, grid1 * F1_WAVES);
+    const int nw1 = grid1 * F1_WAVES;
+    // rounds of the block -> wave map (DDFft1kMap): runs of ~F1_RUN_BLOCKS blocks; DD_FFT_ROUNDS=<K> (tools) forces a count (1 = one
+    // contiguous run per wave, the round-3 mapping)
+    DDFft1kMap M1;
+    {
+        static const char* rounds_env = getenv("DD_FFT_ROUNDS");
+        const int ni = nb1 > 2 ? nb1 - 2 : 0;
+        const int b = ni / nw1;                                  // a wave owns b or b + 1 interior blocks
+        int K = rounds_env ? atoi(rounds_env) : (b + 1 + F1_RUN_BLOCKS - 1) / F1_RUN_BLOCKS;
+        if (K > b + 1) K = b + 1;
+        if (K > F1_MAXK) K = F1_MAXK;
+        if (K < 1) K = 1;
+        const int64_t nbig = (int64_t)ni - (int64_t)b * nw1;     // waves that own b + 1
+        int64_t ws = 0;
+        for (int k = 0; k < K; ++k) {
+            M1.r0[k] = (int)(((int64_t)b * (k + 1)) / K - ((int64_t)b * k) / K);
+            M1.r1[k] = (int)(((int64_t)(b + 1) * (k + 1)) / K - ((int64_t)(b + 1) * k) / K);
+            M1.wstart[k] = (int)ws;
+            ws += (int64_t)(nw1 - nbig) * M1.r0[k] + nbig * M1.r1[k];
+        }
+        for (int k = K; k < F1_MAXK; ++k) M1.r0[k] = M1.r1[k] = M1.wstart[k] = 0;
+        M1.K = K;
+        M1.b = b;
+    }
+    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
+    else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the M = 1 FM chain kernels inside one process (DD_MFMA_KERNEL is read per launch): outputs compared against the
-default kernel, HIP-event time per launch.  KERNELS=ab,fft NTAPS=255 N=26 U8=1"""
+default kernel, HIP-event time per launch.  KERNELS=ab,fft NTAPS=255 N=26 U8=1 INPUT=A|B NORESET=1"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,10 @@ _hip.require_gpu()
 lib = _hip.lib()
 dev = torch.device("cuda", 0)
 n = 1 << int(os.environ.get("N", "26"))
-x = bench.make_input(torch, n, 0, dev, 3)
+if os.environ.get("INPUT", "B") == "A":       # SURVEY 8(d) input A: iid uniform u8 noise (source.py:117-118 on a dead channel), seed 1234
+    x = (torch.from_numpy(np.random.default_rng(1234).integers(0, 256, size=(n, 2), dtype=np.uint8)).to(dev).float() - 127.5).contiguous()
+else:
+    x = bench.make_input(torch, n, 0, dev, 3)
 U8 = bool(os.environ.get("U8"))
 if U8:
     x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
