@@ -600,15 +600,19 @@ def run_rank(args):
         if rank == 0:
             sys.stderr.write("bench.py: %d ranks, %d GPU(s) visible on this node\n" % (world, torch.cuda.device_count()))
         raise SystemExit(2)
+    # DD_BENCH_FORCE_DIST=1 (tests/test_gpu_bench_nccl.py): take the distributed branch with ONE rank too -- process group on the
+    # nccl (= RCCL) backend, barriers, the variable-count gather and the timed all_gather -- so that the RCCL leg has run on the
+    # 1-GPU test box before the driver's 8-GPU node is the first place it ever executes
+    dist_on = world > 1 or bool(os.environ.get("DD_BENCH_FORCE_DIST"))
     if not stub:
         build_once_per_node()                      # before any rendezvous: ranks never race on the build
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
     eng = (StubStep if stub else HipStep)(args, rank, local_rank)
     device = eng.device
     cdev = torch.device("cpu") if one_device else device       # where the small reduction tensors live
-    if world > 1:
+    if dist_on:
         if stub or one_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -618,7 +622,7 @@ def run_rank(args):
 
     def barrier():
         eng.sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         eng.sync()
 
@@ -672,7 +676,7 @@ def run_rank(args):
 
     tmax = torch.tensor([dt, kern_ms, long_ms, cold_ms, first_ms], dtype=torch.float64, device=cdev)
     per_rank = None
-    if world > 1:
+    if dist_on:
         allk = [torch.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(allk, tmax)
         per_rank = [round(float(t[1]), 4) for t in allk]
@@ -680,15 +684,15 @@ def run_rank(args):
     dt_max, kern_ms_max, long_ms_max, cold_ms_max, first_ms_max = (float(v) for v in tmax)
 
     extra = {}
-    if world > 1:
+    if dist_on:
         extra["backend"] = dist.get_backend()
         extra["world_size_seen"] = dist.get_world_size()
-    if world > 1 and not args.no_gather:
+    if dist_on and not args.no_gather:
         from directdemod_amd import shard
         shard_out, cnt = eng.shard_output()                 # this rank's outputs (a view) and how many are valid
         if one_device:
             shard_out = shard_out.cpu()                     # gloo leg of the one-device functional check
-        parts = shard.gather_outputs(shard_out, cnt, world, dist)      # variable counts: checks the assembled stream length
+        parts = shard.gather_outputs(shard_out, cnt, world, dist, force=True)      # variable counts: checks the assembled stream length
         total_out = sum(int(p.numel()) for p in parts)
         assert total_out == world * n - 1, (total_out, world * n - 1)
         del parts
@@ -768,7 +772,7 @@ def run_rank(args):
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_log2n)
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

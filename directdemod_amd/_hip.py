@@ -21,6 +21,7 @@ DD_ERR_HIP = -2
 DD_ERR_NOMEM = -3
 DD_ERR_UNSUPPORTED = -4
 DD_ERR_NODEVICE = -5
+DD_ERR_TIMEOUT = -6
 
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
@@ -57,6 +58,8 @@ SIGNATURES = {
     "dd_host_register": (_int, [_p, _sz]),
     "dd_host_unregister": (_int, [_p]),
     "dd_debug_fill_lds": (_int, [C.c_uint32, _p]),
+    "dd_debug_select_kernel": (_int, [C.c_char_p]),
+    "dd_debug_seam": (_int, [_int, _int]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2h": (_int, [_p, _p, _sz, _p]),
     "dd_memcpy_d2d": (_int, [_p, _p, _sz, _p]),
@@ -189,6 +192,17 @@ def check(rc, what=""):
     if rc == DD_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise HipError(msg)
+
+
+def select_kernel(name=None):
+    """Tools and tests: force one of the M = 1 chain kernels ("ab", "ws", "fft1k") for every later launch of this process,
+    or go back to the choice by tap class (None / "auto").  Mirrors the choice into os.environ["DD_MFMA_KERNEL"] (which only
+    seeds the library's choice, once per process) so that code which looks there sees the same thing."""
+    check(lib().dd_debug_select_kernel((name or "auto").encode()), "dd_debug_select_kernel")
+    if name and name != "auto":
+        os.environ["DD_MFMA_KERNEL"] = name
+    else:
+        os.environ.pop("DD_MFMA_KERNEL", None)
 
 
 def require_gpu():

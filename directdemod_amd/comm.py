@@ -283,6 +283,7 @@ class commSignal:
             f = np.ascontiguousarray(freqOffset, dtype=np.float64).ravel()
             if len(f) != self.length:
                 raise ValueError("operands could not be broadcast together with shapes (%d,) (%d,)" % (self.length, len(f)))
+            self._settle()                 # (a container that noted this signal in extend() takes its samples first: comm.py:163 copies)
             self._materialise()
             d = self._device(_C64)
             out = DevArray(d.n, _C64)
@@ -314,6 +315,7 @@ class commSignal:
             if self._ops and self._ops[-1][0] == "fm":
                 self._record(("resample", num))               # real (FM) data: runs with the chain, batched over a chunk list
             else:
+                self._settle()
                 self._materialise()
                 self._store(_ops.resample_fft(self._device(), num), copy=False)
             self.__sampRate = tsampRate

@@ -58,6 +58,28 @@ static int get_plan(hipfftHandle* out, hipfftType type, int64_t n, int batch, hi
 
 static inline unsigned grid1(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+struct DDCztKey;
+static void czt_forget_stream(int dev, hipStream_t s);
+// the stream is about to be destroyed (dd_stream_destroy, after it has been synchronised): its plans (with their work areas) and
+// its chirp-z tables go with it -- a later stream that happens to get the same address must not inherit a plan bound to a dead
+// stream, and dead entries must not fill the 64-entry chirp-z cache
+void dd_audio_forget_stream(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        for (auto it = g_plans.begin(); it != g_plans.end();) {
+            if (it->first.dev == dev && it->first.stream == s) {
+                (void)hipfftDestroy(it->second);
+                it = g_plans.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    czt_forget_stream(dev, s);
+}
+
 // ---------------------------------------------------------------- A1: abs(hilbert(x)) per block
 // scipy.signal.hilbert: Xf = fft(x); h[0] = 1, h[1..(N-1)/2 or N/2-1] = 2, h[N/2] = 1 (N even),
 // 0 elsewhere; ifft(Xf * h); demod_am takes the magnitude (demod_am.py:29).
@@ -271,6 +293,18 @@ struct DDCztKey {
 struct DDCztTab { double2* w; double2* bspec; };
 static std::mutex g_czt_mu;
 static std::map<DDCztKey, DDCztTab> g_czt;
+static void czt_forget_stream(int dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_czt_mu);
+    for (auto it = g_czt.begin(); it != g_czt.end();) {
+        if (it->first.dev == dev && it->first.s == s) {
+            (void)hipFree(it->second.w);
+            (void)hipFree(it->second.bspec);
+            it = g_czt.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
 
 __global__ void __launch_bounds__(256) k_czt_tables(double2* __restrict__ w, double2* __restrict__ bt, int64_t n, int64_t K, int64_t L) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -182,14 +182,20 @@ __global__ void __launch_bounds__(DD_DENSE_THREADS) k_chain_dense(const DDChainP
 // the workgroup meets, then everybody reads with plain loads.  The flags are zeroed by a memset ahead of every launch.
 // Producers have lower workgroup indices than their consumers and only two workgroups per chunk ever wait, so a
 // waiting workgroup cannot keep its producer off the device; the spin is bounded all the same.
-__device__ __forceinline__ void dd_seam_wait(unsigned int* flag) {
+// A wait that gives up (the producer is not resident -- ascending dispatch order of workgroups is what the hardware does, not an
+// architectural promise -- or is held up by a debugger or profiler) counts itself in *err and goes on with whatever the state
+// buffers hold: the launch completes, its outputs are wrong, and the host turns the count into DD_ERR_TIMEOUT.
+__device__ __forceinline__ void dd_seam_wait(unsigned int* flag, unsigned int* err, int spin_log2) {
     if (threadIdx.x == 0) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
         gu32* f = (gu32*)flag;
-        for (unsigned spins = 0; spins < (1u << 24); ++spins) {
-            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        const unsigned bound = 1u << (spin_log2 > 0 && spin_log2 < 31 ? spin_log2 : 24);
+        bool seen = false;
+        for (unsigned spins = 0; spins < bound; ++spins) {
+            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
+        if (!seen && err) __hip_atomic_fetch_add((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -224,7 +230,7 @@ __device__ __forceinline__ void dd_decim_edge_tile(const DDChainParams& P, const
     const int64_t pfirst = dd_tile_pfirst(P, b);
     const int64_t ns = (int64_t)P.off + pfirst * M - (K - 1);
     const bool fm = (P.flags & DD_CHAIN_FM) != 0;
-    if (P.seam_wait && (ns < 0 || pfirst < 0)) dd_seam_wait(P.seam_wait);      // this tile reads the previous chunk's state
+    if (P.seam_wait && (ns < 0 || pfirst < 0)) dd_seam_wait(P.seam_wait, P.seam_err, P.seam_spin_log2);      // this tile reads the previous chunk's state
 
     const int ngroups = (S + 63) / 64;
     // interior tile (whole span inside the chunk, complex64 input): the WHOLE tile is requested at
@@ -723,6 +729,53 @@ void dd_mfma_destroy(void* st);
 int dd_mfma_launch(void* st, const DDChainParams& P, hipStream_t s, int* kernel_id);
 
 // ---------------------------------------------------------------- dd_fir (taps + history)
+// ---- chunk-list launches: hand-overs that timed out (dd_seam_wait) become DD_ERR_TIMEOUT --------------------------------
+static std::mutex g_seam_mu;
+static std::vector<dd_fir*> g_seam_pending;          // filters with a mirror copy of their error count in flight
+static int g_seam_withhold = -1, g_seam_spin_log2 = 0;
+
+extern "C" int dd_debug_seam(int withhold_chunk, int spin_log2) {
+    std::lock_guard<std::mutex> lk(g_seam_mu);
+    g_seam_withhold = withhold_chunk;
+    g_seam_spin_log2 = spin_log2;
+    return DD_OK;
+}
+// look at one filter's mirror word if its copy has completed (or wait for it); caller holds g_seam_mu
+static int seam_look(dd_fir* f, bool wait) {
+    if (!f->seam_pending) return DD_OK;
+    if (wait) (void)hipEventSynchronize(f->seam_ev);
+    else if (hipEventQuery(f->seam_ev) != hipSuccess) return DD_OK;          // still running: a later call looks again
+    f->seam_pending = 0;
+    for (size_t i = 0; i < g_seam_pending.size(); ++i)
+        if (g_seam_pending[i] == f) { g_seam_pending.erase(g_seam_pending.begin() + i); break; }
+    const unsigned n = *reinterpret_cast<volatile unsigned int*>(f->seam_err_host);
+    if (n == 0) return DD_OK;
+    *f->seam_err_host = 0;
+    (void)hipMemset(f->seam_err, 0, sizeof(unsigned int));
+    dd_set_error("chunk-list launch: %u in-launch hand-over wait(s) of the carried FIR / FM state timed out; the outputs of that "
+                 "dd_*_process_chunks call are invalid (run the chunks one by one, or raise the bound with dd_debug_seam)", n);
+    return DD_ERR_TIMEOUT;
+}
+int dd_seam_poll_all(void) {
+    std::lock_guard<std::mutex> lk(g_seam_mu);
+    int rc = DD_OK;
+    const std::vector<dd_fir*> firs = g_seam_pending;
+    for (dd_fir* f : firs) {
+        const int r = seam_look(f, false);
+        if (r != DD_OK) rc = r;
+    }
+    return rc;
+}
+static void seam_forget(dd_fir* f) {
+    std::lock_guard<std::mutex> lk(g_seam_mu);
+    for (size_t i = 0; i < g_seam_pending.size(); ++i)
+        if (g_seam_pending[i] == f) { g_seam_pending.erase(g_seam_pending.begin() + i); break; }
+    if (f->seam_ev) (void)hipEventDestroy(f->seam_ev);
+    if (f->seam_err_host) (void)hipHostFree(f->seam_err_host);
+    if (f->seam_err) (void)hipFree(f->seam_err);
+    f->seam_ev = nullptr; f->seam_err_host = nullptr; f->seam_err = nullptr; f->seam_pending = 0;
+}
+
 extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     DD_REQUIRE(h && taps, "null argument");
     DD_REQUIRE(ntaps >= 1 && ntaps <= 4096, "ntaps must be in [1, 4096]");
@@ -747,6 +800,10 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->last_kernel = DD_KERNEL_NONE;
     f->multi = nullptr;
     f->multi_bytes = 0;
+    f->seam_err = nullptr;
+    f->seam_err_host = nullptr;
+    f->seam_ev = nullptr;
+    f->seam_pending = 0;
     const int R = DD_DENSE_R;
     const int K = ntaps;
     // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
@@ -785,6 +842,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
 extern "C" int dd_fir_destroy(dd_fir* f) {
     if (!f) return DD_OK;
     if (f->mfma) dd_mfma_destroy(f->mfma);
+    seam_forget(f);
     (void)hipFree(f->multi);
     (void)hipFree(f->taps_rev);
     (void)hipFree(f->tail[0]);
@@ -1220,6 +1278,33 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     const bool u8 = (flags & DD_CHAIN_U8_INPUT) != 0;
     const size_t isz = u8 ? 2 : sizeof(float2), osz = isfm ? sizeof(float) : sizeof(float2);
     if (!(M > 1 && nchunks >= 2 && !(flags & DD_CHAIN_FORCE_DIRECT) && fir->K >= 2)) return 0;
+    int withhold = -1, spin_log2 = 0;
+    {
+        // an earlier chunk-list launch through this filter whose hand-over timed out: say so now, before anything is enqueued
+        std::lock_guard<std::mutex> lk(g_seam_mu);
+        const int rc0 = seam_look(fir, false);
+        if (rc0 != DD_OK) return rc0;
+        withhold = g_seam_withhold;
+        g_seam_withhold = -1;                  // (one launch)
+        spin_log2 = g_seam_spin_log2;
+    }
+    if (!fir->seam_err) {
+        DD_HIP_CHECK(hipMalloc((void**)&fir->seam_err, 2 * sizeof(unsigned int)));
+        DD_HIP_CHECK(hipMemset(fir->seam_err, 0, 2 * sizeof(unsigned int)));
+        DD_HIP_CHECK(hipHostMalloc((void**)&fir->seam_err_host, sizeof(unsigned int), hipHostMallocDefault));
+        *fir->seam_err_host = 0;
+        DD_HIP_CHECK(hipEventCreateWithFlags(&fir->seam_ev, hipEventDisableTiming));
+    }
+    {
+        // (the multi kernels' dynamic LDS limit: a chunk list whose chunks have no interior run never passes through
+        // decim_plan's persistent branch, where it used to be raised)
+        static DDOncePerDevice attr_m;
+        if (attr_m.need()) {
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_decim_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_m.mark();
+        }
+    }
     std::vector<DDChainParams> Pv;
     std::vector<DDDecimPlan> plv;
     std::vector<int64_t> nout(nchunks, 0);
@@ -1291,6 +1376,9 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
         }
         P.seam_wait = i > 0 ? seam_flags + (i - 1) : nullptr;
         P.seam_post = i < nchunks - 1 ? seam_flags + i : nullptr;
+        if (P.seam_post && i == withhold) P.seam_post = fir->seam_err + 1;       // (dd_debug_seam: this chunk's flag is never set)
+        P.seam_err = fir->seam_err;
+        P.seam_spin_log2 = spin_log2;
         hP[i] = P;
         hS[i].in = P.in; hS[i].out = P.out; hS[i].abs0 = P.abs0; hS[i].off = P.off; hS[i].s = P.s; hS[i].lo = plv[i].lo; hS[i].pad = 0;
         hI[i + 1] = hI[i] + (plv[i].hi - plv[i].lo);
@@ -1314,6 +1402,15 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     if (u8) hipLaunchKernelGGL(k_chain_decim_multi<true>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
     else hipLaunchKernelGGL(k_chain_decim_multi<false>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
     DD_LAUNCH_CHECK();
+    {
+        // mirror the error count behind the launch; looked at by the next chunk-list call through this filter or by dd_stream_sync
+        std::lock_guard<std::mutex> lk(g_seam_mu);
+        if (fir->seam_pending) (void)hipEventSynchronize(fir->seam_ev);       // (one mirror copy in flight per filter)
+        DD_HIP_CHECK(hipMemcpyAsync(fir->seam_err_host, fir->seam_err, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        DD_HIP_CHECK(hipEventRecord(fir->seam_ev, s));
+        if (!fir->seam_pending) g_seam_pending.push_back(fir);
+        fir->seam_pending = 1;
+    }
     fir->last_kernel = DD_KERNEL_DECIM_MULTI;
     fir->parity ^= 1;
     fir->tail_override = nullptr;

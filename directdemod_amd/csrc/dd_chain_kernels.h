@@ -24,7 +24,14 @@ struct dd_fir {
     int last_kernel;        // DD_KERNEL_* of the last fused launch through this filter
     char* multi;            // chunk-list launches: seam flags, per-chunk parameter blocks, prefix tables, seam state (grow-only)
     size_t multi_bytes;
+    // chunk-list launches: hand-overs that timed out (dd_seam_wait), counted on the device, mirrored into a pinned word
+    // behind every launch and looked at by the next chunk-list call on this filter and by dd_stream_sync
+    unsigned int* seam_err;         // device
+    unsigned int* seam_err_host;    // pinned
+    hipEvent_t seam_ev;             // recorded behind the mirror copy
+    int seam_pending;               // a mirror copy has been enqueued and not looked at yet
 };
+
 // demod_fm object: carried last sample (demod_fm.py:43-49)
 struct dd_fm {
     float2* last;           // device: [2] ping-pong
@@ -75,6 +82,8 @@ struct DDChainParams {
     // lasty_in; seam_post: set, behind an agent-scope release, by the tile that has written tail_out / lasty_out.
     unsigned int* seam_wait;
     unsigned int* seam_post;
+    unsigned int* seam_err;    // counts waits that gave up (the launch's outputs are then invalid: reported as DD_ERR_TIMEOUT)
+    int seam_spin_log2;        // bound of the wait, in polls of one lane (s_sleep 8 between polls)
 };
 
 // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the

@@ -8,6 +8,7 @@
 #include "../../include/directdemod_hip.h"
 
 void dd_set_error(const char* fmt, ...);
+int dd_seam_poll_all(void);         // (dd_chain.hip) chunk-list launches whose in-launch hand-over timed out: DD_OK or DD_ERR_TIMEOUT
 
 #define DD_HIP_CHECK(expr)                                                        \
     do {                                                                          \
@@ -48,6 +49,7 @@ struct DDScratchLock {
     DDScratchLock& operator=(const DDScratchLock&) = delete;
 };
 void dd_scratch_forget_stream(hipStream_t s);  // the stream is about to be destroyed: free its buffers
+void dd_audio_forget_stream(hipStream_t s);    // ... and its hipFFT plans and chirp-z tables (dd_audio.hip)
 
 
 // Per-device one-time work (hipFuncSetAttribute and friends apply to the current device only; the C-ABI has

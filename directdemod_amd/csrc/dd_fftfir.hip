@@ -246,7 +246,7 @@ __device__ __forceinline__ float ff_atan_small(float y, float x) {
 #define F1_HP_OFF (F1_WAVES * F1_WAVE_BYTES)     // the tap spectrum as the lanes multiply it, [16][64] complex64: one copy per workgroup
 #define F1_LDS_BYTES (F1_HP_OFF + 16 * 64 * 8)
 #ifndef F1_RUN_BLOCKS
-#define F1_RUN_BLOCKS 4            // blocks per contiguous run of a wave (DDFft1kMap)
+#define F1_RUN_BLOCKS 8            // blocks per contiguous run of a wave (DDFft1kMap)
 #endif
 
 // Which interior blocks a wave takes (blocks 1 .. nblk-2; NI of them, NW waves).  Wave w owns B_w = b or b + 1 blocks (the
@@ -268,9 +268,10 @@ struct DDFft1kTabs {
     const float2* tw1;     // [64][16]   W1024^{lane k}
     const float2* tw2;     // [4][16]    W64^{n0 k}
     const float2* hp;      // [16][64]   H[k0 + 16 (4 c + j) + 256 k2] / 1024 at [4 c + k2][4 k0 + j]
-    float2 crot;
+    float2 crot;           // e^{-j theta}
     float theta_sub;       // != 0: |theta| is small -- the discriminator subtracts it from the angle instead of rotating every
-                           // product by crot (crot is then 1): 12 packed adds instead of 24 packed multiply-adds per block
+                           // product by crot: 12 packed adds instead of 24 packed multiply-adds per block (groups of outputs
+                           // that need the full-range arctangent are rotated after all)
     int base;              // block b covers FIR outputs [768 b + base, 768 b + base + 768), base in [s - 15, s]: chosen on the host so
                            // that every interior store instruction writes whole 64-byte lines of `out` (a stream START drops one
                            // angle, demod_fm.py:43-49, which put every 512-byte store 4 bytes ahead of a line boundary: PMC WRITE_SIZE
@@ -302,11 +303,18 @@ __device__ __forceinline__ void f1_load_pairs(const void* in, int64_t n0, int la
         unsigned m = (unsigned)lane + 64u * (r0 + i);
         if (CLAMP) m = m < lim ? m : lim;
         if (U8) {
+#ifndef FF_NO_NT_LOAD
+            const unsigned uu = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const uchar2*>(in) + n0) + m);
+            const uchar4 u = make_uchar4(uu & 255u, (uu >> 8) & 255u, (uu >> 16) & 255u, uu >> 24);
+#else
             const uchar4 u = reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(in) + n0)[m];
+#endif
             x[2 * (r0 + i)] = (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
             x[2 * (r0 + i) + 1] = (v2f){(float)u.z - 127.5f, (float)u.w - 127.5f};
         } else {
-#ifdef FF_NT_LOAD
+            // non-temporal (streamed once): with the moving-window block map the memory side of this kernel (-DFF_NO_COMPUTE) runs
+            // 0.1553 ms instead of 0.1622 (profiles/r04_fft_map_sweep.txt); -DFF_NO_NT_LOAD / -DFF_NO_NT_STORE: plain accesses
+#ifndef FF_NO_NT_LOAD
             typedef float v4f_ __attribute__((ext_vector_type(4)));
             const v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(reinterpret_cast<const float2*>(in) + n0) + m);
 #else
@@ -362,63 +370,64 @@ __device__ __forceinline__ v2f f1_edge_sample(const DDChainParams& P, int64_t n)
     return (v2f){v.x, v.y};
 }
 
-// angles of row pairs 2..7 from zz (two per lane and row pair: zz[2 r], zz[2 r + 1]), three groups of two row pairs:
-// angles | two of the next block's loads | two 8-byte stores
+// angles of row pairs 2 + 2 g, 3 + 2 g (group g of three) from zz (two per lane and row pair: zz[2 r], zz[2 r + 1]):
+// angles | two of the next block's loads | two 8-byte stores.  FAST: every product of the group has |im| < tan(pi/8) re
+// (wave-uniform, decided per group of 256 outputs: an angle beyond 22.5 degrees -- an amplitude null of a noise-like input,
+// SURVEY 8(d) input A -- sends 256 outputs through the full-range form, not the block's 768).
 template <bool U8, bool PARTIAL, bool LOADNEXT, bool FAST>
-__device__ __forceinline__ void f1_tail(const v2f (&zz)[16], v2f (&a)[16], const void* in, const int64_t n0_next, const int lane, float* const ob, const int lim_lo, const int limit,
-                                        const float theta_sub) {
+__device__ __forceinline__ void f1_tail_group(const int g, const v2f (&zz)[16], v2f (&a)[16], const void* in, const int64_t n0_next, const int lane, float* const ob, const int lim_lo,
+                                              const int limit, const float theta_sub, const v2f crot) {
+    float ang[4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        float ang[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const v2f z = zz[4 + 4 * g + i];
+    for (int i = 0; i < 4; ++i) {
+        v2f z = zz[4 + 4 * g + i];
 #ifdef FF_NO_DISC
-            ang[i] = z.x;
+        ang[i] = z.x;
 #else
-            // theta_sub: the NCO's per-sample rotation taken off the angle (|theta| <= 0.25, so the fast path's result stays
-            // inside (-pi, pi); the full-range form wraps)
-            if (FAST) {
-                ang[i] = ff_atan_small(z.y, z.x) - theta_sub;          // (the compiler pairs these into packed instructions)
-            } else {
-                float r = ff_atan2(z.y, z.x) - theta_sub;
-                r = r > 3.14159265358979f ? r - 6.28318530717959f : r;
-                r = r <= -3.14159265358979f ? r + 6.28318530717959f : r;
-                ang[i] = r;
+        if (FAST) {
+            // theta_sub: the NCO's per-sample rotation taken off the angle (|theta| <= 0.25, so the result stays inside (-pi, pi))
+            ang[i] = ff_atan_small(z.y, z.x) - theta_sub;          // (the compiler pairs these into packed instructions)
+        } else {
+            // full range: the rotation is applied to the product instead (nothing to wrap), and a zero product -- digital
+            // silence -- gives exactly 0 like np.angle(0) (demod_fm.py:40-49): ff_atan2's mx == 0 guard
+            if (theta_sub != 0.f) {                                // (wave-uniform)
+                const v2f t = ff_mul_lo(z, crot);
+                z = ff_fma_hi(z, crot, t);
             }
-#endif
-        }
-#ifdef FF_LOAD_NOWAIT
-        if (LOADNEXT) {                        // same loads, never consumed
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(in) + n0_next) + lane + 64 * (2 + 2 * g + i);
-                float4 junk;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(q) : "memory");
-            }
-        }
-#elif !defined(FF_NO_LOAD)
-        if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
-#endif
-#ifdef FF_NO_STORE
-        if (ang[0] + ang[1] + ang[2] + ang[3] == 1234.5f) ob[0] = ang[0];
-#else
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o = 128 * (2 * g + i);                    // output of this lane's first sample of the row pair, relative to ob
-            if (!PARTIAL) {
-#ifdef FF_NT_STORE
-                __builtin_nontemporal_store((v2f){ang[2 * i], ang[2 * i + 1]}, reinterpret_cast<v2f*>(ob + o));
-#else
-                *reinterpret_cast<float2*>(ob + o) = make_float2(ang[2 * i], ang[2 * i + 1]);
-#endif
-            } else {
-                if (2 * lane + o >= lim_lo && 2 * lane + o < limit) ob[o] = ang[2 * i];
-                if (2 * lane + o + 1 >= lim_lo && 2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
-            }
+            ang[i] = ff_atan2(z.y, z.x);
         }
 #endif
     }
+#ifdef FF_LOAD_NOWAIT
+    if (LOADNEXT) {                        // same loads, never consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(in) + n0_next) + lane + 64 * (2 + 2 * g + i);
+            float4 junk;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(q) : "memory");
+        }
+    }
+#elif !defined(FF_NO_LOAD)
+    if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
+#endif
+#ifdef FF_NO_STORE
+    if (ang[0] + ang[1] + ang[2] + ang[3] == 1234.5f) ob[0] = ang[0];
+#else
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int o = 128 * (2 * g + i);                    // output of this lane's first sample of the row pair, relative to ob
+        if (!PARTIAL) {
+#ifndef FF_NO_NT_STORE
+            __builtin_nontemporal_store((v2f){ang[2 * i], ang[2 * i + 1]}, reinterpret_cast<v2f*>(ob + o));
+#else
+            *reinterpret_cast<float2*>(ob + o) = make_float2(ang[2 * i], ang[2 * i + 1]);
+#endif
+        } else {
+            if (2 * lane + o >= lim_lo && 2 * lane + o < limit) ob[o] = ang[2 * i];
+            if (2 * lane + o + 1 >= lim_lo && 2 * lane + o + 1 < limit) ob[o + 1] = ang[2 * i + 1];
+        }
+    }
+#endif
 }
 
 // one block.  On entry a[0..3] hold rows 0..3 of column t (the overlap kept from the previous block, or swapped by the
@@ -575,22 +584,51 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
 #ifndef FF_NO_LOAD
     if (LOADNEXT && jump) f1_load_pairs<U8, false, 4>(in, n0_next, lane, jl, 0, 2);
 #endif
-    // wave-uniform fast path: every |angle| of the block's 768 outputs below 22.5 degrees (|im| <= tan(pi/8) re)
-    float worst = -1.0f;
+    // wave-uniform fast path per group of two row pairs: every |angle| of its 256 outputs below 22.5 degrees, |im| < tan(pi/8) re
+    // (strictly: a product of exactly zero -- 1024 samples of digital silence -- must take the full-range form, whose
+    // result for it is 0; the small-angle form would divide 0 by 0)
+    bool fast[3];
 #pragma unroll
-    for (int r = 4; r < 16; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
-    const bool fast = __builtin_amdgcn_ballot_w64(worst > 0.f) == 0;
+    for (int g = 0; g < 3; ++g) {
+        float worst = -1.0f;
+#pragma unroll
+        for (int r = 4 + 4 * g; r < 8 + 4 * g; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
+        fast[g] = __builtin_amdgcn_ballot_w64(worst >= 0.f) == 0;
+    }
     FF_T(11);
     float* const ob = out_row4 + 2 * lane;
-    if (fast) f1_tail<U8, PARTIAL, LOADNEXT, true>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
-    else f1_tail<U8, PARTIAL, LOADNEXT, false>(zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        if (fast[g]) f1_tail_group<U8, PARTIAL, LOADNEXT, true>(g, zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub, crot);
+        else f1_tail_group<U8, PARTIAL, LOADNEXT, false>(g, zz, a, in, n0_next, lane, ob, lim_lo, limit, theta_sub, crot);
+    }
     FF_T(12);
 }
 
 // one edge block (the chunk's first and / or last): samples fetched one by one through f1_edge_sample, stores
 // predicated on [s, L), carried state read and written.  Cold: two blocks per chunk.
+// The kernel's arguments as they lie in the kernarg segment.  The edge block reads them THERE: structs handed by value to a
+// function that is not inlined are first copied to scratch memory -- by every wave, at kernel entry, whether it makes the call
+// or not: 9 KB per wave x 3072 waves = 28 MB of stores per launch, the "10 % more bytes written than the output holds" of
+// round 3's WRITE_SIZE reading (profiles/r04_inputA_and_write_size_before.txt: 1.098 x on an aligned continuing chunk).
+struct F1KernArgs {
+    DDChainParams P;
+    DDFft1kTabs T;
+    DDFft1kMap M;
+    int nblk, nwaves;
+};
+typedef const __attribute__((address_space(4))) F1KernArgs* F1KernArgsPtr;
+
 template <bool U8>
-__device__ __noinline__ void f1_edge_block(const DDChainParams P, const DDFft1kTabs T, int q, int nblk, v2f* const X, const v2f* const hp, const int lane) {
+__device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X, const v2f* const hp, const int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const F1KernArgs* const kg = (const F1KernArgs*)ka;        // (address-space cast: device pass only)
+#else
+    const F1KernArgs* const kg = nullptr;
+#endif
+    const DDChainParams P = kg->P;
+    const DDFft1kTabs T = kg->T;
+    const int nblk = kg->nblk;
     // (its own copy of the twiddles: arrays handed to a function that is not inlined would live in scratch memory for
     // the whole kernel)
     const int tcol = 2 * (lane & 31) + (lane >> 5);
@@ -676,7 +714,8 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     __syncthreads();                           // the only barrier of the kernel, before any wave may leave
     const v2f* const hp = HP + lane;
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
-    if (gw == 0) f1_edge_block<U8>(P, T, 0, nblk, X, hp, lane);
+    F1KernArgsPtr ka = (F1KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (gw == 0) f1_edge_block<U8>(ka, 0, X, hp, lane);
     // this wave's interior blocks: run k = [1 + start_k, 1 + start_k + len_k)
     const int ni = nblk - 2;
     const int w0 = ni > 0 ? (int)(((int64_t)ni * gw) / nwaves) : 0, w1 = ni > 0 ? (int)(((int64_t)ni * (gw + 1)) / nwaves) : 0;
@@ -754,16 +793,25 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
 #endif
     }
 #undef F1_RUN
-    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8>(P, T, nblk - 1, nblk, X, hp, lane);
+    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8>(ka, nblk - 1, X, hp, lane);
 }
 
 // ============================================================================ host side
+#define F1_HP_SLOTS 4
 struct DDFftState {
     int K;
     std::vector<double> taps;
     float2* tw1;        // [64][16]  W1024^{t k}
     float2* tw2;        // [4][16]   W64^{n0 k}
-    float2* hp;         // [16][64]  the tap spectrum for the frequency in `cyc`, as pass 3 multiplies it
+    // the tap spectrum for the frequency in `cyc`, as pass 3 multiplies it ([16][64]): a ring of device tables, each with a
+    // pinned staging copy and an event, so that a caller that retunes from chunk to chunk (a Doppler-tracking loop, cf.
+    // decode_funcube.py:228) never stalls the stream: the new spectrum is computed on the host, copied asynchronously in
+    // stream order into the NEXT slot, and a slot is only rewritten once everything that used it has finished
+    float2* hp[F1_HP_SLOTS];
+    float2* hp_host[F1_HP_SLOTS];
+    hipEvent_t hp_ev[F1_HP_SLOTS];
+    int hp_ev_set[F1_HP_SLOTS];
+    int cur;
     uint64_t cyc;
     int have_h;
     int nco;
@@ -799,7 +847,9 @@ int dd_fft_create(void** st, const double* taps, int K) {
     DDFftState* s = new DDFftState();
     s->K = K;
     s->taps.assign(taps, taps + K);
-    s->tw1 = s->tw2 = s->hp = nullptr;
+    s->tw1 = s->tw2 = nullptr;
+    for (int i = 0; i < F1_HP_SLOTS; ++i) { s->hp[i] = nullptr; s->hp_host[i] = nullptr; s->hp_ev[i] = nullptr; s->hp_ev_set[i] = 0; }
+    s->cur = 0;
     s->cyc = 0;
     s->have_h = 0;
     s->nco = 0;
@@ -816,7 +866,11 @@ int dd_fft_create(void** st, const double* taps, int K) {
         }
     hipError_t e = hipMalloc((void**)&s->tw1, u1.size() * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void**)&s->tw2, u2.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->hp, 64 * 16 * sizeof(float2));
+    for (int i = 0; i < F1_HP_SLOTS && e == hipSuccess; ++i) {
+        e = hipMalloc((void**)&s->hp[i], 64 * 16 * sizeof(float2));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s->hp_host[i], 64 * 16 * sizeof(float2), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->hp_ev[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMemcpy(s->tw1, u1.data(), u1.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->tw2, u2.data(), u2.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -833,7 +887,11 @@ void dd_fft_destroy(void* stv) {
     if (!s) return;
     if (s->tw1) (void)hipFree(s->tw1);
     if (s->tw2) (void)hipFree(s->tw2);
-    if (s->hp) (void)hipFree(s->hp);
+    for (int i = 0; i < F1_HP_SLOTS; ++i) {
+        if (s->hp[i]) (void)hipFree(s->hp[i]);
+        if (s->hp_host[i]) (void)hipHostFree(s->hp_host[i]);
+        if (s->hp_ev[i]) (void)hipEventDestroy(s->hp_ev[i]);
+    }
     delete s;
 }
 
@@ -850,7 +908,14 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
         g[k] = std::complex<double>((double)(s->taps[k] * cosl(a)), (double)(s->taps[k] * sinl(a)));
     }
     fft_pow2(g);
-    std::vector<float2> hp(64 * 16);
+    // the slot after the current one; whatever used it last (>= F1_HP_SLOTS - 1 retunes ago) is waited for -- normally long done
+    const int nxt = s->have_h ? (s->cur + 1) % F1_HP_SLOTS : s->cur;
+    if (s->have_h) {
+        DD_HIP_CHECK(hipEventRecord(s->hp_ev[s->cur], stream));        // every launch so far that read the current table
+        s->hp_ev_set[s->cur] = 1;
+    }
+    if (s->hp_ev_set[nxt]) DD_HIP_CHECK(hipEventSynchronize(s->hp_ev[nxt]));
+    float2* const hp = s->hp_host[nxt];
     for (int k0 = 0; k0 < 16; ++k0)
         for (int j = 0; j < 4; ++j)
             for (int c = 0; c < 4; ++c)
@@ -858,9 +923,8 @@ static int fft_prepare(DDFftState* s, bool nco, uint64_t cyc, hipStream_t stream
                     const std::complex<double> h = g[k0 + 16 * (4 * c + j) + 256 * k2] / (double)F1_N;
                     hp[(4 * c + k2) * 64 + 4 * k0 + j] = make_float2((float)h.real(), (float)h.imag());
                 }
-    // an earlier launch on this stream may still read the table (a chain changes its frequency rarely: once per handle)
-    DD_HIP_CHECK(hipStreamSynchronize(stream));
-    DD_HIP_CHECK(hipMemcpy(s->hp, hp.data(), hp.size() * sizeof(float2), hipMemcpyHostToDevice));
+    DD_HIP_CHECK(hipMemcpyAsync(s->hp[nxt], hp, 64 * 16 * sizeof(float2), hipMemcpyHostToDevice, stream));
+    s->cur = nxt;
     s->cyc = cyc;
     s->nco = (int)nco;
     s->have_h = 1;
@@ -888,7 +952,7 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
         attr1.mark();
     }
     DDFft1kTabs T1;
-    T1.tw1 = s->tw1; T1.tw2 = s->tw2; T1.hp = s->hp;
+    T1.tw1 = s->tw1; T1.tw2 = s->tw2; T1.hp = s->hp[s->cur];
     {
         const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * frac;
@@ -897,7 +961,7 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
         static const char* rot_env = getenv("DD_FFT_ROTATE");          // tools: force the rotation form
         if (fabsl(th) <= 0.25L && th != 0.0L && !(rot_env && atoi(rot_env))) {
             T1.theta_sub = (float)th;
-            T1.crot = make_float2(1.f, 0.f);
+            T1.crot = make_float2((float)cosl(a), (float)-sinl(a));     // (the full-range angle path rotates by it instead)
         } else {
             T1.theta_sub = 0.f;
             T1.crot = make_float2((float)cosl(a), (float)-sinl(a));

@@ -30,6 +30,7 @@
 #include "dd_chain_kernels.h"
 #include "dd_fftfir.h"
 #include <stdlib.h>
+#include <atomic>
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
@@ -1010,6 +1011,37 @@ void dd_mfma_destroy(void* st) {
 
 #define DD_STAMP_WGS 1024      // workgroups the DD_STAMPS diagnostic buffer holds
 
+// Which M = 1 kernel runs: by tap class, unless a tool or test has forced one.  The choice is a process-wide word set
+// through dd_debug_select_kernel (a debug entry like dd_debug_fill_lds); the environment variable DD_MFMA_KERNEL only
+// seeds it, read ONCE when the first chain is launched (no getenv in the launch path).
+enum { DD_KSEL_UNREAD = -1, DD_KSEL_AUTO = 0, DD_KSEL_AB = 1, DD_KSEL_WS = 2, DD_KSEL_FFT1K = 3 };
+static std::atomic<int> g_kernel_sel{DD_KSEL_UNREAD};
+static int kernel_sel_parse(const char* name) {
+    if (!name || !*name || strcmp(name, "auto") == 0) return DD_KSEL_AUTO;
+    if (strcmp(name, "ab") == 0) return DD_KSEL_AB;
+    if (strcmp(name, "ws") == 0) return DD_KSEL_WS;
+    if (strcmp(name, "fft1k") == 0) return DD_KSEL_FFT1K;
+    return -2;
+}
+static int kernel_sel() {
+    int c = g_kernel_sel.load(std::memory_order_relaxed);
+    if (c == DD_KSEL_UNREAD) {
+        c = kernel_sel_parse(getenv("DD_MFMA_KERNEL"));
+        if (c < 0) c = DD_KSEL_AUTO;
+        g_kernel_sel.store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+extern "C" int dd_debug_select_kernel(const char* name) {
+    const int c = kernel_sel_parse(name);
+    if (c < 0) {
+        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k)", name);
+        return DD_ERR_INVALID;
+    }
+    g_kernel_sel.store(c, std::memory_order_relaxed);
+    return DD_OK;
+}
+
 template <int NKS>
 static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* kernel_id) {
     using G = MfmaGeom<NKS>;
@@ -1044,8 +1076,8 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
     static int launches = 0;
     const bool want_stamps_env = stamps_env != nullptr && launches++ == stamps_at;
-    const char* kern_env0 = getenv("DD_MFMA_KERNEL");
-    const bool ws_env = kern_env0 && strcmp(kern_env0, "ws") == 0;
+    const int ksel = kernel_sel();
+    const bool ws_env = ksel == DD_KSEL_WS;
     // only these have an instantiation with the stamps compiled in: 255-tap class, complex64 input; FM output, or k_chain_mfma_ws
     const bool want_stamps = want_stamps_env && NKS == 18 && !(P.flags & DD_CHAIN_U8_INPUT) && ((P.flags & DD_CHAIN_FM) || ws_env);
     if (want_stamps) {
@@ -1068,15 +1100,15 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
         if (hi >= lo) { t_first = (int)lo; t_last = (int)hi + 1; }
     }
     const int n_int = t_last - t_first;
-    // DD_MFMA_KERNEL (read per launch: tools and tests switch kernels inside one process): "ab" / "ws" force the MFMA
-    // kernels, "fft1k" the overlap-save FFT kernel wherever it applies; unset = by tap class
-    const char* kern_env1 = getenv("DD_MFMA_KERNEL");
-    const bool force_fft1k = kern_env1 && strcmp(kern_env1, "fft1k") == 0;
-    const bool force_mfma = kern_env1 && (strcmp(kern_env1, "ab") == 0 || strcmp(kern_env1, "ws") == 0);
+    // dd_debug_select_kernel (tools and tests switch kernels inside one process): "ab" / "ws" force the MFMA kernels,
+    // "fft1k" the overlap-save FFT kernel wherever it applies; "auto" = by tap class
+    const bool force_fft1k = ksel == DD_KSEL_FFT1K;
+    const bool force_mfma = ksel == DD_KSEL_AB || ksel == DD_KSEL_WS;
     // The FFT kernel's time does not depend on the tap count (0.221 ms per 2^26 samples, 0.207 from raw u8); the MFMA
     // kernel's does: 0.227 ms in the 162..257-tap class, 0.20 below.  FM output only.
     const bool fft_class = NKS == 18;
-    if ((force_fft1k || (fft_class && !force_mfma)) && dd_fft1k_supported(st->K, 1, P.flags) && aligned) {
+    // (any input alignment: its block grid follows the alignment of `out`, dd_fftfir.hip DDFft1kTabs::base)
+    if ((force_fft1k || (fft_class && !force_mfma)) && dd_fft1k_supported(st->K, 1, P.flags)) {
         if (!st->fft && !st->fft_tried) {
             st->fft_tried = 1;
             if (dd_fft_create(&st->fft, st->taps.data(), st->K) != DD_OK) st->fft = nullptr;
@@ -1099,8 +1131,7 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
         const bool cx = !(P.flags & DD_CHAIN_FM);
         const dim3 g(grid + n_edge), b(WS_THREADS);
         // the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
-        const char* kern_env = kern_env1;
-        const bool use_ab = !(kern_env && strcmp(kern_env, "ws") == 0);
+        const bool use_ab = !ws_env;
         const size_t lds_ab = (size_t)AbGeom<NKS>::LDS_BYTES;
         if (use_ab) {
             if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true, true>), g, b, lds_ab, s, P, t, t_first, t_last, grid);

@@ -216,13 +216,14 @@ extern "C" int dd_stream_destroy(void* stream) {
     if (stream) {
         DD_HIP_CHECK(hipStreamSynchronize(dd_stream(stream)));
         dd_scratch_forget_stream(dd_stream(stream));
+        dd_audio_forget_stream(dd_stream(stream));
         DD_HIP_CHECK(hipStreamDestroy(dd_stream(stream)));
     }
     return DD_OK;
 }
 extern "C" int dd_stream_sync(void* stream) {
     DD_HIP_CHECK(hipStreamSynchronize(dd_stream(stream)));
-    return DD_OK;
+    return dd_seam_poll_all();          // a chunk-list launch whose in-launch hand-over timed out (DD_ERR_TIMEOUT)
 }
 extern "C" int dd_event_create(void** ev) {
     DD_REQUIRE(ev, "ev");

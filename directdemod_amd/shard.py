@@ -98,11 +98,12 @@ def run_shard(engine, read_ptr, start, stop, ntaps, decim, out_ptr):
     return engine.process(read_ptr(start), out_ptr, stop - start)
 
 
-def gather_outputs(local, count, world, dist, device=None):
+def gather_outputs(local, count, world, dist, device=None, force=False):
     """all_gather of variable-length per-rank outputs (torch tensors); returns the list of
-    per-rank tensors trimmed to their counts.  No-op for world == 1."""
+    per-rank tensors trimmed to their counts.  No-op for world == 1 (unless `force`: the
+    collectives then run on the one-rank group, a functional check of the backend)."""
     import torch
-    if world == 1:
+    if world == 1 and not force:
         return [local[:count]]
     cnt = torch.tensor([count], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(cnt) for _ in range(world)]

@@ -37,6 +37,9 @@ extern "C" {
 #define DD_ERR_NOMEM       -3
 #define DD_ERR_UNSUPPORTED -4
 #define DD_ERR_NODEVICE    -5   /* no MI355X visible: the product path fails loudly */
+#define DD_ERR_TIMEOUT     -6   /* a chunk-list launch (dd_*_process_chunks) gave up waiting for the carried state of the previous
+                                 * chunk inside the launch: the outputs of THAT call are invalid.  Reported by the next chunk-list
+                                 * call on the same filter or by dd_stream_sync, whichever comes first */
 
 /* FIR history initialisation (filters.py:44-48, 64-70) */
 #define DD_HIST_ZEROS 0     /* plain lfilter / lfiltic with no past inputs */
@@ -68,6 +71,15 @@ int  dd_host_unregister(void* hptr);
 /* diagnostic: fill the LDS of every compute unit with `pattern` (LDS is not cleared between workgroups).  The parity
  * suite runs the chain kernels after a NaN fill and after a zero fill and requires bit-identical outputs. */
 int  dd_debug_fill_lds(uint32_t pattern, void* stream);
+/* diagnostic: force one of the M = 1 chain kernels for every later launch of this process -- "ab" (k_chain_mfma_ab), "ws"
+ * (k_chain_mfma_ws), "fft1k" (k_chain_fft1k, wherever it applies), "auto" / NULL (by tap class, the default).  The parity,
+ * full-size and determinism suites run both FM kernels this way; the environment variable DD_MFMA_KERNEL seeds the choice
+ * once per process.  No reference counterpart. */
+int  dd_debug_select_kernel(const char* name);
+/* diagnostic: the NEXT chunk-list launch withholds the hand-over flag of chunk `withhold_chunk` (>= 0; -1: none) and every
+ * later one bounds its in-launch waits by 2^spin_log2 polls (0: the default, 2^24 = seconds).  Lets a test see DD_ERR_TIMEOUT
+ * instead of silently wrong samples.  No reference counterpart (the reference's chunk loop is sequential, decode_noaa.py:619-624). */
+int  dd_debug_seam(int withhold_chunk, int spin_log2);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

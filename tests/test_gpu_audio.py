@@ -319,6 +319,44 @@ def test_class_chunk_loop_deferred_extend_keeps_the_reference_order_of_events(dd
     assert np.array_equal(got.signal, ref.signal)
 
 
+@pytest.mark.parametrize("which", ["strict", "freqs"])
+def test_chunk_changed_after_extend_by_an_unrecorded_operation(dd, which):
+    """extend() copies at call time in the reference (comm.py:163).  Here a chunk with pending operations is only NOTED by the
+    container, so every operation that changes the chunk afterwards must first let the container take the samples the chunk had:
+    the recorded operations do (through _record), and so must the two that run at once -- the strict bwLim behind anything but an
+    FM demodulation (comm.py:110-116) and offsetFreq with a per-sample frequency array (decode_funcube.py:228)  (ADVICE r3)."""
+    rate, L, chunk, M = 2048000, 300000, 100000, 34
+    x = O.grid_c64(O.synth_iq_fm(L, rate, 19, f_carrier=30000.0, f_mod=1e3, dev=5.0))
+    res = dd.hip.DevArray.from_host(x, dtype=np.complex64)
+    taps = O.win_blackmanharris(151)
+
+    def loop(meddle):
+        class _Src:
+            length = L
+        ck = dd.chunker.chunker(_Src(), chunk)
+        out = dd.comm.commSignal((rate // M) // 2 if which == "strict" else rate // M)
+        filt = dd.filters.filter(taps, 1, storeState=True)
+        fm = dd.demod_fm.demod_fm()
+        for a, b in ck.getChunks:
+            s = dd.comm.commSignal(rate, res.view(a, b - a), ck).offsetFreq(30000.0).filter(filt).bwLim(rate // M, uniq="First")
+            if which == "strict":
+                # real data whose last pending operation is NOT the demodulation: the strict bwLim then runs at once
+                # (after an FM demodulation it is recorded with the chain)
+                s.funcApply(fm.demod).bwLim(s.sampRate // 2, uniq="Second")
+            out.extend(s)                                   # operations pending: noted, not copied
+            if meddle and which == "strict":
+                s.bwLim(s.sampRate // 2, True)
+            elif meddle:
+                keep = ck.get(dd.constants.CHUNK_FREQOFFSET)
+                s.offsetFreq(np.full(s.length, 123.0))
+                ck.set(dd.constants.CHUNK_FREQOFFSET, keep)          # (the meddling must not move the NEXT chunk's NCO index)
+        return out
+
+    got, ref = loop(True), loop(False)
+    assert got.length == ref.length
+    assert np.array_equal(got.signal, ref.signal)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_class_chunk_loop_random_shapes_three_ways(dd, seed):
     """seeded random chunk loops (length, chunk size, taps, decimation, NCO on/off, FM on/off, strict resample on/off, u8 or

@@ -84,14 +84,11 @@ def _hamming(K):
 @pytest.mark.parametrize("ntaps", [255, 151, 127, 63])
 @pytest.mark.parametrize("u8", [False, True])
 @pytest.mark.parametrize("kernel", ["auto", "ab", "fft1k"])
-def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, monkeypatch):
+def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, select_kernel):
     """NCO + FIR + FM at M = 1: k_chain_fft1k (the 162..256-tap class by default, every class when forced: no atomics, one
     wave per block, LDS image rewritten completely before it is read) and k_chain_mfma_ab (every tap class) with the edge
     tiles riding along."""
-    if kernel == "auto":
-        monkeypatch.delenv("DD_MFMA_KERNEL", raising=False)
-    else:
-        monkeypatch.setenv("DD_MFMA_KERNEL", kernel)
+    select_kernel(None if kernel == "auto" else kernel)
     want = g.hip.DD_KERNEL_FFT_OS if (kernel == "fft1k" or (kernel == "auto" and ntaps > 161)) else g.hip.DD_KERNEL_MFMA_AB
     t = g.torch
     n = (1 << 23) + 12345
@@ -197,6 +194,57 @@ def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm
         assert bool(t.isfinite(ref[:tot]).all())
         diff = int((out[:tot].view(t.int32) != ref[:tot].view(t.int32)).sum())
         assert diff == 0, "%d of %d output words differ from the chunk loop (rep %d)" % (diff, tot, rep)
+    lib.dd_chain_destroy(h)
+
+
+def test_withheld_hand_over_is_reported_not_silently_wrong(g):
+    """dd_chain_process_chunks hands the carried FIR / FM state from chunk to chunk INSIDE one launch (agent-scope flags).  A
+    consumer whose flag never arrives gives up after a bounded spin and reads whatever the state buffers hold; that used to end
+    with DD_OK and wrong samples.  dd_debug_seam withholds one chunk's flag (and shortens the spin bound): the call itself still
+    returns (the kernel completes), the error surfaces as DD_ERR_TIMEOUT at dd_stream_sync -- or at the next chunk-list call on
+    the filter, whichever comes first -- and a run without the fault afterwards is bit-identical to the chunk loop again."""
+    t, lib, hip = g.torch, g.lib, g.hip
+    M, taps, n = 34, np.ascontiguousarray(_hamming(151), dtype=np.float64), 1 << 22
+    cuts = [0, 1000000, 2000001, 3000000, n]
+    x = g.bench.make_input(t, n, 0, g.dev, 99)
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps), hip.cycles_q64(30000.0, FS), M,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "create")
+    bounds = (C.c_int64 * len(cuts))(*cuts)
+    nout = (C.c_int64 * (len(cuts) - 1))()
+    nfl = n // M + 8
+
+    def one_launch():
+        lib.dd_chain_reset(h, g.stream)
+        out = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
+        rc = lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), bounds, len(cuts) - 1, nout, g.stream)
+        return rc, out
+    rc, good = one_launch()
+    assert rc == 0 and lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_MULTI
+    assert lib.dd_stream_sync(g.stream) == 0
+    # fault 1: reported by dd_stream_sync
+    hip.check(lib.dd_debug_seam(1, 12), "dd_debug_seam")              # chunk 1's flag withheld, waits bounded by 2^12 polls
+    rc, bad = one_launch()
+    assert rc == 0                                                   # (the launch is asynchronous: nothing is known yet)
+    rc = lib.dd_stream_sync(g.stream)
+    assert rc == hip.DD_ERR_TIMEOUT, rc
+    assert b"hand-over" in lib.dd_last_error()
+    assert lib.dd_stream_sync(g.stream) == 0                         # reported once
+    # fault 2: reported by the next chunk-list call through the same filter (once the faulty launch has finished)
+    hip.check(lib.dd_debug_seam(2, 12), "dd_debug_seam")
+    rc, bad = one_launch()
+    assert rc == 0
+    t.cuda.synchronize()                                             # (torch's own sync: the library has not looked yet)
+    rc, _ = one_launch()
+    assert rc == hip.DD_ERR_TIMEOUT, rc
+    with pytest.raises(hip.HipError):
+        hip.check(rc, "dd_chain_process_chunks")
+    # and without the fault everything is as before
+    hip.check(lib.dd_debug_seam(-1, 0), "dd_debug_seam")
+    rc, again = one_launch()
+    assert rc == 0 and lib.dd_stream_sync(g.stream) == 0
+    tot = sum(nout)
+    assert int((again[:tot].view(t.int32) != good[:tot].view(t.int32)).sum()) == 0
     lib.dd_chain_destroy(h)
 
 

@@ -39,18 +39,15 @@ def _wrapped_max(torch, a, b, blk=1 << 24):
 @pytest.fixture(scope="module", params=["fft1k", "ab"])
 def run(request):
     """every test of this module under both M = 1 FM kernels: k_chain_fft1k (the default for 255 taps) and, forced with
-    DD_MFMA_KERNEL=ab (read per launch), k_chain_mfma_ab"""
+    dd_debug_select_kernel("ab"), k_chain_mfma_ab"""
     torch = pytest.importorskip("torch")
     old_env = os.environ.get("DD_MFMA_KERNEL")
-    if request.param == "ab":
-        os.environ["DD_MFMA_KERNEL"] = "ab"
-    else:
-        os.environ.pop("DD_MFMA_KERNEL", None)
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
     from directdemod_amd import _hip
     _hip.require_gpu()
+    _hip.select_kernel("ab" if request.param == "ab" else None)
     import bench
     n = 1 << LOG2N
     dev = torch.device("cuda", 0)
@@ -87,10 +84,7 @@ def run(request):
         torch, _hip, lib, x, one, n, taps, chain, process, stream, dev
     r.kernel = request.param
     yield r
-    if old_env is None:
-        os.environ.pop("DD_MFMA_KERNEL", None)
-    else:
-        os.environ["DD_MFMA_KERNEL"] = old_env
+    _hip.select_kernel(old_env)
 
 
 def test_mfma_path_equals_direct_f32_path_everywhere(run):

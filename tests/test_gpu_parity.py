@@ -275,13 +275,13 @@ def test_chain_c2_golden(dd, ops):
 
 @pytest.mark.parametrize("K", [162, 200, 255, 256])
 @pytest.mark.parametrize("f_off", [25000.0, -31000.0, 0.0, 700000.0])
-def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, monkeypatch):
+def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, select_kernel):
     """k_chain_fft1k (the default M = 1 FM kernel for 162..256 taps; forced here): 768-output blocks, the chunk's first and
     last block are edge blocks (carried history rotated back into the un-rotated frame, y[-1] from the carried last output,
     predicated stores, new state).  Chunks of 1, 2, K-2, 767, 768, 769, 1535, 1536 ... samples with state carried, the
     angle-subtraction form of the NCO step (|theta| <= 0.25 rad), the rotation form (700 kHz at 2.4 MS/s: theta = 1.83 rad),
     a negative offset, no offset; against the float64 oracle."""
-    monkeypatch.setenv("DD_MFMA_KERNEL", "fft1k")
+    select_kernel("fft1k")
     fs = 2400000
     cuts = np.cumsum([0, 1, 2, K - 2, 767, 768, 769, 1535, 1536, 5000, 3, 40000, 777])
     L = int(cuts[-1])
@@ -312,13 +312,40 @@ def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, monkeypatch):
     fm_check(out.signal, ref, np.concatenate(mags))
 
 
+def test_fft_kernel_retuned_every_chunk(dd, select_kernel):
+    """A caller that changes the NCO frequency from chunk to chunk (a Doppler-tracking loop; decode_funcube.py:228 goes as far
+    as a per-sample offset): k_chain_fft1k carries the NCO inside its tap spectrum, so every retune is a new spectrum -- computed
+    on the host and copied in stream order into the next of four table slots, without a stream synchronisation.  Nine chunks
+    (more retunes than slots, one chunk repeating its predecessor's frequency), carried FIR / FM state, against the oracle."""
+    select_kernel("fft1k")
+    fs, n = 2400000, 20000
+    freqs = [25000.0, -40000.0, 700000.0, 1234.5, 1234.5, 300000.0, 25000.0, -1100000.0, 5.0]
+    L = n * len(freqs)
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 4711, f_carrier=3000.0, f_mod=700.0, dev=4.0))
+    flt, fm = dd.filters.hamming(255), dd.demod_fm.demod_fm()
+    ck = dd.chunker.chunker(_Src(L), n)
+    fo = O.FilterState(O.win_hamming(255))
+    out = dd.comm.commSignal(fs)
+    last, refs, mags = None, [], []
+    for (a, b), f in zip(ck.getChunks, freqs):
+        out.extend(dd.comm.commSignal(fs, x[a:b], ck).offsetFreq(f).filter(flt).funcApply(fm.demod))
+        y = fo.applyOn(O.nco(x[a:b], f, fs, a))
+        prv = last
+        r, last = O.fm_demod(y, last)
+        refs.append(r)
+        yy = y if prv is None else np.concatenate([[prv], y])
+        mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
+    assert flt._last_kernel() == dd.hip.DD_KERNEL_FFT_OS
+    fm_check(out.signal, np.concatenate(refs), np.concatenate(mags))
+
+
 @pytest.mark.parametrize("kern", ["fft1k", "ab"])
 @pytest.mark.parametrize("seed", range(8))
-def test_m1_fm_chain_random_taps_and_cuts(dd, kern, seed, monkeypatch):
+def test_m1_fm_chain_random_taps_and_cuts(dd, kern, seed, select_kernel):
     """both M = 1 FM kernels on seeded random cases: taps that are no window (a low-pass design with random perturbations and sign
     changes, random length), random chunk cuts (lengths 1 .. 60 000, state carried), a random NCO frequency (either sign, up to
     fs/2) or none, raw u8 or complex64 chunks; against the float64 oracle chunk by chunk"""
-    monkeypatch.setenv("DD_MFMA_KERNEL", kern)
+    select_kernel(kern)
     rng = np.random.default_rng(7000 + seed)
     fs = int(rng.choice([2400000, 2048000, 10000000]))
     K = int(rng.integers(2, 257)) if kern == "fft1k" else int(rng.integers(16, 288))
@@ -570,7 +597,7 @@ def test_k_shards_on_one_gpu_equal_one_shot(dd):
 
 # ----------------------------------------------------------------------------- dynamic range of the MFMA path
 @pytest.mark.parametrize("profile", ["tiny", "huge", "mixed_tiles", "one_spike", "halo_spike", "zeros_then_signal"])
-def test_mfma_tile_scaling_paths(dd, profile, monkeypatch):
+def test_mfma_tile_scaling_paths(dd, profile, select_kernel):
     """The f16-limb tiles are used unscaled while their peak lies in [0.25, 32768) and with a
     per-tile power-of-two scale otherwise; the decision is taken per wave with two ballots and
     published through an LDS flag.  Drive interior (persistent-kernel) tiles through every
@@ -616,7 +643,7 @@ def test_mfma_tile_scaling_paths(dd, profile, monkeypatch):
     loc_tile = np.array([np.max(prod[max(0, i - blk):i + blk]) for i in range(0, len(prod), blk)]).repeat(blk)[:len(prod)]
     loc_fft = maximum_filter1d(prod, size=2049, mode="nearest")
     for kernel, loc in (("ab", loc_tile), ("fft1k", loc_fft)):
-        monkeypatch.setenv("DD_MFMA_KERNEL", kernel)
+        select_kernel(kernel)
         a = dd.comm.commSignal(fs, x).offsetFreq(25000.0).filter(dd.filters.hamming(255)) \
             .funcApply(dd.demod_fm.demod_fm().demod).signal
         mask = prod >= 1e-3 * loc
@@ -624,6 +651,13 @@ def test_mfma_tile_scaling_paths(dd, profile, monkeypatch):
         d = np.abs(np.angle(np.exp(1j * (np.asarray(a, dtype=np.float64) - a_ref))))
         assert len(a) == L - 1
         assert np.max(d[mask]) <= 5e-5, (profile, kernel, float(np.max(d[mask])))
+        if profile == "zeros_then_signal":
+            # digital silence: np.angle(0) = 0 in the reference (demod_fm.py:40-49).  A block / tile whose samples are all
+            # exactly zero must give exactly 0 -- not 0 * rcp(0) = NaN from the small-angle arctangent, which would
+            # poison every carried filter state behind the demodulator
+            assert np.all(np.isfinite(np.asarray(a))), (profile, kernel)
+            assert np.all(np.asarray(a)[8192:24000] == 0.0), (profile, kernel)
+            assert np.all(a_ref[8192:24000] == 0.0)
 
 
 def test_seek_with_lead_in_equals_primed_shard(dd):
@@ -760,7 +794,8 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         # first chunk (4-byte aligned bytes): the two-matrix-set kernel's u8 flavour (FM or complex output); the second
         # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
         # (FM output with 255 taps: the overlap-save FFT kernel takes the aligned chunk, whole)
-        want = (hip.DD_KERNEL_FFT_OS if fm else hip.DD_KERNEL_MFMA_AB) if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES
+        # (round 4: the FFT kernel lays its block grid by the OUTPUT's alignment and takes any input alignment)
+        want = hip.DD_KERNEL_FFT_OS if fm else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n

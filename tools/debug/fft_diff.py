@@ -16,7 +16,7 @@ ntaps = 255
 taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1)))
 outs = {}
 for kern in ("ab", "fft1k"):
-    os.environ["DD_MFMA_KERNEL"] = kern
+    _hip.select_kernel(kern)
     out = torch.zeros(n, dtype=torch.float32, device=dev)
     h = C.c_void_p()
     fl = _hip.DD_CHAIN_FM | (0 if os.environ.get("NONCO") else _hip.DD_CHAIN_NCO)

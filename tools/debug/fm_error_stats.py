@@ -16,7 +16,7 @@ for seed, kind in ((1235, "fm"), (1234, "noise")):
     ref, _ = O.fm_demod(y, None)
     mag = np.abs(y[1:] * np.conj(y[:-1]))
     for kern in os.environ.get("KERNELS", "fft1k,ab").split(","):
-        os.environ["DD_MFMA_KERNEL"] = kern
+        _hip.select_kernel(kern)
         s = comm.commSignal(fs, x).offsetFreq(25000.0).filter(filters.hamming(255)).funcApply(demod_fm.demod_fm().demod)
         d = np.abs(np.angle(np.exp(1j * (s.signal - ref))))
         well = mag >= 0.1 * np.median(mag)

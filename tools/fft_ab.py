@@ -27,7 +27,7 @@ for ntaps in [int(v) for v in os.environ.get("NTAPS", "255").split(",")]:
     ref = None
     for rnd in range(int(os.environ.get("ROUNDS", "2"))):
         for kern in kernels:
-            os.environ["DD_MFMA_KERNEL"] = kern
+            _hip.select_kernel(kern)
             out = torch.zeros(n, dtype=torch.float32, device=dev)
             h = C.c_void_p()
             _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), ntaps, _hip.cycles_q64(25000.0, 2400000), 1,

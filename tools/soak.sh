@@ -18,7 +18,7 @@ n = 1 << 26
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(255) / 254))
 for kern, u8 in (("fft1k", False), ("fft1k", True), ("ab", False), ("ab", True)):
-    os.environ["DD_MFMA_KERNEL"] = kern
+    _hip.select_kernel(kern)
     want = _hip.DD_KERNEL_FFT_OS if kern == "fft1k" else _hip.DD_KERNEL_MFMA_AB
     x = bench.make_input(torch, n, 0, dev, 11)
     if u8:
