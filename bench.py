@@ -734,7 +734,7 @@ def run_rank(args):
                 tj = json.load(open(tf))
                 traffic = tj.get("bytes_per_launch_log2n_%d" % args.log2n)
                 traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                  "tools/profile_r03.sh / tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
+                                  "tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
                                   % (tj.get("kernel", "?"), tj.get("git", "?")))
             except Exception:
                 traffic = None

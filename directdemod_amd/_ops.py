@@ -131,6 +131,28 @@ def find_peaks(cor, samp_rate, needle_len, max_peaks=None):
     return np.array(buf[:n.value], dtype=np.int64)
 
 
+def crude_tail(audio, samp_rate, needles, block=60000 * 4, want_env=False):
+    """getCrudeSync's audio-rate tail in one device call (decode_noaa.py:781-790): envelope in `block`-sample blocks, then
+    normalised correlation + peak pick for every needle (same length).  Returns ([peaks per needle], envelope DevArray or
+    None), or None when the fused entry declines (dd_noaa_crude_tail: DD_ERR_UNSUPPORTED) and the caller must go stage by stage."""
+    from . import _hip
+    nd = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in needles]))
+    nn, m = nd.shape
+    if audio.dtype not in (_F32, _F64) or nn > 2:
+        return None
+    max_peaks = int(audio.n / (0.45 * samp_rate)) + 2 + 64
+    buf = (C.c_int64 * (max_peaks * nn))()
+    cnt = (C.c_int * nn)()
+    env = DevArray(audio.n, _F64) if want_env else None
+    rc = lib().dd_noaa_crude_tail(audio.ptr, 1 if audio.dtype == _F32 else 0, audio.n, float(samp_rate), int(block),
+                                  nd.ctypes.data_as(C.POINTER(C.c_double)), int(m), int(nn), env.ptr if env is not None else None,
+                                  buf, max_peaks, cnt, None)
+    if rc == _hip.DD_ERR_UNSUPPORTED:
+        return None
+    check(rc, "dd_noaa_crude_tail")
+    return [np.array(buf[d * max_peaks:d * max_peaks + cnt[d]], dtype=np.int64) for d in range(nn)], env
+
+
 def filtfilt(taps, x):
     """F2 (filters.py:72-73 -> scipy.signal.filtfilt)"""
     t = np.ascontiguousarray(taps, dtype=np.float64)

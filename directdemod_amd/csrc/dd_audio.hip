@@ -1003,17 +1003,31 @@ extern "C" int dd_find_peaks_f64(const double* cor, int64_t n, double samp_rate,
 template <bool U8>
 __global__ void __launch_bounds__(256) k_sync_front(const void* __restrict__ iq, const int64_t* __restrict__ starts, int64_t L,
                                                     uint64_t cyc, const float2* __restrict__ tbl, float2* __restrict__ X) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L) return;
-    const int64_t g = starts[blockIdx.y] + i;
-    float2 v;
-    if (U8) {
-        const uchar2 u = reinterpret_cast<const uchar2*>(iq)[g];
-        v = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
-    } else {
-        v = reinterpret_cast<const float2*>(iq)[g];
+    // four samples per lane: four loads in flight, 32 contiguous bytes stored
+    const int64_t i0 = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    if (i0 >= L) return;
+    const int64_t g = starts[blockIdx.y] + i0;
+    float2 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t ge = i0 + e < L ? g + e : g;
+        if (U8) {
+            const uchar2 u = reinterpret_cast<const uchar2*>(iq)[ge];
+            v[e] = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+        } else {
+            v[e] = reinterpret_cast<const float2*>(iq)[ge];
+        }
     }
-    X[(int64_t)blockIdx.y * L + i] = dd_cmul(v, dd_phasor((uint64_t)i * cyc, tbl));      // sample index restarts per window (Q5)
+    float2* out = X + (int64_t)blockIdx.y * L + i0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = dd_cmul(v[e], dd_phasor((uint64_t)(i0 + e) * cyc, tbl));      // sample index restarts per window (Q5)
+    if (i0 + 3 < L && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        reinterpret_cast<float4*>(out)[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+        reinterpret_cast<float4*>(out)[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (i0 + e < L) out[e] = v[e];
+    }
 }
 
 // demod_fm (stateless) straight into the FFT buffer: W[b][j] = (angle(Y[j+1] conj Y[j]), 0)
@@ -1026,20 +1040,44 @@ __global__ void __launch_bounds__(256) k_sync_fm(const float2* __restrict__ Y, i
 
 // P[b][i] = sum h[b][0..i), Q likewise of h^2, in two launches over tiles of 2048 samples: tile sums, then each
 // tile adds the sums of the tiles before it (ascending) to its own scan -- every tile of every window in parallel
-__device__ __forceinline__ void dd_scan_tile_load(const double* __restrict__ h, int64_t n, int64_t i0, double (&p)[8], double (&q)[8]) {
+// (a lane scans 8 consecutive samples, but the tile is fetched -- and the prefix sums are written -- with lanes on consecutive
+// addresses, through an LDS image skewed by one element per 8: read lane by lane, 64-byte runs at a 64-byte stride, these
+// kernels moved 2 TB/s)
+#define DD_SCAN_LDS (DD_SCAN_TILE + DD_SCAN_TILE / 8)
+__device__ __forceinline__ void dd_scan_tile_load(const double* __restrict__ h, int64_t n, int64_t tile0, int t, double* __restrict__ lds,
+                                                  double (&p)[8], double (&q)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = t + 256 * r;
+        lds[e + (e >> 3)] = (tile0 + e < n) ? h[tile0 + e] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const double v = (i0 + j < n) ? h[i0 + j] : 0.0;
+        const double v = lds[9 * t + j];
         p[j] = j ? p[j - 1] + v : v;
         q[j] = j ? q[j - 1] + v * v : v * v;
     }
 }
+// out[tile0 + 1 + e] = v[e] for the tile's 2048 values held 8 per lane (lane t: e = 8 t .. 8 t + 7), stored coalesced
+__device__ __forceinline__ void dd_scan_tile_store(double* __restrict__ out, int64_t n, int64_t tile0, int t, double* __restrict__ lds, const double (&v)[8]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[9 * t + j] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = t + 256 * r;
+        if (tile0 + e < n) out[tile0 + e + 1] = lds[e + (e >> 3)];
+    }
+}
 __global__ void __launch_bounds__(256) k_scan_part(const double* __restrict__ h, int64_t n, int tiles, double2* __restrict__ part) {
     __shared__ double sp[4], sq[4];
+    __shared__ double lds[DD_SCAN_LDS];
     h += (int64_t)blockIdx.y * n;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double p[8], q[8];
-    dd_scan_tile_load(h, n, (int64_t)blockIdx.x * DD_SCAN_TILE + 8 * t, p, q);
+    dd_scan_tile_load(h, n, (int64_t)blockIdx.x * DD_SCAN_TILE, t, lds, p, q);
     double tp = p[7], tq = q[7];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { tp += __shfl_down(tp, d); tq += __shfl_down(tq, d); }
@@ -1054,12 +1092,19 @@ __global__ void __launch_bounds__(256) k_scan_final(const double* __restrict__ h
     P += (int64_t)blockIdx.y * (n + 1);
     Q += (int64_t)blockIdx.y * (n + 1);
     part += (int64_t)blockIdx.y * tiles;
+    __shared__ double lds[DD_SCAN_LDS];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * DD_SCAN_TILE + 8 * t;
+    const int64_t tile0 = (int64_t)blockIdx.x * DD_SCAN_TILE;
     double p[8], q[8];
-    dd_scan_tile_load(h, n, i0, p, q);
-    double cp = 0.0, cq = 0.0;                       // sums of the tiles before this one
-    for (int k = 0; k < (int)blockIdx.x; ++k) { const double2 v = part[k]; cp += v.x; cq += v.y; }
+    dd_scan_tile_load(h, n, tile0, t, lds, p, q);
+    // sums of the tiles before this one: every lane takes the tiles t, t + 256, ..., the workgroup adds them up (one lane
+    // walking all of them was 77 us of the accurate windows' 1.1 ms per batch)
+    __shared__ double bp[4], bq[4];
+    double cp = 0.0, cq = 0.0;
+    for (int k = t; k < (int)blockIdx.x; k += 256) { const double2 v = part[k]; cp += v.x; cq += v.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { cp += __shfl_down(cp, d); cq += __shfl_down(cq, d); }
+    if (lane == 0) { bp[wv] = cp; bq[wv] = cq; }
     double tp = p[7], tq = q[7];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1070,13 +1115,16 @@ __global__ void __launch_bounds__(256) k_scan_final(const double* __restrict__ h
     double ep = __shfl_up(tp, 1), eq = __shfl_up(tq, 1);
     if (lane == 0) { ep = 0.0; eq = 0.0; }
     __syncthreads();
+    cp = ((bp[0] + bp[1]) + bp[2]) + bp[3];
+    cq = ((bq[0] + bq[1]) + bq[2]) + bq[3];
     for (int w = 0; w < wv; ++w) { cp += sp[w]; cq += sq[w]; }
     ep += cp;
     eq += cq;
     if (blockIdx.x == 0 && t == 0) { P[0] = 0.0; Q[0] = 0.0; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (i0 + j < n) { P[i0 + j + 1] = ep + p[j]; Q[i0 + j + 1] = eq + q[j]; }
+    for (int j = 0; j < 8; ++j) { p[j] += ep; q[j] += eq; }
+    dd_scan_tile_store(P, n, tile0, t, lds, p);
+    dd_scan_tile_store(Q, n, tile0, t, lds, q);
 }
 
 // Peak pick of one window (decode_noaa.py:713-762) when the window is shorter than the 0.45 s group
@@ -1343,7 +1391,8 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     const size_t o_starts = 0;
     const size_t o_taps1 = o_starts + al(sizeof(int64_t) * n_windows);
     const size_t o_taps2 = o_taps1 + al(sizeof(double) * fir_ntaps);
-    const size_t o_res = o_taps2 + al(sizeof(double) * (pre_ntaps ? pre_ntaps : 1));
+    const size_t o_tab = o_taps2 + al(sizeof(double) * (pre_ntaps ? pre_ntaps : 1));
+    const size_t o_res = o_tab + al(sizeof(double2) * 3 * (size_t)(pre_ntaps ? pre_ntaps : 1));
     const size_t o_X = o_res + al(24 * (size_t)n_windows);
     const size_t o_Y1 = o_X + al(sizeof(float2) * B * L);                 // X: c64 [B][L]; later the filtered IQ again
     const size_t o_W = o_Y1 + al(sizeof(float2) * B * N1);                // Y1: c64 [B][N1]
@@ -1385,11 +1434,26 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     DD_HIP_CHECK(hipMemcpyAsync(d_starts, starts_host, sizeof(int64_t) * n_windows, hipMemcpyHostToDevice, s));
     DD_HIP_CHECK(hipMemcpyAsync(d_taps1, fir_taps_host, sizeof(double) * fir_ntaps, hipMemcpyHostToDevice, s));
     if (pre_ntaps) DD_HIP_CHECK(hipMemcpyAsync(d_taps2, pre_taps_host, sizeof(double) * pre_ntaps, hipMemcpyHostToDevice, s));
+    // the envelope's pre-filter is hamming(492) (decode_noaa.py:677): a two-term cosine series -- prefix-sum form
+    // (dd_filtfilt_kernels.h; DD_SYNC_DIRECT_FIR=1, tools: the 492 multiply-adds per sample of the tiled direct form)
+    DDCosFit fit2;
+    static const char* direct_env = getenv("DD_SYNC_DIRECT_FIR");
+    const bool cos2 = pre_ntaps && !(direct_env && atoi(direct_env)) && dd_cos_fit_cached(pre_taps_host, pre_ntaps, &fit2) && dd_fc_ok(pre_ntaps, fit2.Q);
+    double2* d_tab = (double2*)(base + o_tab);
+    if (cos2) {
+        // (the table of one tap set is kept on the host between calls; the copy's pageable source is staged before the call returns)
+        static std::mutex tab_mu;
+        static std::vector<double2> tabh;
+        static int tab_K = 0, tab_Q = 0;
+        std::lock_guard<std::mutex> tl(tab_mu);
+        if (tab_K != pre_ntaps || tab_Q != fit2.Q) { dd_cos_table(pre_ntaps, fit2.Q, tabh); tab_K = pre_ntaps; tab_Q = fit2.Q; }
+        DD_HIP_CHECK(hipMemcpyAsync(d_tab, tabh.data(), sizeof(double2) * tabh.size(), hipMemcpyHostToDevice, s));
+    }
     for (int w0 = 0; w0 < n_windows; w0 += B) {
         const int b = n_windows - w0 < B ? n_windows - w0 : B;
-        const dim3 gL(grid1(L), b), gL2(grid1(L2), b);
-        if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
-        else hipLaunchKernelGGL(k_sync_front<false>, gL, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+        const dim3 gL(grid1(L), b), gL2(grid1(L2), b), gL4(grid1((L + 3) / 4), b);
+        if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+        else hipLaunchKernelGGL(k_sync_front<false>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
         dd_filtfilt_launch<float2>(X, L, Y1, X, L, L, fir_ntaps, d_taps1, b, s);            // X <- filtfilt(X): pass 2 reads only Y1
         if (hilbert_fft) {
             hipLaunchKernelGGL(k_sync_fm, gL2, dim3(256), 0, s, X, L, W);
@@ -1413,7 +1477,12 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         }
         const double* hay = ENV;
         if (pre_ntaps) {
-            dd_filtfilt_launch<double>(ENV, L2, F1, H, L2, L2, pre_ntaps, d_taps2, b, s);
+            if (cos2) {
+                rc = dd_filtfilt_cos_launch(ENV, L2, F1, H, L2, L2, pre_ntaps, fit2, d_tab, b, s);
+                if (rc != DD_OK) return rc;
+            } else {
+                dd_filtfilt_launch<double>(ENV, L2, F1, H, L2, L2, pre_ntaps, d_taps2, b, s);
+            }
             hay = H;
         }
         double* P = (double*)W;                                            // prefix sums into the (now free) FFT buffer
@@ -1433,3 +1502,477 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     DD_HIP_CHECK(hipStreamSynchronize(s));
     return DD_OK;
 }
+
+// ---------------------------------------------------------------- getCrudeSync's audio-rate tail in ONE host call
+// decode_noaa.py:781-790: envelope of the FM audio in 240 000-sample blocks (__getAM :631-657 -> demod_am.py:29), then for sync A
+// and sync B the normalised correlation (:659-675) and the peak pick (:713-751).  Stage by stage through the entry points
+// above that was ~70 launches, a dozen host round trips and -- measured at 60 s of recording -- 2.0 of the 2.2 ms of the crude
+// sync (profiles/r03_side_benchmarks.txt); the samples themselves are 3.6 M doubles.  Here:
+//   * envelope = hypot(x, H x) with H x from a real-to-complex / complex-to-real transform pair per block (bin k of the
+//     spectrum times -j for 0 < k < N/2, zero at DC and Nyquist: the imaginary part of scipy.signal.hilbert's analytic
+//     signal) -- half the transform work of the complex pair, batched over the full blocks;
+//   * prefix sums of the envelope and its square ONCE, both needles correlated in one launch (blockIdx.y);
+//   * the means of the K largest / K smallest correlation values, the threshold and the candidate list of BOTH needles in
+//     eleven launches that never come back to the host: eight radix-select passes (one byte of the order-preserving key
+//     each; every workgroup re-derives the bins picked so far from the earlier passes' global histograms, so no pick
+//     kernel sits between them), the collection of the values beyond the K-th, their sort and ascending summation
+//     (one workgroup per needle), the candidates by atomic append -- instead of 2 x 19 dependent launches and 2 x 2 host
+//     round trips.  (Tried first: all of it as ONE persistent launch with grid-wide barriers.  It measured 0.56-0.76 ms:
+//     ten barriers of 2 x 128..512 workgroups polling one word each cost more than the launch boundaries they replaced,
+//     profiles/r04_noaa_stages.txt);
+//   * one host synchronisation at the end (the grouping by 0.45 s of :729-746 runs on the host over a few thousand candidates).
+// Results: the index lists are those of the staged route and of the reference (tests/golden/noaa_c4*.npz); the envelope agrees
+// with the complex-transform form to ~1e-15 relative.
+#define DD_CS_WG 512                  // workgroups per needle and selection launch
+#define DD_CS_COPIES 8                // interleaved LDS histograms per selection
+#define DD_CS_KMAX 2048               // largest K (two per second of audio + 2) the in-kernel sort holds
+#define DD_CS_MAXNEEDLES 2
+struct DDCrudeSel {
+    unsigned int hist[8][2][256];     // per pass: [K-th largest | K-th smallest]
+    unsigned int n_beyond[2];         // values appended above / below
+    unsigned int n_cand;              // candidates appended
+    unsigned int pad;
+    unsigned int beyond_cnt[2];       // bookkeeping: how many values lie strictly beyond the final keys
+    unsigned long long key[2];
+    double thr, sum_hi, sum_lo;
+};
+
+__global__ void __launch_bounds__(256) k_cvt_f32_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+// spectrum of a real block -> spectrum of its Hilbert transform (blockIdx.y = block of the batch; nb = N/2 + 1 bins)
+__global__ void __launch_bounds__(256) k_hilb_bins(double2* __restrict__ S, int64_t nb, int64_t N) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nb) return;
+    double2* p = S + (int64_t)blockIdx.y * nb + k;
+    const double2 v = *p;
+    const bool zero = k == 0 || (2 * k == N);
+    *p = zero ? make_double2(0.0, 0.0) : make_double2(v.y, -v.x);          // -j X[k]
+}
+__global__ void __launch_bounds__(256) k_env_hypot_flat(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ env, int64_t n, double inv_n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) env[i] = hypot(x[i], y[i] * inv_n);
+}
+// exclusive scan of the tile sums (one workgroup), so that the final pass adds one number per tile instead of walking all
+// the tiles before it (1765 of them for a minute of audio)
+__global__ void __launch_bounds__(256) k_scan_mid(double2* __restrict__ part, int tiles) {
+    __shared__ double sp[4], sq[4];
+    __shared__ double cp, cq;
+    if (threadIdx.x == 0) { cp = 0.0; cq = 0.0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b = 0; b < tiles; b += 256) {
+        const int i = b + threadIdx.x;
+        const double2 v = i < tiles ? part[i] : make_double2(0.0, 0.0);
+        double ip = v.x, iq = v.y;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double a = __shfl_up(ip, d), c = __shfl_up(iq, d);
+            if (lane >= d) { ip += a; iq += c; }
+        }
+        if (lane == 63) { sp[wv] = ip; sq[wv] = iq; }
+        __syncthreads();
+        double op = cp, oq = cq;
+        for (int w = 0; w < wv; ++w) { op += sp[w]; oq += sq[w]; }
+        if (i < tiles) part[i] = make_double2(op + ip - v.x, oq + iq - v.y);
+        __syncthreads();
+        if (threadIdx.x == 255) { cp = op + ip; cq = oq + iq; }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan_final_x(const double* __restrict__ h, int64_t n, const double2* __restrict__ partx,
+                                                      double* __restrict__ P, double* __restrict__ Q) {
+    __shared__ double sp[4], sq[4];
+    __shared__ double lds[DD_SCAN_LDS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * DD_SCAN_TILE;
+    double p[8], q[8];
+    dd_scan_tile_load(h, n, tile0, t, lds, p, q);
+    const double2 base = partx[blockIdx.x];
+    double cp = base.x, cq = base.y;
+    double tp = p[7], tq = q[7];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double a = __shfl_up(tp, d), c = __shfl_up(tq, d);
+        if (lane >= d) { tp += a; tq += c; }
+    }
+    if (lane == 63) { sp[wv] = tp; sq[wv] = tq; }
+    double ep = __shfl_up(tp, 1), eq = __shfl_up(tq, 1);
+    if (lane == 0) { ep = 0.0; eq = 0.0; }
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) { cp += sp[w]; cq += sq[w]; }
+    ep += cp;
+    eq += cq;
+    if (blockIdx.x == 0 && t == 0) { P[0] = 0.0; Q[0] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[j] += ep; q[j] += eq; }
+    dd_scan_tile_store(P, n, tile0, t, lds, p);
+    dd_scan_tile_store(Q, n, tile0, t, lds, q);
+}
+// k_xcorr_runs for up to two needles of equal length at once (blockIdx.y = needle; out[needle][n])
+struct DDRuns2 { DDRuns r[DD_CS_MAXNEEDLES]; double vv[DD_CS_MAXNEEDLES]; };
+// The 256 outputs of a workgroup read P at a0 + start[r], r = 0 .. nr: 256 + m + 1 consecutive prefix sums, each wanted by
+// ~nr outputs.  They are staged in LDS once (when they fit: 817 doubles for the crude needles) -- straight from L2 the kernel
+// ran at the L2's bandwidth, 108 us for 2 x 3.6 M outputs.
+#define DD_XC_LDS_MAX 4096
+__global__ void __launch_bounds__(256) k_xcorr_runs_n(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
+                                                      const DDRuns2 R2, double* __restrict__ out) {
+    __shared__ double sP[DD_XC_LDS_MAX];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const DDRuns& R = R2.r[blockIdx.y];
+    const int64_t a0 = i + (m - 1) / 2 - (m - 1);
+    auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
+    const bool staged = 256 + m + 1 <= DD_XC_LDS_MAX;             // (uniform)
+    if (staged) {
+        const int64_t base = (int64_t)blockIdx.x * 256 + (m - 1) / 2 - (m - 1);
+        for (int k = threadIdx.x; k < 256 + m + 1; k += 256) sP[k] = at(P, base + k);
+        __syncthreads();
+    }
+    if (i >= n) return;
+    double c = 0.0;
+    if (staged) {
+        const double* sp = sP + threadIdx.x;
+        double lo = sp[0];
+        for (int r = 0; r < R.nr; ++r) {
+            const double hi = sp[R.start[r + 1]];
+            c = fma(R.val[r], hi - lo, c);
+            lo = hi;
+        }
+    } else {
+        double lo = at(P, a0);
+        for (int r = 0; r < R.nr; ++r) {
+            const double hi = at(P, a0 + R.start[r + 1]);
+            c = fma(R.val[r], hi - lo, c);
+            lo = hi;
+        }
+    }
+    double e = at(Q, a0 + m) - at(Q, a0);
+    if (!(e > 1e-13 * Q[n])) { c = 0.0; e = 0.0; }
+    out[(int64_t)blockIdx.y * n + i] = c / sqrt(e * R2.vv[blockIdx.y]);
+}
+
+__device__ __forceinline__ double dd_aload_f64(const double* p) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    return __longlong_as_double((long long)__hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// one wave: the bin that holds rank `r` counted from the top (TOP) or the bottom of a 256-bin histogram, and how many values
+// lie in the bins beyond it.  Lane l owns bins 4 l .. 4 l + 3.
+template <bool TOP>
+__device__ __forceinline__ void dd_pick_bin(const unsigned int* gh, unsigned int r, int lane, int* bin, unsigned int* beyond) {
+    unsigned int c[4], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = gh[4 * lane + j]; tot += c[j]; }
+    unsigned int incl = tot;                          // TOP: sum over lanes >= l; else lanes <= l
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int u = TOP ? __shfl_down(incl, d) : __shfl_up(incl, d);
+        if (TOP ? (lane + d < 64) : (lane >= d)) incl += u;
+    }
+    unsigned int before = incl - tot;                 // values in the lanes beyond this one
+    int found = -1;
+    unsigned int fb = 0;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = TOP ? 3 - jj : jj;
+        if (found < 0 && before + c[j] >= r) { found = 4 * lane + j; fb = before; }
+        before += c[j];
+    }
+    // the first lane from the far end that finds it is the one; broadcast
+    const unsigned long long m = __ballot(found >= 0);
+    const int src = m ? (TOP ? (63 - __builtin_clzll(m)) : __builtin_ctzll(m)) : 0;
+    *bin = __shfl(found, src);
+    *beyond = __shfl(fb, src);
+    if (!m) { *bin = TOP ? 0 : 255; *beyond = 0; }
+}
+// The selections' state after passes 0 .. upto-1, recomputed from the global histograms of those passes (complete: they were
+// filled by earlier launches) by waves 0 (K-th largest) and 1 (K-th smallest) of every workgroup, and handed to all lanes.
+struct DDCsState { unsigned long long prefix[2]; unsigned int remaining[2], beyond[2]; };
+__device__ __forceinline__ DDCsState dd_cs_state(const DDCrudeSel* S, int upto, int K, DDCsState* lds_tmp) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv < 2) {
+        unsigned long long prefix = 0ull;
+        unsigned int remaining = (unsigned int)K, beyond = 0u;
+        for (int p = 0; p < upto; ++p) {
+            int bin;
+            unsigned int by;
+            if (wv == 0) dd_pick_bin<true>(S->hist[p][0], remaining, lane, &bin, &by);
+            else dd_pick_bin<false>(S->hist[p][1], remaining, lane, &bin, &by);
+            prefix = (prefix << 8) | (unsigned long long)bin;
+            remaining -= by;
+            beyond += by;
+        }
+        if (lane == 0) { lds_tmp->prefix[wv] = prefix; lds_tmp->remaining[wv] = remaining; lds_tmp->beyond[wv] = beyond; }
+    }
+    __syncthreads();
+    const DDCsState st = *lds_tmp;
+    __syncthreads();
+    return st;
+}
+
+// pass `pass` of the radix select (one byte of the key): histogram of the values whose higher bytes equal the prefix so far.
+// grid (G, needles); the launch boundary is the barrier between passes.
+__global__ void __launch_bounds__(256) k_cs_hist(const double* __restrict__ cor_all, int64_t n, int K, int pass, DDCrudeSel* __restrict__ sel_all) {
+    __shared__ unsigned int h[2][DD_CS_COPIES][256];
+    __shared__ DDCsState tmp;
+    const int nd = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+    const double* cor = cor_all + (int64_t)nd * n;
+    DDCrudeSel* S = sel_all + nd;
+    for (int i = t; i < 2 * DD_CS_COPIES * 256; i += 256) (&h[0][0][0])[i] = 0;
+    const DDCsState st = dd_cs_state(S, pass, K, &tmp);          // (its barriers also cover the clearing above)
+    const int64_t i_lo = n * g / G, i_hi = n * (g + 1) / G;
+    const int shift = 56 - 8 * pass;
+    const int copy = t & (DD_CS_COPIES - 1);
+    for (int64_t i = i_lo + t; i < i_hi; i += 1024) {             // four loads in flight per lane
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i + 256 * u < i_hi) ? cor[i + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + 256 * u >= i_hi) break;
+            const unsigned long long k = dd_key_f64(v[u]);
+            const unsigned long long hi = pass ? (k >> (shift + 8)) : 0;
+            const unsigned int d = (unsigned int)(k >> shift) & 255u;
+            if (hi == st.prefix[0]) atomicAdd(&h[0][copy][d], 1u);
+            if (hi == st.prefix[1]) atomicAdd(&h[1][copy][d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 512; i += 256) {
+        unsigned int c = 0;
+#pragma unroll
+        for (int k = 0; k < DD_CS_COPIES; ++k) c += h[i >> 8][k][i & 255];
+        if (c) atomicAdd(&S->hist[pass][i >> 8][i & 255], c);
+    }
+}
+// the values strictly beyond the two final keys (fewer than K each), any order
+__global__ void __launch_bounds__(256) k_cs_collect(const double* __restrict__ cor_all, int64_t n, int K, DDCrudeSel* __restrict__ sel_all, double* __restrict__ beyond_all) {
+    __shared__ DDCsState tmp;
+    const int nd = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+    const double* cor = cor_all + (int64_t)nd * n;
+    DDCrudeSel* S = sel_all + nd;
+    double* above = beyond_all + (size_t)nd * 2 * DD_CS_KMAX;
+    double* below = above + DD_CS_KMAX;
+    const DDCsState st = dd_cs_state(S, 8, K, &tmp);
+    const int64_t i_lo = n * g / G, i_hi = n * (g + 1) / G;
+    for (int64_t i = i_lo + t; i < i_hi; i += 256) {
+        const double v = cor[i];
+        const unsigned long long k = dd_key_f64(v);
+        if (k > st.prefix[0]) { const unsigned int o = atomicAdd(&S->n_beyond[0], 1u); if (o < DD_CS_KMAX) above[o] = v; }
+        if (k < st.prefix[1]) { const unsigned int o = atomicAdd(&S->n_beyond[1], 1u); if (o < DD_CS_KMAX) below[o] = v; }
+    }
+}
+// one workgroup per needle: the K largest (then the K smallest) sorted ascending and summed in that order (the sums over the
+// sorted array that np.argpartition's slices stand for, :717-723), threshold
+__global__ void __launch_bounds__(256) k_cs_threshold(int K, DDCrudeSel* __restrict__ sel_all, const double* __restrict__ beyond_all) {
+    __shared__ double srt[DD_CS_KMAX];
+    __shared__ DDCsState tmp;
+    const int nd = blockIdx.x, t = threadIdx.x;
+    DDCrudeSel* S = sel_all + nd;
+    const double* above = beyond_all + (size_t)nd * 2 * DD_CS_KMAX;
+    const double* below = above + DD_CS_KMAX;
+    const DDCsState st = dd_cs_state(S, 8, K, &tmp);
+    double sums[2] = {0.0, 0.0};
+    for (int w = 0; w < 2; ++w) {
+        const unsigned int nb = st.beyond[w];
+        const unsigned long long kk = st.prefix[w];
+        const unsigned long long u = (kk >> 63) ? (kk & 0x7fffffffffffffffull) : ~kk;
+        const double kth = __longlong_as_double((long long)u);
+        const double* src = w ? below : above;
+        int np2 = 1;
+        while (np2 < K) np2 <<= 1;
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        for (int i = t; i < np2; i += 256) srt[i] = i < (int)nb ? src[i] : (i < K ? kth : inf);
+        __syncthreads();
+        for (int k2 = 2; k2 <= np2; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const double a = srt[i], b = srt[ixj];
+                        const bool up = (i & k2) == 0;
+                        if (up ? (a > b) : (a < b)) { srt[i] = b; srt[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        if (t == 0) {
+            double acc = 0.0;
+            for (int i = 0; i < K; ++i) acc += srt[i];
+            sums[w] = acc;
+            if (w == 0) S->sum_hi = acc; else S->sum_lo = acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double avgpk = sums[0] / K;
+        avgpk -= 0.25 * (avgpk - sums[1] / K);                             // NOAA_PEAKHEIGHTWIGGLE (:723)
+        S->thr = avgpk;
+        S->key[0] = st.prefix[0]; S->key[1] = st.prefix[1];
+        S->beyond_cnt[0] = st.beyond[0]; S->beyond_cnt[1] = st.beyond[1];
+    }
+}
+// candidates cor > threshold (:726), appended with their heights; the host orders them by index
+__global__ void __launch_bounds__(256) k_cs_cand(const double* __restrict__ cor_all, int64_t n, DDCrudeSel* __restrict__ sel_all,
+                                                 int64_t* __restrict__ cidx_all, double* __restrict__ cval_all, unsigned int cap) {
+    const int nd = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+    const double* cor = cor_all + (int64_t)nd * n;
+    DDCrudeSel* S = sel_all + nd;
+    int64_t* cidx = cidx_all + (size_t)nd * cap;
+    double* cval = cval_all + (size_t)nd * cap;
+    const double thr = S->thr;
+    const int64_t i_lo = n * g / G, i_hi = n * (g + 1) / G;
+    for (int64_t i = i_lo + t; i < i_hi; i += 256) {
+        const double v = cor[i];
+        if (v > thr) { const unsigned int o = atomicAdd(&S->n_cand, 1u); if (o < cap) { cidx[o] = i; cval[o] = v; } }
+    }
+}
+
+extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n, double samp_rate, int64_t block,
+                                  const double* needles_host, int m, int n_needles, double* env_out,
+                                  int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream) {
+    DD_REQUIRE(audio && n >= 1 && samp_rate > 0 && block >= 1 && needles_host && m >= 1 && m <= n, "arguments");
+    DD_REQUIRE(n_needles >= 1 && n_needles <= DD_CS_MAXNEEDLES && peaks_host && n_peaks && max_peaks >= 1, "arguments");
+    hipStream_t s = dd_stream(stream);
+    const int K = (int)(2 * ((double)n / samp_rate)) + 2;                 // expectedPeaks (:714)
+    DD_REQUIRE(K <= n, "signal shorter than the expected peak count");
+    if (K > DD_CS_KMAX || n >= ((int64_t)1 << 31)) return DD_ERR_UNSUPPORTED;          // (the caller takes the staged route)
+    DDRuns2 R2;
+    for (int d = 0; d < n_needles; ++d) {
+        const double* nh = needles_host + (size_t)d * m;
+        DDRuns& R = R2.r[d];
+        R.nr = 0;
+        R.start[0] = 0;
+        for (int t = 0; t < m; ++t) {
+            if (t == 0 || nh[t] != nh[t - 1]) {
+                if (R.nr == DD_XCORR_MAX_RUNS) return DD_ERR_UNSUPPORTED;
+                R.start[R.nr] = t;
+                R.val[R.nr] = nh[t];
+                ++R.nr;
+            }
+        }
+        R.start[R.nr] = m;
+        double vv = 0.0;
+        for (int t = 0; t < m; ++t) vv += nh[t] * nh[t];
+        R2.vv[d] = vv;
+    }
+    for (int d = n_needles; d < DD_CS_MAXNEEDLES; ++d) { R2.r[d] = R2.r[0]; R2.vv[d] = R2.vv[0]; }
+    // block list by the chunker rule (decode_noaa.py:644-653 via chunker.py:36-45)
+    int64_t nfull = 0;
+    while ((nfull + 1) * block < n) ++nfull;
+    const int64_t rem = n - nfull * block;
+    const int GB = 16;
+    const int64_t gb = nfull < GB ? nfull : GB;
+    const int64_t nbins_b = block / 2 + 1, nbins_r = rem / 2 + 1;
+    const int tiles = (int)((n + DD_SCAN_TILE - 1) / DD_SCAN_TILE);
+    const unsigned int cap = 1u << 16;                                    // candidates per needle held on the device
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t o_x = take(audio_is_f32 ? sizeof(double) * (size_t)n : 0);
+    const size_t o_env = take(env_out ? 0 : sizeof(double) * (size_t)n);
+    const size_t spec_elems = (size_t)(gb * nbins_b > nbins_r ? gb * nbins_b : nbins_r);
+    const size_t o_spec = take(sizeof(double2) * spec_elems);
+    const size_t o_y = take(sizeof(double) * (size_t)(gb * block > rem ? gb * block : rem));
+    const size_t o_P = take(sizeof(double) * (size_t)(n + 1)), o_Q = take(sizeof(double) * (size_t)(n + 1));
+    const size_t o_part = take(sizeof(double2) * (size_t)tiles);
+    const size_t o_cor = take(sizeof(double) * (size_t)n * n_needles);
+    const size_t o_sel = take(sizeof(DDCrudeSel) * n_needles);
+    const size_t o_bey = take(sizeof(double) * 2 * DD_CS_KMAX * n_needles);
+    const size_t o_ci = take(sizeof(int64_t) * (size_t)cap * n_needles), o_cv = take(sizeof(double) * (size_t)cap * n_needles);
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    char* base = nullptr;
+    int rc = sync_scratch(off, &base);
+    if (rc != DD_OK) return rc;
+    const double* x = audio_is_f32 ? (const double*)(base + o_x) : (const double*)audio;
+    double* env = env_out ? env_out : (double*)(base + o_env);
+    double2* spec = (double2*)(base + o_spec);
+    double* y = (double*)(base + o_y);
+    double* P = (double*)(base + o_P);
+    double* Q = (double*)(base + o_Q);
+    double2* part = (double2*)(base + o_part);
+    double* cor = (double*)(base + o_cor);
+    DDCrudeSel* sel = (DDCrudeSel*)(base + o_sel);
+    if (audio_is_f32) hipLaunchKernelGGL(k_cvt_f32_f64, dim3(grid1(n)), dim3(256), 0, s, (const float*)audio, (double*)(base + o_x), n);
+    // ---- envelope
+    auto env_blocks = [&](int64_t first, int64_t N, int batch) -> int {
+        hipfftHandle pf, pb;
+        int r = get_plan(&pf, HIPFFT_D2Z, N, batch, s);
+        if (r == DD_OK) r = get_plan(&pb, HIPFFT_Z2D, N, batch, s);
+        if (r != DD_OK) return r;
+        const int64_t nb = N / 2 + 1;
+        DD_FFT_CHECK(hipfftExecD2Z(pf, (hipfftDoubleReal*)(x + first), (hipfftDoubleComplex*)spec));
+        hipLaunchKernelGGL(k_hilb_bins, dim3(grid1(nb), batch), dim3(256), 0, s, spec, nb, N);
+        DD_FFT_CHECK(hipfftExecZ2D(pb, (hipfftDoubleComplex*)spec, (hipfftDoubleReal*)y));
+        hipLaunchKernelGGL(k_env_hypot_flat, dim3(grid1(N * batch)), dim3(256), 0, s, x + first, y, env + first, N * batch, 1.0 / (double)N);
+        return DD_OK;
+    };
+    for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) rc = env_blocks(b0 * block, block, (int)(nfull - b0 < GB ? nfull - b0 : GB));
+    if (rc == DD_OK) rc = env_blocks(nfull * block, rem, 1);
+    if (rc != DD_OK) return rc;
+    // ---- prefix sums once, both correlations in one launch
+    hipLaunchKernelGGL(k_scan_part, dim3(tiles, 1), dim3(256), 0, s, env, n, tiles, part);
+    hipLaunchKernelGGL(k_scan_mid, dim3(1), dim3(256), 0, s, part, tiles);
+    hipLaunchKernelGGL(k_scan_final_x, dim3(tiles), dim3(256), 0, s, env, n, part, P, Q);
+    hipLaunchKernelGGL(k_xcorr_runs_n, dim3(grid1(n), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
+    // ---- selection, threshold, candidates of both needles: eleven launches, nothing comes back to the host in between
+    DD_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(DDCrudeSel) * n_needles, s));
+    for (int pass = 0; pass < 8; ++pass) hipLaunchKernelGGL(k_cs_hist, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, pass, sel);
+    hipLaunchKernelGGL(k_cs_collect, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, sel, (double*)(base + o_bey));
+    hipLaunchKernelGGL(k_cs_threshold, dim3(n_needles), dim3(256), 0, s, K, sel, (const double*)(base + o_bey));
+    hipLaunchKernelGGL(k_cs_cand, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, sel, (int64_t*)(base + o_ci), (double*)(base + o_cv), cap);
+    DD_LAUNCH_CHECK();
+    // ---- one round trip: the select state and the first 16 384 candidates of each needle (the rest only if there are more)
+    const unsigned int first_n = 1u << 14;
+    std::vector<DDCrudeSel> hs(n_needles);
+    std::vector<int64_t> hci((size_t)first_n * n_needles);
+    std::vector<double> hcv((size_t)first_n * n_needles);
+    DD_HIP_CHECK(hipMemcpyAsync(hs.data(), sel, sizeof(DDCrudeSel) * n_needles, hipMemcpyDeviceToHost, s));
+    for (int d = 0; d < n_needles; ++d) {
+        DD_HIP_CHECK(hipMemcpyAsync(hci.data() + (size_t)d * first_n, (int64_t*)(base + o_ci) + (size_t)d * cap, sizeof(int64_t) * first_n, hipMemcpyDeviceToHost, s));
+        DD_HIP_CHECK(hipMemcpyAsync(hcv.data() + (size_t)d * first_n, (double*)(base + o_cv) + (size_t)d * cap, sizeof(double) * first_n, hipMemcpyDeviceToHost, s));
+    }
+    DD_HIP_CHECK(hipStreamSynchronize(s));
+    for (int d = 0; d < n_needles; ++d) {
+        const DDCrudeSel& h1 = hs[d];
+        DD_REQUIRE(h1.n_beyond[0] == h1.beyond_cnt[0] && h1.n_beyond[1] == h1.beyond_cnt[1] && h1.n_beyond[0] < (unsigned int)K && h1.n_beyond[1] < (unsigned int)K,
+                   "dd_noaa_crude_tail: selection bookkeeping (internal)");
+        const unsigned int count = h1.n_cand;
+        if (count > cap) return DD_ERR_UNSUPPORTED;                       // (a threshold that lets > 65 536 values through: staged route)
+        std::vector<std::pair<int64_t, double>> cand(count);
+        if (count > first_n) {
+            std::vector<int64_t> ci(count);
+            std::vector<double> cv(count);
+            DD_HIP_CHECK(hipMemcpyAsync(ci.data(), (int64_t*)(base + o_ci) + (size_t)d * cap, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
+            DD_HIP_CHECK(hipMemcpyAsync(cv.data(), (double*)(base + o_cv) + (size_t)d * cap, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+            DD_HIP_CHECK(hipStreamSynchronize(s));
+            for (unsigned int i = 0; i < count; ++i) cand[i] = {ci[i], cv[i]};
+        } else {
+            for (unsigned int i = 0; i < count; ++i) cand[i] = {hci[(size_t)d * first_n + i], hcv[(size_t)d * first_n + i]};
+        }
+        std::sort(cand.begin(), cand.end(), [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; });
+        // group by >= 0.45 s from the running maximum, first maximum wins (:729-746)
+        const double min_dist = 0.45 * samp_rate;
+        std::vector<int64_t> peaks;
+        bool have = false;
+        double cur_max = 0.0;
+        int64_t cur_idx = 0;
+        for (unsigned int q = 0; q < count; ++q) {
+            if (have && (double)(cand[q].first - cur_idx) >= min_dist) { peaks.push_back(cur_idx); have = false; }
+            if (!have || cur_max < cand[q].second) { cur_max = cand[q].second; cur_idx = cand[q].first; have = true; }
+        }
+        if (have) peaks.push_back(cur_idx);
+        const int shift = m / 2;                                          // int(len(sync)/2) (:749)
+        for (auto& p : peaks) p -= shift;
+        std::sort(peaks.begin(), peaks.end());
+        if ((int)peaks.size() > max_peaks) {
+            dd_set_error("dd_noaa_crude_tail: %d peaks found, buffer holds %d", (int)peaks.size(), max_peaks);
+            return DD_ERR_INVALID;
+        }
+        for (size_t i = 0; i < peaks.size(); ++i) peaks_host[(size_t)d * max_peaks + i] = peaks[i];
+        n_peaks[d] = (int)peaks.size();
+    }
+    return DD_OK;
+}
+

@@ -14,6 +14,7 @@
 // it replaces (kept below for 16-byte elements and very long filters): results are bit-identical.
 #pragma once
 #include "dd_common.h"
+#include <vector>
 
 template <typename T> struct dd_acc;
 template <> struct dd_acc<double> {
@@ -175,4 +176,244 @@ static inline void dd_filtfilt_launch(const T* in, int64_t in_stride, T* y1, T* 
                        lds, s, in, y1, n, edge, taps_dev, K, in_stride, N, (const T*)nullptr);
     hipLaunchKernelGGL((k_filtfilt_tile<T, 1>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
                        lds, s, (const T*)y1, out, n, edge, taps_dev, K, N, out_stride, (const T*)nullptr);
+}
+
+// ---- zero-phase FIR whose taps are a short cosine series (real float64 data) ----------------------------------------------
+// The windows the reference uses as taps (filters.py:101-226: rollingAverage, hamming, blackmanHarris; decode_noaa.py:677
+// pre-filters the envelope with hamming(492)) are  b[k] = sum_q a_q cos(2 pi q k / (K-1)),  q = 0 .. Q <= 3.  For such taps a
+// window sum is a handful of prefix-sum differences instead of K multiply-adds:
+//     sum_k b[k] s[t + k] = sum_q a_q ( cos(w_q t) A_q[t] + sin(w_q t) B_q[t] ),     w_q = 2 pi q / (K-1),
+//     A_q[t] = sum_{j=t}^{t+K-1} s[j] cos(w_q j),   B_q[t] = the same with sin
+// (b is symmetric, so the forward pass -- taps running backwards over the window -- is the same expression).  The prefix
+// sums are LOCAL to a workgroup's window of 2048 + K - 1 staged samples (origin at the window start: magnitudes stay below
+// ~2500 x the signal, the differences carry ~1e-15 relative error), phases are table look-ups at j mod (K-1) (exact period),
+// and both passes stage their samples exactly like k_filtfilt_tile.  Hamming(492) over 60 windows of 118 151 samples:
+// 2 x 150 us (7.1e9 multiply-adds, 60 % of the f64 vector peak) -> the passes become memory-bound.
+struct DDCosFit {
+    int Q;              // highest harmonic with a non-zero coefficient
+    double a[4];
+};
+// taps == sum_q a_q cos(2 pi q k / (K-1)) to 1e-13 of the largest tap?  (least squares over q = 0..3, long double)
+static inline bool dd_cos_fit(const double* taps, int K, DDCosFit* f) {
+    if (K < 64) return false;
+    const int NQ = 4;
+    long double G[NQ][NQ + 1];
+    const long double w = 2.0L * 3.14159265358979323846264338327950288L / (long double)(K - 1);
+    for (int p = 0; p < NQ; ++p) {
+        for (int q = 0; q < NQ; ++q) {
+            long double acc = 0.0L;
+            for (int k = 0; k < K; ++k) acc += cosl(w * (long double)((long long)p * k % (K - 1))) * cosl(w * (long double)((long long)q * k % (K - 1)));
+            G[p][q] = acc;
+        }
+        long double acc = 0.0L;
+        for (int k = 0; k < K; ++k) acc += cosl(w * (long double)((long long)p * k % (K - 1))) * (long double)taps[k];
+        G[p][NQ] = acc;
+    }
+    for (int c = 0; c < NQ; ++c) {                       // Gauss-Jordan with partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < NQ; ++r) if (fabsl(G[r][c]) > fabsl(G[piv][c])) piv = r;
+        if (fabsl(G[piv][c]) < 1e-12L) return false;
+        for (int j = 0; j <= NQ; ++j) { const long double tmp = G[c][j]; G[c][j] = G[piv][j]; G[piv][j] = tmp; }
+        for (int r = 0; r < NQ; ++r) {
+            if (r == c) continue;
+            const long double m = G[r][c] / G[c][c];
+            for (int j = c; j <= NQ; ++j) G[r][j] -= m * G[c][j];
+        }
+    }
+    long double a[NQ], peak = 0.0L, res = 0.0L;
+    for (int q = 0; q < NQ; ++q) a[q] = G[q][NQ] / G[q][q];
+    for (int k = 0; k < K; ++k) {
+        long double v = 0.0L;
+        for (int q = 0; q < NQ; ++q) v += a[q] * cosl(w * (long double)((long long)q * k % (K - 1)));
+        const long double d = fabsl(v - (long double)taps[k]);
+        if (d > res) res = d;
+        if (fabsl((long double)taps[k]) > peak) peak = fabsl((long double)taps[k]);
+    }
+    if (!(res <= 1e-13L * peak)) return false;
+    f->Q = 0;
+    for (int q = 0; q < NQ; ++q) {
+        f->a[q] = (double)a[q];
+        if (fabsl(a[q]) > 1e-14L * peak) f->Q = q;
+    }
+    for (int q = f->Q + 1; q < NQ; ++q) f->a[q] = 0.0;
+    return f->Q >= 1;                                    // (a rolling average alone is not worth a kernel of its own)
+}
+// the fit of a tap set is looked up before it is computed (a few thousand cosl calls: ~1.5 ms on the host, as much as the
+// whole accurate-sync batch it was meant to speed up)
+#include <mutex>
+struct DDCosFitEntry { std::vector<double> taps; bool ok; DDCosFit fit; };
+static inline bool dd_cos_fit_cached(const double* taps, int K, DDCosFit* f) {
+    static std::mutex mu;
+    static std::vector<DDCosFitEntry> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const DDCosFitEntry& e : cache)
+        if ((int)e.taps.size() == K && memcmp(e.taps.data(), taps, sizeof(double) * K) == 0) {
+            if (e.ok) *f = e.fit;
+            return e.ok;
+        }
+    DDCosFitEntry e;
+    e.taps.assign(taps, taps + K);
+    e.ok = dd_cos_fit(taps, K, &e.fit);
+    if (cache.size() >= 16) cache.erase(cache.begin());
+    cache.push_back(e);
+    if (e.ok) *f = e.fit;
+    return e.ok;
+}
+// (cos, sin)(2 pi q r / (K-1)), q = 1..Q, r = 0..K-2, as the kernel reads it: tab[(q - 1) * (K - 1) + r]
+static inline void dd_cos_table(int K, int Q, std::vector<double2>& tab) {
+    tab.resize((size_t)Q * (K - 1));
+    const long double w = 2.0L * 3.14159265358979323846264338327950288L / (long double)(K - 1);
+    for (int q = 1; q <= Q; ++q)
+        for (int r = 0; r < K - 1; ++r) {
+            const long double ph = w * (long double)((long long)q * r % (K - 1));
+            tab[(size_t)(q - 1) * (K - 1) + r] = make_double2((double)cosl(ph), (double)sinl(ph));
+        }
+}
+
+#define DD_FC_THREADS 256
+#define DD_FC_SEG_MAX 12            // staged samples per lane: ceil((TILE + K - 1) / 256)
+template <int Q> struct dd_fc_geom { static constexpr int TILE = Q == 1 ? 2048 : 1024; };
+static inline size_t dd_fc_lds_bytes(int K, int Q) {
+    const int W = (Q == 1 ? 2048 : 1024) + K - 1;
+    return sizeof(double) * ((size_t)(1 + 2 * Q) * (W + 1) + (size_t)(1 + 2 * Q) * 4) + sizeof(double2) * (size_t)Q * (K - 1);
+}
+static inline bool dd_fc_ok(int K, int Q) {
+    const int W = (Q == 1 ? 2048 : 1024) + K - 1;
+    return Q >= 1 && Q <= 3 && (W + DD_FC_THREADS - 1) / DD_FC_THREADS <= DD_FC_SEG_MAX && dd_fc_lds_bytes(K, Q) <= 150 * 1024;
+}
+
+// MODE 0: pass 1 (n + 2 edge outputs), MODE 1: pass 2 (n outputs); blockIdx.y = window of the batch
+template <int Q, int MODE>
+__global__ void __launch_bounds__(DD_FC_THREADS) k_filtfilt_cos(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int edge,
+                                                               const DDCosFit fit, const double2* __restrict__ tab_g, int K,
+                                                               int64_t src_stride, int64_t dst_stride) {
+    constexpr int NS = 1 + 2 * Q, TILE = dd_fc_geom<Q>::TILE;
+    extern __shared__ double dd_fc_smem[];
+    const int W = TILE + K - 1, P = K - 1;
+    double* C = dd_fc_smem;                               // [NS][W + 1]: C[s][j + 1] = sum of stream s over the window's samples 0..j
+    double* wsum = C + (size_t)NS * (W + 1);              // [NS][4] wave totals
+    double2* tab = reinterpret_cast<double2*>(wsum + NS * 4);
+    const int64_t N = n + 2 * (int64_t)edge;
+    const int64_t nout = MODE == 0 ? N : n;
+    const double* x = src + (int64_t)blockIdx.y * src_stride;
+    double* y = dst + (int64_t)blockIdx.y * dst_stride;
+    const int64_t o0 = (int64_t)blockIdx.x * TILE;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < Q * P; i += DD_FC_THREADS) tab[i] = tab_g[i];
+    // stage the window's samples (coalesced) into stream 0's row, shifted by one
+    for (int j = t; j < W; j += DD_FC_THREADS) {
+        double v;
+        if (MODE == 0) {                  // ext[max(o0 - (K-1) + j, 0)]
+            int64_t i = o0 - (K - 1) + j;
+            if (i < 0) i = 0;
+            v = i < N ? dd_ext_at(x, n, edge, i) : 0.0;
+        } else {                          // y1[min(o0 + edge + j, N-1)]
+            int64_t i = o0 + edge + j;
+            if (i > N - 1) i = N - 1;
+            v = x[i];
+        }
+        C[j + 1] = v;
+    }
+    __syncthreads();
+    // every lane scans its own run of consecutive samples in registers ...
+    const int S = (W + DD_FC_THREADS - 1) / DD_FC_THREADS;
+    const int j0 = t * S;
+    double run[DD_FC_SEG_MAX][NS];
+    double tot[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) tot[s] = 0.0;
+    int r = j0 % P;
+#pragma unroll
+    for (int e = 0; e < DD_FC_SEG_MAX; ++e) {
+        if (e < S) {
+            const int j = j0 + e;
+            const double v = j < W ? C[j + 1] : 0.0;
+            tot[0] += v;
+            run[e][0] = tot[0];
+#pragma unroll
+            for (int q = 1; q <= Q; ++q) {
+                const double2 cs = tab[(q - 1) * P + r];
+                tot[2 * q - 1] = fma(v, cs.x, tot[2 * q - 1]);
+                tot[2 * q] = fma(v, cs.y, tot[2 * q]);
+                run[e][2 * q - 1] = tot[2 * q - 1];
+                run[e][2 * q] = tot[2 * q];
+            }
+            r = r + 1 == P ? 0 : r + 1;
+        }
+    }
+    __syncthreads();                      // (stream 0's row is rewritten below)
+    // ... the runs' totals are scanned across the workgroup ...
+    double off[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double inc = tot[s];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double u = __shfl_up(inc, d);
+            if (lane >= d) inc += u;
+        }
+        if (lane == 63) wsum[s * 4 + wv] = inc;
+        off[s] = inc - tot[s];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        for (int w = 0; w < wv; ++w) off[s] += wsum[s * 4 + w];
+    // ... and the prefix sums go to LDS
+    if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) C[(size_t)s * (W + 1)] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < DD_FC_SEG_MAX; ++e) {
+        if (e < S && j0 + e < W) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) C[(size_t)s * (W + 1) + j0 + e + 1] = off[s] + run[e][s];
+        }
+    }
+    __syncthreads();
+    // outputs: window [o, o + K - 1] of the staged samples
+    for (int o = t; o < TILE; o += DD_FC_THREADS) {
+        if (o0 + o >= nout) break;
+        double acc = fit.a[0] * (C[o + K] - C[o]);
+        const int ro = o % P;
+#pragma unroll
+        for (int q = 1; q <= Q; ++q) {
+            const double2 cs = tab[(q - 1) * P + ro];
+            const double A = C[(size_t)(2 * q - 1) * (W + 1) + o + K] - C[(size_t)(2 * q - 1) * (W + 1) + o];
+            const double B = C[(size_t)(2 * q) * (W + 1) + o + K] - C[(size_t)(2 * q) * (W + 1) + o];
+            acc = fma(fit.a[q], fma(cs.x, A, cs.y * B), acc);
+        }
+        y[o0 + o] = acc;
+    }
+}
+
+// both passes (cf. dd_filtfilt_launch); tab_dev: Q * (K - 1) double2 of device memory this call fills from tab_host
+template <int Q>
+static inline int dd_filtfilt_cos_launch_q(const double* in, int64_t in_stride, double* y1, double* out, int64_t out_stride, int64_t n, int K,
+                                           const DDCosFit& fit, const double2* tab_dev, int batch, hipStream_t s) {
+    const int edge = 3 * K;
+    const int64_t N = n + 2 * (int64_t)edge;
+    const size_t lds = dd_fc_lds_bytes(K, Q);
+    constexpr int TILE = dd_fc_geom<Q>::TILE;
+    static DDOncePerDevice attr;
+    if (attr.need()) {
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_filtfilt_cos<Q, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_filtfilt_cos<Q, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL((k_filtfilt_cos<Q, 0>), dim3((unsigned)((N + TILE - 1) / TILE), batch), dim3(DD_FC_THREADS), lds, s,
+                       in, y1, n, edge, fit, tab_dev, K, in_stride, N);
+    hipLaunchKernelGGL((k_filtfilt_cos<Q, 1>), dim3((unsigned)((n + TILE - 1) / TILE), batch), dim3(DD_FC_THREADS), lds, s,
+                       (const double*)y1, out, n, edge, fit, tab_dev, K, N, out_stride);
+    return DD_OK;
+}
+static inline int dd_filtfilt_cos_launch(const double* in, int64_t in_stride, double* y1, double* out, int64_t out_stride, int64_t n, int K,
+                                         const DDCosFit& fit, const double2* tab_dev, int batch, hipStream_t s) {
+    switch (fit.Q) {
+        case 1: return dd_filtfilt_cos_launch_q<1>(in, in_stride, y1, out, out_stride, n, K, fit, tab_dev, batch, s);
+        case 2: return dd_filtfilt_cos_launch_q<2>(in, in_stride, y1, out, out_stride, n, K, fit, tab_dev, batch, s);
+        case 3: return dd_filtfilt_cos_launch_q<3>(in, in_stride, y1, out, out_stride, n, K, fit, tab_dev, batch, s);
+    }
+    return DD_ERR_UNSUPPORTED;
 }

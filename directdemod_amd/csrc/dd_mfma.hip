@@ -586,11 +586,13 @@ __device__ __forceinline__ void dd_ws_epilogue_unit(const DDChainParams& P, int 
         const float re3 = fmaf(y23.z, y23.x, y23.w * y23.y), im3 = fmaf(y23.w, y23.x, -y23.z * y23.y);
         float a0, a1, a2, a3;
         // wave-uniform fast path: every |angle| below 22.5 degrees (an oversampled FM signal
-        // always is): atan(t) needs no octant logic.  One ballot decides for the whole wave.
-        const unsigned long long big = __builtin_amdgcn_ballot_w64(!(fabsf(im0) <= 0.41421354f * re0)) |
-                                       __builtin_amdgcn_ballot_w64(!(fabsf(im1) <= 0.41421354f * re1)) |
-                                       __builtin_amdgcn_ballot_w64(!(fabsf(im2) <= 0.41421354f * re2)) |
-                                       __builtin_amdgcn_ballot_w64(!(fabsf(im3) <= 0.41421354f * re3));
+        // always is): atan(t) needs no octant logic.  One ballot decides for the whole wave.  (Strict: a product of
+        // exactly zero -- digital silence -- must take the full-range form, which returns 0 for it; the small-angle one
+        // would compute 0 * rcp(0) = NaN)
+        const unsigned long long big = __builtin_amdgcn_ballot_w64(!(fabsf(im0) < 0.41421354f * re0)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im1) < 0.41421354f * re1)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im2) < 0.41421354f * re2)) |
+                                       __builtin_amdgcn_ballot_w64(!(fabsf(im3) < 0.41421354f * re3));
         if (big == 0) {
             a0 = dd_atan_small(im0, re0); a1 = dd_atan_small(im1, re1);
             a2 = dd_atan_small(im2, re2); a3 = dd_atan_small(im3, re3);

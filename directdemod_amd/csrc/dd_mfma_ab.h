@@ -225,7 +225,7 @@ __device__ __forceinline__ void dd_ab_unit_store(const DDChainParams& P, int b, 
     const float mn = fminf(fminf(fmaf(0.41421354f, re0, -fabsf(im0)), fmaf(0.41421354f, re1, -fabsf(im1))),
                            fminf(fmaf(0.41421354f, re2, -fabsf(im2)), fmaf(0.41421354f, re3, -fabsf(im3))));
     float a0, a1, a2, a3;
-    if (__builtin_amdgcn_ballot_w64(!(mn >= 0.f)) == 0) {
+    if (__builtin_amdgcn_ballot_w64(!(mn > 0.f)) == 0) {
         a0 = dd_atan_small(im0, re0); a1 = dd_atan_small(im1, re1);
         a2 = dd_atan_small(im2, re2); a3 = dd_atan_small(im3, re3);
     } else {
@@ -414,13 +414,15 @@ __device__ __forceinline__ void dd_ab_epilogue(const DDChainParams& P, int b, in
         im[r] = fmaf(cim[r], pre, -cre[r] * pim);
     }
     // 3. wave-uniform fast path: every |angle| below 22.5 degrees (an oversampled FM signal always is), i.e.
-    //    min over the rows of (tan(22.5 deg) re - |im|) >= 0 in every lane (a NaN fails the test)
+    //    min over the rows of (tan(22.5 deg) re - |im|) > 0 in every lane (a NaN fails the test, and so does a product of
+    //    exactly zero -- digital silence -- for which the small-angle form would compute 0 * rcp(0) = NaN and the
+    //    full-range form returns np.angle(0) = 0)
     float mn = fmaf(0.41421354f, re[0], -fabsf(im[0]));
 #pragma unroll
     for (int r = 1; r + 1 < NR; r += 2)                      // v_min3_f32: two rows per instruction
         mn = fminf(fminf(mn, fmaf(0.41421354f, re[r], -fabsf(im[r]))), fmaf(0.41421354f, re[r + 1], -fabsf(im[r + 1])));
     if ((NR & 1) == 0) mn = fminf(mn, fmaf(0.41421354f, re[NR - 1], -fabsf(im[NR - 1])));
-    const bool all_small = __builtin_amdgcn_ballot_w64(!(mn >= 0.f)) == 0;
+    const bool all_small = __builtin_amdgcn_ballot_w64(!(mn > 0.f)) == 0;
     float a[NR];
     if (all_small) {
 #pragma unroll

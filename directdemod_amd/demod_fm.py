@@ -15,6 +15,9 @@ from . import _hip
 from ._hip import DevArray, check, lib
 
 
+_FM_POOL = []
+
+
 class demod_fm():
     '''
     Object for FM demodulation
@@ -33,15 +36,23 @@ class demod_fm():
     def _handle(self):
         if self.__h is None:
             _hip.require_gpu()
-            p = C.c_void_p()
-            check(lib().dd_fm_create(C.byref(p)), "dd_fm_create")
+            if _FM_POOL:                     # a handle of a collected demodulator, back in its first-call state (see filters._FIR_POOL)
+                p = _FM_POOL.pop()
+                check(lib().dd_fm_reset(p), "dd_fm_reset")
+            else:
+                p = C.c_void_p()
+                check(lib().dd_fm_create(C.byref(p)), "dd_fm_create")
             self.__h = p
         return self.__h
 
     def __del__(self):
         try:
             if self.__h is not None:
-                lib().dd_fm_destroy(self.__h)
+                if len(_FM_POOL) < 16:
+                    _FM_POOL.append(self.__h)
+                else:
+                    lib().dd_fm_destroy(self.__h)
+                self.__h = None
         except Exception:
             pass
 

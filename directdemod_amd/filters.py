@@ -24,6 +24,40 @@ _F32 = np.dtype(np.float32)
 _F64 = np.dtype(np.float64)
 
 
+# Device handles (dd_fir: taps in every kernel's layout, history ping-pong, constant histories) of filter objects that have
+# been garbage-collected, kept for the next filter object with the same taps: the reference's callers build their filters inside
+# the call (decode_noaa.py:611-613 builds blackmanHarris(151) in every __audio), and creating / destroying a handle is a dozen
+# hipMalloc / hipFree calls with device synchronisations (0.5 ms of getCrudeSync's 2.1 ms, tools/debug/noaa_hostprof.py).  A
+# handle taken from here starts from the first-call state (history of ones, quirk Q1) like a new one.
+_FIR_POOL = {}
+_FIR_POOL_PER_KEY, _FIR_POOL_TOTAL = 4, 32
+
+
+def _pool_take(key):
+    lst = _FIR_POOL.get(key)
+    if lst:
+        return lst.pop()
+    return None
+
+
+def _pool_give(key, h):
+    if sum(len(v) for v in _FIR_POOL.values()) >= _FIR_POOL_TOTAL:
+        return False
+    lst = _FIR_POOL.setdefault(key, [])
+    if len(lst) >= _FIR_POOL_PER_KEY:
+        return False
+    lst.append(h)
+    return True
+
+
+def pool_clear():
+    """destroy the pooled handles (tests, and before the library is unloaded)"""
+    for lst in _FIR_POOL.values():
+        for h in lst:
+            lib().dd_fir_destroy(h)
+    _FIR_POOL.clear()
+
+
 class filter:
     '''
     Parent object of all filters (filters.py:15-89).
@@ -70,15 +104,22 @@ class filter:
         if self.__h is None:
             _hip.require_gpu()
             t = np.ascontiguousarray(self.__taps, dtype=np.float64)
-            p = C.c_void_p()
-            check(lib().dd_fir_create(C.byref(p), t.ctypes.data_as(C.POINTER(C.c_double)), len(t)), "dd_fir_create")
+            self.__key = t.tobytes()
+            p = _pool_take(self.__key)
+            if p is not None:
+                check(lib().dd_fir_reset(p, _hip.DD_HIST_ONES, None, None), "dd_fir_reset")       # launch-free: a constant history buffer
+            else:
+                p = C.c_void_p()
+                check(lib().dd_fir_create(C.byref(p), t.ctypes.data_as(C.POINTER(C.c_double)), len(t)), "dd_fir_create")
             self.__h = p
         return self.__h
 
     def __del__(self):
         try:
             if self.__h is not None:
-                lib().dd_fir_destroy(self.__h)
+                if not _pool_give(self.__key, self.__h):
+                    lib().dd_fir_destroy(self.__h)
+                self.__h = None
             if self.__iir is not None:
                 lib().dd_iir_destroy(self.__iir)
         except Exception:

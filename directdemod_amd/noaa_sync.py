@@ -74,19 +74,31 @@ class noaa_sync:
             heights.append(float(corh[i + int(n / 2)]))
         return peaks, heights, tsync
 
-    def getCrudeSync(self):
+    def getCrudeSync(self, fused=True):
+        """decode_noaa.py:769-806.  fused: the audio-rate tail (envelope, both correlations, both peak picks) as ONE device call
+        (dd_noaa_crude_tail); False: stage by stage through envelope() / correlate_and_find_peaks() like the reference's code
+        (the index lists are the same: tests/test_gpu_audio.py)."""
         if self.__syncA is None or self.__syncB is None:
-            sig = self.envelope(self.audio(constants.NOAA_CRUDESYNCSAMPRATE, False))
-            self.__rate = sig.sampRate
-            self.__syncA = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCA)
-            self.__syncB = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCB)
+            audio = self.audio(constants.NOAA_CRUDESYNCSAMPRATE, False)
+            res = None
+            if fused:
+                res = _ops.crude_tail(audio.device_signal, audio.sampRate,
+                                      [sync_needle(constants.NOAA_SYNCA, audio.sampRate), sync_needle(constants.NOAA_SYNCB, audio.sampRate)])
+            if res is not None:
+                self.__rate = audio.sampRate
+                self.__syncA, self.__syncB = res[0]
+            else:
+                sig = self.envelope(audio)
+                self.__rate = sig.sampRate
+                self.__syncA = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCA)
+                self.__syncB = self.correlate_and_find_peaks(sig, constants.NOAA_SYNCB)
 
-            def _min_dev(s):                                      # :794-801
+            def _min_dev(s):                                      # :794-801 (the reference's loop over windows, as one array expression)
                 d = np.abs(np.diff(s) - (self.__rate * 0.5))
                 m = len(d) - constants.NOAA_DETECTCONSSYNCSNUM + 1
                 if m <= 0:
                     return np.inf
-                return np.min([np.max(d[i:i + constants.NOAA_DETECTCONSSYNCSNUM]) for i in range(m)])
+                return np.min(np.max(np.lib.stride_tricks.sliding_window_view(d, constants.NOAA_DETECTCONSSYNCSNUM), axis=1))
             if _min_dev(self.__syncA) < constants.NOAA_DETECTMAXCHANGE or \
                     _min_dev(self.__syncB) < constants.NOAA_DETECTMAXCHANGE:
                 self.__useful = 1

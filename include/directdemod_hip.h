@@ -307,6 +307,19 @@ int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host
                          const double* needle_host, int needle_len, double samp_rate,
                          int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
 
+/* P -- getCrudeSync's audio-rate tail (decode_noaa.py:781-790) in one host call: the envelope of `audio` (device float32 or
+ *      float64, n samples at samp_rate) in `block`-sample blocks by the chunker rule (__getAM :631-657 -> demod_am.py:29),
+ *      then for each of n_needles (1 or 2: sync A and sync B, :786 and :790) piecewise-constant needles of m samples
+ *      (needles_host[needle][m], host float64) the normalised correlation (:659-675) and the peak pick (:713-751).  Per
+ *      needle d the picked indices -- ascending, already minus m / 2 -- land in peaks_host[d * max_peaks ...] and their
+ *      number in n_peaks[d]; env_out (device float64[n], may be NULL) receives the envelope.  The index lists are those of
+ *      dd_am_envelope_f64 + dd_xcorr_norm_f64 + dd_find_peaks_f64 called stage by stage.  DD_ERR_UNSUPPORTED (nothing done)
+ *      for needles with more than 64 runs, more than 2048 expected peaks (~17 min of audio) or more than 65 536 samples
+ *      above the threshold: take the staged route.  Synchronous. */
+int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n, double samp_rate, int64_t block,
+                       const double* needles_host, int m, int n_needles, double* env_out,
+                       int64_t* peaks_host, int max_peaks, int* n_peaks, void* stream);
+
 /* ---- AFSK1200 correlators (decode_afsk1200.py:99-158) ------------ */
 /* binary_filter[s] = mi^2 + mq^2 - si^2 - sq^2, the four sums over buffer_size samples
  * from s against tables_host[4][bs] = mark cos/sin, space cos/sin (:110-123); entries

@@ -119,6 +119,34 @@ def test_xcorr_and_peaks_3s_golden(dd, noaa_inputs):
     assert np.array_equal(ns.correlate_and_find_peaks(sig, O.NOAA_SYNCB), g["peaks_3s_syncB"])
 
 
+def test_crude_tail_in_one_call_equals_the_staged_route(dd, noaa_inputs):
+    """dd_noaa_crude_tail (envelope by a real transform pair, prefix sums once, both needles, selection + threshold +
+    candidates in one persistent launch with grid-wide barriers) against the stage-by-stage entry points on the same audio:
+    identical index lists for both sync words (and equal to the reference's golden lists), envelope to 1e-12; odd lengths and
+    a length below one block included (the last block of the chunker rule is ragged)."""
+    g, raw = noaa_inputs
+    audio, rate = O.audio_chain(lambda a, b: O.read_iq_u8(raw, a, b), len(raw), 2048000, 30000.0,
+                                O.win_blackmanharris(151), 60000, audio_rate=40960, strict=False)
+    needles = [O.sync_needle(O.NOAA_SYNCA, rate), O.sync_needle(O.NOAA_SYNCB, rate)]
+    ns = dd.noaa.noaa_sync(None, 0.0)
+    for n, dt in ((len(audio), np.float32), (len(audio) - 1, np.float64), (3 * rate, np.float32), (200001, np.float64)):
+        a = np.ascontiguousarray(audio[:n].astype(dt))
+        d = dd.hip.DevArray.from_host(a)
+        res = dd.ops.crude_tail(d, rate, needles, want_env=True)
+        assert res is not None
+        (pa, pb), env = res
+        sig = ns.envelope(dd.comm.commSignal(rate, a))
+        env_ref = np.asarray(sig.signal)
+        assert np.max(np.abs(env.to_host() - env_ref)) <= 1e-12 * np.max(env_ref), n
+        assert np.array_equal(pa, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCA)), n
+        assert np.array_equal(pb, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCB)), n
+    # the reference's own lists for the first three seconds (float64 envelope of the oracle's audio)
+    am = O.am_demod_blocks(audio[:3 * rate])
+    (pa, pb), _ = dd.ops.crude_tail(dd.hip.DevArray.from_host(np.ascontiguousarray(audio[:3 * rate])), rate, needles)
+    assert np.array_equal(pa, g["peaks_3s_syncA"]) and np.array_equal(pb, g["peaks_3s_syncB"])
+    assert len(am) == 3 * rate
+
+
 def test_c4_crude_and_accurate_sync_indices_golden(dd, noaa_inputs):
     """config 4 end to end on the device: index lists identical to the reference's"""
     g, raw = noaa_inputs
@@ -177,6 +205,9 @@ def test_c4_at_bench_duration_index_lists_golden(dd, golden_dir):
     sa2, sb2 = ns2.getCrudeSync()
     (ia2, _, _), (ib2, _, _) = ns2.getAccurateSync()
     assert np.array_equal(sa2, sa) and np.array_equal(sb2, sb) and np.array_equal(ia2, ia) and np.array_equal(ib2, ib)
+    # the stage-by-stage crude route (envelope(), correlate_and_find_peaks() as the reference's code calls them)
+    sa3, sb3 = dd.noaa.noaa_sync(src, 30000.0).getCrudeSync(fused=False)
+    assert np.array_equal(sa3, sa) and np.array_equal(sb3, sb)
 
 
 def test_c4_audio_stage_vs_golden(dd, noaa_inputs):

@@ -336,7 +336,18 @@ def test_fft_kernel_retuned_every_chunk(dd, select_kernel):
         yy = y if prv is None else np.concatenate([[prv], y])
         mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
     assert flt._last_kernel() == dd.hip.DD_KERNEL_FFT_OS
-    fm_check(out.signal, np.concatenate(refs), np.concatenate(mags))
+    # (the chunks' output levels differ by three orders of magnitude -- a retune to 700 kHz puts the signal deep in the stop
+    # band -- so "well-conditioned" is judged against the local level, the running maximum over +-1024 outputs: the FFT kernel's
+    # rounding noise is that of the largest values of the 1024-sample block an output is computed in)
+    from scipy.ndimage import maximum_filter1d
+    ref, prod = np.concatenate(refs), np.concatenate(mags)
+    got = np.asarray(out.signal, dtype=np.float64)
+    assert got.shape == ref.shape
+    d = np.abs(np.angle(np.exp(1j * (got - ref))))
+    loc = maximum_filter1d(prod, size=2049, mode="nearest")
+    assert np.max(d[prod >= 1e-3 * loc]) <= FM_MAX
+    assert np.max(d[prod >= 0.1 * loc]) <= FM_WELL
+    assert np.median(d) <= FM_MED
 
 
 @pytest.mark.parametrize("kern", ["fft1k", "ab"])
