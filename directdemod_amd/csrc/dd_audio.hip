@@ -1431,9 +1431,11 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     double* ENV = (double*)(base + o_ENV);
     double* F1 = (double*)(base + o_F1);
     double* H = (double*)(base + o_H);
-    DD_HIP_CHECK(hipMemcpyAsync(d_starts, starts_host, sizeof(int64_t) * n_windows, hipMemcpyHostToDevice, s));
-    DD_HIP_CHECK(hipMemcpyAsync(d_taps1, fir_taps_host, sizeof(double) * fir_ntaps, hipMemcpyHostToDevice, s));
-    if (pre_ntaps) DD_HIP_CHECK(hipMemcpyAsync(d_taps2, pre_taps_host, sizeof(double) * pre_ntaps, hipMemcpyHostToDevice, s));
+    // window starts, both tap sets and the cosine table go up as ONE copy (they are neighbours in the layout)
+    std::vector<char> up(o_res, 0);
+    memcpy(up.data() + o_starts, starts_host, sizeof(int64_t) * n_windows);
+    memcpy(up.data() + o_taps1, fir_taps_host, sizeof(double) * fir_ntaps);
+    if (pre_ntaps) memcpy(up.data() + o_taps2, pre_taps_host, sizeof(double) * pre_ntaps);
     // the envelope's pre-filter is hamming(492) (decode_noaa.py:677): a two-term cosine series -- prefix-sum form
     // (dd_filtfilt_kernels.h; DD_SYNC_DIRECT_FIR=1, tools: the 492 multiply-adds per sample of the tiled direct form)
     DDCosFit fit2;
@@ -1447,8 +1449,9 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         static int tab_K = 0, tab_Q = 0;
         std::lock_guard<std::mutex> tl(tab_mu);
         if (tab_K != pre_ntaps || tab_Q != fit2.Q) { dd_cos_table(pre_ntaps, fit2.Q, tabh); tab_K = pre_ntaps; tab_Q = fit2.Q; }
-        DD_HIP_CHECK(hipMemcpyAsync(d_tab, tabh.data(), sizeof(double2) * tabh.size(), hipMemcpyHostToDevice, s));
+        memcpy(up.data() + o_tab, tabh.data(), sizeof(double2) * tabh.size());
     }
+    DD_HIP_CHECK(hipMemcpyAsync(base, up.data(), o_res, hipMemcpyHostToDevice, s));          // (pageable source: staged before the call returns)
     for (int w0 = 0; w0 < n_windows; w0 += B) {
         const int b = n_windows - w0 < B ? n_windows - w0 : B;
         const dim3 gL(grid1(L), b), gL2(grid1(L2), b), gL4(grid1((L + 3) / 4), b);
@@ -1496,10 +1499,12 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         hipLaunchKernelGGL(k_sync_peak, dim3(b), dim3(256), 0, s, ppart, xtiles, ENV, L2, needle_len, d_peak + w0, d_height + w0, d_tsync + w0);
         DD_LAUNCH_CHECK();
     }
-    DD_HIP_CHECK(hipMemcpyAsync(peak_host, d_peak, sizeof(int64_t) * n_windows, hipMemcpyDeviceToHost, s));
-    DD_HIP_CHECK(hipMemcpyAsync(height_host, d_height, sizeof(double) * n_windows, hipMemcpyDeviceToHost, s));
-    DD_HIP_CHECK(hipMemcpyAsync(tsync_host, d_tsync, sizeof(double) * n_windows, hipMemcpyDeviceToHost, s));
+    std::vector<char> down(24 * (size_t)n_windows);                                              // the three result arrays, one copy
+    DD_HIP_CHECK(hipMemcpyAsync(down.data(), base + o_res, down.size(), hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(peak_host, down.data(), 8 * (size_t)n_windows);
+    memcpy(height_host, down.data() + 8 * (size_t)n_windows, 8 * (size_t)n_windows);
+    memcpy(tsync_host, down.data() + 16 * (size_t)n_windows, 8 * (size_t)n_windows);
     return DD_OK;
 }
 

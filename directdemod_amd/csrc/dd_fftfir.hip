@@ -272,6 +272,7 @@ struct DDFft1kTabs {
     float theta_sub;       // != 0: |theta| is small -- the discriminator subtracts it from the angle instead of rotating every
                            // product by crot: 12 packed adds instead of 24 packed multiply-adds per block (groups of outputs
                            // that need the full-range arctangent are rotated after all)
+    float2 rowph[6];       // complex64 output (no demod_fm): e^{-j theta 128 i}, the NCO factor from one row pair of a block to the next
     int base;              // block b covers FIR outputs [768 b + base, 768 b + base + 768), base in [s - 15, s]: chosen on the host so
                            // that every interior store instruction writes whole 64-byte lines of `out` (a stream START drops one
                            // angle, demod_fm.py:43-49, which put every 512-byte store 4 bytes ahead of a line boundary: PMC WRITE_SIZE
@@ -350,7 +351,7 @@ __device__ __forceinline__ float2 f1_cmulf(v2f a, float2 w) {
 
 // sample n of the chunk as this kernel's un-rotated frame sees it: inside the chunk the input itself; before it the
 // carried history (K-1 samples AFTER the NCO, filters.py:45,69 / comm.py:77), rotated back; zeros before that; behind
-// the chunk's end a copy of its last sample (only outputs that are not stored depend on those)
+// the chunk's end zeros (only outputs that are not stored depend on those)
 template <bool U8>
 __device__ __forceinline__ v2f f1_edge_sample(const DDChainParams& P, int64_t n) {
     if (n < 0) {
@@ -361,12 +362,15 @@ __device__ __forceinline__ v2f f1_edge_sample(const DDChainParams& P, int64_t n)
         const float2 w = dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl);     // e^{-j theta (abs0 + n)}
         return (v2f){fmaf(t.x, w.x, t.y * w.y), fmaf(t.y, w.x, -t.x * w.y)};       // t * conj(w)
     }
-    const int64_t nc = n < P.L ? n : P.L - 1;
+    // behind the chunk's end: zeros (only outputs that are not stored depend on those samples; a copy of the last sample, as
+    // rounds 3's kernel padded, put a run of up to 1023 equal samples -- a DC line 137 x the sample -- into a short chunk's
+    // block, and the block's rounding noise is that of its LARGEST output: 2.2e-6 of max|y| on the 3-chunk golden vector)
+    if (n >= P.L) return (v2f){0.f, 0.f};
     if (U8) {
-        const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[nc];
+        const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
         return (v2f){(float)u.x - 127.5f, (float)u.y - 127.5f};
     }
-    const float2 v = reinterpret_cast<const float2*>(P.in)[nc];
+    const float2 v = reinterpret_cast<const float2*>(P.in)[n];
     return (v2f){v.x, v.y};
 }
 
@@ -433,10 +437,20 @@ __device__ __forceinline__ void f1_tail_group(const int g, const v2f (&zz)[16], 
 // one block.  On entry a[0..3] hold rows 0..3 of column t (the overlap kept from the previous block, or swapped by the
 // caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
 // at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
-template <bool U8, bool PARTIAL, bool LOADNEXT>
+// complex64 output flavour (commSignal.filter without a demodulator, comm.py:80-92): y[p] = e^{-j theta (abs0 + p)} w[p] -- the NCO
+// factor the FM flavour never needs (it cancels in y[p] conj(y[p-1]) up to the constant rotation) is applied to every output as
+// (block's first output) x (row pair) x (lane): pb = e^{-j theta (abs0 + p0)} from the exact phase table, once per block
+struct F1Cx {
+    v2f pb;                // e^{-j theta (abs0 + p0)}
+    v2f lp0, lp1;          // e^{-j theta (2 lane)}, e^{-j theta (2 lane + 1)}
+    const float2* rowph;   // [6] e^{-j theta 128 i} (kernel argument)
+};
+__device__ __forceinline__ v2f f1_cmul(v2f a, v2f b) { return (v2f){fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)}; }
+
+template <bool U8, bool PARTIAL, bool LOADNEXT, bool CX = false>
 __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)[4], v2f* const Xp, const v2f (&tw1)[16], const v2f (&tw3)[16], const v2f* const hp,
                                          const v2f crot, const float theta_sub, const int lane, const void* in, const int64_t n0_next, float* const out_row4, const int lim_lo, const int limit,
-                                         const bool jump = false, const F1Edge* edge = nullptr
+                                         const bool jump = false, const F1Edge* edge = nullptr, const F1Cx* cx = nullptr
 #ifdef FF_TRACE
                                          , unsigned* tr = nullptr
 #endif
@@ -532,6 +546,44 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
         v2f B[8], A[8];
 #pragma unroll
         for (int r = 1; r < 8; ++r) { B[r] = a[FF_P(2 * r)]; A[r] = a[FF_P(2 * r + 1)]; f1_swap(B[r], A[r]); }
+        if (CX) {
+            // ---- complex64 output: NCO factor, 16-byte stores of two outputs per lane; the next block's loads in between
+#ifndef FF_NO_LOAD
+            if (LOADNEXT && jump) f1_load_pairs<U8, false, 4>(in, n0_next, lane, jl, 0, 2);
+#endif
+            float2* const oc = reinterpret_cast<float2*>(out_row4) + 2 * lane;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                v2f y[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = 2 + 2 * g + i;
+                    const float2 rw = cx->rowph[r - 2];
+                    const v2f rp = f1_cmul(cx->pb, (v2f){rw.x, rw.y});
+                    y[2 * i] = f1_cmul(B[r], f1_cmul(rp, cx->lp0));
+                    y[2 * i + 1] = f1_cmul(A[r], f1_cmul(rp, cx->lp1));
+                }
+#ifndef FF_NO_LOAD
+                if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
+#endif
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int o = 128 * (2 * g + i);
+                    if (!PARTIAL) {
+                        typedef float v4f_ __attribute__((ext_vector_type(4)));
+#ifndef FF_NO_NT_STORE
+                        __builtin_nontemporal_store((v4f_){y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y}, reinterpret_cast<v4f_*>(oc + o));
+#else
+                        *reinterpret_cast<v4f_*>(oc + o) = (v4f_){y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y};
+#endif
+                    } else {
+                        if (2 * lane + o >= lim_lo && 2 * lane + o < limit) oc[o] = make_float2(y[2 * i].x, y[2 * i].y);
+                        if (2 * lane + o + 1 >= lim_lo && 2 * lane + o + 1 < limit) oc[o + 1] = make_float2(y[2 * i + 1].x, y[2 * i + 1].y);
+                    }
+                }
+            }
+            return;
+        }
         if (PARTIAL && edge) {
             // chunk edges (cold path).  First block of a chunk that continues a stream: the FIR output before the chunk's
             // first one is the carried state (demod_fm.py:47-49), brought into this kernel's un-rotated frame.  Last block:
@@ -619,7 +671,7 @@ struct F1KernArgs {
 };
 typedef const __attribute__((address_space(4))) F1KernArgs* F1KernArgsPtr;
 
-template <bool U8>
+template <bool U8, bool CX>
 __device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X, const v2f* const hp, const int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const F1KernArgs* const kg = (const F1KernArgs*)ka;        // (address-space cast: device pass only)
@@ -659,7 +711,7 @@ __device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X
     e.last_rot = make_float2(1.f, 0.f);
     e.lasty_out = P.lasty_out;
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
-    if (q == 0 && P.s == 0) {
+    if (!CX && q == 0 && P.s == 0) {
         // y[-1] = e^{-j theta (abs0 - 1)} w[-1]  ->  w[-1] = y[-1] e^{+j theta (abs0 - 1)}
         const float2 ly = *P.lasty_in;
         const float2 w = nco ? dd_phasor((uint64_t)(P.abs0 - 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
@@ -672,7 +724,17 @@ __device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X
     }
     const int64_t lo64 = (int64_t)P.s - p0, hi64 = P.L - p0;
     const int lim_lo = lo64 > 0 ? (int)lo64 : 0, lim_hi = hi64 < F1_ADV ? (int)hi64 : F1_ADV;
-    f1_block<U8, true, false>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, false, &e);
+    if (CX) {
+        F1Cx cx;
+        const float2 pbf = nco ? dd_phasor((uint64_t)(P.abs0 + p0) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        const float2 l0 = nco ? dd_phasor((uint64_t)(2 * lane) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        const float2 l1 = nco ? dd_phasor((uint64_t)(2 * lane + 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+        cx.pb = (v2f){pbf.x, pbf.y}; cx.lp0 = (v2f){l0.x, l0.y}; cx.lp1 = (v2f){l1.x, l1.y};
+        cx.rowph = kg->T.rowph;
+        f1_block<U8, true, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(reinterpret_cast<float2*>(P.out) + p0), lim_lo, lim_hi, false, &e, &cx);
+    } else {
+        f1_block<U8, true, false>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, 0, reinterpret_cast<float*>(P.out) + (p0 - P.s), lim_lo, lim_hi, false, &e);
+    }
     if (q == nblk - 1 && P.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < P.K - 1; i += 64) {
@@ -699,7 +761,7 @@ __device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X
 // The whole chunk in one launch: FIR outputs [0, L) -> FM angles out[p - s] for p >= s, carried state read (history,
 // last FIR output) and written.  Block q covers outputs [768 q + base, 768 q + base + 768), base <= s (DDFft1kTabs); every wave
 // takes a contiguous run of the nblk blocks; block 0 and block nblk-1 are edge blocks.
-template <bool U8>
+template <bool U8, bool CX>
 __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainParams P, const DDFft1kTabs T, const DDFft1kMap M, int nblk, int nwaves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform by construction: the
@@ -715,7 +777,7 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     const v2f* const hp = HP + lane;
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
     F1KernArgsPtr ka = (F1KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    if (gw == 0) f1_edge_block<U8>(ka, 0, X, hp, lane);
+    if (gw == 0) f1_edge_block<U8, CX>(ka, 0, X, hp, lane);
     // this wave's interior blocks: run k = [1 + start_k, 1 + start_k + len_k)
     const int ni = nblk - 2;
     const int w0 = ni > 0 ? (int)(((int64_t)ni * gw) / nwaves) : 0, w1 = ni > 0 ? (int)(((int64_t)ni * (gw + 1)) / nwaves) : 0;
@@ -741,6 +803,15 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
         }
         const v2f crot = {T.crot.x, T.crot.y};
         float* const outp = reinterpret_cast<float*>(P.out);
+        F1Cx cx;
+        if (CX) {
+            const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+            const float2 l0 = nco ? dd_phasor((uint64_t)(2 * lane) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+            const float2 l1 = nco ? dd_phasor((uint64_t)(2 * lane + 1) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+            cx.lp0 = (v2f){l0.x, l0.y}; cx.lp1 = (v2f){l1.x, l1.y};
+            cx.pb = (v2f){1.f, 0.f};
+            cx.rowph = T.rowph;
+        }
         v2f a[16], keep[4], jl[4];
         f1_load_pairs<U8>(P.in, (int64_t)F1_ADV * q + T.base - 256, lane, a, 0, 8);
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
@@ -766,11 +837,18 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
             }
             const int64_t p0 = (int64_t)F1_ADV * q + T.base;
             const int64_t n0_next = (int64_t)F1_ADV * qn + T.base - 256;
+            if (CX) {
+                const float2 pbf = (P.flags & DD_CHAIN_NCO) ? dd_phasor((uint64_t)(P.abs0 + p0) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
+                cx.pb = (v2f){pbf.x, pbf.y};
+                f1_block<U8, false, true, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next,
+                                                reinterpret_cast<float*>(reinterpret_cast<float2*>(P.out) + p0), 0, F1_ADV, jump, nullptr, &cx);
+            } else {
 #ifdef FF_TRACE
-            f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump, nullptr, tr);
+                f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump, nullptr, nullptr, tr);
 #else
-            f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump);
+                f1_block<U8, false, true>(a, keep, jl, X, tw1, tw3, hp, crot, T.theta_sub, lane, P.in, n0_next, outp + (p0 - P.s), 0, F1_ADV, jump);
 #endif
+            }
             if (done) break;
             if (jump) {
                 f1_swap(jl[0], jl[1]);
@@ -793,7 +871,7 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
 #endif
     }
 #undef F1_RUN
-    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8>(ka, nblk - 1, X, hp, lane);
+    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8, CX>(ka, nblk - 1, X, hp, lane);
 }
 
 // ============================================================================ host side
@@ -839,7 +917,8 @@ static void fft_pow2(std::vector<std::complex<double>>& v) {
 }
 
 int dd_fft1k_supported(int K, int M, int flags) {
-    return (M == 1 && K >= 2 && K <= 256 && (flags & DD_CHAIN_FM)) ? 1 : 0;
+    (void)flags;                          // FM angles or complex64 output, complex64 or raw u8 input
+    return (M == 1 && K >= 2 && K <= 256) ? 1 : 0;
 }
 
 int dd_fft_create(void** st, const double* taps, int K) {
@@ -947,8 +1026,10 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     if (rc != DD_OK) return rc;
     static DDOncePerDevice attr1;
     if (attr1.need()) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_fft1k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
         attr1.mark();
     }
     DDFft1kTabs T1;
@@ -970,8 +1051,17 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     // the block grid is laid so that block b's first angle, out[768 b + base - s], starts a 64-byte line of `out`
     // (DD_FFT_FRAME=0, tools: the grid starts at output 0 whatever the alignment, as before round 4)
     static const char* frame_env = getenv("DD_FFT_FRAME");
+    const bool cxout = !(P.flags & DD_CHAIN_FM);
     {
-        const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
+        const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
+        for (int i = 0; i < 6; ++i) {
+            long double ph = frac * (long double)(128 * i);
+            ph -= floorl(ph);
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * ph;
+            T1.rowph[i] = make_float2((float)cosl(ang), (float)-sinl(ang));
+        }
+        // float32 angles: 16 per 64-byte line; complex64 outputs: 8 per line (and no demod_fm shift)
+        const int a16 = cxout ? (int)((reinterpret_cast<uintptr_t>(P.out) >> 3) & 7) : (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
         T1.base = (frame_env && atoi(frame_env) == 0) ? 0 : P.s - a16;
         while (T1.base > P.L - 1) T1.base -= 16;                 // (a chunk of one sample: the last block must hold output L - 1)
     }
@@ -1004,8 +1094,11 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
         M1.K = K;
         M1.b = b;
     }
-    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_fft1k<true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
-    else hipLaunchKernelGGL((k_chain_fft1k<false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
+    const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+    if (u8 && cxout) hipLaunchKernelGGL((k_chain_fft1k<true, true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
+    else if (u8) hipLaunchKernelGGL((k_chain_fft1k<true, false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
+    else if (cxout) hipLaunchKernelGGL((k_chain_fft1k<false, true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
+    else hipLaunchKernelGGL((k_chain_fft1k<false, false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

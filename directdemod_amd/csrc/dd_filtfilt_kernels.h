@@ -270,12 +270,13 @@ static inline void dd_cos_table(int K, int Q, std::vector<double2>& tab) {
         }
 }
 
-#define DD_FC_THREADS 256
-#define DD_FC_SEG_MAX 12            // staged samples per lane: ceil((TILE + K - 1) / 256)
+#define DD_FC_THREADS 512           // (eight waves per workgroup: two workgroups of 69 KB per CU then keep 16 waves in flight)
+#define DD_FC_WAVES (DD_FC_THREADS / 64)
+#define DD_FC_SEG_MAX 6             // staged samples per lane: ceil((TILE + K - 1) / 512)
 template <int Q> struct dd_fc_geom { static constexpr int TILE = Q == 1 ? 2048 : 1024; };
 static inline size_t dd_fc_lds_bytes(int K, int Q) {
     const int W = (Q == 1 ? 2048 : 1024) + K - 1;
-    return sizeof(double) * ((size_t)(1 + 2 * Q) * (W + 1) + (size_t)(1 + 2 * Q) * 4) + sizeof(double2) * (size_t)Q * (K - 1);
+    return sizeof(double) * ((size_t)(1 + 2 * Q) * (W + 1) + (size_t)(1 + 2 * Q) * DD_FC_WAVES) + sizeof(double2) * (size_t)Q * (K - 1);
 }
 static inline bool dd_fc_ok(int K, int Q) {
     const int W = (Q == 1 ? 2048 : 1024) + K - 1;
@@ -291,8 +292,8 @@ __global__ void __launch_bounds__(DD_FC_THREADS) k_filtfilt_cos(const double* __
     extern __shared__ double dd_fc_smem[];
     const int W = TILE + K - 1, P = K - 1;
     double* C = dd_fc_smem;                               // [NS][W + 1]: C[s][j + 1] = sum of stream s over the window's samples 0..j
-    double* wsum = C + (size_t)NS * (W + 1);              // [NS][4] wave totals
-    double2* tab = reinterpret_cast<double2*>(wsum + NS * 4);
+    double* wsum = C + (size_t)NS * (W + 1);              // [NS][waves] wave totals
+    double2* tab = reinterpret_cast<double2*>(wsum + NS * DD_FC_WAVES);
     const int64_t N = n + 2 * (int64_t)edge;
     const int64_t nout = MODE == 0 ? N : n;
     const double* x = src + (int64_t)blockIdx.y * src_stride;
@@ -352,13 +353,13 @@ __global__ void __launch_bounds__(DD_FC_THREADS) k_filtfilt_cos(const double* __
             const double u = __shfl_up(inc, d);
             if (lane >= d) inc += u;
         }
-        if (lane == 63) wsum[s * 4 + wv] = inc;
+        if (lane == 63) wsum[s * DD_FC_WAVES + wv] = inc;
         off[s] = inc - tot[s];
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        for (int w = 0; w < wv; ++w) off[s] += wsum[s * 4 + w];
+        for (int w = 0; w < wv; ++w) off[s] += wsum[s * DD_FC_WAVES + w];
     // ... and the prefix sums go to LDS
     if (t == 0) {
 #pragma unroll

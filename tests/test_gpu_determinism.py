@@ -102,13 +102,16 @@ def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, select_k
     _assert_identical(g, outs, 1)
 
 
-def test_complex_output_chain_is_bit_reproducible(g):
-    """NCO + FIR, complex64 out: k_chain_mfma_ab's complex-output flavour (and k_chain_mfma_ws behind DD_MFMA_KERNEL=ws)."""
+@pytest.mark.parametrize("kernel", ["auto", "ab"])
+def test_complex_output_chain_is_bit_reproducible(g, kernel, select_kernel):
+    """NCO + FIR, complex64 out: k_chain_fft1k's complex-output flavour (the default for 255 taps since round 4) and
+    k_chain_mfma_ab's (forced)."""
+    select_kernel(None if kernel == "auto" else kernel)
     t = g.torch
     n = (1 << 23) + 777
     x = g.bench.make_input(t, n, 0, g.dev, 99)
     outs, kernels = _chain_runs(g, _hamming(255), 1, g.hip.DD_CHAIN_NCO, x, n, 2 * n)
-    assert set(kernels) == {g.hip.DD_KERNEL_MFMA_WS if os.environ.get("DD_MFMA_KERNEL") == "ws" else g.hip.DD_KERNEL_MFMA_AB}
+    assert set(kernels) == {g.hip.DD_KERNEL_FFT_OS if kernel == "auto" else g.hip.DD_KERNEL_MFMA_AB}
     _assert_identical(g, outs, 2)
 
 

@@ -312,6 +312,41 @@ def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, select_kernel):
     fm_check(out.signal, ref, np.concatenate(mags))
 
 
+@pytest.mark.parametrize("K", [162, 255, 256])
+@pytest.mark.parametrize("f_off", [25000.0, -700000.0, 0.0])
+@pytest.mark.parametrize("u8", [False, True])
+def test_fft_kernel_complex_output_block_edges_and_carried_state(dd, K, f_off, u8, select_kernel):
+    """k_chain_fft1k's complex64-output flavour (commSignal.filter without a demodulator, comm.py:80-92; round 4): the NCO factor
+    e^{-j theta (abs0 + p)} applied per output as block x row pair x lane phasors, 16-byte stores, the block grid laid by the
+    alignment of the OUTPUT (chunks of odd lengths put every later chunk's `out` off the 64-byte grid), edge blocks, carried
+    history; chunks of 1, 2, K-2, 767 ... samples, complex64 and raw u8 chunks, against the float64 oracle."""
+    select_kernel("fft1k")
+    fs = 2400000
+    cuts = np.cumsum([0, 1, 2, K - 2, 767, 768, 769, 1535, 1536, 5000, 3, 40001, 777])
+    L = int(cuts[-1])
+    raw = O.synth_iq_fm(L, fs, 1900 + K, f_carrier=abs(f_off) if f_off else 1000.0, f_mod=700.0, dev=4.0)
+    x = O.grid_c64(raw)
+    flt = dd.filters.hamming(K)
+    fo = O.FilterState(O.win_hamming(K))
+    ck = dd.chunker.chunker(_Src(L))
+    out = dd.comm.commSignal(fs)
+    from directdemod_amd import source
+    rec = source.IQarray(raw, fs) if u8 else None        # read_device_raw: views of the recording kept in HBM as raw uint8 pairs
+    refs, idx = [], 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        src = rec.read_device_raw(int(a), int(b)) if u8 else x[a:b]
+        s = dd.comm.commSignal(fs, src, ck)
+        if f_off:
+            s.offsetFreq(f_off)
+        out.extend(s.filter(flt))
+        refs.append(fo.applyOn(O.nco(x[a:b], f_off, fs, idx) if f_off else x[a:b]))
+        idx += b - a
+    ref = np.concatenate(refs)
+    assert out.length == L
+    assert flt._last_kernel() == dd.hip.DD_KERNEL_FFT_OS
+    assert rel_err(out.signal, ref) < FIR_TOL
+
+
 def test_fft_kernel_retuned_every_chunk(dd, select_kernel):
     """A caller that changes the NCO frequency from chunk to chunk (a Doppler-tracking loop; decode_funcube.py:228 goes as far
     as a per-sample offset): k_chain_fft1k carries the NCO inside its tap spectrum, so every retune is a new spectrum -- computed
@@ -782,11 +817,14 @@ def test_u8_ingest_long_chunks_persistent_path(dd, M, fm):
         assert rel_err(got, y) < FIR_TOL
 
 
+@pytest.mark.parametrize("kern", ["auto", "ab"])
 @pytest.mark.parametrize("fm", [True, False])
-def test_u8_ingest_mfma_interior_tiles(dd, fm):
-    """raw u8 input through the MFMA path's persistent kernel (M = 1, interior tiles read and widen the bytes
-    themselves), two chunks, against the oracle"""
+def test_u8_ingest_mfma_interior_tiles(dd, fm, kern, select_kernel):
+    """raw u8 input through the M = 1 kernels (255 taps: the overlap-save FFT kernel by default, FM or complex64 output; forced
+    "ab": the MFMA path's persistent kernel, whose interior tiles read and widen the bytes themselves, and the tile-per-
+    workgroup kernel for a chunk on an odd sample), two chunks, against the oracle"""
     import ctypes as C
+    select_kernel(None if kern == "auto" else kern)
     hip = dd.hip
     lib = hip.lib()
     fs = 2400000
@@ -806,7 +844,7 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm):
         # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
         # (FM output with 255 taps: the overlap-save FFT kernel takes the aligned chunk, whole)
         # (round 4: the FFT kernel lays its block grid by the OUTPUT's alignment and takes any input alignment)
-        want = hip.DD_KERNEL_FFT_OS if fm else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
+        want = hip.DD_KERNEL_FFT_OS if kern == "auto" else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
