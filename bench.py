@@ -411,10 +411,43 @@ def side_configs(eng, steps=10):
         e1.record()
         eng.sync()
         ms = e0.elapsed_time(e1) / (10 * steps)
-        res.append({"config": name + ", 2^26 samples, one chunk", "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
+        res.append({"config": name + ", 2^26 samples, one chunk", "kernel": KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?"),
+                    "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
                     "bytes_per_sample": bps, "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
         lib.dd_chain_destroy(h)
         del out
+    # SURVEY 8(d) defines two C2 inputs: B (FM tone + noise, the headline above) and A, what source.py:117-118 hands out on a dead
+    # channel -- I, Q iid uniform integers 0..255 minus 127.5, np.random.default_rng(1234).  The angle stage is data dependent
+    # (a group of 256 outputs takes the small-angle arctangent only if every |angle| in it is below 22.5 degrees), so both are
+    # timed here through the same call, the same way, back to back.
+    xa = (torch.from_numpy(np.random.default_rng(1234).integers(0, 256, size=(n, 2), dtype=np.uint8)).to(eng.out.device).float() - 127.5).contiguous()
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), ham.ctypes.data_as(C.POINTER(C.c_double)), NTAPS, hip.cycles_q64(F_OFFSET, FS), 1,
+                                  hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "dd_chain_create")
+    got = C.c_int64(0)
+    ab = {}
+    for rnd in range(2):
+        for name, src in (("B", eng.xin), ("A", xa)):
+            def step():
+                hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+                hip.check(lib.dd_chain_process(h, src.data_ptr(), eng.out.data_ptr(), n, C.byref(got), eng.stream), "dd_chain_process")
+            for _ in range(100):
+                step()
+            eng.sync()
+            e0, e1 = eng.events()
+            e0.record()
+            for _ in range(10 * steps):
+                step()
+            e1.record()
+            eng.sync()
+            ab[name] = min(ab.get(name, 1e9), e0.elapsed_time(e1) / (10 * steps))
+    kname = KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?")
+    lib.dd_chain_destroy(h)
+    del xa
+    res.append({"config": "C2 input A (I, Q iid uniform u8 noise, default_rng(1234): SURVEY 8d; source.py:117-118) beside input B (the headline's FM tone + noise), same call, back to back, 2^26 samples",
+                "kernel": kname, "ms_per_pass_input_A": round(ab["A"], 4), "ms_per_pass_input_B": round(ab["B"], 4),
+                "input_A_over_B": round(ab["A"] / ab["B"], 4), "bytes_per_sample": 12.0,
+                "frac_of_8TBs_input_A": round(n * 12.0 / (ab["A"] * 1e-3) / 8e12, 4), "frac_of_8TBs_input_B": round(n * 12.0 / (ab["B"] * 1e-3) / 8e12, 4)})
     res.append(side_c3_end_to_end(eng, steps))
     res.append(side_c3_through_classes(eng, steps))
     res.append(side_c4_end_to_end())

@@ -1283,6 +1283,7 @@ __global__ void __launch_bounds__(256) k_env_hypot(const double* __restrict__ XR
 }
 
 static std::map<std::pair<int, int64_t>, double2*> g_hilb;      // (device, N) -> spectrum of the padded kernel / M
+static std::vector<std::pair<int, int64_t>> g_hilb_order;
 
 // sin(pi num / den) for integers num >= 0, den > 0: the argument is reduced to [0, pi/2] exactly in integers first
 static double dd_sinpi_frac(int64_t num, int64_t den) {
@@ -1325,6 +1326,14 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
         (void)hipFree(HH);
         dd_set_error("Hilbert kernel spectrum: hipfft %d, hip %s", (int)r2, hipGetErrorString(e0 != hipSuccess ? e0 : e));
         return DD_ERR_HIP;
+    }
+    // (one spectrum per length: up to 8 MB each; a process that walks through recordings of many different lengths keeps the
+    // eight most recently built -- both callers hold g_sync_mu and synchronise before they return, so none is in use now)
+    g_hilb_order.push_back(key);
+    while (g_hilb_order.size() > 8) {
+        auto old = g_hilb.find(g_hilb_order.front());
+        if (old != g_hilb.end()) { (void)hipFree(old->second); g_hilb.erase(old); }
+        g_hilb_order.erase(g_hilb_order.begin());
     }
     g_hilb[key] = HH;
     *out = HH;
@@ -1559,6 +1568,10 @@ __global__ void __launch_bounds__(256) k_env_hypot_flat(const double* __restrict
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) env[i] = hypot(x[i], y[i] * inv_n);
 }
+__global__ void __launch_bounds__(256) k_pad_f64(const double* __restrict__ x, int64_t n, double* __restrict__ XR, int64_t M) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < M) XR[j] = j < n ? x[j] : 0.0;
+}
 // exclusive scan of the tile sums (one workgroup), so that the final pass adds one number per tile instead of walking all
 // the tiles before it (1765 of them for a minute of audio)
 __global__ void __launch_bounds__(256) k_scan_mid(double2* __restrict__ part, int tiles) {
@@ -1620,41 +1633,46 @@ struct DDRuns2 { DDRuns r[DD_CS_MAXNEEDLES]; double vv[DD_CS_MAXNEEDLES]; };
 // The 256 outputs of a workgroup read P at a0 + start[r], r = 0 .. nr: 256 + m + 1 consecutive prefix sums, each wanted by
 // ~nr outputs.  They are staged in LDS once (when they fit: 817 doubles for the crude needles) -- straight from L2 the kernel
 // ran at the L2's bandwidth, 108 us for 2 x 3.6 M outputs.
+// A lane owns outputs t, t + 256, t + 512, t + 768 of a 1024-output tile: four independent chains per run boundary (one
+// output per lane was a chain of ~15 dependent LDS reads per wave: 93 us for 2 x 3.6 M outputs, latency bound).
 #define DD_XC_LDS_MAX 4096
+#define DD_XCN_TILE 1024
 __global__ void __launch_bounds__(256) k_xcorr_runs_n(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                       const DDRuns2 R2, double* __restrict__ out) {
     __shared__ double sP[DD_XC_LDS_MAX];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const DDRuns& R = R2.r[blockIdx.y];
-    const int64_t a0 = i + (m - 1) / 2 - (m - 1);
+    const int64_t i0 = (int64_t)blockIdx.x * DD_XCN_TILE;
+    const int64_t base = i0 + (m - 1) / 2 - (m - 1);             // window of output i: P[base + (i - i0) + start[r]]
     auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
-    const bool staged = 256 + m + 1 <= DD_XC_LDS_MAX;             // (uniform)
+    const bool staged = DD_XCN_TILE + m + 1 <= DD_XC_LDS_MAX;     // (uniform)
     if (staged) {
-        const int64_t base = (int64_t)blockIdx.x * 256 + (m - 1) / 2 - (m - 1);
-        for (int k = threadIdx.x; k < 256 + m + 1; k += 256) sP[k] = at(P, base + k);
+        for (int k = threadIdx.x; k < DD_XCN_TILE + m + 1; k += 256) sP[k] = at(P, base + k);
         __syncthreads();
     }
-    if (i >= n) return;
-    double c = 0.0;
-    if (staged) {
-        const double* sp = sP + threadIdx.x;
-        double lo = sp[0];
-        for (int r = 0; r < R.nr; ++r) {
-            const double hi = sp[R.start[r + 1]];
-            c = fma(R.val[r], hi - lo, c);
-            lo = hi;
-        }
-    } else {
-        double lo = at(P, a0);
-        for (int r = 0; r < R.nr; ++r) {
-            const double hi = at(P, a0 + R.start[r + 1]);
-            c = fma(R.val[r], hi - lo, c);
-            lo = hi;
+    double c[4] = {0.0, 0.0, 0.0, 0.0}, lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lo[u] = staged ? sP[threadIdx.x + 256 * u] : at(P, base + threadIdx.x + 256 * u);
+    for (int r = 0; r < R.nr; ++r) {
+        const int st = R.start[r + 1];
+        const double v = R.val[r];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double hi = staged ? sP[threadIdx.x + 256 * u + st] : at(P, base + threadIdx.x + 256 * u + st);
+            c[u] = fma(v, hi - lo[u], c[u]);
+            lo[u] = hi;
         }
     }
-    double e = at(Q, a0 + m) - at(Q, a0);
-    if (!(e > 1e-13 * Q[n])) { c = 0.0; e = 0.0; }
-    out[(int64_t)blockIdx.y * n + i] = c / sqrt(e * R2.vv[blockIdx.y]);
+    const double qn = 1e-13 * Q[n], vv = R2.vv[blockIdx.y];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + threadIdx.x + 256 * u;
+        if (i >= n) break;
+        const int64_t a0 = base + threadIdx.x + 256 * u;
+        double e = at(Q, a0 + m) - at(Q, a0);
+        double cc = c[u];
+        if (!(e > qn)) { cc = 0.0; e = 0.0; }
+        out[(int64_t)blockIdx.y * n + i] = cc / sqrt(e * vv);
+    }
 }
 
 __device__ __forceinline__ double dd_aload_f64(const double* p) {
@@ -1877,9 +1895,17 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_x = take(audio_is_f32 ? sizeof(double) * (size_t)n : 0);
     const size_t o_env = take(env_out ? 0 : sizeof(double) * (size_t)n);
-    const size_t spec_elems = (size_t)(gb * nbins_b > nbins_r ? gb * nbins_b : nbins_r);
+    // the ragged last block: a length with a large prime factor (14 100 = 2^2 3 5^2 47 for a minute of audio) makes the library
+    // run Bluestein's algorithm -- twenty launches for 14 100 samples.  Its envelope then goes through the zero-padded cyclic
+    // convolution with the Hilbert kernel that the accurate-sync windows use (hilbert_kernel_spectrum): four launches and two
+    // power-of-two transforms.
+    int64_t Mr = 0;
+    if (rem >= 2 && largest_prime_factor(rem) > 17) { Mr = 1; while (Mr < 2 * rem + 2) Mr <<= 1; }
+    const size_t spec_r = (size_t)(Mr ? Mr / 2 + 1 : nbins_r);
+    const size_t spec_elems = (size_t)(gb * nbins_b) > spec_r ? (size_t)(gb * nbins_b) : spec_r;
     const size_t o_spec = take(sizeof(double2) * spec_elems);
-    const size_t o_y = take(sizeof(double) * (size_t)(gb * block > rem ? gb * block : rem));
+    const size_t y_r = (size_t)(Mr ? 2 * Mr : rem);
+    const size_t o_y = take(sizeof(double) * ((size_t)(gb * block) > y_r ? (size_t)(gb * block) : y_r));
     const size_t o_P = take(sizeof(double) * (size_t)(n + 1)), o_Q = take(sizeof(double) * (size_t)(n + 1));
     const size_t o_part = take(sizeof(double2) * (size_t)tiles);
     const size_t o_cor = take(sizeof(double) * (size_t)n * n_needles);
@@ -1914,13 +1940,30 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         return DD_OK;
     };
     for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) rc = env_blocks(b0 * block, block, (int)(nfull - b0 < GB ? nfull - b0 : GB));
-    if (rc == DD_OK) rc = env_blocks(nfull * block, rem, 1);
+    if (rc == DD_OK && Mr) {
+        const double2* HH = nullptr;
+        rc = hilbert_kernel_spectrum(rem, Mr, &HH, s);
+        hipfftHandle pf, pb;
+        if (rc == DD_OK) rc = get_plan(&pf, HIPFFT_D2Z, Mr, 1, s);
+        if (rc == DD_OK) rc = get_plan(&pb, HIPFFT_Z2D, Mr, 1, s);
+        if (rc == DD_OK) {
+            double* XR = y, *YR = y + Mr;
+            const int64_t nb = Mr / 2 + 1;
+            hipLaunchKernelGGL(k_pad_f64, dim3(grid1(Mr)), dim3(256), 0, s, x + nfull * block, rem, XR, Mr);
+            DD_FFT_CHECK(hipfftExecD2Z(pf, XR, (hipfftDoubleComplex*)spec));
+            hipLaunchKernelGGL(k_spec_mul, dim3(grid1(nb), 1), dim3(256), 0, s, spec, HH, nb);
+            DD_FFT_CHECK(hipfftExecZ2D(pb, (hipfftDoubleComplex*)spec, YR));
+            hipLaunchKernelGGL(k_env_hypot, dim3(grid1(rem), 1), dim3(256), 0, s, XR, YR, Mr, rem, env + nfull * block);
+        }
+    } else if (rc == DD_OK) {
+        rc = env_blocks(nfull * block, rem, 1);
+    }
     if (rc != DD_OK) return rc;
     // ---- prefix sums once, both correlations in one launch
     hipLaunchKernelGGL(k_scan_part, dim3(tiles, 1), dim3(256), 0, s, env, n, tiles, part);
     hipLaunchKernelGGL(k_scan_mid, dim3(1), dim3(256), 0, s, part, tiles);
     hipLaunchKernelGGL(k_scan_final_x, dim3(tiles), dim3(256), 0, s, env, n, part, P, Q);
-    hipLaunchKernelGGL(k_xcorr_runs_n, dim3(grid1(n), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
+    hipLaunchKernelGGL(k_xcorr_runs_n, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
     // ---- selection, threshold, candidates of both needles: eleven launches, nothing comes back to the host in between
     DD_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(DDCrudeSel) * n_needles, s));
     for (int pass = 0; pass < 8; ++pass) hipLaunchKernelGGL(k_cs_hist, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, pass, sel);

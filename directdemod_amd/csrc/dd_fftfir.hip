@@ -411,7 +411,7 @@ __device__ __forceinline__ void f1_tail_group(const int g, const v2f (&zz)[16], 
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(q) : "memory");
         }
     }
-#elif !defined(FF_NO_LOAD)
+#elif !defined(FF_NO_LOAD) && defined(FF_LOADS_IN_TAIL)
     if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
 #endif
 #ifdef FF_NO_STORE
@@ -550,6 +550,10 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
             // ---- complex64 output: NCO factor, 16-byte stores of two outputs per lane; the next block's loads in between
 #ifndef FF_NO_LOAD
             if (LOADNEXT && jump) f1_load_pairs<U8, false, 4>(in, n0_next, lane, jl, 0, 2);
+#ifndef FF_LOADS_IN_TAIL
+            // (B and A hold this block's results: a[] is free for the next block's samples, requested ahead of every store)
+            if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2, 6);
+#endif
 #endif
             float2* const oc = reinterpret_cast<float2*>(out_row4) + 2 * lane;
 #pragma unroll
@@ -563,7 +567,7 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
                     y[2 * i] = f1_cmul(B[r], f1_cmul(rp, cx->lp0));
                     y[2 * i + 1] = f1_cmul(A[r], f1_cmul(rp, cx->lp1));
                 }
-#ifndef FF_NO_LOAD
+#if !defined(FF_NO_LOAD) && defined(FF_LOADS_IN_TAIL)
                 if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2 + 2 * g, 2);
 #endif
 #pragma unroll
@@ -635,6 +639,15 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
     // block's samples anyway; otherwise the caller copies `keep`)
 #ifndef FF_NO_LOAD
     if (LOADNEXT && jump) f1_load_pairs<U8, false, 4>(in, n0_next, lane, jl, 0, 2);
+#ifndef FF_LOADS_IN_TAIL
+    // ALL of the next block's loads go out here, ahead of every store of this block.  The memory counter (vmcnt) of gfx9 counts
+    // loads and stores alike and retires them in issue order, so a wave that waits for a load also waits for every store it
+    // issued before that load.  Round 3 interleaved "angles | two loads | two stores" three times: the wait for the last loads
+    // at the top of the next block then included four stores issued a few hundred cycles earlier -- a store round trip exposed
+    // per block and wave.  (Found when the arithmetic-only build, forced onto the bench input's angle path, measured 0.129 ms
+    // and the memory-only build 0.141 ms against 0.200 ms for the kernel: profiles/r04_fft1k_overlap.txt.)
+    if (LOADNEXT) f1_load_pairs<U8>(in, n0_next, lane, a, 2, 6);
+#endif
 #endif
     // wave-uniform fast path per group of two row pairs: every |angle| of its 256 outputs below 22.5 degrees, |im| < tan(pi/8) re
     // (strictly: a product of exactly zero -- 1024 samples of digital silence -- must take the full-range form, whose
@@ -646,6 +659,9 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
 #pragma unroll
         for (int r = 4 + 4 * g; r < 8 + 4 * g; ++r) worst = fmaxf(worst, fmaf(-0.41421356f, zz[r].x, fabsf(zz[r].y)));
         fast[g] = __builtin_amdgcn_ballot_w64(worst >= 0.f) == 0;
+#ifdef FF_FORCE_FAST
+        fast[g] = true;       // (ablation builds without loads run on whatever the registers hold: keep them on the path the bench input takes)
+#endif
     }
     FF_T(11);
     float* const ob = out_row4 + 2 * lane;

@@ -153,6 +153,46 @@ def test_oracle_windows_of_the_full_run(run, where):
     assert np.max(d) < TOL and np.median(d) < 2e-6
 
 
+def test_oracle_windows_on_input_A_at_full_size(run):
+    """SURVEY 8(d) input A: I, Q iid uniform integers 0..255 minus 127.5, np.random.default_rng(1234) -- what source.py:117-118
+    hands out on a dead channel.  Low-pass filtered noise: the amplitude wanders through nulls, so some groups of 256 outputs
+    leave the small-angle arctangent (the wave-uniform decision of both M = 1 FM kernels) and some products are tiny.  The whole
+    2^26-sample chunk through the C-ABI, then oracle windows at the stream start, in the middle and at the end, with the
+    conditioning mask of SURVEY H3: wrapped error <= 1e-4 rad where |y[n] conj y[n-1]| >= 1e-3 of the window's median (2e-5
+    where it is >= 0.1 of it), median <= 2e-6; every output finite."""
+    t, hip, lib = run.torch, run.hip, run.lib
+    n = run.n
+    xa = (t.from_numpy(np.random.default_rng(1234).integers(0, 256, size=(n, 2), dtype=np.uint8)).to(run.dev).float() - 127.5).contiguous()
+    out = t.empty(n, dtype=t.float32, device=run.dev)
+    h = run.chain()
+    assert run.process(h, xa.data_ptr(), out.data_ptr(), n) == n - 1
+    assert lib.dd_chain_last_kernel(h) == (hip.DD_KERNEL_FFT_OS if run.kernel == "fft1k" else hip.DD_KERNEL_MFMA_AB)
+    lib.dd_chain_destroy(h)
+    t.cuda.synchronize()
+    assert bool(t.isfinite(out[:n - 1]).all())
+    W = 16384
+    for w0 in (0, n // 2 + 777, n - W):
+        h0 = max(0, w0 - (NTAPS - 1) - 1)
+        xs = xa[h0:w0 + W].cpu().numpy().astype(np.float32)
+        xc = (xs[:, 0] + 1j * xs[:, 1]).astype(np.complex64)
+        y = O.nco(xc, F_OFF, FS, h0)
+        if h0 == 0:
+            y = O.FilterState(run.taps).applyOn(y)
+        else:
+            y = O.lfilter_fir(run.taps, y, None)[NTAPS - 1:]
+            h0 += NTAPS - 1
+        a_ref, _ = O.fm_demod(y, None)
+        first = h0 + 1
+        got = out[first - 1:first - 1 + len(a_ref)].cpu().numpy().astype(np.float64)
+        d = np.abs(np.angle(np.exp(1j * (got - a_ref))))
+        prod = np.abs(y[1:] * np.conj(y[:-1]))
+        med = np.median(prod)
+        assert np.max(d[prod >= 1e-3 * med]) <= 1e-4, (w0, float(np.max(d[prod >= 1e-3 * med])))
+        assert np.max(d[prod >= 0.1 * med]) <= 2e-5, (w0, float(np.max(d[prod >= 0.1 * med])))
+        assert np.median(d) <= 2e-6
+    del xa, out
+
+
 def test_decimating_kernels_agree_with_the_dense_path_at_full_size(run):
     """C4-shaped front end at 2^26 samples: the persistent decimating kernel (BH151, /34, complex output) against the
     M = 1 MFMA path's output taken every 34th sample -- two unrelated kernels; then its raw-u8 flavour against the
