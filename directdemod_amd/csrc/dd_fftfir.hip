@@ -243,8 +243,9 @@ __device__ __forceinline__ float ff_atan_small(float y, float x) {
 #define F1_S2 84
 #define F1_WAVE_BYTES (16 * F1_S2 * 8)          // 10752
 #define F1_WAVES 4
-#define F1_HP_OFF (F1_WAVES * F1_WAVE_BYTES)     // the tap spectrum as the lanes multiply it, [16][64] complex64: one copy per workgroup
-#define F1_LDS_BYTES (F1_HP_OFF + 16 * 64 * 8)
+#define F1_HP_OFF (F1_WAVES * F1_WAVE_BYTES)     // the tap spectrum as the lanes multiply it: one copy per workgroup, a lane's sixteen
+#define F1_HP_STRIDE 18                          // values contiguous -- eight 16-byte reads per block instead of sixteen 8-byte ones; lane
+#define F1_LDS_BYTES (F1_HP_OFF + 64 * F1_HP_STRIDE * 8)   // stride 18 elements = 36 banks: the 16 lanes of a ds_read_b128 group fall on distinct banks
 #ifndef F1_RUN_BLOCKS
 #define F1_RUN_BLOCKS 8            // blocks per contiguous run of a wave (DDFft1kMap)
 #endif
@@ -434,6 +435,9 @@ __device__ __forceinline__ void f1_tail_group(const int g, const v2f (&zz)[16], 
 #endif
 }
 
+// (Round 4 also tried the exchanges' sixteen reads as explicit ds_read_b64 -- the compiler merges them into eight ds_read2_b64, which
+// the LDS serves at half the rate -- through inline asm with the wait as part of the sequence: 0.1956 against 0.1962 ms, nothing.
+// The exchanges cost latency, not LDS throughput; profiles/r04_fft1k_overlap.txt.)
 // one block.  On entry a[0..3] hold rows 0..3 of column t (the overlap kept from the previous block, or swapped by the
 // caller) and a[4..15] row pairs 2..7 as loaded; on exit, when LOADNEXT, the same for the next block.  out_row4 points
 // at the block's first output (row 4, column 0).  PARTIAL: outputs at or beyond `limit` (relative to it) are not stored.
@@ -506,7 +510,12 @@ __device__ __forceinline__ void f1_block(v2f (&a)[16], v2f (&keep)[4], v2f (&jl)
     {
         v2f h[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) h[k] = hp[64 * k];        // (this lane's column of the spectrum image in LDS)
+        for (int k = 0; k < 16; k += 2) {                      // (this lane's row of the spectrum image in LDS)
+            typedef float v4f_h __attribute__((ext_vector_type(4)));
+            const v4f_h hh = *reinterpret_cast<const v4f_h*>(hp + k);
+            h[k] = (v2f){hh.x, hh.y};
+            h[k + 1] = (v2f){hh.z, hh.w};
+        }
         ff_stage<true, false, 1, 0xFFFFu, 0u, false>(a, h);
     }
     {
@@ -787,10 +796,11 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float2 h = T.hp[threadIdx.x + 256 * i];
-        HP[threadIdx.x + 256 * i] = (v2f){h.x, h.y};
+        const int e = threadIdx.x + 256 * i;                   // T.hp is [16][64]: value k of lane l at 64 k + l
+        HP[(e & 63) * F1_HP_STRIDE + (e >> 6)] = (v2f){h.x, h.y};
     }
     __syncthreads();                           // the only barrier of the kernel, before any wave may leave
-    const v2f* const hp = HP + lane;
+    const v2f* const hp = HP + lane * F1_HP_STRIDE;
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
     F1KernArgsPtr ka = (F1KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     if (gw == 0) f1_edge_block<U8, CX>(ka, 0, X, hp, lane);
