@@ -1340,6 +1340,18 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
     return DD_OK;
 }
 
+// diagnostic (no GPU needed): is this tap set a cosine series b[k] = sum_q a[q] cos(2 pi q k / (K - 1)), q <= 3, as the windows of
+// filters.py:101-226 are?  Returns 1 and fills a[0..3], *Q (highest harmonic) when the zero-phase filter of the accurate-sync
+// windows takes the prefix-sum form for it, 0 when it keeps the tiled direct form.
+extern "C" int dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out) {
+    DD_REQUIRE(taps_host && K >= 1 && a_out && Q_out, "arguments");
+    DDCosFit f;
+    if (!dd_cos_fit(taps_host, K, &f) || !dd_fc_ok(K, f.Q)) return 0;
+    for (int q = 0; q < 4; ++q) a_out[q] = f.a[q];
+    *Q_out = f.Q;
+    return 1;
+}
+
 extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host, int n_windows, int64_t win_len,
                                     uint64_t cycles_q64, const double* fir_taps_host, int fir_ntaps,
                                     const double* pre_taps_host, int pre_ntaps, const double* needle_host, int needle_len,

@@ -1044,6 +1044,52 @@ extern "C" int dd_debug_fft_trace(unsigned long long* out, int nwaves) {
 }
 #endif
 
+// Host arithmetic of a launch -- where the block grid sits (DDFft1kTabs::base), how many blocks and waves there are and which
+// blocks a wave takes in which round (DDFft1kMap) -- as a function of its own, so that the CPU test suite can check it without a
+// GPU (dd_debug_fft1k_plan: every interior block exactly once, waves balanced, runs contiguous).
+struct DDFft1kPlan { int base, nblk, grid, nwaves; DDFft1kMap map; };
+static void fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int per_cu, int rounds, DDFft1kPlan* pl) {
+    pl->base = s - out_align_elems;
+    while (pl->base > L - 1) pl->base -= 16;                     // (a chunk of one sample: the last block must hold output L - 1)
+    const int nb = (int)((L - pl->base + F1_ADV - 1) / F1_ADV);
+    int grid = ncu * (per_cu > 0 ? per_cu : 3);
+    if (grid * F1_WAVES > nb) grid = (nb + F1_WAVES - 1) / F1_WAVES;
+    const int nw = grid * F1_WAVES;
+    // rounds of the block -> wave map: runs of ~F1_RUN_BLOCKS blocks (rounds > 0 forces a count; 1 = round 3's map)
+    DDFft1kMap& M = pl->map;
+    const int ni = nb > 2 ? nb - 2 : 0;
+    const int b = ni / nw;                                       // a wave owns b or b + 1 interior blocks
+    int K = rounds > 0 ? rounds : (b + 1 + F1_RUN_BLOCKS - 1) / F1_RUN_BLOCKS;
+    if (K > b + 1) K = b + 1;
+    if (K > F1_MAXK) K = F1_MAXK;
+    if (K < 1) K = 1;
+    const int64_t nbig = (int64_t)ni - (int64_t)b * nw;          // waves that own b + 1
+    int64_t ws = 0;
+    for (int k = 0; k < K; ++k) {
+        M.r0[k] = (int)(((int64_t)b * (k + 1)) / K - ((int64_t)b * k) / K);
+        M.r1[k] = (int)(((int64_t)(b + 1) * (k + 1)) / K - ((int64_t)(b + 1) * k) / K);
+        M.wstart[k] = (int)ws;
+        ws += (int64_t)(nw - nbig) * M.r0[k] + nbig * M.r1[k];
+    }
+    for (int k = K; k < F1_MAXK; ++k) M.r0[k] = M.r1[k] = M.wstart[k] = 0;
+    M.K = K;
+    M.b = b;
+    pl->nblk = nb;
+    pl->grid = grid;
+    pl->nwaves = nw;
+}
+// diagnostic (no GPU needed): the plan for a chunk of L samples whose first `s` FIR outputs have no angle, whose `out` pointer sits
+// `out_align_elems` elements behind a 64-byte line, on ncu compute units; out[0..6] = base, nblk, grid, nwaves, K, b, F1_MAXK, then
+// r0[32], r1[32], wstart[32]
+extern "C" int dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rounds, int* out) {
+    DD_REQUIRE(L >= 1 && (s == 0 || s == 1) && out_align_elems >= 0 && out_align_elems < 16 && ncu >= 1 && out, "arguments");
+    DDFft1kPlan pl;
+    fft1k_plan(L, s, out_align_elems, ncu, 3, rounds, &pl);
+    out[0] = pl.base; out[1] = pl.nblk; out[2] = pl.grid; out[3] = pl.nwaves; out[4] = pl.map.K; out[5] = pl.map.b; out[6] = F1_MAXK;
+    for (int k = 0; k < F1_MAXK; ++k) { out[7 + k] = pl.map.r0[k]; out[7 + F1_MAXK + k] = pl.map.r1[k]; out[7 + 2 * F1_MAXK + k] = pl.map.wstart[k]; }
+    return DD_OK;
+}
+
 // the whole chunk through k_chain_fft1k (one launch, carried state included)
 int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     DDFftState* s = reinterpret_cast<DDFftState*>(stv);
@@ -1086,40 +1132,16 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
             const long double ang = 2.0L * 3.14159265358979323846264338327950288L * ph;
             T1.rowph[i] = make_float2((float)cosl(ang), (float)-sinl(ang));
         }
-        // float32 angles: 16 per 64-byte line; complex64 outputs: 8 per line (and no demod_fm shift)
-        const int a16 = cxout ? (int)((reinterpret_cast<uintptr_t>(P.out) >> 3) & 7) : (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
-        T1.base = (frame_env && atoi(frame_env) == 0) ? 0 : P.s - a16;
-        while (T1.base > P.L - 1) T1.base -= 16;                 // (a chunk of one sample: the last block must hold output L - 1)
     }
-    const int nb1 = (int)((P.L - T1.base + F1_ADV - 1) / F1_ADV);
+    // float32 angles: 16 per 64-byte line; complex64 outputs: 8 per line (and no demod_fm shift)
+    const int a16 = cxout ? (int)((reinterpret_cast<uintptr_t>(P.out) >> 3) & 7) : (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
     static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");           // tools: occupancy experiments
-    const int per_cu1 = wg_env1 ? atoi(wg_env1) : 3;
-    int grid1 = dd_cu_count() * (per_cu1 > 0 ? per_cu1 : 3);
-    if (grid1 * F1_WAVES > nb1) grid1 = (nb1 + F1_WAVES - 1) / F1_WAVES;
-    const int nw1 = grid1 * F1_WAVES;
-    // rounds of the block -> wave map (DDFft1kMap): runs of ~F1_RUN_BLOCKS blocks; DD_FFT_ROUNDS=<K> (tools) forces a count (1 = one
-    // contiguous run per wave, the round-3 mapping)
-    DDFft1kMap M1;
-    {
-        static const char* rounds_env = getenv("DD_FFT_ROUNDS");
-        const int ni = nb1 > 2 ? nb1 - 2 : 0;
-        const int b = ni / nw1;                                  // a wave owns b or b + 1 interior blocks
-        int K = rounds_env ? atoi(rounds_env) : (b + 1 + F1_RUN_BLOCKS - 1) / F1_RUN_BLOCKS;
-        if (K > b + 1) K = b + 1;
-        if (K > F1_MAXK) K = F1_MAXK;
-        if (K < 1) K = 1;
-        const int64_t nbig = (int64_t)ni - (int64_t)b * nw1;     // waves that own b + 1
-        int64_t ws = 0;
-        for (int k = 0; k < K; ++k) {
-            M1.r0[k] = (int)(((int64_t)b * (k + 1)) / K - ((int64_t)b * k) / K);
-            M1.r1[k] = (int)(((int64_t)(b + 1) * (k + 1)) / K - ((int64_t)(b + 1) * k) / K);
-            M1.wstart[k] = (int)ws;
-            ws += (int64_t)(nw1 - nbig) * M1.r0[k] + nbig * M1.r1[k];
-        }
-        for (int k = K; k < F1_MAXK; ++k) M1.r0[k] = M1.r1[k] = M1.wstart[k] = 0;
-        M1.K = K;
-        M1.b = b;
-    }
+    static const char* rounds_env = getenv("DD_FFT_ROUNDS");            // tools: a fixed number of rounds (1 = round 3's map)
+    DDFft1kPlan pl;
+    fft1k_plan(P.L, P.s, (frame_env && atoi(frame_env) == 0) ? P.s : a16, dd_cu_count(), wg_env1 ? atoi(wg_env1) : 3, rounds_env ? atoi(rounds_env) : 0, &pl);
+    T1.base = pl.base;
+    const int nb1 = pl.nblk, grid1 = pl.grid, nw1 = pl.nwaves;
+    const DDFft1kMap& M1 = pl.map;
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
     if (u8 && cxout) hipLaunchKernelGGL((k_chain_fft1k<true, true>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);
     else if (u8) hipLaunchKernelGGL((k_chain_fft1k<true, false>), dim3(grid1), dim3(64 * F1_WAVES), F1_LDS_BYTES, stream, P, T1, M1, nb1, nw1);

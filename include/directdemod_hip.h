@@ -80,6 +80,14 @@ int  dd_debug_select_kernel(const char* name);
  * later one bounds its in-launch waits by 2^spin_log2 polls (0: the default, 2^24 = seconds).  Lets a test see DD_ERR_TIMEOUT
  * instead of silently wrong samples.  No reference counterpart (the reference's chunk loop is sequential, decode_noaa.py:619-624). */
 int  dd_debug_seam(int withhold_chunk, int spin_log2);
+/* diagnostics that need no GPU (host arithmetic of two launch paths, checked by the CPU test suite):
+ * dd_debug_fft1k_plan -- the block grid and the block -> wave map of a k_chain_fft1k launch over a chunk of L samples (s = 1: a
+ *   stream start, no angle for the first output; out_align_elems: how many elements `out` sits behind a 64-byte line; ncu compute
+ *   units; rounds: 0 = default).  out[0..6] = base, nblk, grid, nwaves, K, b, 32, then r0[32], r1[32], wstart[32].
+ * dd_debug_cos_fit -- 1 when the taps are a cosine series of at most four terms for which the zero-phase filter of the
+ *   accurate-sync windows takes its prefix-sum form (a[0..3], *Q filled), else 0. */
+int  dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rounds, int* out);
+int  dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
