@@ -343,8 +343,50 @@ def test_fft_kernel_complex_output_block_edges_and_carried_state(dd, K, f_off, u
         idx += b - a
     ref = np.concatenate(refs)
     assert out.length == L
+    got = out.signal                                            # (chunks that are views of a resident recording run when the result is read)
     assert flt._last_kernel() == dd.hip.DD_KERNEL_FFT_OS
-    assert rel_err(out.signal, ref) < FIR_TOL
+    assert rel_err(got, ref) < FIR_TOL
+
+
+@pytest.mark.parametrize("fm", [True, False])
+@pytest.mark.parametrize("kern", ["fft1k", "ab"])
+def test_chunks_written_back_to_back_at_any_output_alignment(dd, fm, kern, select_kernel):
+    """dd_chain_process over chunks of odd lengths whose outputs go back to back into ONE buffer: every later chunk's `out` pointer
+    sits at an arbitrary element offset (4-byte aligned for angles, 8-byte for complex64).  k_chain_fft1k lays its block grid by
+    that alignment (DDFft1kTabs::base: whole 64-byte lines per store instruction), so every residue 0..15 of the offset is a
+    different first-block geometry; the MFMA kernel takes its own edge-tile route.  Against the float64 oracle."""
+    import ctypes as C
+    select_kernel(kern)
+    hip = dd.hip
+    lib = hip.lib()
+    fs = 2400000
+    lens = [3001, 70001, 33, 1, 2, 50002, 7, 767, 769, 4099, 13, 20011, 5, 3, 2049, 1025, 40003]
+    L = sum(lens)
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 77))
+    d = hip.DevArray.from_host(x)
+    taps = np.ascontiguousarray(O.win_hamming(255))
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, hip.cycles_q64(25000.0, fs), 1,
+                                  hip.DD_CHAIN_NCO | (hip.DD_CHAIN_FM if fm else 0)))
+    out = hip.DevArray(L + 8, np.float32 if fm else np.complex64)
+    esz = 4 if fm else 8
+    pos, opos, got, offs = 0, 0, C.c_int64(0), set()
+    for n in lens:
+        offs.add(opos % 16)
+        hip.check(lib.dd_chain_process(h, d.ptr + 8 * pos, out.ptr + esz * opos, n, C.byref(got), None))
+        pos += n
+        opos += got.value
+    assert len(offs) >= 8                                   # many different alignments of `out` were exercised
+    lib.dd_chain_destroy(h)
+    res = out.to_host()[:opos]
+    y = O.FilterState(taps).applyOn(O.nco(x, 25000.0, fs, 0))
+    if fm:
+        assert opos == L - 1
+        a_ref, _ = O.fm_demod(y, None)
+        fm_check(res, a_ref, np.abs(y[1:] * np.conj(y[:-1])))
+    else:
+        assert opos == L
+        assert rel_err(res, y) < FIR_TOL
 
 
 def test_fft_kernel_retuned_every_chunk(dd, select_kernel):
