@@ -432,7 +432,10 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS) k_chain_decim(const DDChainP
 // ============================================================================
 // decimating kernel, interior tiles, persistent
 // ============================================================================
-// One launch-long workgroup per third of a CU (LDS bound, 3 per CU) walks a contiguous run of
+// One launch-long workgroup per third of a CU (LDS bound, 3 per CU) walks the interior tiles blockIdx.x, blockIdx.x + nwg,
+// ... (round 4: the device then works on one moving window of nwg tiles, and the tile loads are non-temporal -- what
+// tools/ubench/stream_2to1 found for streaming kernels: C3 / C4 one-chunk passes 0.110 / 0.113 -> 0.0985 / 0.102 ms = 0.69 / 0.67 of
+// 8 TB/s, profiles/r04_decim_map.txt; -DDD_DECIM_CONTIG / -DDD_DECIM_NO_NT: a contiguous run per workgroup, plain loads) of the
 // interior tiles: whole span inside the chunk, every output valid, complex64 input.  The next
 // tile's samples are requested (12 x 16 B per lane) the moment the current tile has been staged
 // into LDS -- into the same registers, which staging has just freed -- so they are in flight
@@ -451,7 +454,11 @@ __device__ __forceinline__ void dd_decim_issue(const DDChainParams& P, int b, in
     for (int u = 0; u < DD_DECIM_NV; ++u) {
         int q = t + u * DD_DECIM_THREADS;
         q = q < nq ? q : nq - 1;                          // past the span: harmless re-read, never used
+#ifndef DD_DECIM_NO_NT
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const dd_v4f_a8*>(src + 2 * q));
+#else
         v[u] = *reinterpret_cast<const dd_v4f_a8*>(src + 2 * q);
+#endif
     }
 }
 
@@ -466,7 +473,11 @@ __device__ __forceinline__ void dd_decim_issue_u8(const DDChainParams& P, int b,
     for (int u = 0; u < DD_DECIM_NV8; ++u) {
         int q = t + u * DD_DECIM_THREADS;
         q = q < nq8 ? q : nq8 - 1;
+#ifndef DD_DECIM_NO_NT
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const dd_v4u_a4*>(src + 16 * q));
+#else
         v[u] = *reinterpret_cast<const dd_v4u_a4*>(src + 16 * q);
+#endif
     }
 }
 
@@ -601,8 +612,14 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
     const int t = threadIdx.x;
     // contiguous run of tiles per workgroup, and per XCD (workgroups are dealt round-robin to the 8 XCDs)
     const int n = b_hi - b_lo;
+#ifndef DD_DECIM_CONTIG
+    // tiles blockIdx.x, blockIdx.x + nwg, ...: the device works on one moving window of nwg tiles (tools/ubench/stream_2to1)
+    const int begin = b_lo + (int)blockIdx.x, end = b_hi, step = nwg;
+#else
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int begin = b_lo + (int)(((int64_t)wg * n) / nwg), end = b_lo + (int)(((int64_t)(wg + 1) * n) / nwg);
+    const int begin = b_lo + (int)(((int64_t)wg * n) / nwg), end = b_lo + (int)(((int64_t)(wg + 1) * n) / nwg), step = 1;
+#endif
+    (void)n;
     if (begin >= end) return;
 
     dd_v4f_a8 v[DD_DECIM_NV];
@@ -621,7 +638,7 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_p(const DDC
     for (int k = 0; k < 8; ++k)
         w18[k] = (U8 && (P.flags & DD_CHAIN_NCO)) ? dd_phasor((uint64_t)(((8 * t) & 63) + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
     __syncthreads();
-    for (int b = begin; b < end; ++b) dd_decim_tile<U8>(P, b, P, b + 1 < end ? b + 1 : -1, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
+    for (int b = begin; b < end; b += step) dd_decim_tile<U8>(P, b, P, b + step < end ? b + step : -1, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
 }
 
 // ---- several chunks, ONE launch (dd_chain_process_chunks) -------------------------------------------------------------
@@ -660,8 +677,12 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_multi(const
     float* gl = reinterpret_cast<float*>(smem + ((sizeof(float2) * ((size_t)S + 4 + (S / 64 + 2) + DD_DECIM_THREADS) + 15) & ~(size_t)15));
     const int t = threadIdx.x;
     const int n = ipre[nchunks];
+#ifndef DD_DECIM_CONTIG
+    const int begin = (int)blockIdx.x, end = n, step = nwg;
+#else
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int begin = (int)(((int64_t)wg * n) / nwg), end = (int)(((int64_t)(wg + 1) * n) / nwg);      // global interior tile indices
+    const int begin = (int)(((int64_t)wg * n) / nwg), end = (int)(((int64_t)(wg + 1) * n) / nwg), step = 1;      // global interior tile indices
+#endif
     if (begin >= end) return;
     int c = 0;
     while (begin >= ipre[c + 1]) ++c;
@@ -688,15 +709,15 @@ __global__ void __launch_bounds__(DD_DECIM_THREADS, 3) k_chain_decim_multi(const
     for (int k = 0; k < 8; ++k)
         w18[k] = (U8 && (P.flags & DD_CHAIN_NCO)) ? dd_phasor((uint64_t)(((8 * t) & 63) + k) * P.cyc, P.nco_tbl) : make_float2(1.f, 0.f);
     __syncthreads();
-    for (int g = begin; g < end; ++g) {
+    for (int g = begin; g < end; g += step) {
         const int b = lo + (g - ipre[c]);
         int b_next = -1, cn = c, lon = lo;
-        if (g + 1 < end) {
-            if (g + 1 >= ipre[c + 1]) {                               // the next tile opens the next chunk with an interior run
-                do { ++cn; } while (g + 1 >= ipre[cn + 1]);
+        if (g + step < end) {
+            if (g + step >= ipre[c + 1]) {                            // the next tile opens the next chunk with an interior run
+                do { ++cn; } while (g + step >= ipre[cn + 1]);
                 lon = load_seg(Pn, cn);
             }
-            b_next = lon + (g + 1 - ipre[cn]);
+            b_next = lon + (g + step - ipre[cn]);
         }
         dd_decim_tile<U8>(P, b, Pn, b_next, nq, t, v, v8, w18, sx, w2, yblk, gl, w1a, w1b);
         if (cn != c) { P = Pn; c = cn; lo = lon; }
