@@ -1282,7 +1282,33 @@ __global__ void __launch_bounds__(256) k_env_hypot(const double* __restrict__ XR
     env[(int64_t)blockIdx.y * n + i] = hypot(XR[(int64_t)blockIdx.y * M + i], YR[(int64_t)blockIdx.y * M + i]);
 }
 
+#include "dd_hconv_kernels.h"
 static std::map<std::pair<int, int64_t>, double2*> g_hilb;      // (device, N) -> spectrum of the padded kernel / M
+static double2* g_hc_tab[64] = {nullptr};                        // device -> W_512^j | W_M^j, 512 entries each (callers hold g_sync_mu)
+
+static int hc_tables(const double2** TA, const double2** TB) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (!g_hc_tab[dev]) {
+        std::vector<double2> h(2 * DD_HC_N);
+        const long double tp = 6.283185307179586476925286766559L;
+        for (int j = 0; j < DD_HC_N; ++j) {
+            h[j] = make_double2((double)cosl(tp * j / DD_HC_N), (double)-sinl(tp * j / DD_HC_N));
+            h[DD_HC_N + j] = make_double2((double)cosl(tp * j / DD_HC_M), (double)-sinl(tp * j / DD_HC_M));
+        }
+        double2* d = nullptr;
+        DD_HIP_CHECK(hipMalloc((void**)&d, sizeof(double2) * h.size()));
+        hipError_t e = hipMemcpy(d, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); dd_set_error("twiddle table upload: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_hc_cols_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_hc_cols_inv, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS));
+        g_hc_tab[dev] = d;
+    }
+    *TA = g_hc_tab[dev];
+    *TB = g_hc_tab[dev] + DD_HC_N;
+    return DD_OK;
+}
 static std::vector<std::pair<int, int64_t>> g_hilb_order;
 
 // sin(pi num / den) for integers num >= 0, den > 0: the argument is reduced to [0, pi/2] exactly in integers first
@@ -1313,13 +1339,15 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
     double2* HH = nullptr;
     double* buf = nullptr;
     DD_HIP_CHECK(hipMalloc((void**)&buf, sizeof(double) * M));
-    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * nb));
+    // (M = 2^18: the same spectrum once more behind the bins, in the order k_hc_rows reads it -- one allocation, one eviction)
+    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * (nb + (M == DD_HC_M ? M : 0))));
     hipfftHandle pm;
     int rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
     if (rc != DD_OK) { (void)hipFree(buf); (void)hipFree(HH); return rc; }
     hipError_t e0 = hipMemcpyAsync(buf, host.data(), sizeof(double) * M, hipMemcpyHostToDevice, s);
     hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
     hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
+    if (M == DD_HC_M) hipLaunchKernelGGL(k_hc_perm, dim3(DD_HC_M / 256), dim3(256), 0, s, HH, HH + nb);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(buf);
     if (e0 != hipSuccess || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
@@ -1350,6 +1378,58 @@ extern "C" int dd_debug_cos_fit(const double* taps_host, int K, double* a_out, i
     for (int q = 0; q < 4; ++q) a_out[q] = f.a[q];
     *Q_out = f.Q;
     return 1;
+}
+
+// diagnostic: the envelope stage of dd_noaa_sync_windows alone.  X: device c64 [nwin][L] (what the zero-phase FIR leaves),
+// env: device f64 [nwin][L - 1] = abs(hilbert(angle(X[n+1] conj X[n]))).  route 0: dd_hconv_kernels.h (needs the padded length
+// 2^18, i.e. 65 536 < L <= 131 072; DD_ERR_INVALID otherwise), route 1: the library's padded real transforms.  Synchronises.
+extern "C" int dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, int route, double* env_dev, void* stream) {
+    DD_REQUIRE(X_dev && env_dev && nwin >= 1 && L >= 4 && L < ((int64_t)1 << 30) && (route == 0 || route == 1), "arguments");
+    const int64_t L2 = L - 1;
+    int64_t M = 1;
+    while (M < 2 * L2 + 2) M <<= 1;
+    DD_REQUIRE(route == 1 || M == DD_HC_M, "route 0 needs 65536 < L <= 131072");
+    const int64_t nb = M / 2 + 1;
+    hipStream_t s = dd_stream(stream);
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    const double2* HH = nullptr;
+    int rc = hilbert_kernel_spectrum(L2, M, &HH, s);
+    if (rc != DD_OK) return rc;
+    const float2* X = (const float2*)X_dev;
+    const int pairs = (nwin + 1) / 2;
+    char* buf = nullptr;
+    const size_t bW = sizeof(double2) * (size_t)pairs * M, bSP = sizeof(double2) * (size_t)nwin * nb, bYR = sizeof(double) * (size_t)nwin * M;
+    DD_HIP_CHECK(hipMalloc((void**)&buf, bW + (route ? bSP + bYR : 0)));
+    if (route == 0) {
+        const double2 *TA = nullptr, *TB = nullptr;
+        rc = hc_tables(&TA, &TB);
+        if (rc == DD_OK) {
+            double2* W = (double2*)buf;
+            hipLaunchKernelGGL(k_hc_cols_fwd, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, X, L, L2, nwin, W, TA);
+            hipLaunchKernelGGL(k_hc_rows, dim3(DD_HC_N / 4, pairs), dim3(256), 0, s, W, HH + nb, TA, TB);
+            hipLaunchKernelGGL(k_hc_cols_inv, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, W, X, L, L2, nwin, env_dev, TA);
+        }
+    } else {
+        double* XR = (double*)buf;
+        double2* SP = (double2*)(buf + bW);
+        double* YR = (double*)(buf + bW + bSP);
+        hipfftHandle pf, pb;
+        rc = get_plan(&pf, HIPFFT_D2Z, M, nwin, s);
+        if (rc == DD_OK) rc = get_plan(&pb, HIPFFT_Z2D, M, nwin, s);
+        if (rc == DD_OK) {
+            hipLaunchKernelGGL(k_sync_fm_pad, dim3(grid1(M), nwin), dim3(256), 0, s, X, L, XR, M);
+            hipfftResult r1 = hipfftExecD2Z(pf, XR, (hipfftDoubleComplex*)SP);
+            hipLaunchKernelGGL(k_spec_mul, dim3(grid1(nb), nwin), dim3(256), 0, s, SP, HH, nb);
+            hipfftResult r2 = hipfftExecZ2D(pb, (hipfftDoubleComplex*)SP, YR);
+            hipLaunchKernelGGL(k_env_hypot, dim3(grid1(L2), nwin), dim3(256), 0, s, XR, YR, M, L2, env_dev);
+            if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) { dd_set_error("hipfft exec failed (%d, %d)", (int)r1, (int)r2); rc = DD_ERR_HIP; }
+        }
+    }
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    if (rc != DD_OK) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) { dd_set_error("dd_debug_sync_envelope: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return DD_ERR_HIP; }
+    return DD_OK;
 }
 
 extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host, int n_windows, int64_t win_len,
@@ -1421,8 +1501,9 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     while (M < 2 * L2 + 2) M <<= 1;                                       // cyclic convolution length of the envelope stage
     const int64_t nb = M / 2 + 1;
     const char* hm = getenv("DD_SYNC_HILBERT");
-    const bool hilbert_fft = hm && !strcmp(hm, "fft");                    // A/B switch: the library's length-N transforms
-    const size_t o_SP = o_W + al(sizeof(double) * B * M);                 // W/XR: f64 [B][M] (or c128 [B][L2]); later P, Q: f64 [B][L2+1] each
+    const bool hilbert_fft = hm && !strcmp(hm, "fft");                    // A/B switches: the library's length-N transforms ("fft"),
+    const bool hilbert_own = !hilbert_fft && M == DD_HC_M && !(hm && !strcmp(hm, "lib"));   // its padded real transforms ("lib"); dd_hconv_kernels.h
+    const size_t o_SP = o_W + al(sizeof(double) * (B + (B & 1)) * M);     // (two windows share one complex [M] image in dd_hconv_kernels.h)                 // W/XR: f64 [B][M] (or c128 [B][L2]); later P, Q: f64 [B][L2+1] each
     const size_t o_YR = o_SP + al(sizeof(double2) * B * nb);              // SP: c128 [B][M/2+1]
     const size_t o_ENV = o_YR + al(sizeof(double) * B * M);               // YR: f64 [B][M]
     const size_t o_F1 = o_ENV + al(sizeof(double) * B * L2);              // ENV f64 [B][L2]
@@ -1447,6 +1528,11 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     const double2* HH = nullptr;
     if (!hilbert_fft) {
         rc = hilbert_kernel_spectrum(L2, M, &HH, s);
+        if (rc != DD_OK) return rc;
+    }
+    const double2 *TA = nullptr, *TB = nullptr;
+    if (hilbert_own) {
+        rc = hc_tables(&TA, &TB);
         if (rc != DD_OK) return rc;
     }
     double* ENV = (double*)(base + o_ENV);
@@ -1488,6 +1574,11 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
             hipLaunchKernelGGL(k_hilbert_mask_b, gL2, dim3(256), 0, s, W, L2);
             DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_BACKWARD));
             hipLaunchKernelGGL(k_cplx_abs_b, gL2, dim3(256), 0, s, W, ENV, L2, 1.0 / (double)L2);
+        } else if (hilbert_own) {
+            const int pairs = (b + 1) / 2;
+            hipLaunchKernelGGL(k_hc_cols_fwd, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, X, L, L2, b, W, TA);
+            hipLaunchKernelGGL(k_hc_rows, dim3(DD_HC_N / 4, pairs), dim3(256), 0, s, W, HH + nb, TA, TB);
+            hipLaunchKernelGGL(k_hc_cols_inv, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, W, X, L, L2, b, ENV, TA);
         } else {
             hipfftHandle pf, pb;
             rc = get_plan(&pf, HIPFFT_D2Z, M, b, s);

@@ -85,9 +85,13 @@ int  dd_debug_seam(int withhold_chunk, int spin_log2);
  *   stream start, no angle for the first output; out_align_elems: how many elements `out` sits behind a 64-byte line; ncu compute
  *   units; rounds: 0 = default).  out[0..6] = base, nblk, grid, nwaves, K, b, 32, then r0[32], r1[32], wstart[32].
  * dd_debug_cos_fit -- 1 when the taps are a cosine series of at most four terms for which the zero-phase filter of the
- *   accurate-sync windows takes its prefix-sum form (a[0..3], *Q filled), else 0. */
+ *   accurate-sync windows takes its prefix-sum form (a[0..3], *Q filled), else 0.
+ * dd_debug_sync_envelope -- the envelope stage of dd_noaa_sync_windows alone: X_dev c64 [nwin][L] (device) -> env_dev f64
+ *   [nwin][L - 1] = abs(hilbert(angle(X[n+1] conj X[n]))) (decode_noaa.py:852 -> demod_am.py:29).  route 0: the three-launch
+ *   512 x 512 transform of csrc/dd_hconv_kernels.h (65 536 < L <= 131 072), route 1: the FFT library's padded real transforms. */
 int  dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rounds, int* out);
 int  dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out);
+int  dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, int route, double* env_dev, void* stream);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

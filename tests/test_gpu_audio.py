@@ -779,7 +779,7 @@ def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
         assert np.array_equal(i1, i2) and np.max(np.abs(np.array(p1) - np.array(p2))) < 1e-9
     # default batch and batches smaller than the window count; the envelope as one real convolution (default)
     # and through the library's length-N transforms
-    for batch, hilbert in ((None, None), ("3", None), (None, "fft")):
+    for batch, hilbert in ((None, None), ("3", None), (None, "fft"), (None, "lib"), ("3", "lib")):
         monkeypatch.delenv("DD_SYNC_BATCH", raising=False)
         monkeypatch.delenv("DD_SYNC_HILBERT", raising=False)
         if batch:
@@ -796,6 +796,32 @@ def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
             assert np.max(np.abs(a - b)) < 1e-9 * np.max(np.abs(a))
     # golden index lists of the reference through both forms
     assert np.array_equal(one[0][0], g["acc_syncA"]) and np.array_equal(many[1][0], g["acc_syncB"])
+
+
+@pytest.mark.parametrize("L,nwin", [(118152, 5), (65537, 2), (131072, 1), (100001, 4)])
+def test_sync_envelope_three_launch_transform(dd, L, nwin):
+    """The envelope stage of the accurate-sync windows alone (decode_noaa.py:852 -> demod_am.py:29, abs(hilbert(x)) of each
+    window's FM audio): the 512 x 512 float64 transform of csrc/dd_hconv_kernels.h (two windows per complex image, three
+    launches) against the FFT library's padded real transforms on the same device-side audio (agreement at rounding level),
+    and against scipy.signal.hilbert on the host (the float32 discriminator differs in the last bit there).  Odd window counts
+    (a pair with an empty second half), the shortest and the longest window the 2^18 padding takes."""
+    import ctypes as C
+    import scipy.signal
+    rng = np.random.default_rng(L + nwin)
+    # a wandering phase with a wandering amplitude: audio with structure at every scale, like the filtered IQ of a window
+    ph = np.cumsum(rng.normal(0, 0.3, (nwin, L)) + 0.2 * np.sin(np.arange(L) * 2 * np.pi / 493.0), axis=1)
+    x = ((1.0 + 0.5 * np.sin(np.arange(L) / 37.0)) * np.exp(1j * ph)).astype(np.complex64)
+    d_x = dd.hip.DevArray.from_host(x.reshape(-1))
+    envs = []
+    for route in (0, 1):
+        d_e = dd.hip.DevArray(nwin * (L - 1), np.float64)
+        dd.hip.check(dd.hip.lib().dd_debug_sync_envelope(d_x.ptr, L, nwin, route, d_e.ptr, None), "dd_debug_sync_envelope")
+        envs.append(d_e.to_host().reshape(nwin, L - 1))
+    scale = np.max(envs[1])
+    assert np.max(np.abs(envs[0] - envs[1])) <= 1e-12 * scale
+    audio = np.angle(x[:, 1:].astype(np.complex128) * np.conj(x[:, :-1].astype(np.complex128)))
+    ref = np.abs(scipy.signal.hilbert(audio, axis=1))
+    assert np.max(np.abs(envs[0] - ref)) <= 2e-6 * scale
 
 
 def test_accurate_sync_windows_oracle_chain(dd):
