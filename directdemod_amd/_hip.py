@@ -121,6 +121,9 @@ SIGNATURES = {
     "dd_noaa_sync_windows": (_int, [_p, _int, _pi64, _int, _i64, C.c_uint64, C.POINTER(C.c_double), _int,
                                     C.POINTER(C.c_double), _int, C.POINTER(C.c_double), _int, C.c_double,
                                     _pi64, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
+    "dd_noaa_sync_windows_multi": (_int, [_p, _int, _pi64, C.POINTER(_int), _int, _i64, C.c_uint64, C.POINTER(C.c_double), _int,
+                                          C.POINTER(C.c_double), _int, C.POINTER(C.c_double), _int, _int, C.c_double,
+                                          _pi64, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
     "dd_noaa_crude_tail": (_int, [_p, _int, _i64, C.c_double, _i64, C.POINTER(C.c_double), _int, _int, _p,
                                   _pi64, _int, C.POINTER(_int), _p]),
     "dd_afsk_binary_filter_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),

@@ -631,6 +631,24 @@ static int sync_scratch(size_t bytes, char** out) {
     return DD_OK;
 }
 
+// pinned host staging per device for the entry points' one copy back (grow-only; callers hold g_sync_mu)
+static void* g_pin[64] = {nullptr};
+static size_t g_pin_bytes[64] = {0};
+static int sync_pinned(size_t bytes, char** out) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (g_pin_bytes[dev] < bytes) {
+        if (g_pin[dev]) DD_HIP_CHECK(hipHostFree(g_pin[dev]));
+        g_pin[dev] = nullptr;
+        g_pin_bytes[dev] = 0;
+        DD_HIP_CHECK(hipHostMalloc(&g_pin[dev], bytes, hipHostMallocDefault));
+        g_pin_bytes[dev] = bytes;
+    }
+    *out = (char*)g_pin[dev];
+    return DD_OK;
+}
+
 // ---------------------------------------------------------------- X1: normalised correlation
 // cor = correlate(h, needle, 'same'); sums = convolve(h*h, ones(m), 'same');
 // out = cor / sqrt(sums * sum(needle^2))  (decode_noaa.py:671-673).  Both windows are
@@ -665,6 +683,8 @@ struct DDRuns {
     int start[DD_XCORR_MAX_RUNS + 1];
     double val[DD_XCORR_MAX_RUNS];
 };
+#define DD_CS_MAXNEEDLES 2               // needles (sync words) one call correlates
+struct DDRuns2 { DDRuns r[DD_CS_MAXNEEDLES]; double vv[DD_CS_MAXNEEDLES]; };
 
 __global__ void __launch_bounds__(256) k_xcorr_runs(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                     const DDRuns R, double vv, double* __restrict__ out) {
@@ -1167,11 +1187,14 @@ __device__ __forceinline__ DDPk dd_pk_empty() {
 // reads of every prefix-sum element come out of one XCD's L2.
 #define DD_XC_TILE 1024
 __global__ void __launch_bounds__(256) k_xcorr_runs_pk(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
-                                                       const DDRuns R, double vv, int tiles, int nwin, DDPk* __restrict__ part) {
+                                                       const DDRuns2 R2, const int* __restrict__ group, int tiles, int nwin, DDPk* __restrict__ part) {
     __shared__ DDPk sw[4];
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int win = (k / tiles) * 8 + xcd, tile = k % tiles;
     if (win >= nwin) return;
+    const int gsel = group ? __builtin_amdgcn_readfirstlane(group[win]) : 0;        // which needle this window is searched for
+    const DDRuns& R = R2.r[gsel];
+    const double vv = R2.vv[gsel];
     P += (int64_t)win * (n + 1);
     Q += (int64_t)win * (n + 1);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1437,12 +1460,28 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
                                     const double* pre_taps_host, int pre_ntaps, const double* needle_host, int needle_len,
                                     double samp_rate, int64_t* peak_host, double* height_host, double* tsync_host,
                                     void* stream) {
+    return dd_noaa_sync_windows_multi(iq, iq_kind, starts_host, nullptr, n_windows, win_len, cycles_q64, fir_taps_host, fir_ntaps,
+                                      pre_taps_host, pre_ntaps, needle_host, needle_len, 1, samp_rate, peak_host, height_host, tsync_host, stream);
+}
+
+// The windows of several sync words in one call (getAccurateSync searches sync A around the crude A positions and sync B around
+// the crude B positions, decode_noaa.py:828-835: two window lists, one chain, two needles of one length): needle_of_window_host[w]
+// says which of the n_needles needles window w is correlated with (NULL: needle 0).  One upload, batches that mix the lists, one
+// copy back, one synchronisation -- the second call's host work no longer sits between the two lists' kernels.
+extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int64_t* starts_host, const int* needle_of_window_host,
+                                          int n_windows, int64_t win_len, uint64_t cycles_q64, const double* fir_taps_host, int fir_ntaps,
+                                          const double* pre_taps_host, int pre_ntaps, const double* needle_host, int needle_len, int n_needles,
+                                          double samp_rate, int64_t* peak_host, double* height_host, double* tsync_host,
+                                          void* stream) {
     DD_REQUIRE(n_windows >= 0, "n_windows");
     if (n_windows == 0) return DD_OK;
     DD_REQUIRE(iq && starts_host && peak_host && height_host && tsync_host, "null buffer");
     DD_REQUIRE(iq_kind == 0 || iq_kind == 1, "iq_kind (0 complex64, 1 uint8 pairs)");
     DD_REQUIRE(fir_taps_host && fir_ntaps >= 1 && pre_ntaps >= 0 && (pre_taps_host || pre_ntaps == 0), "taps");
     DD_REQUIRE(needle_host && needle_len >= 1 && samp_rate > 0, "needle/samp_rate");
+    DD_REQUIRE(n_needles >= 1 && n_needles <= DD_CS_MAXNEEDLES, "n_needles (1 or 2)");
+    if (needle_of_window_host)
+        for (int w = 0; w < n_windows; ++w) DD_REQUIRE(needle_of_window_host[w] >= 0 && needle_of_window_host[w] < n_needles, "needle_of_window");
     const int64_t L = win_len, L2 = win_len - 1;
     DD_REQUIRE(L2 >= 2 && needle_len <= L2 && L < ((int64_t)1 << 30), "window length");
     if (!((double)L2 < 0.45 * samp_rate)) {
@@ -1459,23 +1498,29 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         dd_set_error("dd_noaa_sync_windows: filter too long for the tiled zero-phase kernel");
         return DD_ERR_INVALID;
     }
-    // piecewise-constant needle -> runs
-    DDRuns R;
-    R.nr = 0;
-    for (int t = 0; t < needle_len; ++t) {
-        if (t == 0 || needle_host[t] != needle_host[t - 1]) {
-            if (R.nr == DD_XCORR_MAX_RUNS) {
-                dd_set_error("dd_noaa_sync_windows: the needle has more than %d constant runs", DD_XCORR_MAX_RUNS);
-                return DD_ERR_INVALID;
+    // piecewise-constant needles -> runs
+    DDRuns2 R2;
+    for (int d = 0; d < n_needles; ++d) {
+        const double* nh = needle_host + (size_t)d * needle_len;
+        DDRuns& R = R2.r[d];
+        R.nr = 0;
+        for (int t = 0; t < needle_len; ++t) {
+            if (t == 0 || nh[t] != nh[t - 1]) {
+                if (R.nr == DD_XCORR_MAX_RUNS) {
+                    dd_set_error("dd_noaa_sync_windows: the needle has more than %d constant runs", DD_XCORR_MAX_RUNS);
+                    return DD_ERR_INVALID;
+                }
+                R.start[R.nr] = t;
+                R.val[R.nr] = nh[t];
+                ++R.nr;
             }
-            R.start[R.nr] = t;
-            R.val[R.nr] = needle_host[t];
-            ++R.nr;
         }
+        R.start[R.nr] = needle_len;
+        double vv = 0.0;
+        for (int t = 0; t < needle_len; ++t) vv += nh[t] * nh[t];
+        R2.vv[d] = vv;
     }
-    R.start[R.nr] = needle_len;
-    double vv = 0.0;
-    for (int t = 0; t < needle_len; ++t) vv += needle_host[t] * needle_host[t];
+    for (int d = n_needles; d < DD_CS_MAXNEEDLES; ++d) { R2.r[d] = R2.r[0]; R2.vv[d] = R2.vv[0]; }
 
     hipStream_t s = dd_stream(stream);
     const float2* tbl = dd_nco_table();
@@ -1490,7 +1535,8 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // layout (per batch of B windows)
     const size_t o_starts = 0;
-    const size_t o_taps1 = o_starts + al(sizeof(int64_t) * n_windows);
+    const size_t o_group = o_starts + al(sizeof(int64_t) * n_windows);
+    const size_t o_taps1 = o_group + al(sizeof(int) * n_windows);
     const size_t o_taps2 = o_taps1 + al(sizeof(double) * fir_ntaps);
     const size_t o_tab = o_taps2 + al(sizeof(double) * (pre_ntaps ? pre_ntaps : 1));
     const size_t o_res = o_tab + al(sizeof(double2) * 3 * (size_t)(pre_ntaps ? pre_ntaps : 1));
@@ -1514,6 +1560,7 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     int rc = sync_scratch(total + 4096, &base);
     if (rc != DD_OK) return rc;
     int64_t* d_starts = (int64_t*)(base + o_starts);
+    const int* d_group = needle_of_window_host ? (const int*)(base + o_group) : nullptr;
     double* d_taps1 = (double*)(base + o_taps1);
     double* d_taps2 = (double*)(base + o_taps2);
     int64_t* d_peak = (int64_t*)(base + o_res);
@@ -1541,6 +1588,7 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
     // window starts, both tap sets and the cosine table go up as ONE copy (they are neighbours in the layout)
     std::vector<char> up(o_res, 0);
     memcpy(up.data() + o_starts, starts_host, sizeof(int64_t) * n_windows);
+    if (needle_of_window_host) memcpy(up.data() + o_group, needle_of_window_host, sizeof(int) * n_windows);
     memcpy(up.data() + o_taps1, fir_taps_host, sizeof(double) * fir_ntaps);
     if (pre_ntaps) memcpy(up.data() + o_taps2, pre_taps_host, sizeof(double) * pre_ntaps);
     // the envelope's pre-filter is hamming(492) (decode_noaa.py:677): a two-term cosine series -- prefix-sum form
@@ -1607,16 +1655,18 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
         DDPk* ppart = (DDPk*)(F1 + 2 * (size_t)b * stiles);                // both in the pre-filter's (now free) work buffer
         hipLaunchKernelGGL(k_scan_part, dim3(stiles, b), dim3(256), 0, s, hay, L2, stiles, spart);
         hipLaunchKernelGGL(k_scan_final, dim3(stiles, b), dim3(256), 0, s, hay, L2, stiles, spart, P, Q);
-        hipLaunchKernelGGL(k_xcorr_runs_pk, dim3(8 * ((b + 7) / 8) * xtiles), dim3(256), 0, s, P, Q, L2, needle_len, R, vv, xtiles, b, ppart);
+        hipLaunchKernelGGL(k_xcorr_runs_pk, dim3(8 * ((b + 7) / 8) * xtiles), dim3(256), 0, s, P, Q, L2, needle_len, R2, d_group ? d_group + w0 : nullptr, xtiles, b, ppart);
         hipLaunchKernelGGL(k_sync_peak, dim3(b), dim3(256), 0, s, ppart, xtiles, ENV, L2, needle_len, d_peak + w0, d_height + w0, d_tsync + w0);
         DD_LAUNCH_CHECK();
     }
-    std::vector<char> down(24 * (size_t)n_windows);                                              // the three result arrays, one copy
-    DD_HIP_CHECK(hipMemcpyAsync(down.data(), base + o_res, down.size(), hipMemcpyDeviceToHost, s));
+    char* down = nullptr;                                                                        // the three result arrays, one copy (pinned)
+    rc = sync_pinned(24 * (size_t)n_windows, &down);
+    if (rc != DD_OK) return rc;
+    DD_HIP_CHECK(hipMemcpyAsync(down, base + o_res, 24 * (size_t)n_windows, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
-    memcpy(peak_host, down.data(), 8 * (size_t)n_windows);
-    memcpy(height_host, down.data() + 8 * (size_t)n_windows, 8 * (size_t)n_windows);
-    memcpy(tsync_host, down.data() + 16 * (size_t)n_windows, 8 * (size_t)n_windows);
+    memcpy(peak_host, down, 8 * (size_t)n_windows);
+    memcpy(height_host, down + 8 * (size_t)n_windows, 8 * (size_t)n_windows);
+    memcpy(tsync_host, down + 16 * (size_t)n_windows, 8 * (size_t)n_windows);
     return DD_OK;
 }
 
@@ -1643,7 +1693,6 @@ extern "C" int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* 
 #define DD_CS_WG 512                  // workgroups per needle and selection launch
 #define DD_CS_COPIES 8                // interleaved LDS histograms per selection
 #define DD_CS_KMAX 2048               // largest K (two per second of audio + 2) the in-kernel sort holds
-#define DD_CS_MAXNEEDLES 2
 struct DDCrudeSel {
     unsigned int hist[8][2][256];     // per pass: [K-th largest | K-th smallest]
     unsigned int n_beyond[2];         // values appended above / below
@@ -1732,7 +1781,6 @@ __global__ void __launch_bounds__(256) k_scan_final_x(const double* __restrict__
     dd_scan_tile_store(Q, n, tile0, t, lds, q);
 }
 // k_xcorr_runs for up to two needles of equal length at once (blockIdx.y = needle; out[needle][n])
-struct DDRuns2 { DDRuns r[DD_CS_MAXNEEDLES]; double vv[DD_CS_MAXNEEDLES]; };
 // The 256 outputs of a workgroup read P at a0 + start[r], r = 0 .. nr: 256 + m + 1 consecutive prefix sums, each wanted by
 // ~nr outputs.  They are staged in LDS once (when they fit: 817 doubles for the crude needles) -- straight from L2 the kernel
 // ran at the L2's bandwidth, 108 us for 2 x 3.6 M outputs.
@@ -1939,21 +1987,37 @@ __global__ void __launch_bounds__(256) k_cs_threshold(int K, DDCrudeSel* __restr
         S->beyond_cnt[0] = st.beyond[0]; S->beyond_cnt[1] = st.beyond[1];
     }
 }
-// candidates cor > threshold (:726), appended with their heights; the host orders them by index
+// candidates cor > threshold (:726), appended with their heights; the host orders them by index.  The first DD_CS_HEAD of a needle
+// go into the block the host fetches in its one copy (behind the counters), later ones into the overflow arrays
+#define DD_CS_HEAD 8192
+struct DDCand { int64_t idx; double val; };
+struct DDCrudeHead { unsigned int n_cand, n_beyond[2], beyond_cnt[2], pad[3]; };      // 32 bytes per needle, then DDCand[needles][DD_CS_HEAD]
 __global__ void __launch_bounds__(256) k_cs_cand(const double* __restrict__ cor_all, int64_t n, DDCrudeSel* __restrict__ sel_all,
-                                                 int64_t* __restrict__ cidx_all, double* __restrict__ cval_all, unsigned int cap) {
+                                                 DDCand* __restrict__ head_all, int64_t* __restrict__ cidx_all, double* __restrict__ cval_all, unsigned int cap) {
     const int nd = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
     const double* cor = cor_all + (int64_t)nd * n;
     DDCrudeSel* S = sel_all + nd;
+    DDCand* head = head_all + (size_t)nd * DD_CS_HEAD;
     int64_t* cidx = cidx_all + (size_t)nd * cap;
     double* cval = cval_all + (size_t)nd * cap;
     const double thr = S->thr;
     const int64_t i_lo = n * g / G, i_hi = n * (g + 1) / G;
     for (int64_t i = i_lo + t; i < i_hi; i += 256) {
         const double v = cor[i];
-        if (v > thr) { const unsigned int o = atomicAdd(&S->n_cand, 1u); if (o < cap) { cidx[o] = i; cval[o] = v; } }
+        if (v > thr) {
+            const unsigned int o = atomicAdd(&S->n_cand, 1u);
+            if (o < DD_CS_HEAD) head[o] = DDCand{i, v};
+            else if (o < cap) { cidx[o] = i; cval[o] = v; }
+        }
     }
 }
+__global__ void k_cs_head(const DDCrudeSel* __restrict__ sel, DDCrudeHead* __restrict__ hdr, int n_needles) {
+    const int d = threadIdx.x;
+    if (d >= n_needles) return;
+    DDCrudeHead h = {sel[d].n_cand, {sel[d].n_beyond[0], sel[d].n_beyond[1]}, {sel[d].beyond_cnt[0], sel[d].beyond_cnt[1]}, {0, 0, 0}};
+    hdr[d] = h;
+}
+
 
 extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n, double samp_rate, int64_t block,
                                   const double* needles_host, int m, int n_needles, double* env_out,
@@ -2015,6 +2079,8 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     const size_t o_sel = take(sizeof(DDCrudeSel) * n_needles);
     const size_t o_bey = take(sizeof(double) * 2 * DD_CS_KMAX * n_needles);
     const size_t o_ci = take(sizeof(int64_t) * (size_t)cap * n_needles), o_cv = take(sizeof(double) * (size_t)cap * n_needles);
+    const size_t head_bytes = sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES + sizeof(DDCand) * (size_t)DD_CS_HEAD * n_needles;
+    const size_t o_head = take(head_bytes);
     std::lock_guard<std::mutex> lk(g_sync_mu);
     char* base = nullptr;
     int rc = sync_scratch(off, &base);
@@ -2072,35 +2138,38 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     for (int pass = 0; pass < 8; ++pass) hipLaunchKernelGGL(k_cs_hist, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, pass, sel);
     hipLaunchKernelGGL(k_cs_collect, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, sel, (double*)(base + o_bey));
     hipLaunchKernelGGL(k_cs_threshold, dim3(n_needles), dim3(256), 0, s, K, sel, (const double*)(base + o_bey));
-    hipLaunchKernelGGL(k_cs_cand, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, sel, (int64_t*)(base + o_ci), (double*)(base + o_cv), cap);
+    DDCrudeHead* d_hdr = (DDCrudeHead*)(base + o_head);
+    DDCand* d_head = (DDCand*)(base + o_head + sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES);
+    hipLaunchKernelGGL(k_cs_cand, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, sel, d_head, (int64_t*)(base + o_ci), (double*)(base + o_cv), cap);
+    hipLaunchKernelGGL(k_cs_head, dim3(1), dim3(64), 0, s, sel, d_hdr, n_needles);
     DD_LAUNCH_CHECK();
-    // ---- one round trip: the select state and the first 16 384 candidates of each needle (the rest only if there are more)
-    const unsigned int first_n = 1u << 14;
-    std::vector<DDCrudeSel> hs(n_needles);
-    std::vector<int64_t> hci((size_t)first_n * n_needles);
-    std::vector<double> hcv((size_t)first_n * n_needles);
-    DD_HIP_CHECK(hipMemcpyAsync(hs.data(), sel, sizeof(DDCrudeSel) * n_needles, hipMemcpyDeviceToHost, s));
-    for (int d = 0; d < n_needles; ++d) {
-        DD_HIP_CHECK(hipMemcpyAsync(hci.data() + (size_t)d * first_n, (int64_t*)(base + o_ci) + (size_t)d * cap, sizeof(int64_t) * first_n, hipMemcpyDeviceToHost, s));
-        DD_HIP_CHECK(hipMemcpyAsync(hcv.data() + (size_t)d * first_n, (double*)(base + o_cv) + (size_t)d * cap, sizeof(double) * first_n, hipMemcpyDeviceToHost, s));
-    }
+    // ---- one round trip, ONE copy into pinned memory: the counters and the first DD_CS_HEAD candidates of each needle (a second
+    // copy only for a needle with more).  (Five copies into pageable vectors -- the 16 KB select state and two arrays per needle --
+    // took 0.39 ms of the 1.1 ms call under the profiler, each a blocking staged transfer: profiles/r04_noaa_timeline.txt)
+    char* pin = nullptr;
+    rc = sync_pinned(head_bytes, &pin);
+    if (rc != DD_OK) return rc;
+    DD_HIP_CHECK(hipMemcpyAsync(pin, base + o_head, head_bytes, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    const DDCrudeHead* hs = (const DDCrudeHead*)pin;
+    const DDCand* hc = (const DDCand*)(pin + sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES);
+    const unsigned int first_n = DD_CS_HEAD;
     for (int d = 0; d < n_needles; ++d) {
-        const DDCrudeSel& h1 = hs[d];
+        const DDCrudeHead& h1 = hs[d];
         DD_REQUIRE(h1.n_beyond[0] == h1.beyond_cnt[0] && h1.n_beyond[1] == h1.beyond_cnt[1] && h1.n_beyond[0] < (unsigned int)K && h1.n_beyond[1] < (unsigned int)K,
                    "dd_noaa_crude_tail: selection bookkeeping (internal)");
         const unsigned int count = h1.n_cand;
         if (count > cap) return DD_ERR_UNSUPPORTED;                       // (a threshold that lets > 65 536 values through: staged route)
         std::vector<std::pair<int64_t, double>> cand(count);
+        for (unsigned int i = 0; i < count && i < first_n; ++i) cand[i] = {hc[(size_t)d * first_n + i].idx, hc[(size_t)d * first_n + i].val};
         if (count > first_n) {
-            std::vector<int64_t> ci(count);
-            std::vector<double> cv(count);
-            DD_HIP_CHECK(hipMemcpyAsync(ci.data(), (int64_t*)(base + o_ci) + (size_t)d * cap, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
-            DD_HIP_CHECK(hipMemcpyAsync(cv.data(), (double*)(base + o_cv) + (size_t)d * cap, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+            const unsigned int more = count - first_n;
+            std::vector<int64_t> ci(more);
+            std::vector<double> cv(more);
+            DD_HIP_CHECK(hipMemcpyAsync(ci.data(), (int64_t*)(base + o_ci) + (size_t)d * cap + first_n, sizeof(int64_t) * more, hipMemcpyDeviceToHost, s));
+            DD_HIP_CHECK(hipMemcpyAsync(cv.data(), (double*)(base + o_cv) + (size_t)d * cap + first_n, sizeof(double) * more, hipMemcpyDeviceToHost, s));
             DD_HIP_CHECK(hipStreamSynchronize(s));
-            for (unsigned int i = 0; i < count; ++i) cand[i] = {ci[i], cv[i]};
-        } else {
-            for (unsigned int i = 0; i < count; ++i) cand[i] = {hci[(size_t)d * first_n + i], hcv[(size_t)d * first_n + i]};
+            for (unsigned int i = 0; i < more; ++i) cand[first_n + i] = {ci[i], cv[i]};
         }
         std::sort(cand.begin(), cand.end(), [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; });
         // group by >= 0.45 s from the running maximum, first maximum wins (:729-746)

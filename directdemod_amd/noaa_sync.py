@@ -135,14 +135,21 @@ class noaa_sync:
     def accurate_windows(self, starts, length, sync, raw=None, resident=True):
         """All search windows of one sync type in one batched device call (dd_noaa_sync_windows): the chain
         of accurate_window over [windows][samples] arrays.  Returns (indices, heights, times) like the
-        per-window loop of decode_noaa.py:828-835."""
+        per-window loop of decode_noaa.py:828-835.  `sync` may also be a list of sync words with `starts` the list of their
+        window lists (dd_noaa_sync_windows_multi: both searches of getAccurateSync in one call); the return value is then
+        a list of such triples."""
         import ctypes as C
         from . import _hip
         src = self.__sigsrc
         fs = src.sampFreq
+        multi = len(starts) > 0 and isinstance(starts[0], (list, tuple, np.ndarray))
+        if multi:
+            lists, syncs = [list(s) for s in starts], list(sync)
+            starts = [a for lst in lists for a in lst]
+            group = np.ascontiguousarray([g for g, lst in enumerate(lists) for _ in lst], dtype=np.int32)
         nw = len(starts)
         if nw == 0:
-            return np.zeros(0, dtype=np.int64), [], []
+            return [(np.zeros(0, dtype=np.int64), [], []) for _ in lists] if multi else (np.zeros(0, dtype=np.int64), [], [])
         st = (np.arange(nw, dtype=np.int64) * length)
         res = None
         if raw is None and resident and hasattr(src, "resident_raw"):
@@ -158,20 +165,36 @@ class noaa_sync:
             d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
         bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
         pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
-        needle = np.ascontiguousarray(sync_needle(sync, fs), dtype=np.float64)
         pk = np.empty(nw, dtype=np.int64)
         ht = np.empty(nw, dtype=np.float64)
         ts = np.empty(nw, dtype=np.float64)
         dp = C.POINTER(C.c_double)
-        _hip.check(_hip.lib().dd_noaa_sync_windows(
-            d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), nw, int(length), _hip.cycles_q64(self.__offset, fs),
-            bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre), needle.ctypes.data_as(dp), len(needle),
-            float(fs), pk.ctypes.data_as(C.POINTER(C.c_int64)), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None),
-            "dd_noaa_sync_windows")
+        if multi:
+            needle = np.ascontiguousarray(np.stack([sync_needle(sy, fs) for sy in syncs]), dtype=np.float64)
+            _hip.check(_hip.lib().dd_noaa_sync_windows_multi(
+                d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), group.ctypes.data_as(C.POINTER(C.c_int)), nw, int(length),
+                _hip.cycles_q64(self.__offset, fs), bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre),
+                needle.ctypes.data_as(dp), needle.shape[1], needle.shape[0],
+                float(fs), pk.ctypes.data_as(C.POINTER(C.c_int64)), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None),
+                "dd_noaa_sync_windows_multi")
+        else:
+            needle = np.ascontiguousarray(sync_needle(sync, fs), dtype=np.float64)
+            _hip.check(_hip.lib().dd_noaa_sync_windows(
+                d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), nw, int(length), _hip.cycles_q64(self.__offset, fs),
+                bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre), needle.ctypes.data_as(dp), len(needle),
+                float(fs), pk.ctypes.data_as(C.POINTER(C.c_int64)), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None),
+                "dd_noaa_sync_windows")
         if np.any(pk == np.iinfo(np.int64).min):
             raise IndexError("index 0 is out of bounds for axis 0 with size 0")      # pk[0] of an empty pick (:853)
         idx = pk + np.asarray(starts, dtype=np.int64)
-        return idx, [float(v) for v in ht], [None if np.isnan(v) else float(v) for v in ts]
+        hts, tss = ht.tolist(), [None if v != v else v for v in ts.tolist()]
+        if not multi:
+            return idx, hts, tss
+        out, o = [], 0
+        for lst in lists:
+            out.append((idx[o:o + len(lst)], hts[o:o + len(lst)], tss[o:o + len(lst)]))
+            o += len(lst)
+        return out
 
     def getAccurateSync(self, batched=True, resident=True):
         sa, sb = self.getCrudeSync()
@@ -199,9 +222,10 @@ class noaa_sync:
                 tms.append(t)
             out.append((np.array(idx, dtype=np.int64), pks, tms))
         if jobs and resident and hasattr(src, "resident_raw") and src.read_device_raw(0, 1) is not None:
-            # the recording sits in HBM as raw pairs (the crude pass put it there): the windows are read in place
-            for slot, st, sync in jobs:
-                a, b, c = self.accurate_windows(st, 2 * width, sync)
+            # the recording sits in HBM as raw pairs (the crude pass put it there): the windows are read in place, both
+            # searches in one device call
+            res = self.accurate_windows([st for _, st, _ in jobs], 2 * width, [sync for _, _, sync in jobs])
+            for (slot, _, _), (a, b, c) in zip(jobs, res):
                 out[slot] = (np.asarray(a, dtype=np.int64), b, c)
             jobs = []
         if jobs:

@@ -318,6 +318,16 @@ int dd_noaa_sync_windows(const void* iq, int iq_kind, const int64_t* starts_host
                          const double* pre_taps_host, int pre_ntaps,
                          const double* needle_host, int needle_len, double samp_rate,
                          int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
+/* ... the window lists of several sync words in one call (getAccurateSync, decode_noaa.py:828-835, searches sync A around the
+ *      crude A positions and sync B around the crude B positions: two lists, one chain, two needles of one length).
+ *      needle_host holds n_needles (1 or 2) needles of needle_len values back to back; needle_of_window_host[w] names the
+ *      needle window w is correlated with (NULL: needle 0).  Results in window order.  One upload, one copy back. */
+int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int64_t* starts_host, const int* needle_of_window_host,
+                               int n_windows, int64_t win_len, uint64_t cycles_q64,
+                               const double* fir_taps_host, int fir_ntaps,
+                               const double* pre_taps_host, int pre_ntaps,
+                               const double* needle_host, int needle_len, int n_needles, double samp_rate,
+                               int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
 
 /* P -- getCrudeSync's audio-rate tail (decode_noaa.py:781-790) in one host call: the envelope of `audio` (device float32 or
  *      float64, n samples at samp_rate) in `block`-sample blocks by the chunker rule (__getAM :631-657 -> demod_am.py:29),

@@ -147,6 +147,38 @@ def test_crude_tail_in_one_call_equals_the_staged_route(dd, noaa_inputs):
     assert len(am) == 3 * rate
 
 
+def test_crude_tail_many_candidates(dd):
+    """Audio without sync words (noise): the peak threshold (decode_noaa.py:723-726) lets a good part of the correlation values
+    through -- more than the 8192 candidates per needle that come back with the counters in the entry's one copy, so the rest is
+    fetched in a second one; with still more than 65 536 the entry declines and the caller goes stage by stage.  Index lists
+    against the staged route."""
+    rate = 40960
+    rng = np.random.default_rng(99)
+    needles = [O.sync_needle(O.NOAA_SYNCA, rate), O.sync_needle(O.NOAA_SYNCB, rate)]
+    ns = dd.noaa.noaa_sync(None, 0.0)
+    seen = set()
+    for n in (20 * rate + 17, 3 * rate + 5, 2 * rate, rate + 999):
+        a = np.ascontiguousarray(rng.normal(0.0, 0.3, n))
+        sig = ns.envelope(dd.comm.commSignal(rate, a))
+        counts = []
+        for nd in needles:                      # values above the threshold, from the staged correlation
+            cor = np.sort(dd.ops.xcorr_norm(sig.device_signal, nd).to_host())
+            K = int(2 * (n / rate)) + 2
+            avgpk = np.mean(cor[-K:])
+            counts.append(int(np.count_nonzero(cor > avgpk - 0.25 * (avgpk - np.mean(cor[:K])))))
+        res = dd.ops.crude_tail(dd.hip.DevArray.from_host(a), rate, needles)
+        if max(counts) > 65536:
+            assert res is None, (n, counts)
+            seen.add("declined")
+            continue
+        assert res is not None, (n, counts)
+        pa, pb = res[0]
+        assert np.array_equal(pa, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCA)), (n, counts)
+        assert np.array_equal(pb, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCB)), (n, counts)
+        seen.add("second copy" if max(counts) > 8192 else "one copy")
+    assert "second copy" in seen, seen
+
+
 def test_c4_crude_and_accurate_sync_indices_golden(dd, noaa_inputs):
     """config 4 end to end on the device: index lists identical to the reference's"""
     g, raw = noaa_inputs
