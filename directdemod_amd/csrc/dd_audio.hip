@@ -1186,6 +1186,11 @@ __device__ __forceinline__ DDPk dd_pk_empty() {
 // Workgroups are dealt to the XCDs window by window (dispatch is round-robin over the 8 XCDs), so the ~14
 // reads of every prefix-sum element come out of one XCD's L2.
 #define DD_XC_TILE 1024
+// (Tried in round 4 and not kept, same call, 64 windows: the run table in scalar registers with the loop unrolled -- all 64
+// look-ups of a lane in flight, 169 registers, 2 waves per SIMD -- 129 us; the look-ups staged in LDS along the comb of the
+// needle's run-boundary grid (984 / 492 samples: 1.5-2.7 loads from L2 per output instead of 16, but 32 KB of LDS per wave =
+// 5 waves per CU) 107-162 us; this loop, 8 waves per SIMD walking the runs in step so that neighbouring workgroups read
+// neighbouring prefix sums at the same time: 80 us.  profiles/r04_noaa_timeline.txt)
 __global__ void __launch_bounds__(256) k_xcorr_runs_pk(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                        const DDRuns2 R2, const int* __restrict__ group, int tiles, int nwin, DDPk* __restrict__ part) {
     __shared__ DDPk sw[4];
@@ -1528,6 +1533,8 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
         dd_set_error("NCO table initialisation failed (no GPU?)");
         return DD_ERR_NODEVICE;
     }
+    const char* fr_env = getenv("DD_SYNC_FRONT");                     // tools / tests: "kernel" = the front end as a launch of its own
+    const bool front_fused = !(fr_env && !strcmp(fr_env, "kernel"));
     int bmax = 64;
     if (const char* e = getenv("DD_SYNC_BATCH")) bmax = atoi(e) > 0 ? atoi(e) : bmax;
     const int B = n_windows < bmax ? n_windows : bmax;
@@ -1610,9 +1617,15 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     for (int w0 = 0; w0 < n_windows; w0 += B) {
         const int b = n_windows - w0 < B ? n_windows - w0 : B;
         const dim3 gL(grid1(L), b), gL2(grid1(L2), b), gL4(grid1((L + 3) / 4), b);
-        if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
-        else hipLaunchKernelGGL(k_sync_front<false>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
-        dd_filtfilt_launch<float2>(X, L, Y1, X, L, L, fir_ntaps, d_taps1, b, s);            // X <- filtfilt(X): pass 2 reads only Y1
+        if (front_fused) {
+            // X <- filtfilt(oscillator x raw IQ): pass 1 computes the samples where it stages them
+            const DDFrontSrc F = {iq, d_starts + w0, cycles_q64, tbl, iq_kind};
+            dd_filtfilt_front_launch(F, Y1, X, L, L, fir_ntaps, d_taps1, b, s);
+        } else {
+            if (iq_kind == 1) hipLaunchKernelGGL(k_sync_front<true>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+            else hipLaunchKernelGGL(k_sync_front<false>, gL4, dim3(256), 0, s, iq, d_starts + w0, L, cycles_q64, tbl, X);
+            dd_filtfilt_launch<float2>(X, L, Y1, X, L, L, fir_ntaps, d_taps1, b, s);        // X <- filtfilt(X): pass 2 reads only Y1
+        }
         if (hilbert_fft) {
             hipLaunchKernelGGL(k_sync_fm, gL2, dim3(256), 0, s, X, L, W);
             hipfftHandle plan;
@@ -1788,41 +1801,71 @@ __global__ void __launch_bounds__(256) k_scan_final_x(const double* __restrict__
 // output per lane was a chain of ~15 dependent LDS reads per wave: 93 us for 2 x 3.6 M outputs, latency bound).
 #define DD_XC_LDS_MAX 4096
 #define DD_XCN_TILE 1024
+// (round 4: the run table comes out of LDS instead of one scalar load from the kernel arguments per run and the loop is
+// unrolled by four -- the loop used to wait for that load, then for its four reads, run after run; the energy look-ups of
+// the four outputs are issued together.  Same operations in the same order per output.)
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_xcorr_runs_n(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                       const DDRuns2 R2, double* __restrict__ out) {
-    __shared__ double sP[DD_XC_LDS_MAX];
+    __shared__ double sP[STAGED ? DD_XC_LDS_MAX : 1];
+    __shared__ double sval[DD_XCORR_MAX_RUNS];
+    __shared__ int sst[DD_XCORR_MAX_RUNS + 4];
     const DDRuns& R = R2.r[blockIdx.y];
+    const int nr = R.nr;
     const int64_t i0 = (int64_t)blockIdx.x * DD_XCN_TILE;
     const int64_t base = i0 + (m - 1) / 2 - (m - 1);             // window of output i: P[base + (i - i0) + start[r]]
     auto at = [&](const double* S, int64_t x) { return S[x < 0 ? 0 : (x > n ? n : x)]; };
-    const bool staged = DD_XCN_TILE + m + 1 <= DD_XC_LDS_MAX;     // (uniform)
-    if (staged) {
-        for (int k = threadIdx.x; k < DD_XCN_TILE + m + 1; k += 256) sP[k] = at(P, base + k);
-        __syncthreads();
+    if (threadIdx.x < DD_XCORR_MAX_RUNS) {
+        const int r = threadIdx.x;
+        sst[r] = r < nr ? R.start[r + 1] : 0;                     // sst[r] = end of run r
+        sval[r] = r < nr ? R.val[r] : 0.0;
     }
+    if (STAGED)
+        for (int k = threadIdx.x; k < DD_XCN_TILE + m + 1; k += 256) sP[k] = at(P, base + k);
+    // energy window ends of this lane's four outputs (independent of the loop below: in flight across it)
+    double qa[4], qb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t a0 = base + threadIdx.x + 256 * u;
+        qa[u] = at(Q, a0);
+        qb[u] = at(Q, a0 + m);
+    }
+    __syncthreads();
+    auto look = [&](int u, int st) -> double {
+        return STAGED ? sP[threadIdx.x + 256 * u + st] : at(P, base + threadIdx.x + 256 * u + st);
+    };
     double c[4] = {0.0, 0.0, 0.0, 0.0}, lo[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lo[u] = staged ? sP[threadIdx.x + 256 * u] : at(P, base + threadIdx.x + 256 * u);
-    for (int r = 0; r < R.nr; ++r) {
-        const int st = R.start[r + 1];
-        const double v = R.val[r];
+    for (int u = 0; u < 4; ++u) lo[u] = look(u, 0);
+    int r = 0;
+    for (; r + 4 <= nr; r += 4) {
+        int st[4];
+        double v[4], hi[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double hi = staged ? sP[threadIdx.x + 256 * u + st] : at(P, base + threadIdx.x + 256 * u + st);
-            c[u] = fma(v, hi - lo[u], c[u]);
-            lo[u] = hi;
-        }
+        for (int k = 0; k < 4; ++k) { st[k] = sst[r + k]; v[k] = sval[r + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hi[k][u] = look(u, st[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = fma(v[k], hi[k][u] - lo[u], c[u]); lo[u] = hi[k][u]; }
+    }
+    for (; r < nr; ++r) {
+        const int st = sst[r];
+        const double v = sval[r];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double hi = look(u, st); c[u] = fma(v, hi - lo[u], c[u]); lo[u] = hi; }
     }
     const double qn = 1e-13 * Q[n], vv = R2.vv[blockIdx.y];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t i = i0 + threadIdx.x + 256 * u;
-        if (i >= n) break;
-        const int64_t a0 = base + threadIdx.x + 256 * u;
-        double e = at(Q, a0 + m) - at(Q, a0);
+        double e = qb[u] - qa[u];
         double cc = c[u];
         if (!(e > qn)) { cc = 0.0; e = 0.0; }
-        out[(int64_t)blockIdx.y * n + i] = cc / sqrt(e * vv);
+        if (i < n) out[(int64_t)blockIdx.y * n + i] = cc / sqrt(e * vv);
     }
 }
 
@@ -2132,7 +2175,10 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     hipLaunchKernelGGL(k_scan_part, dim3(tiles, 1), dim3(256), 0, s, env, n, tiles, part);
     hipLaunchKernelGGL(k_scan_mid, dim3(1), dim3(256), 0, s, part, tiles);
     hipLaunchKernelGGL(k_scan_final_x, dim3(tiles), dim3(256), 0, s, env, n, part, P, Q);
-    hipLaunchKernelGGL(k_xcorr_runs_n, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
+    if (DD_XCN_TILE + m + 1 <= DD_XC_LDS_MAX)
+        hipLaunchKernelGGL(k_xcorr_runs_n<true>, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
+    else
+        hipLaunchKernelGGL(k_xcorr_runs_n<false>, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
     // ---- selection, threshold, candidates of both needles: eleven launches, nothing comes back to the host in between
     DD_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(DDCrudeSel) * n_needles, s));
     for (int pass = 0; pass < 8; ++pass) hipLaunchKernelGGL(k_cs_hist, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, pass, sel);

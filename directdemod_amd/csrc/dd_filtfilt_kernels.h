@@ -84,13 +84,36 @@ __host__ __device__ __forceinline__ int dd_ff_phys(int j) { return j + (j >> 3);
 static inline size_t dd_ff_lds_bytes(int K) { return (size_t)(dd_ff_phys(DD_FF_TILE + K - 1) + 1) * 8; }
 static inline bool dd_ff_tiled_ok(int K, size_t elem_bytes) { return elem_bytes == 8 && dd_ff_lds_bytes(K) <= DD_FF_LDS_MAX; }
 
+// MODE 3's source (float2 only): the samples of a search window are computed where pass 1 stages them -- raw IQ (uint8 pairs minus
+// 127.5, source.py:117-118, or complex64) at starts[window] + k times the oscillator whose sample index restarts at 0 in every
+// window (comm.py:77 on the window's own commSignal) -- instead of being written out by a kernel of their own and read back
+struct DDFrontSrc {
+    const void* iq;
+    const int64_t* starts;        // device, one per window of the batch
+    uint64_t cyc;
+    const float2* tbl;
+    int u8;
+};
+__device__ __forceinline__ float2 dd_front_at(const DDFrontSrc& F, int64_t g0, int64_t k) {
+    float2 v;
+    if (F.u8) {
+        const uchar2 u = reinterpret_cast<const uchar2*>(F.iq)[g0 + k];
+        v = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+    } else {
+        v = reinterpret_cast<const float2*>(F.iq)[g0 + k];
+    }
+    return dd_cmul(v, dd_phasor((uint64_t)k * F.cyc, F.tbl));
+}
+
 // blockIdx.y = window of the batch; src/dst advance by their strides (elements) per window.
 // MODE 0: zero-phase pass 1, MODE 1: zero-phase pass 2, MODE 2: plain causal FIR y[i] = sum_k b[k] x[i-k] whose
-// samples before the array come from `hist` (the K-1 inputs that preceded it: filters.py:64-70 with the state kept).
+// samples before the array come from `hist` (the K-1 inputs that preceded it: filters.py:64-70 with the state kept),
+// MODE 3: pass 1 over samples computed from `front` (src unused).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int edge,
                                                                  const double* __restrict__ taps, int K,
-                                                                 int64_t src_stride, int64_t dst_stride, const T* __restrict__ hist = nullptr) {
+                                                                 int64_t src_stride, int64_t dst_stride, const T* __restrict__ hist = nullptr,
+                                                                 const DDFrontSrc front = DDFrontSrc()) {
     constexpr bool BWD = MODE == 1;
     typedef typename dd_acc<T>::tap_t tap_t;
     static_assert(sizeof(T) == 8, "tiled filtfilt: 8-byte elements");
@@ -98,7 +121,7 @@ __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __rest
     T* s = reinterpret_cast<T*>(dd_ff_smem);
     constexpr int R = DD_FF_R, U = 8;
     const int64_t N = n + 2 * (int64_t)edge;
-    const int64_t nout = MODE == 0 ? N : n;
+    const int64_t nout = (MODE == 0 || MODE == 3) ? N : n;
     const T* x = src + (int64_t)blockIdx.y * src_stride;
     T* y = dst + (int64_t)blockIdx.y * dst_stride;
     const int64_t o0 = (int64_t)blockIdx.x * DD_FF_TILE;
@@ -108,6 +131,14 @@ __global__ void __launch_bounds__(DD_FF_THREADS) k_filtfilt_tile(const T* __rest
         if (MODE == 2) {                  // s[j] = x[o0 - (K-1) + j], the carried history before the array
             const int64_t i = o0 - (K - 1) + j;
             v = i >= 0 ? (i < n ? x[i] : dd_acc<T>::zero()) : hist[(K - 1) + i];
+        } else if constexpr (MODE == 3) { // the same extension over computed samples
+            int64_t i = o0 - (K - 1) + j;
+            if (i < 0) i = 0;
+            const int64_t g0 = front.starts[blockIdx.y];
+            if (i >= N) v = dd_acc<T>::zero();
+            else if (i < edge) v = dd_acc<T>::oddext(dd_front_at(front, g0, 0), dd_front_at(front, g0, edge - i));
+            else if (i < edge + n) v = dd_front_at(front, g0, i - edge);
+            else v = dd_acc<T>::oddext(dd_front_at(front, g0, n - 1), dd_front_at(front, g0, n - 2 - (i - edge - n)));
         } else if (!BWD) {                // s[j] = ext[max(o0 - (K-1) + j, 0)]
             int64_t i = o0 - (K - 1) + j;
             if (i < 0) i = 0;
@@ -176,6 +207,18 @@ static inline void dd_filtfilt_launch(const T* in, int64_t in_stride, T* y1, T* 
                        lds, s, in, y1, n, edge, taps_dev, K, in_stride, N, (const T*)nullptr);
     hipLaunchKernelGGL((k_filtfilt_tile<T, 1>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
                        lds, s, (const T*)y1, out, n, edge, taps_dev, K, N, out_stride, (const T*)nullptr);
+}
+
+// both passes over windows whose samples pass 1 computes from raw IQ (MODE 3)
+static inline void dd_filtfilt_front_launch(const DDFrontSrc& F, float2* y1, float2* out, int64_t out_stride, int64_t n, int K,
+                                            const double* taps_dev, int batch, hipStream_t s) {
+    const int edge = 3 * K;
+    const int64_t N = n + 2 * (int64_t)edge;
+    const size_t lds = dd_ff_lds_bytes(K);
+    hipLaunchKernelGGL((k_filtfilt_tile<float2, 3>), dim3((unsigned)((N + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
+                       lds, s, (const float2*)nullptr, y1, n, edge, taps_dev, K, (int64_t)0, N, (const float2*)nullptr, F);
+    hipLaunchKernelGGL((k_filtfilt_tile<float2, 1>), dim3((unsigned)((n + DD_FF_TILE - 1) / DD_FF_TILE), batch), dim3(DD_FF_THREADS),
+                       lds, s, (const float2*)y1, out, n, edge, taps_dev, K, N, out_stride, (const float2*)nullptr, DDFrontSrc());
 }
 
 // ---- zero-phase FIR whose taps are a short cosine series (real float64 data) ----------------------------------------------

@@ -856,6 +856,48 @@ def test_sync_envelope_three_launch_transform(dd, L, nwin):
     assert np.max(np.abs(envs[0] - ref)) <= 2e-6 * scale
 
 
+def test_accurate_sync_both_words_in_one_call(dd):
+    """dd_noaa_sync_windows_multi (both window lists of getAccurateSync in one call, a needle index per window) against one
+    call per sync word: identical picks; heights to rounding (two windows share one complex transform in the envelope stage, so a
+    window's last bits depend on its partner).  Window counts that leave the last pair half empty."""
+    raw = O.synth_apt_iq(1.4, 2048000, seed=11)
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    ns.getCrudeSync()                                                   # (puts the recording into HBM)
+    width = int(3 * dd.constants.NOAA_T * len(dd.constants.NOAA_SYNCA) * 2048000)
+    sa = [int(v) for v in np.linspace(0, src.length - 2 * width, 7)]
+    sb = [int(v) for v in np.linspace(1234, src.length - 2 * width - 77, 4)]
+    both = ns.accurate_windows([sa, sb], 2 * width, [dd.constants.NOAA_SYNCA, dd.constants.NOAA_SYNCB])
+    each = [ns.accurate_windows(sa, 2 * width, dd.constants.NOAA_SYNCA), ns.accurate_windows(sb, 2 * width, dd.constants.NOAA_SYNCB)]
+    for (i1, h1, t1), (i2, h2, t2) in zip(both, each):
+        assert len(i1) == len(i2) and np.array_equal(i1, i2)
+        assert np.max(np.abs(np.array(h1) - np.array(h2))) < 1e-12
+        assert [v is None for v in t1] == [v is None for v in t2]
+    # an empty list beside a full one
+    only_b = ns.accurate_windows([[], sb], 2 * width, [dd.constants.NOAA_SYNCA, dd.constants.NOAA_SYNCB])
+    assert len(only_b[0][0]) == 0 and np.array_equal(only_b[1][0], each[1][0])
+
+
+def test_accurate_sync_front_end_fused_into_the_first_filter_pass(dd, monkeypatch):
+    """The windows' front end (uint8 pairs -> complex64, oscillator restarting at 0 per window) computed where the zero-phase
+    filter's first pass stages its samples (k_filtfilt_tile mode 3, the default) against the front end as a kernel of its own
+    writing the [windows][samples] array first: the same float32 operations on the same values, so every result is equal
+    bit for bit.  Windows at both ends of the recording (the odd extension evaluates two samples per staged element there)."""
+    raw = O.synth_apt_iq(1.3, 2048000, seed=12)
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    ns.getCrudeSync()
+    width = int(3 * dd.constants.NOAA_T * len(dd.constants.NOAA_SYNCA) * 2048000)
+    st = [0, 1, 54321, src.length - 2 * width - 1, src.length - 2 * width]
+    res = {}
+    for fr in ("kernel", None):
+        monkeypatch.delenv("DD_SYNC_FRONT", raising=False)
+        if fr:
+            monkeypatch.setenv("DD_SYNC_FRONT", fr)
+        res[fr] = ns.accurate_windows(st, 2 * width, dd.constants.NOAA_SYNCA)
+    assert np.array_equal(res["kernel"][0], res[None][0]) and res["kernel"][1] == res[None][1] and res["kernel"][2] == res[None][2]
+
+
 def test_accurate_sync_windows_oracle_chain(dd):
     """one window against the oracle's restatement of decode_noaa.py:852-853 (float64 SciPy chain)"""
     raw = O.synth_apt_iq(1.2, 2048000, seed=3)
