@@ -10,3 +10,4 @@ bash tools/profile_bench.sh > gpurun_out/r04_profile_bench.txt 2>&1; head -8 gpu
 bash tools/pmc_traffic.sh
 python3 tools/bench_noaa.py 60 --stages > gpurun_out/r04_noaa_stages.txt 2>&1; grep -v amdgpu.ids gpurun_out/r04_noaa_stages.txt | tail -10
 bash tools/profile_noaa.sh 60 > gpurun_out/r04_noaa_profile.txt 2>&1; head -12 gpurun_out/r04_noaa_profile.txt | cut -c1-200
+bash tools/noaa_timeline.sh 60 > gpurun_out/r04_noaa_timeline.txt 2>&1; tail -3 gpurun_out/r04_noaa_timeline.txt
