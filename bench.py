@@ -71,7 +71,7 @@ def make_input(torch, n, start, device, seed):
 
 # ----------------------------------------------------------------------------- CPU baselines
 def cpu_baseline_scipy(n):
-    """The reference's own CPU arithmetic for this chain, call for call (kind 'scipy'):
+    """The reference's own CPU arithmetic for this chain restated call for call (kind 'port', calls 'scipy'):
     comm.py:77 (np.exp NCO, in place on complex64), filters.py:45,69 (lfilter_zi + lfilter
     with carried zi), demod_fm.py:40-49 (np.angle of the conj-lagged product).  One thread."""
     import scipy.signal as ss
@@ -90,14 +90,14 @@ def cpu_baseline_scipy(n):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert len(ang) == n - 1
-    return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "scipy",
+    return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "port", "calls": "scipy",
             "sample": "2^%d samples of the same workload: np.exp NCO, scipy.signal.lfilter(b,[1],x,zi=lfilter_zi), "
                       "np.angle (comm.py:77, filters.py:45,69, demod_fm.py:40-49), best of 2, %.2f s"
                       % (int(np.log2(n)), best)}
 
 
 def cpu_baseline_port(n):
-    """The oracle's restatement of the same path (kind 'port': np.convolve-based FIR), one thread."""
+    """The oracle's restatement of the same path (oracle/dd_oracle.py, np.convolve-based FIR), one thread."""
     from oracle import dd_oracle as O
     x = O.grid_c64(O.synth_iq_fm(n, FS, 1235))
     taps = O.win_hamming(NTAPS)
@@ -109,7 +109,7 @@ def cpu_baseline_port(n):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert len(a) == n - 1
-    return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
+    return {"value": round(n / best / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "port", "calls": "oracle/dd_oracle.py (numpy)",
             "sample": "2^%d samples (numpy float64, best of 2, %.2f s)" % (int(np.log2(n)), best)}
 
 
@@ -139,7 +139,7 @@ def cpu_baseline(n):
     res = cpu_baseline_scipy(n)
     res["host_cpus"] = os.cpu_count()
     res["usable_cpus"] = len(os.sched_getaffinity(0))
-    res["port"] = cpu_baseline_port(n)
+    res["oracle"] = cpu_baseline_port(n)
     res["all_cores"] = cpu_baseline_all_cores()
     return res
 

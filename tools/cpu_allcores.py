@@ -111,7 +111,7 @@ def main():
         rate, dt = run(w, log2w, cpus)
         sweep.append({"workers": w, "MSamples_per_s": round(rate, 3), "seconds": round(dt, 2)})
     best = max(sweep, key=lambda e: e["MSamples_per_s"])
-    print(json.dumps({"value": best["MSamples_per_s"], "unit": "MSamples/s", "cores": best["workers"], "kind": "scipy",
+    print(json.dumps({"value": best["MSamples_per_s"], "unit": "MSamples/s", "cores": best["workers"], "kind": "port", "calls": "scipy",
                       "usable_cpus": usable, "physical_cores": physical, "host_cpus": os.cpu_count(), "sweep": sweep,
                       "sample": "best of a sweep over the worker count: %d x 2^%d samples in contiguous shards, one pinned process each, "
                                 "started together (%.2f s)" % (best["workers"], log2w, best["seconds"])}))
