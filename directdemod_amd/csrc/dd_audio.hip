@@ -58,6 +58,64 @@ static int get_plan(hipfftHandle* out, hipfftType type, int64_t n, int batch, hi
 
 static inline unsigned grid1(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// ---------------------------------------------------------------- own float64 cyclic convolution of length 2^17 / 2^18 (dd_hconv_kernels.h)
+#include "dd_hconv_kernels.h"
+static std::mutex g_hc_mu;
+static double2* g_hc_tab[64] = {nullptr};                        // device -> W_512^j (512) | W_{2^18}^j (512) | W_{2^17}^j (256)
+static bool hc_length_ok(int64_t M) { return M == ((int64_t)1 << 17) || M == ((int64_t)1 << 18); }
+// lg: 9 (M = 2^18) or 8 (M = 2^17)
+static int hc_tables(int lg, const double2** TA, const double2** TB) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    std::lock_guard<std::mutex> lk(g_hc_mu);
+    if (!g_hc_tab[dev]) {
+        std::vector<double2> h(2 * DD_HC_N + 256);
+        const long double tp = 6.283185307179586476925286766559L;
+        for (int j = 0; j < DD_HC_N; ++j) {
+            h[j] = make_double2((double)cosl(tp * j / DD_HC_N), (double)-sinl(tp * j / DD_HC_N));
+            h[DD_HC_N + j] = make_double2((double)cosl(tp * j / 262144.0L), (double)-sinl(tp * j / 262144.0L));
+        }
+        for (int j = 0; j < 256; ++j) h[2 * DD_HC_N + j] = make_double2((double)cosl(tp * j / 131072.0L), (double)-sinl(tp * j / 131072.0L));
+        double2* d = nullptr;
+        DD_HIP_CHECK(hipMalloc((void**)&d, sizeof(double2) * h.size()));
+        hipError_t e = hipMemcpy(d, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); dd_set_error("twiddle table upload: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
+        g_hc_tab[dev] = d;
+    }
+    *TA = g_hc_tab[dev];
+    *TB = g_hc_tab[dev] + (lg == 9 ? DD_HC_N : 2 * DD_HC_N);
+    return DD_OK;
+}
+// the column passes take 64 KB of dynamic LDS: once per device and instantiation
+template <int LG, typename SRC, typename DST>
+static int hc_ready() {
+    static DDOncePerDevice once;
+    if (once.need()) {
+        DD_HIP_CHECK((hc_set_lds_attr<LG, SRC, DST>()));
+        once.mark();
+    }
+    return DD_OK;
+}
+// envelope of `nwin` windows (two per image) through the three launches; HHp: the kernel spectrum in row-pass order
+static int hc_envelope(int64_t M, const float2* X, int64_t L, int nwin, const double2* HHp, double2* W, double* ENV, hipStream_t s) {
+    const int lg = M == ((int64_t)1 << 18) ? 9 : 8;
+    const double2 *TA = nullptr, *TB = nullptr;
+    int rc = hc_tables(lg, &TA, &TB);
+    if (rc != DD_OK) return rc;
+    const HcEnvIO io = {X, L, L - 1, nwin, ENV};
+    const HcOneSpec sp = {HHp};
+    const int pairs = (nwin + 1) / 2;
+    if (lg == 9) {
+        rc = hc_ready<9, HcEnvIO, HcEnvIO>();
+        if (rc == DD_OK) hc_convolve<9>(io, sp, io, W, pairs, TA, TB, s);
+    } else {
+        rc = hc_ready<8, HcEnvIO, HcEnvIO>();
+        if (rc == DD_OK) hc_convolve<8>(io, sp, io, W, pairs, TA, TB, s);
+    }
+    return rc;
+}
+
 struct DDCztKey;
 static void czt_forget_stream(int dev, hipStream_t s);
 // the stream is about to be destroyed (dd_stream_destroy, after it has been synchronised): its plans (with their work areas) and
@@ -290,7 +348,7 @@ struct DDCztKey {
         return L < o.L;
     }
 };
-struct DDCztTab { double2* w; double2* bspec; };
+struct DDCztTab { double2* w; double2* bspec; double2* bspec_p; };     // bspec_p: bspec / L in the row-pass order of dd_hconv_kernels.h (L = 2^17, 2^18), else null
 static std::mutex g_czt_mu;
 static std::map<DDCztKey, DDCztTab> g_czt;
 static void czt_forget_stream(int dev, hipStream_t s) {
@@ -299,6 +357,7 @@ static void czt_forget_stream(int dev, hipStream_t s) {
         if (it->first.dev == dev && it->first.s == s) {
             (void)hipFree(it->second.w);
             (void)hipFree(it->second.bspec);
+            if (it->second.bspec_p) (void)hipFree(it->second.bspec_p);
             it = g_czt.erase(it);
         } else {
             ++it;
@@ -353,7 +412,7 @@ static int czt_tables(int64_t n, int64_t K, int64_t L, hipStream_t s, DDCztTab* 
         // a chunk loop has one or two lengths.  Tables are never freed (another thread may be using them): past 64 of them the
         // caller takes the library's own transform instead
         if (g_czt.size() >= 64) return 1;
-        DDCztTab t{nullptr, nullptr};
+        DDCztTab t{nullptr, nullptr, nullptr};
         DD_HIP_CHECK(hipMalloc((void**)&t.w, sizeof(double2) * (size_t)n));
         hipError_t e = hipMalloc((void**)&t.bspec, sizeof(double2) * (size_t)L);
         if (e != hipSuccess) { (void)hipFree(t.w); DD_HIP_CHECK(e); }
@@ -366,6 +425,12 @@ static int czt_tables(int64_t n, int64_t K, int64_t L, hipStream_t s, DDCztTab* 
             dd_set_error("hipfft exec failed (chirp spectrum)");
             return DD_ERR_HIP;
         }
+        if (hc_length_ok(L)) {
+            e = hipMalloc((void**)&t.bspec_p, sizeof(double2) * (size_t)L);
+            if (e != hipSuccess) { (void)hipFree(t.w); (void)hipFree(t.bspec); DD_HIP_CHECK(e); }
+            if (L == ((int64_t)1 << 18)) hipLaunchKernelGGL(k_hc_perm<9>, dim3((unsigned)(L / 256)), dim3(256), 0, s, t.bspec, t.bspec_p, 0, 1.0 / (double)L);
+            else hipLaunchKernelGGL(k_hc_perm<8>, dim3((unsigned)(L / 256)), dim3(256), 0, s, t.bspec, t.bspec_p, 0, 1.0 / (double)L);
+        }
         it = g_czt.emplace(key, t).first;
     }
     *out = it->second;
@@ -375,11 +440,46 @@ static int czt_tables(int64_t n, int64_t K, int64_t L, hipStream_t s, DDCztTab* 
 struct DDCztJob {
     int64_t in_off, out_off, n;
     const double2* w;
-    const double2* bspec;
+    const double2* bspec;                                  // (bspec_p when the convolution runs through dd_hconv_kernels.h)
     double scale;                                          // 1 / n
 };
 #define DD_CZT_MAXB 16
 struct DDCztJobs { DDCztJob j[DD_CZT_MAXB]; };             // passed by value: no upload per call
+// source, spectrum and sink of the chirp convolution as three launches of dd_hconv_kernels.h: a[m] = x[m] w[m] (m < n, zero
+// beyond), times the chirp's spectrum (1 / L folded in), and of the result the K lowest elements times w[k] -- k_czt_pre, k_czt_mul
+// and k_czt_bins inside the column and row passes, the library's two length-L transforms replaced
+struct HcCztIO {
+    const void* in;
+    int in_is_f32;
+    DDCztJobs jobs;
+    double2* Y;                  // sink: [jobs][K]
+    int64_t K, num;
+    __device__ int rows(int, int) const { return 0; }
+};
+struct HcCztSrc : HcCztIO {
+    __device__ int rows(int job, int N2) const { return (int)((jobs.j[job].n + N2 - 1) / N2); }
+    __device__ double2 at(int job, int64_t m) const {
+        const DDCztJob& j = jobs.j[job];
+        if (m >= j.n) return make_double2(0.0, 0.0);
+        const double x = in_is_f32 ? (double)reinterpret_cast<const float*>(in)[j.in_off + m] : reinterpret_cast<const double*>(in)[j.in_off + m];
+        const double2 w = j.w[m];
+        return make_double2(x * w.x, x * w.y);
+    }
+};
+struct HcCztDst : HcCztIO {
+    __device__ int rows(int, int N2) const { return (int)((K + N2 - 1) / N2); }
+    __device__ void put(int job, int64_t k, double2 c) const {
+        if (k >= K) return;
+        const double2 w = jobs.j[job].w[k];
+        double2 v = make_double2(c.x * w.x - c.y * w.y, c.x * w.y + c.y * w.x);
+        if ((num & 1) == 0 && k == num / 2) { v.x *= 2.0; v.y *= 2.0; }
+        Y[(int64_t)job * K + k] = v;
+    }
+};
+struct HcCztSpec {
+    DDCztJobs jobs;
+    __device__ const double2* ptr(int job) const { return jobs.j[job].bspec; }
+};
 template <typename T>
 __global__ void __launch_bounds__(256) k_czt_pre(const T* __restrict__ in, const DDCztJobs jobs, int64_t L, double2* __restrict__ A) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -430,9 +530,13 @@ static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_o
     // 3.2^15 0.103, 131 072 0.112, 114 688 = 7.2^14 0.116, 86 400 = the smallest 7-smooth multiple of 16 0.140, 90 112 = 11.2^13
     // 0.147: the library's power-of-two passes beat less data).  DD_CZT_LEN=<n> (tools) forces a length
     static const char* lenv = getenv("DD_CZT_LEN");
+    const char* oenv = getenv("DD_CZT_OWN");                // tools / tests: 0 = the library's transforms at any length
     int64_t L = 1;
     while (L < nmax + K - 1) L <<= 1;
-    if (L >= 4 && 3 * (L / 4) >= nmax + K - 1) L = 3 * (L / 4);
+    // 2^17 / 2^18: the convolution as three launches of our own float64 transform (dd_hconv_kernels.h) instead of pre-multiply +
+    // library transform + multiply + library transform + post-multiply (config 3: ten launches -> three)
+    const bool own = hc_length_ok(L) && !(oenv && atoi(oenv) == 0) && !lenv;
+    if (!own && L >= 4 && 3 * (L / 4) >= nmax + K - 1) L = 3 * (L / 4);
     if (lenv && atoll(lenv) >= nmax + K - 1) L = atoll(lenv);
     for (int j : idx_all) {                                  // every table first: 1 = not taken, nothing enqueued yet
         DDCztTab t;
@@ -448,10 +552,10 @@ static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_o
             DDCztTab t;
             int rc = czt_tables(n_host[j], K, L, s, &t);
             if (rc != DD_OK) return rc;
-            jobs.j[b] = DDCztJob{in_off[j], out_off[j], n_host[j], t.w, t.bspec, 1.0 / (double)n_host[j]};
+            jobs.j[b] = DDCztJob{in_off[j], out_off[j], n_host[j], t.w, own ? t.bspec_p : t.bspec, 1.0 / (double)n_host[j]};
         }
-        hipfftHandle pz, pb;
-        int rc = get_plan(&pz, HIPFFT_Z2Z, L, B, s);
+        hipfftHandle pz = nullptr, pb;
+        int rc = own ? DD_OK : get_plan(&pz, HIPFFT_Z2Z, L, B, s);
         if (rc != DD_OK) return rc;
         rc = get_plan(&pb, HIPFFT_Z2D, num, B, s);
         if (rc != DD_OK) return rc;
@@ -464,12 +568,27 @@ static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_o
         double2* A = reinterpret_cast<double2*>(scr.ptr);
         double2* Y = reinterpret_cast<double2*>(scr.ptr + o_y);
         double* res = reinterpret_cast<double*>(scr.ptr + o_r);
-        if (in_is_f32) hipLaunchKernelGGL(k_czt_pre<float>, dim3(grid1(L), B), dim3(256), 0, s, (const float*)in, jobs, L, A);
-        else hipLaunchKernelGGL(k_czt_pre<double>, dim3(grid1(L), B), dim3(256), 0, s, (const double*)in, jobs, L, A);
-        const hipfftResult r1 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_FORWARD);
-        hipLaunchKernelGGL(k_czt_mul, dim3(grid1(L), B), dim3(256), 0, s, A, jobs, L);
-        const hipfftResult r2 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_BACKWARD);
-        hipLaunchKernelGGL(k_czt_bins, dim3(grid1(K), B), dim3(256), 0, s, A, jobs, L, Y, K, num);
+        hipfftResult r1 = HIPFFT_SUCCESS, r2 = HIPFFT_SUCCESS;
+        if (own) {
+            HcCztSrc src; HcCztDst dst; HcCztSpec sp;
+            src.in = in; src.in_is_f32 = in_is_f32; src.jobs = jobs; src.Y = Y; src.K = K; src.num = num;
+            static_cast<HcCztIO&>(dst) = static_cast<const HcCztIO&>(src);
+            sp.jobs = jobs;
+            const double2 *TA = nullptr, *TB = nullptr;
+            const int lg = L == ((int64_t)1 << 18) ? 9 : 8;
+            rc = hc_tables(lg, &TA, &TB);
+            if (rc == DD_OK) rc = lg == 9 ? hc_ready<9, HcCztSrc, HcCztDst>() : hc_ready<8, HcCztSrc, HcCztDst>();
+            if (rc != DD_OK) return rc;
+            if (lg == 9) hc_convolve<9>(src, sp, dst, A, B, TA, TB, s);
+            else hc_convolve<8>(src, sp, dst, A, B, TA, TB, s);
+        } else {
+            if (in_is_f32) hipLaunchKernelGGL(k_czt_pre<float>, dim3(grid1(L), B), dim3(256), 0, s, (const float*)in, jobs, L, A);
+            else hipLaunchKernelGGL(k_czt_pre<double>, dim3(grid1(L), B), dim3(256), 0, s, (const double*)in, jobs, L, A);
+            r1 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_FORWARD);
+            hipLaunchKernelGGL(k_czt_mul, dim3(grid1(L), B), dim3(256), 0, s, A, jobs, L);
+            r2 = hipfftExecZ2Z(pz, (hipfftDoubleComplex*)A, (hipfftDoubleComplex*)A, HIPFFT_BACKWARD);
+            hipLaunchKernelGGL(k_czt_bins, dim3(grid1(K), B), dim3(256), 0, s, A, jobs, L, Y, K, num);
+        }
         const hipfftResult r3 = hipfftExecZ2D(pb, (hipfftDoubleComplex*)Y, res);
         hipLaunchKernelGGL(k_czt_scatter, dim3(grid1(num), B), dim3(256), 0, s, res, jobs, num, out);
         if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || r3 != HIPFFT_SUCCESS) {
@@ -1310,35 +1429,8 @@ __global__ void __launch_bounds__(256) k_env_hypot(const double* __restrict__ XR
     env[(int64_t)blockIdx.y * n + i] = hypot(XR[(int64_t)blockIdx.y * M + i], YR[(int64_t)blockIdx.y * M + i]);
 }
 
-#include "dd_hconv_kernels.h"
 static std::map<std::pair<int, int64_t>, double2*> g_hilb;      // (device, N) -> spectrum of the padded kernel / M
-static double2* g_hc_tab[64] = {nullptr};                        // device -> W_512^j | W_M^j, 512 entries each (callers hold g_sync_mu)
-
-static int hc_tables(const double2** TA, const double2** TB) {
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    DD_REQUIRE(dev >= 0 && dev < 64, "device index");
-    if (!g_hc_tab[dev]) {
-        std::vector<double2> h(2 * DD_HC_N);
-        const long double tp = 6.283185307179586476925286766559L;
-        for (int j = 0; j < DD_HC_N; ++j) {
-            h[j] = make_double2((double)cosl(tp * j / DD_HC_N), (double)-sinl(tp * j / DD_HC_N));
-            h[DD_HC_N + j] = make_double2((double)cosl(tp * j / DD_HC_M), (double)-sinl(tp * j / DD_HC_M));
-        }
-        double2* d = nullptr;
-        DD_HIP_CHECK(hipMalloc((void**)&d, sizeof(double2) * h.size()));
-        hipError_t e = hipMemcpy(d, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d); dd_set_error("twiddle table upload: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_hc_cols_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_hc_cols_inv, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS));
-        g_hc_tab[dev] = d;
-    }
-    *TA = g_hc_tab[dev];
-    *TB = g_hc_tab[dev] + DD_HC_N;
-    return DD_OK;
-}
 static std::vector<std::pair<int, int64_t>> g_hilb_order;
-
 // sin(pi num / den) for integers num >= 0, den > 0: the argument is reduced to [0, pi/2] exactly in integers first
 static double dd_sinpi_frac(int64_t num, int64_t den) {
     int64_t r = num % (2 * den);
@@ -1367,15 +1459,16 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
     double2* HH = nullptr;
     double* buf = nullptr;
     DD_HIP_CHECK(hipMalloc((void**)&buf, sizeof(double) * M));
-    // (M = 2^18: the same spectrum once more behind the bins, in the order k_hc_rows reads it -- one allocation, one eviction)
-    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * (nb + (M == DD_HC_M ? M : 0))));
+    // (M = 2^17 / 2^18: the same spectrum once more behind the bins, in the order the row pass reads it -- one allocation, one eviction)
+    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * (nb + (hc_length_ok(M) ? M : 0))));
     hipfftHandle pm;
     int rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
     if (rc != DD_OK) { (void)hipFree(buf); (void)hipFree(HH); return rc; }
     hipError_t e0 = hipMemcpyAsync(buf, host.data(), sizeof(double) * M, hipMemcpyHostToDevice, s);
     hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
     hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
-    if (M == DD_HC_M) hipLaunchKernelGGL(k_hc_perm, dim3(DD_HC_M / 256), dim3(256), 0, s, HH, HH + nb);
+    if (M == ((int64_t)1 << 18)) hipLaunchKernelGGL(k_hc_perm<9>, dim3((unsigned)(M / 256)), dim3(256), 0, s, HH, HH + nb, 1, 1.0);
+    if (M == ((int64_t)1 << 17)) hipLaunchKernelGGL(k_hc_perm<8>, dim3((unsigned)(M / 256)), dim3(256), 0, s, HH, HH + nb, 1, 1.0);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(buf);
     if (e0 != hipSuccess || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
@@ -1416,7 +1509,7 @@ extern "C" int dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, in
     const int64_t L2 = L - 1;
     int64_t M = 1;
     while (M < 2 * L2 + 2) M <<= 1;
-    DD_REQUIRE(route == 1 || M == DD_HC_M, "route 0 needs 65536 < L <= 131072");
+    DD_REQUIRE(route == 1 || hc_length_ok(M), "route 0 needs 32768 < L <= 131072");
     const int64_t nb = M / 2 + 1;
     hipStream_t s = dd_stream(stream);
     std::lock_guard<std::mutex> lk(g_sync_mu);
@@ -1429,14 +1522,7 @@ extern "C" int dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, in
     const size_t bW = sizeof(double2) * (size_t)pairs * M, bSP = sizeof(double2) * (size_t)nwin * nb, bYR = sizeof(double) * (size_t)nwin * M;
     DD_HIP_CHECK(hipMalloc((void**)&buf, bW + (route ? bSP + bYR : 0)));
     if (route == 0) {
-        const double2 *TA = nullptr, *TB = nullptr;
-        rc = hc_tables(&TA, &TB);
-        if (rc == DD_OK) {
-            double2* W = (double2*)buf;
-            hipLaunchKernelGGL(k_hc_cols_fwd, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, X, L, L2, nwin, W, TA);
-            hipLaunchKernelGGL(k_hc_rows, dim3(DD_HC_N / 4, pairs), dim3(256), 0, s, W, HH + nb, TA, TB);
-            hipLaunchKernelGGL(k_hc_cols_inv, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, W, X, L, L2, nwin, env_dev, TA);
-        }
+        rc = hc_envelope(M, X, L, nwin, HH + nb, (double2*)buf, env_dev, s);
     } else {
         double* XR = (double*)buf;
         double2* SP = (double2*)(buf + bW);
@@ -1555,7 +1641,7 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     const int64_t nb = M / 2 + 1;
     const char* hm = getenv("DD_SYNC_HILBERT");
     const bool hilbert_fft = hm && !strcmp(hm, "fft");                    // A/B switches: the library's length-N transforms ("fft"),
-    const bool hilbert_own = !hilbert_fft && M == DD_HC_M && !(hm && !strcmp(hm, "lib"));   // its padded real transforms ("lib"); dd_hconv_kernels.h
+    const bool hilbert_own = !hilbert_fft && hc_length_ok(M) && !(hm && !strcmp(hm, "lib"));   // its padded real transforms ("lib"); dd_hconv_kernels.h
     const size_t o_SP = o_W + al(sizeof(double) * (B + (B & 1)) * M);     // (two windows share one complex [M] image in dd_hconv_kernels.h)                 // W/XR: f64 [B][M] (or c128 [B][L2]); later P, Q: f64 [B][L2+1] each
     const size_t o_YR = o_SP + al(sizeof(double2) * B * nb);              // SP: c128 [B][M/2+1]
     const size_t o_ENV = o_YR + al(sizeof(double) * B * M);               // YR: f64 [B][M]
@@ -1582,11 +1668,6 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     const double2* HH = nullptr;
     if (!hilbert_fft) {
         rc = hilbert_kernel_spectrum(L2, M, &HH, s);
-        if (rc != DD_OK) return rc;
-    }
-    const double2 *TA = nullptr, *TB = nullptr;
-    if (hilbert_own) {
-        rc = hc_tables(&TA, &TB);
         if (rc != DD_OK) return rc;
     }
     double* ENV = (double*)(base + o_ENV);
@@ -1636,10 +1717,8 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
             DD_FFT_CHECK(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)W, (hipfftDoubleComplex*)W, HIPFFT_BACKWARD));
             hipLaunchKernelGGL(k_cplx_abs_b, gL2, dim3(256), 0, s, W, ENV, L2, 1.0 / (double)L2);
         } else if (hilbert_own) {
-            const int pairs = (b + 1) / 2;
-            hipLaunchKernelGGL(k_hc_cols_fwd, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, X, L, L2, b, W, TA);
-            hipLaunchKernelGGL(k_hc_rows, dim3(DD_HC_N / 4, pairs), dim3(256), 0, s, W, HH + nb, TA, TB);
-            hipLaunchKernelGGL(k_hc_cols_inv, dim3(DD_HC_N / DD_HC_COLS, pairs), dim3(512), DD_HC_LDS_COLS, s, W, X, L, L2, b, ENV, TA);
+            rc = hc_envelope(M, X, L, b, HH + nb, W, ENV, s);
+            if (rc != DD_OK) return rc;
         } else {
             hipfftHandle pf, pb;
             rc = get_plan(&pf, HIPFFT_D2Z, M, b, s);

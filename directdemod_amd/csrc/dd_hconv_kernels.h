@@ -1,4 +1,5 @@
-// The accurate-sync envelope stage as three launches (included by dd_audio.hip only).
+// A float64 cyclic convolution of length 2^17 / 2^18 with a fixed kernel spectrum as three launches (included by dd_audio.hip only):
+// first user the accurate-sync envelope stage (below), second the chirp-z resampler's convolution (dd_audio.hip, HcCztSrc / HcCztDst).
 //
 // decode_noaa.py:852 takes abs(scipy.signal.hilbert(x)) of the FM audio of every search window (N = 118 151 samples at
 // 2.048 MS/s).  dd_audio.hip writes that as x + j (x (*) hh) with the length-N circular convolution embedded in a cyclic
@@ -26,7 +27,7 @@
 #include "dd_common.h"
 #include "dd_chain_kernels.h"
 
-#define DD_HC_N 512
+#define DD_HC_N 512                 // column length (rows of an image); the row length is 512 (M = 2^18) or 256 (M = 2^17)
 #define DD_HC_M (DD_HC_N * DD_HC_N)
 #define DD_HC_COLS 8
 #define DD_HC_LDS_COLS (DD_HC_COLS * DD_HC_N * 16)        // 65536
@@ -95,31 +96,72 @@ __device__ __forceinline__ void hc_fft512(double2 (&v)[8], double2* __restrict__
     hc_dft8<INV>(v);
 }
 
-// workgroup x of a pass over 64 column tiles -> tile: the eight workgroups that land on one XCD (x mod 8) take eight
-// neighbouring tiles, whose 64-byte halves of the c64 / f64 rows then meet in that XCD's L2
-__device__ __forceinline__ int hc_tile_of(int bx) { return (bx & 7) * 8 + (bx >> 3); }
+// 16-point DFT (n = 4 n1 + n0, k = k1 + 4 k0: W16^{nk} = W4^{n1 k1} . W16^{n0 k1} . W4^{n0 k0}), in place, natural order
+template <bool INV>
+__device__ __forceinline__ void hc_dft4(double2& a, double2& b, double2& c, double2& d) {
+    const double2 s0 = hc_add(a, c), d0 = hc_sub(a, c), s1 = hc_add(b, d), d1 = hc_rot<INV>(hc_sub(b, d));
+    a = hc_add(s0, s1); c = hc_sub(s0, s1); b = hc_add(d0, d1); d = hc_sub(d0, d1);
+}
+template <bool INV>
+__device__ __forceinline__ void hc_dft16(double2 (&v)[16]) {
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, r = 0.70710678118654752440;
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) hc_dft4<INV>(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);       // v[4 k1 + n0] = y[n0][k1]
+    // y[n0][k1] W16^{n0 k1}: exponents 1, 2, 3 | 2, 4, 6 | 3, 6, 9
+    const double2 w1 = make_double2(c1, -s1), w2 = make_double2(r, -r), w3 = make_double2(s1, -c1);
+    const double2 w6 = make_double2(-r, -r), w9 = make_double2(-c1, s1);
+    v[4 + 1] = hc_tw<INV>(v[4 + 1], w1); v[8 + 1] = hc_tw<INV>(v[8 + 1], w2); v[12 + 1] = hc_tw<INV>(v[12 + 1], w3);
+    v[4 + 2] = hc_tw<INV>(v[4 + 2], w2); v[8 + 2] = hc_rot<INV>(v[8 + 2]);    v[12 + 2] = hc_tw<INV>(v[12 + 2], w6);
+    v[4 + 3] = hc_tw<INV>(v[4 + 3], w3); v[8 + 3] = hc_tw<INV>(v[8 + 3], w6); v[12 + 3] = hc_tw<INV>(v[12 + 3], w9);
+    // X[k1 + 4 k0] = DFT4 over n0 of y'[n0][k1]: in place on (v[4 k1], v[4 k1 + 1], v[4 k1 + 2], v[4 k1 + 3]) -> k0 = 0..3
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) hc_dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    // v[4 k1 + k0] holds X[k1 + 4 k0]: transpose the 4 x 4 index
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) { const double2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
+}
 
-// ---- pass 1: columns, forward.  grid (64, pairs), 512 threads, DD_HC_LDS_COLS bytes of dynamic LDS.
-// X: filtered IQ, c64 [nwin][L]; window w's audio is x[n] = angle(X[n+1] conj X[n]), n < L2 = L - 1 (demod_fm.py:40-49)
-__global__ void __launch_bounds__(512) k_hc_cols_fwd(const float2* __restrict__ X, int64_t L, int64_t L2, int nwin,
-                                                      double2* __restrict__ T, const double2* __restrict__ TA) {
+// 256-point transform on 16 lanes (four of them per wave).  In: lane l, register a = x[l + 16 a]; out: lane l, register b = X[l + 16 b].
+// n = 16 a + l, k = ka + 16 kb: W^{nk} = W16^{a ka} . W256^{l ka} . W16^{l kb}.  S: 256 elements of LDS owned by this 16-lane group; the
+// one exchange stores element (ka, l) at 16 ka + (l ^ ka) (the XOR keeps the transposed read off one bank group).
+// ts[ka - 1] = W_256^{l ka}.
+template <bool INV>
+__device__ __forceinline__ void hc_fft256(double2 (&v)[16], double2* __restrict__ S, const double2 (&ts)[15], int l) {
+    hc_dft16<INV>(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = hc_tw<INV>(v[k], ts[k - 1]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) S[16 * k + (l ^ k)] = v[k];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = S[16 * l + (b ^ l)];
+    hc_dft16<INV>(v);
+}
+
+// Geometry of a 512 x N2 image (N2 = 2^LG columns = row length; 512 rows = column length): n = N2 n1 + n2, k = k1 + 512 k2
+template <int LG>
+struct HcG {
+    static constexpr int N2 = 1 << LG;
+    static constexpr int64_t M = (int64_t)DD_HC_N << LG;
+    static constexpr int TILES = N2 / DD_HC_COLS;
+};
+// workgroup x of a pass over the column tiles -> tile: the workgroups that land on one XCD (x mod 8) take neighbouring tiles, whose
+// 64-byte halves of narrow source rows then meet in that XCD's L2
+template <int LG>
+__device__ __forceinline__ int hc_tile_of(int bx) { return (bx & 7) * (HcG<LG>::TILES / 8) + (bx >> 3); }
+
+// ---- pass 1: columns, forward.  grid (N2 / 8, jobs), 512 threads, DD_HC_LDS_COLS bytes of dynamic LDS.
+// SRC: rows(job) = how many rows of the image hold samples (the rest is zero and is not loaded), at(job, n) = element n.
+template <int LG, typename SRC>
+__global__ void __launch_bounds__(512) k_hc_cols_fwd(const SRC src, double2* __restrict__ T, const double2* __restrict__ TA) {
+    constexpr int N2 = HcG<LG>::N2;
     extern __shared__ __attribute__((aligned(16))) char hc_smem[];
     double2* S = reinterpret_cast<double2*>(hc_smem);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, col = t & 7;
-    const int c0 = hc_tile_of(blockIdx.x) * DD_HC_COLS, pair = blockIdx.y;
-    const bool hasb = 2 * pair + 1 < nwin;
-    const float2* xa = X + (int64_t)(2 * pair) * L;
-    const float2* xb = X + (int64_t)(2 * pair + (hasb ? 1 : 0)) * L;
-    const int R = (int)((L2 + DD_HC_N - 1) / DD_HC_N);                 // rows that hold samples
-    for (int row = t >> 3; row < R; row += 64) {
-        const int64_t n = (int64_t)row * DD_HC_N + c0 + col;
-        double a = 0.0, b = 0.0;
-        if (n < L2) {
-            a = (double)dd_fm_angle(xa[n + 1], xa[n]);
-            if (hasb) b = (double)dd_fm_angle(xb[n + 1], xb[n]);
-        }
-        S[col * DD_HC_N + (row ^ (col << 1))] = make_double2(a, b);
-    }
+    const int c0 = hc_tile_of<LG>(blockIdx.x) * DD_HC_COLS, job = blockIdx.y;
+    const int R = src.rows(job, N2);
+    for (int row = t >> 3; row < R; row += 64) S[col * DD_HC_N + (row ^ (col << 1))] = src.at(job, (int64_t)row * N2 + c0 + col);
     __syncthreads();
     double2 tw1[7], tw2[7];
     hc_lane_twiddles(TA, lane, tw1, tw2);
@@ -134,12 +176,14 @@ __global__ void __launch_bounds__(512) k_hc_cols_fwd(const float2* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) Sw[(lane + 64 * k) ^ (wv << 1)] = v[k];
     __syncthreads();
-    double2* Tp = T + (int64_t)pair * DD_HC_M + c0 + col;
-    for (int row = t >> 3; row < DD_HC_N; row += 64) Tp[(int64_t)row * DD_HC_N] = S[col * DD_HC_N + (row ^ (col << 1))];
+    double2* Tp = T + (int64_t)job * HcG<LG>::M + c0 + col;
+    for (int row = t >> 3; row < DD_HC_N; row += 64) Tp[(int64_t)row * N2] = S[col * DD_HC_N + (row ^ (col << 1))];
 }
 
-// ---- pass 2: rows.  grid (128, pairs), 256 threads (one wave per row), 32 KB of LDS
-__global__ void __launch_bounds__(256) k_hc_rows(double2* __restrict__ T, const double2* __restrict__ HHp,
+// ---- pass 2: rows of 512 (LG = 9).  grid (128, jobs), 256 threads (one wave per row), 32 KB of LDS.  SPEC: ptr(job) = the kernel
+// spectrum in [k1][k2] order with every constant factor folded in
+template <typename SPEC>
+__global__ void __launch_bounds__(256) k_hc_rows(double2* __restrict__ T, const SPEC spec,
                                                   const double2* __restrict__ TA, const double2* __restrict__ TB) {
     __shared__ __attribute__((aligned(16))) double2 S[4 * DD_HC_N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -148,7 +192,7 @@ __global__ void __launch_bounds__(256) k_hc_rows(double2* __restrict__ T, const 
     double2 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = row[64 * q];
-    // W_M^{(lane + 64 q) k1} = W_M^{lane k1} . W_M^{64 q k1}; W_M^{512 h + l} = W_512^h . W_M^l
+    // W_M^{(lane + 64 q) k1} = W_M^{lane k1} . W_M^{64 q k1}; W_M^{512 h + l} = W_512^h . W_M^l   (M = 2^18, TB[j] = W_M^j)
     double2 tw[8];
     {
         const int i1 = lane * k1;
@@ -166,7 +210,7 @@ __global__ void __launch_bounds__(256) k_hc_rows(double2* __restrict__ T, const 
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = hc_mul(v[q], tw[q]);
     hc_fft512<false>(v, Sw, tw1, tw2, lane);
-    const double2* h = HHp + (int64_t)k1 * DD_HC_N + lane;
+    const double2* h = spec.ptr(blockIdx.y) + (int64_t)k1 * DD_HC_N + lane;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = hc_mul(v[q], h[64 * q]);
     hc_fft512<true>(v, Sw, tw1, tw2, lane);
@@ -174,16 +218,55 @@ __global__ void __launch_bounds__(256) k_hc_rows(double2* __restrict__ T, const 
     for (int q = 0; q < 8; ++q) row[64 * q] = hc_mulconj(v[q], tw[q]);
 }
 
-// ---- pass 3: columns, inverse, envelope.  grid (64, pairs), 512 threads, DD_HC_LDS_COLS bytes of dynamic LDS
-__global__ void __launch_bounds__(512) k_hc_cols_inv(const double2* __restrict__ T, const float2* __restrict__ X, int64_t L, int64_t L2, int nwin,
-                                                      double* __restrict__ ENV, const double2* __restrict__ TA) {
+// ---- pass 2: rows of 256 (LG = 8, M = 2^17).  grid (64, jobs), 128 threads: a wave takes four rows, sixteen lanes and sixteen
+// registers per row, 4 KB of LDS per row.  TB[j] = W_M^j, j < 256: W_M^{256 h + l} = W_512^h . W_M^l
+template <typename SPEC>
+__global__ void __launch_bounds__(128) k_hc_rows256(double2* __restrict__ T, const SPEC spec,
+                                                     const double2* __restrict__ TA, const double2* __restrict__ TB) {
+    __shared__ __attribute__((aligned(16))) double2 S[8 * 256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, l = lane & 15;
+    const int k1 = blockIdx.x * 8 + wv * 4 + g;
+    double2* row = T + ((int64_t)blockIdx.y * DD_HC_N + k1) * 256 + l;
+    double2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = row[16 * a];
+    double2 tw[16];
+    {
+        const int i1 = l * k1;
+        const double2 wl = hc_mul(TA[i1 >> 8], TB[i1 & 255]);
+        tw[0] = wl;
+#pragma unroll
+        for (int a = 1; a < 16; ++a) {
+            const int i2 = a * k1;                                 // W_M^{16 a k1} = W_512^{i2 >> 4} . W_M^{16 (i2 & 15)}
+            tw[a] = hc_mul(wl, hc_mul(TA[i2 >> 4], TB[16 * (i2 & 15)]));
+        }
+    }
+    double2 ts[15];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) ts[k - 1] = TA[2 * l * k];
+    double2* Sg = S + (wv * 4 + g) * 256;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = hc_mul(v[a], tw[a]);
+    hc_fft256<false>(v, Sg, ts, l);
+    const double2* h = spec.ptr(blockIdx.y) + (int64_t)k1 * 256 + l;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = hc_mul(v[b], h[16 * b]);
+    hc_fft256<true>(v, Sg, ts, l);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) row[16 * a] = hc_mulconj(v[a], tw[a]);
+}
+
+// ---- pass 3: columns, inverse.  grid (N2 / 8, jobs), 512 threads, DD_HC_LDS_COLS bytes of dynamic LDS.
+// DST: rows(job) = how many rows of the result are wanted, put(job, n, y) = what becomes of element n
+template <int LG, typename DST>
+__global__ void __launch_bounds__(512) k_hc_cols_inv(const double2* __restrict__ T, const DST dst, const double2* __restrict__ TA) {
+    constexpr int N2 = HcG<LG>::N2;
     extern __shared__ __attribute__((aligned(16))) char hc_smem[];
     double2* S = reinterpret_cast<double2*>(hc_smem);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, col = t & 7;
-    const int c0 = hc_tile_of(blockIdx.x) * DD_HC_COLS, pair = blockIdx.y;
-    const bool hasb = 2 * pair + 1 < nwin;
-    const double2* Tp = T + (int64_t)pair * DD_HC_M + c0 + col;
-    for (int row = t >> 3; row < DD_HC_N; row += 64) S[col * DD_HC_N + (row ^ (col << 1))] = Tp[(int64_t)row * DD_HC_N];
+    const int c0 = hc_tile_of<LG>(blockIdx.x) * DD_HC_COLS, job = blockIdx.y;
+    const double2* Tp = T + (int64_t)job * HcG<LG>::M + c0 + col;
+    for (int row = t >> 3; row < DD_HC_N; row += 64) S[col * DD_HC_N + (row ^ (col << 1))] = Tp[(int64_t)row * N2];
     __syncthreads();
     double2 tw1[7], tw2[7];
     hc_lane_twiddles(TA, lane, tw1, tw2);
@@ -192,32 +275,70 @@ __global__ void __launch_bounds__(512) k_hc_cols_inv(const double2* __restrict__
 #pragma unroll
     for (int a = 0; a < 8; ++a) v[a] = Sw[(lane + 64 * a) ^ (wv << 1)];
     hc_fft512<true>(v, Sw, tw1, tw2, lane);
-    const int R = (int)((L2 + DD_HC_N - 1) / DD_HC_N);
+    const int R = dst.rows(job, N2);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = lane + 64 * k;
         if (r < R) Sw[r ^ (wv << 1)] = v[k];
     }
     __syncthreads();
-    const float2* xa = X + (int64_t)(2 * pair) * L;
-    const float2* xb = X + (int64_t)(2 * pair + (hasb ? 1 : 0)) * L;
-    double* ea = ENV + (int64_t)(2 * pair) * L2;
-    double* eb = ENV + (int64_t)(2 * pair + 1) * L2;
-    for (int row = t >> 3; row < R; row += 64) {
-        const int64_t n = (int64_t)row * DD_HC_N + c0 + col;
-        if (n >= L2) continue;
-        const double2 y = S[col * DD_HC_N + (row ^ (col << 1))];
-        ea[n] = hypot((double)dd_fm_angle(xa[n + 1], xa[n]), y.x);
-        if (hasb) eb[n] = hypot((double)dd_fm_angle(xb[n + 1], xb[n]), y.y);
-    }
+    for (int row = t >> 3; row < R; row += 64) dst.put(job, (int64_t)row * N2 + c0 + col, S[col * DD_HC_N + (row ^ (col << 1))]);
 }
 
-// kernel spectrum in the order k_hc_rows multiplies it: HHp[512 k1 + k2] = HH[k1 + 512 k2], HH the M/2 + 1 bins of a real
-// sequence's spectrum (Hermitian extension above M/2)
-__global__ void __launch_bounds__(256) k_hc_perm(const double2* __restrict__ HH, double2* __restrict__ HHp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= DD_HC_M) return;
-    const int k = (i >> 9) + DD_HC_N * (i & 511);
-    const double2 v = k <= DD_HC_M / 2 ? HH[k] : HH[DD_HC_M - k];
-    HHp[i] = k <= DD_HC_M / 2 ? v : make_double2(v.x, -v.y);
+// ---- the accurate-sync envelope's source and sink.  X: filtered IQ, c64 [nwin][L]; window w's audio is x[n] = angle(X[n+1] conj X[n]),
+// n < L2 = L - 1 (demod_fm.py:40-49); job p holds windows 2p (real part) and 2p + 1 (imaginary part)
+struct HcEnvIO {
+    const float2* X;
+    int64_t L, L2;
+    int nwin;
+    double* ENV;          // [nwin][L2] (sink only)
+    __device__ int rows(int, int N2) const { return (int)((L2 + N2 - 1) / N2); }
+    __device__ double2 at(int pair, int64_t n) const {
+        if (n >= L2) return make_double2(0.0, 0.0);
+        const float2* xa = X + (int64_t)(2 * pair) * L;
+        const double a = (double)dd_fm_angle(xa[n + 1], xa[n]);
+        double b = 0.0;
+        if (2 * pair + 1 < nwin) b = (double)dd_fm_angle(xa[L + n + 1], xa[L + n]);
+        return make_double2(a, b);
+    }
+    __device__ void put(int pair, int64_t n, double2 y) const {
+        if (n >= L2) return;
+        const double2 x = at(pair, n);
+        ENV[(int64_t)(2 * pair) * L2 + n] = hypot(x.x, y.x);
+        if (2 * pair + 1 < nwin) ENV[(int64_t)(2 * pair + 1) * L2 + n] = hypot(x.y, y.y);
+    }
+};
+struct HcOneSpec {
+    const double2* p;
+    __device__ const double2* ptr(int) const { return p; }
+};
+
+// kernel spectrum in the order the row pass multiplies it: out[N2 k1 + k2] = scale . in[k1 + 512 k2]; hermitian: `in` holds the
+// M/2 + 1 bins of a real sequence's spectrum (extended by conjugation above M/2), else all M bins
+template <int LG>
+__global__ void __launch_bounds__(256) k_hc_perm(const double2* __restrict__ in, double2* __restrict__ out, int hermitian, double scale) {
+    constexpr int64_t M = HcG<LG>::M;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int64_t k = (i >> LG) + DD_HC_N * (i & (HcG<LG>::N2 - 1));
+    double2 v;
+    if (hermitian && k > M / 2) { v = in[M - k]; v.y = -v.y; }
+    else v = in[k];
+    out[i] = make_double2(v.x * scale, v.y * scale);
+}
+
+// the three launches for `jobs` images (T: [jobs][512 N2] c128 work buffer; TB: W_M^j for this M)
+template <int LG, typename SRC, typename SPEC, typename DST>
+static inline void hc_convolve(const SRC& src, const SPEC& spec, const DST& dst, double2* T, int jobs,
+                               const double2* TA, const double2* TB, hipStream_t s) {
+    hipLaunchKernelGGL((k_hc_cols_fwd<LG, SRC>), dim3(HcG<LG>::TILES, jobs), dim3(512), DD_HC_LDS_COLS, s, src, T, TA);
+    if (LG == 9) hipLaunchKernelGGL((k_hc_rows<SPEC>), dim3(DD_HC_N / 4, jobs), dim3(256), 0, s, T, spec, TA, TB);
+    else hipLaunchKernelGGL((k_hc_rows256<SPEC>), dim3(DD_HC_N / 8, jobs), dim3(128), 0, s, T, spec, TA, TB);
+    hipLaunchKernelGGL((k_hc_cols_inv<LG, DST>), dim3(HcG<LG>::TILES, jobs), dim3(512), DD_HC_LDS_COLS, s, (const double2*)T, dst, TA);
+}
+template <int LG, typename SRC, typename DST>
+static inline hipError_t hc_set_lds_attr() {
+    hipError_t e = hipFuncSetAttribute((const void*)k_hc_cols_fwd<LG, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_hc_cols_inv<LG, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, DD_HC_LDS_COLS);
 }

@@ -217,6 +217,28 @@ def test_resample_chunk_list_equals_per_chunk_resample(dd, dtype):
         assert rel_err(got[out_off[i]:out_off[i] + m], O.resample_fft(piece, m)) < 1e-9, i
 
 
+def test_resample_chirp_convolution_own_transform_equals_the_library(dd, monkeypatch):
+    """The chirp-z resampler's cyclic convolution (length 2^17 for config 3's chunks, 2^18 for longer ones) as three launches of
+    the float64 transform of csrc/dd_hconv_kernels.h (pre-multiply, spectrum product and post-multiply inside them; the default)
+    against the same convolution through the FFT library (DD_CZT_OWN=0), and both against the oracle's scipy.signal.resample."""
+    rng = np.random.default_rng(21)
+    lengths = [83887, 83886, 150001, 83886, 150001, 70001]
+    nums = [int(11025 * n / 200000) for n in lengths]
+    x = rng.standard_normal(sum(lengths))
+    offs = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    d = dd.hip.DevArray.from_host(x)
+    res = {}
+    for own in ("0", None):
+        monkeypatch.delenv("DD_CZT_OWN", raising=False)
+        if own:
+            monkeypatch.setenv("DD_CZT_OWN", own)
+        out, out_off = dd.ops.resample_fft_chunks(d, offs, lengths, nums)
+        res[own] = out.to_host()
+    assert rel_err(res[None], res["0"]) < 1e-12
+    for i, (o, n, m) in enumerate(zip(offs, lengths, nums)):
+        assert rel_err(res[None][out_off[i]:out_off[i] + m], O.resample_fft(x[o:o + n], m)) < 1e-9, i
+
+
 @pytest.mark.timeout(900)
 def test_c4_at_bench_duration_index_lists_golden(dd, golden_dir):
     """config 4 at BENCH duration (60 s, "Pass = identical index lists"): crude and accurate sync over a 60 s
@@ -830,13 +852,14 @@ def test_accurate_sync_batched_equals_per_window(dd, noaa_inputs, monkeypatch):
     assert np.array_equal(one[0][0], g["acc_syncA"]) and np.array_equal(many[1][0], g["acc_syncB"])
 
 
-@pytest.mark.parametrize("L,nwin", [(118152, 5), (65537, 2), (131072, 1), (100001, 4)])
+@pytest.mark.parametrize("L,nwin", [(118152, 5), (65537, 2), (131072, 1), (100001, 4), (65536, 3), (32769, 2), (50001, 1)])
 def test_sync_envelope_three_launch_transform(dd, L, nwin):
     """The envelope stage of the accurate-sync windows alone (decode_noaa.py:852 -> demod_am.py:29, abs(hilbert(x)) of each
     window's FM audio): the 512 x 512 float64 transform of csrc/dd_hconv_kernels.h (two windows per complex image, three
     launches) against the FFT library's padded real transforms on the same device-side audio (agreement at rounding level),
     and against scipy.signal.hilbert on the host (the float32 discriminator differs in the last bit there).  Odd window counts
-    (a pair with an empty second half), the shortest and the longest window the 2^18 padding takes."""
+    (a pair with an empty second half), the shortest and the longest window the 2^18 padding (rows of 512) and the 2^17 padding
+    (rows of 256: four rows per wave) take."""
     import ctypes as C
     import scipy.signal
     rng = np.random.default_rng(L + nwin)
