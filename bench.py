@@ -798,7 +798,11 @@ def run_rank(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kern_ms_max, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                         "power_note": "not measured in this run: profiles/r04_clock_power.txt (rocm-smi while the kernel loops) -- 1381 W at "
+                                       "2016 MHz against the board's 1400 W cap and 283 W idle; dynamic energy 0.2165 J per 2^26-sample launch "
+                                       "(memory side alone 0.094 J, arithmetic + LDS exchanges 0.141 J), i.e. >= 0.194 ms per launch at the cap "
+                                       "whatever the schedule (DESIGN.md 4.2c)"},
             "extra": extra,
         }
         if not args.no_cpu_baseline and world == 1 and not stub:
