@@ -454,7 +454,6 @@ struct HcCztIO {
     DDCztJobs jobs;
     double2* Y;                  // sink: [jobs][K]
     int64_t K, num;
-    __device__ int rows(int, int) const { return 0; }
 };
 struct HcCztSrc : HcCztIO {
     __device__ int rows(int job, int N2) const { return (int)((jobs.j[job].n + N2 - 1) / N2); }

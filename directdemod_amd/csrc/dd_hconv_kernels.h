@@ -9,7 +9,8 @@
 // Here the same arithmetic in float64 is three passes:
 //   * two windows share one complex transform, z = x_a + j x_b: hh is real, so the convolution leaves the two in the
 //     real and the imaginary part -- no real-transform pre/post-processing;
-//   * M = 512 x 512 (four-step form, n = 512 n1 + n2, k = k1 + 512 k2):
+//   * M = 512 rows x N2 columns, N2 = 512 (M = 2^18) or 256 (M = 2^17) (four-step form, n = N2 n1 + n2, k = k1 + 512 k2;
+//     written out for N2 = 512):
 //       k_hc_cols_fwd   FM angle of the filtered IQ pair straight from the c64 rows (the padded f64 copy is never
 //                       written), transform over n1 for eight neighbouring columns per workgroup (the tile goes
 //                       through LDS so that global rows are read and written as 128-byte pieces), rows of zeros
@@ -21,14 +22,16 @@
 //     Traffic per window: 0.95 + 2.1 | 2.1 + 2.1 | 2.1 + 0.95 + 0.95 MB = 11.2 MB against ~29 MB.
 //   * a 512-point transform = radix 8 x 8 x 8 on one wave (8 points per lane in registers, two exchanges through 8 KB of LDS,
 //     XOR-swizzled so that every 16-lane group of a 16-byte access covers the 64 banks once; no workgroup barrier inside).
-//     Twiddles come from two 512-entry tables computed on the host in long double (W_512^j and W_M^j), at most one
+//     Rows of 256: a wave takes four of them, sixteen lanes and sixteen registers per row, radix 16 x 16 with one exchange (k_hc_rows256).
+//     Twiddles come from small tables computed on the host in long double (W_512^j and W_M^j, j < N2), at most one
 //     product of two of them per factor.
+//   * the kernels are templates over their source (what element n of image `job` is), their spectrum and their sink (what becomes of
+//     element n of the result): HcEnvIO below for the envelope, HcCztSrc / HcCztDst in dd_audio.hip for the resampler's chirp convolution.
 #pragma once
 #include "dd_common.h"
 #include "dd_chain_kernels.h"
 
 #define DD_HC_N 512                 // column length (rows of an image); the row length is 512 (M = 2^18) or 256 (M = 2^17)
-#define DD_HC_M (DD_HC_N * DD_HC_N)
 #define DD_HC_COLS 8
 #define DD_HC_LDS_COLS (DD_HC_COLS * DD_HC_N * 16)        // 65536
 
