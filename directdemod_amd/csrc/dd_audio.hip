@@ -1308,7 +1308,9 @@ __device__ __forceinline__ DDPk dd_pk_empty() {
 // look-ups of a lane in flight, 169 registers, 2 waves per SIMD -- 129 us; the look-ups staged in LDS along the comb of the
 // needle's run-boundary grid (984 / 492 samples: 1.5-2.7 loads from L2 per output instead of 16, but 32 KB of LDS per wave =
 // 5 waves per CU) 107-162 us; this loop, 8 waves per SIMD walking the runs in step so that neighbouring workgroups read
-// neighbouring prefix sums at the same time: 80 us.  profiles/r04_noaa_timeline.txt)
+// neighbouring prefix sums at the same time: 80 us.  Two runs' look-ups in flight (66 registers, 7 waves): 79-82 against 81-86, noise;
+// fewer workgroups per CU (so that one XCD's workgroups stay inside one window's prefix sums): 87 us at 7 per CU, 98 at 4, 146 at 2.
+// profiles/r04_noaa_timeline.txt)
 __global__ void __launch_bounds__(256) k_xcorr_runs_pk(const double* __restrict__ P, const double* __restrict__ Q, int64_t n, int m,
                                                        const DDRuns2 R2, const int* __restrict__ group, int tiles, int nwin, DDPk* __restrict__ part) {
     __shared__ DDPk sw[4];
