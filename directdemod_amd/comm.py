@@ -254,9 +254,35 @@ class commSignal:
         if self._ops or self._lazy:
             flush_all()
             lazies, self._lazy = self._lazy, []
+            if lazies and self._adopt(lazies):
+                return
             for sig in lazies:
                 sig._into = None
                 self._append(sig)
+
+    def _adopt(self, lazies):
+        """An empty container whose pending chunks turned out as consecutive pieces of ONE device buffer (the chunk-list call
+        writes a chunk loop's outputs back to back) takes a view of that stretch instead of copying piece by piece.  No
+        operation of this package writes into its input, and growing the container later copies (`_append`), so the shared
+        samples never change under either owner.  (Seven to sixteen device-to-device copies per chunk loop: 5 us each on the
+        device and as much again on the host -- profiles/r04_noaa_timeline.txt.)"""
+        if self._phys_len() != 0 or self._cap is not None:
+            return False
+        first = lazies[0]._dev
+        if first is None or first._base is None or first.dtype == _IQ8:
+            return False
+        end = first.ptr + first.nbytes
+        for s in lazies[1:]:
+            d = s._dev
+            if d is None or d._base is not first._base or d.dtype != first.dtype or d.ptr != end:
+                return False
+            end += d.nbytes
+        base = first._base
+        self._dev = base.view((first.ptr - base.ptr) // first.dtype.itemsize, (end - first.ptr) // first.dtype.itemsize)
+        self._host = None
+        for s in lazies:
+            s._into = None
+        return True
 
     def _settle(self):
         """before this signal changes: if it sits in a container's lazy list, let the container take its samples first"""

@@ -404,6 +404,48 @@ def test_class_chunk_loop_deferred_extend_keeps_the_reference_order_of_events(dd
     assert np.array_equal(got.signal, ref.signal)
 
 
+def test_extend_adopts_the_contiguous_outputs_of_a_chunk_list(dd):
+    """A chunk loop over a resident recording runs as ONE chunk-list call whose outputs lie back to back in one buffer; the empty
+    container the chunks were extend()ed into then takes a VIEW of that stretch (no copy per chunk).  The shared samples must
+    behave like the reference's copies (comm.py:163): growing the container afterwards, changing a chunk signal afterwards and
+    dropping the chunk signals leave both sides intact."""
+    rate, L, chunk, M = 2048000, 500000, 100000, 34
+    x = O.grid_c64(O.synth_iq_fm(L, rate, 19, f_carrier=30000.0, f_mod=1e3, dev=5.0))
+    res = dd.hip.DevArray.from_host(x, dtype=np.complex64)
+    taps = O.win_blackmanharris(151)
+
+    def loop(get):
+        class _Src:
+            length = L
+        ck = dd.chunker.chunker(_Src(), chunk)
+        out = dd.comm.commSignal(rate // M)
+        filt = dd.filters.filter(taps, 1, storeState=True)
+        fm = dd.demod_fm.demod_fm()
+        sigs = []
+        for a, b in ck.getChunks:
+            s = dd.comm.commSignal(rate, get(a, b), ck).offsetFreq(30000.0).filter(filt).bwLim(rate // M, uniq="First")
+            s.funcApply(fm.demod)
+            out.extend(s)
+            sigs.append(s)
+        return out, sigs
+
+    got, sigs = loop(lambda a, b: res.view(a, b - a))
+    ref, _ = loop(lambda a, b: x[a:b])
+    d = got.device_signal
+    assert d._base is not None and d._base is sigs[0]._dev._base and d.ptr == sigs[0]._dev.ptr        # a view, nothing copied
+    first = np.array(got.signal)
+    assert np.array_equal(first, ref.signal)
+    pieces = [np.array(s.signal) for s in sigs]
+    got.extend(dd.comm.commSignal(rate // M, np.arange(5.0)))                  # growing copies into a buffer of the container's own
+    sigs[1].updateSignal(np.zeros(3))                                           # a chunk signal replaced afterwards
+    assert np.array_equal(np.asarray(got.signal)[:len(first)], first) and got.length == len(first) + 5
+    assert np.array_equal(sigs[0].signal, pieces[0]) and np.array_equal(sigs[2].signal, pieces[2])
+    del sigs
+    import gc
+    gc.collect()
+    assert np.array_equal(np.asarray(got.signal)[:len(first)], first)
+
+
 @pytest.mark.parametrize("which", ["strict", "freqs"])
 def test_chunk_changed_after_extend_by_an_unrecorded_operation(dd, which):
     """extend() copies at call time in the reference (comm.py:163).  Here a chunk with pending operations is only NOTED by the
