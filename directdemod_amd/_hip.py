@@ -6,6 +6,7 @@ There is NO CPU fallback: if the shared library is missing, or no MI355X is
 visible when a compute entry point is reached, the call raises.
 """
 import ctypes as C
+import functools
 import os
 import threading
 from fractions import Fraction
@@ -233,12 +234,18 @@ def device_name():
     return buf.value.decode()
 
 
-def cycles_q64(freq_hz, samp_rate):
-    """frac(f/fs) * 2^64 as an unsigned 64-bit integer, from the exact rational value
-    of the two floats (the reference forms 2*pi*f*n/fs in float64, comm.py:77)."""
-    fr = Fraction(float(freq_hz)) / Fraction(int(samp_rate))
+@functools.lru_cache(maxsize=256)
+def _cycles_q64(freq_hz, samp_rate):
+    fr = Fraction(freq_hz) / Fraction(samp_rate)
     q = round(fr * (1 << 64))
     return int(q) % (1 << 64)
+
+
+def cycles_q64(freq_hz, samp_rate):
+    """frac(f/fs) * 2^64 as an unsigned 64-bit integer, from the exact rational value
+    of the two floats (the reference forms 2*pi*f*n/fs in float64, comm.py:77).  (A chunk loop asks for the same pair
+    once per chunk: the rational arithmetic, 14 us, is remembered.)"""
+    return _cycles_q64(float(freq_hz), int(samp_rate))
 
 
 def set_last_path(p):
