@@ -943,6 +943,34 @@ def test_accurate_sync_both_words_in_one_call(dd):
     assert len(only_b[0][0]) == 0 and np.array_equal(only_b[1][0], each[1][0])
 
 
+def test_accurate_sync_windows_at_half_the_sample_rate(dd, monkeypatch):
+    """A recording at 1.024 MS/s: the search windows are 59 076 samples, the envelope's cyclic convolution pads to 2^17 and runs
+    through the rows-of-256 form of the own transform (four rows per wave).  Picks, heights and post-sync means against the
+    library route (DD_SYNC_HILBERT=lib) and, for the picks, against the oracle's per-window chain."""
+    fs = 1024000
+    raw = O.synth_apt_iq(1.6, fs, seed=14)
+    src = dd.source.IQarray(raw, fs)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    width = int(3 * dd.constants.NOAA_T * len(dd.constants.NOAA_SYNCA) * fs)
+    assert 32768 < 2 * width <= 65536
+    starts = [int(v) for v in np.linspace(0, src.length - 2 * width, 5)]
+    res = {}
+    for hm in ("lib", None):
+        monkeypatch.delenv("DD_SYNC_HILBERT", raising=False)
+        if hm:
+            monkeypatch.setenv("DD_SYNC_HILBERT", hm)
+        res[hm] = ns.accurate_windows(starts, 2 * width, dd.constants.NOAA_SYNCA)
+    assert np.array_equal(res["lib"][0], res[None][0])
+    assert np.max(np.abs(np.array(res["lib"][1]) - np.array(res[None][1]))) < 1e-10
+    ta, tb = res["lib"][2], res[None][2]
+    assert [v is None for v in ta] == [v is None for v in tb]
+    assert all(abs(a - b) <= 1e-10 * abs(a) for a, b in zip(ta, tb) if a is not None)
+    for w in (0, 2, 4):
+        a = starts[w]
+        i, h, t = O.accurate_sync_window(O.read_iq_u8(raw, a, a + 2 * width), fs, 30000.0, dd.constants.NOAA_SYNCA)
+        assert res[None][0][w] == i + a and abs(res[None][1][w] - h) < 1e-4
+
+
 def test_accurate_sync_front_end_fused_into_the_first_filter_pass(dd, monkeypatch):
     """The windows' front end (uint8 pairs -> complex64, oscillator restarting at 0 per window) computed where the zero-phase
     filter's first pass stages its samples (k_filtfilt_tile mode 3, the default) against the front end as a kernel of its own
