@@ -9,6 +9,7 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 
 #define DD_FFT_CHECK(expr)                                                     \
     do {                                                                       \
@@ -2110,28 +2111,64 @@ __global__ void __launch_bounds__(256) k_cs_threshold(int K, DDCrudeSel* __restr
         S->beyond_cnt[0] = st.beyond[0]; S->beyond_cnt[1] = st.beyond[1];
     }
 }
-// candidates cor > threshold (:726), appended with their heights; the host orders them by index.  The first DD_CS_HEAD of a needle
-// go into the block the host fetches in its one copy (behind the counters), later ones into the overflow arrays
-#define DD_CS_HEAD 8192
+// candidates cor > threshold (:726) with their heights, IN INDEX ORDER (the grouping of :729-746 walks them in that order; appended
+// by atomics they came out shuffled and the host sorted 5 000 + 17 000 of them for the 60 s recording: 0.45 ms of a 1.0 ms call).
+// Two launches: every wave counts the candidates of its contiguous stretch, then -- its offset = the counts of the waves before
+// it -- writes them where they belong (ballot + prefix count, no barrier).  The first DD_CS_HEAD of a needle go into the block
+// the host fetches in its one copy (behind the counters), later ones into the overflow arrays
+#define DD_CS_HEAD 24576
+#define DD_CS_WAVES (DD_CS_WG * 4)
 struct DDCand { int64_t idx; double val; };
 struct DDCrudeHead { unsigned int n_cand, n_beyond[2], beyond_cnt[2], pad[3]; };      // 32 bytes per needle, then DDCand[needles][DD_CS_HEAD]
-__global__ void __launch_bounds__(256) k_cs_cand(const double* __restrict__ cor_all, int64_t n, DDCrudeSel* __restrict__ sel_all,
-                                                 DDCand* __restrict__ head_all, int64_t* __restrict__ cidx_all, double* __restrict__ cval_all, unsigned int cap) {
-    const int nd = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+__device__ __forceinline__ void dd_cs_stretch(int64_t n, int wave, int64_t* lo, int64_t* hi) {
+    *lo = n * wave / DD_CS_WAVES;
+    *hi = n * (wave + 1) / DD_CS_WAVES;
+}
+__global__ void __launch_bounds__(256) k_cs_cand_count(const double* __restrict__ cor_all, int64_t n, DDCrudeSel* __restrict__ sel_all,
+                                                       unsigned int* __restrict__ cnt_all) {
+    const int nd = blockIdx.y, lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const double* cor = cor_all + (int64_t)nd * n;
     DDCrudeSel* S = sel_all + nd;
+    const double thr = S->thr;
+    int64_t lo, hi;
+    dd_cs_stretch(n, wave, &lo, &hi);
+    unsigned int c = 0;
+    for (int64_t i = lo + lane; i < hi; i += 64) c += cor[i] > thr ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) {
+        cnt_all[(size_t)nd * DD_CS_WAVES + wave] = c;
+        if (c) atomicAdd(&S->n_cand, c);
+    }
+}
+__global__ void __launch_bounds__(256) k_cs_cand_write(const double* __restrict__ cor_all, int64_t n, const DDCrudeSel* __restrict__ sel_all,
+                                                       const unsigned int* __restrict__ cnt_all, DDCand* __restrict__ head_all,
+                                                       int64_t* __restrict__ cidx_all, double* __restrict__ cval_all, unsigned int cap) {
+    const int nd = blockIdx.y, lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double* cor = cor_all + (int64_t)nd * n;
+    const unsigned int* cnt = cnt_all + (size_t)nd * DD_CS_WAVES;
     DDCand* head = head_all + (size_t)nd * DD_CS_HEAD;
     int64_t* cidx = cidx_all + (size_t)nd * cap;
     double* cval = cval_all + (size_t)nd * cap;
-    const double thr = S->thr;
-    const int64_t i_lo = n * g / G, i_hi = n * (g + 1) / G;
-    for (int64_t i = i_lo + t; i < i_hi; i += 256) {
-        const double v = cor[i];
-        if (v > thr) {
-            const unsigned int o = atomicAdd(&S->n_cand, 1u);
+    const double thr = sel_all[nd].thr;
+    if (cnt[wave] == 0) return;                                    // (wave uniform)
+    unsigned int off = 0;
+    for (int w = lane; w < wave; w += 64) off += cnt[w];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) off += __shfl_xor(off, d);
+    int64_t lo, hi;
+    dd_cs_stretch(n, wave, &lo, &hi);
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const double v = i < hi ? cor[i] : 0.0;
+        const bool take = i < hi && v > thr;
+        const unsigned long long mask = __ballot(take);
+        if (take) {
+            const unsigned int o = off + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
             if (o < DD_CS_HEAD) head[o] = DDCand{i, v};
             else if (o < cap) { cidx[o] = i; cval[o] = v; }
         }
+        off += (unsigned int)__popcll(mask);
     }
 }
 __global__ void k_cs_head(const DDCrudeSel* __restrict__ sel, DDCrudeHead* __restrict__ hdr, int n_needles) {
@@ -2204,6 +2241,7 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     const size_t o_ci = take(sizeof(int64_t) * (size_t)cap * n_needles), o_cv = take(sizeof(double) * (size_t)cap * n_needles);
     const size_t head_bytes = sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES + sizeof(DDCand) * (size_t)DD_CS_HEAD * n_needles;
     const size_t o_head = take(head_bytes);
+    const size_t o_cnt = take(sizeof(unsigned int) * DD_CS_WAVES * n_needles);
     std::lock_guard<std::mutex> lk(g_sync_mu);
     char* base = nullptr;
     int rc = sync_scratch(off, &base);
@@ -2217,6 +2255,11 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     double2* part = (double2*)(base + o_part);
     double* cor = (double*)(base + o_cor);
     DDCrudeSel* sel = (DDCrudeSel*)(base + o_sel);
+    static const char* tenv = getenv("DD_CRUDE_TRACE");
+    const bool trace = tenv && atoi(tenv);
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = now_us();
+    double tt[6] = {0, 0, 0, 0, 0, 0};
     if (audio_is_f32) hipLaunchKernelGGL(k_cvt_f32_f64, dim3(grid1(n)), dim3(256), 0, s, (const float*)audio, (double*)(base + o_x), n);
     // ---- envelope
     auto env_blocks = [&](int64_t first, int64_t N, int batch) -> int {
@@ -2232,6 +2275,7 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         return DD_OK;
     };
     for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) rc = env_blocks(b0 * block, block, (int)(nfull - b0 < GB ? nfull - b0 : GB));
+    tt[0] = now_us() - tt0;
     if (rc == DD_OK && Mr) {
         const double2* HH = nullptr;
         rc = hilbert_kernel_spectrum(rem, Mr, &HH, s);
@@ -2251,7 +2295,13 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         rc = env_blocks(nfull * block, rem, 1);
     }
     if (rc != DD_OK) return rc;
-    // ---- prefix sums once, both correlations in one launch
+    tt[1] = now_us() - tt0;
+    // ---- prefix sums once, both correlations in one launch; selection, threshold, candidates of both needles: twelve launches,
+    // nothing comes back to the host in between.  (These eighteen launches of our own kernels were also replayed as ONE captured
+    // graph launch -- 300 calls with identical results -- for no gain, 0.995 against 0.985 ms per call: DD_CRUDE_TRACE=1 shows the
+    // host done enqueueing the whole call after 0.12 ms of the 0.53 ms the device needs.  What the call did lose was 0.45 ms on the
+    // host AFTER the synchronisation, sorting candidates: k_cs_cand_write.  profiles/r04_noaa_timeline.txt)
+    auto enqueue_tail = [&](hipStream_t s) -> int {
     hipLaunchKernelGGL(k_scan_part, dim3(tiles, 1), dim3(256), 0, s, env, n, tiles, part);
     hipLaunchKernelGGL(k_scan_mid, dim3(1), dim3(256), 0, s, part, tiles);
     hipLaunchKernelGGL(k_scan_final_x, dim3(tiles), dim3(256), 0, s, env, n, part, P, Q);
@@ -2259,24 +2309,30 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         hipLaunchKernelGGL(k_xcorr_runs_n<true>, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
     else
         hipLaunchKernelGGL(k_xcorr_runs_n<false>, dim3((unsigned)((n + DD_XCN_TILE - 1) / DD_XCN_TILE), n_needles), dim3(256), 0, s, P, Q, n, m, R2, cor);
-    // ---- selection, threshold, candidates of both needles: eleven launches, nothing comes back to the host in between
     DD_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(DDCrudeSel) * n_needles, s));
     for (int pass = 0; pass < 8; ++pass) hipLaunchKernelGGL(k_cs_hist, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, pass, sel);
     hipLaunchKernelGGL(k_cs_collect, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, K, sel, (double*)(base + o_bey));
     hipLaunchKernelGGL(k_cs_threshold, dim3(n_needles), dim3(256), 0, s, K, sel, (const double*)(base + o_bey));
     DDCrudeHead* d_hdr = (DDCrudeHead*)(base + o_head);
     DDCand* d_head = (DDCand*)(base + o_head + sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES);
-    hipLaunchKernelGGL(k_cs_cand, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, sel, d_head, (int64_t*)(base + o_ci), (double*)(base + o_cv), cap);
+    hipLaunchKernelGGL(k_cs_cand_count, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, sel, (unsigned int*)(base + o_cnt));
+    hipLaunchKernelGGL(k_cs_cand_write, dim3(DD_CS_WG, n_needles), dim3(256), 0, s, cor, n, (const DDCrudeSel*)sel, (const unsigned int*)(base + o_cnt), d_head,
+                       (int64_t*)(base + o_ci), (double*)(base + o_cv), cap);
     hipLaunchKernelGGL(k_cs_head, dim3(1), dim3(64), 0, s, sel, d_hdr, n_needles);
     DD_LAUNCH_CHECK();
-    // ---- one round trip, ONE copy into pinned memory: the counters and the first DD_CS_HEAD candidates of each needle (a second
-    // copy only for a needle with more).  (Five copies into pageable vectors -- the 16 KB select state and two arrays per needle --
-    // took 0.39 ms of the 1.1 ms call under the profiler, each a blocking staged transfer: profiles/r04_noaa_timeline.txt)
+    return DD_OK;
+    };
+    rc = enqueue_tail(s);
+    if (rc != DD_OK) return rc;
+    tt[2] = now_us() - tt0;
     char* pin = nullptr;
     rc = sync_pinned(head_bytes, &pin);
     if (rc != DD_OK) return rc;
     DD_HIP_CHECK(hipMemcpyAsync(pin, base + o_head, head_bytes, hipMemcpyDeviceToHost, s));
+    tt[3] = now_us() - tt0;
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    tt[4] = now_us() - tt0;
+    if (trace) fprintf(stderr, "crude tail host us: blocks enqueued %.0f, remainder %.0f, tail enqueued %.0f, copy enqueued %.0f, synchronised %.0f\n", tt[0], tt[1], tt[2], tt[3], tt[4]);
     const DDCrudeHead* hs = (const DDCrudeHead*)pin;
     const DDCand* hc = (const DDCand*)(pin + sizeof(DDCrudeHead) * DD_CS_MAXNEEDLES);
     const unsigned int first_n = DD_CS_HEAD;
@@ -2297,7 +2353,7 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
             DD_HIP_CHECK(hipStreamSynchronize(s));
             for (unsigned int i = 0; i < more; ++i) cand[first_n + i] = {ci[i], cv[i]};
         }
-        std::sort(cand.begin(), cand.end(), [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; });
+        // (the candidates arrive in index order: k_cs_cand_write)
         // group by >= 0.45 s from the running maximum, first maximum wins (:729-746)
         const double min_dist = 0.45 * samp_rate;
         std::vector<int64_t> peaks;
@@ -2318,6 +2374,7 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         }
         for (size_t i = 0; i < peaks.size(); ++i) peaks_host[(size_t)d * max_peaks + i] = peaks[i];
         n_peaks[d] = (int)peaks.size();
+        if (trace) fprintf(stderr, "   needle %d: %u candidates, %d peaks, done at %.0f us\n", d, count, (int)peaks.size(), now_us() - tt0);
     }
     return DD_OK;
 }

@@ -149,15 +149,16 @@ def test_crude_tail_in_one_call_equals_the_staged_route(dd, noaa_inputs):
 
 def test_crude_tail_many_candidates(dd):
     """Audio without sync words (noise): the peak threshold (decode_noaa.py:723-726) lets a good part of the correlation values
-    through -- more than the 8192 candidates per needle that come back with the counters in the entry's one copy, so the rest is
-    fetched in a second one; with still more than 65 536 the entry declines and the caller goes stage by stage.  Index lists
+    through -- more than the 24 576 candidates per needle that come back with the counters in the entry's one copy, so the rest is
+    fetched in a second one; with still more than 65 536 the entry declines and the caller goes stage by stage.  (The candidates
+    come back in index order: every wave counts those of its stretch, then writes them at the offset the counts before it give.)  Index lists
     against the staged route."""
     rate = 40960
     rng = np.random.default_rng(99)
     needles = [O.sync_needle(O.NOAA_SYNCA, rate), O.sync_needle(O.NOAA_SYNCB, rate)]
     ns = dd.noaa.noaa_sync(None, 0.0)
     seen = set()
-    for n in (20 * rate + 17, 3 * rate + 5, 2 * rate, rate + 999):
+    for n in (20 * rate + 17, 8 * rate + 3, 6 * rate, 5 * rate + 1, 4 * rate, 3 * rate + 5, 2 * rate, rate + 999):
         a = np.ascontiguousarray(rng.normal(0.0, 0.3, n))
         sig = ns.envelope(dd.comm.commSignal(rate, a))
         counts = []
@@ -175,7 +176,7 @@ def test_crude_tail_many_candidates(dd):
         pa, pb = res[0]
         assert np.array_equal(pa, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCA)), (n, counts)
         assert np.array_equal(pb, ns.correlate_and_find_peaks(sig, O.NOAA_SYNCB)), (n, counts)
-        seen.add("second copy" if max(counts) > 8192 else "one copy")
+        seen.add("second copy" if max(counts) > 24576 else "one copy")
     assert "second copy" in seen, seen
 
 
