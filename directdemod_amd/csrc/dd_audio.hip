@@ -1568,6 +1568,10 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
                                           void* stream) {
     DD_REQUIRE(n_windows >= 0, "n_windows");
     if (n_windows == 0) return DD_OK;
+    static const char* tenv = getenv("DD_SYNC_TRACE");               // tools: host-side time stamps inside the call, to stderr
+    const bool trace = tenv && atoi(tenv);
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = now_us();
     DD_REQUIRE(iq && starts_host && peak_host && height_host && tsync_host, "null buffer");
     DD_REQUIRE(iq_kind == 0 || iq_kind == 1, "iq_kind (0 complex64, 1 uint8 pairs)");
     DD_REQUIRE(fir_taps_host && fir_ntaps >= 1 && pre_ntaps >= 0 && (pre_taps_host || pre_ntaps == 0), "taps");
@@ -1696,7 +1700,9 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
         if (tab_K != pre_ntaps || tab_Q != fit2.Q) { dd_cos_table(pre_ntaps, fit2.Q, tabh); tab_K = pre_ntaps; tab_Q = fit2.Q; }
         memcpy(up.data() + o_tab, tabh.data(), sizeof(double2) * tabh.size());
     }
+    const double tt_up0 = now_us() - tt0;
     DD_HIP_CHECK(hipMemcpyAsync(base, up.data(), o_res, hipMemcpyHostToDevice, s));          // (pageable source: staged before the call returns)
+    const double tt_up1 = now_us() - tt0;
     for (int w0 = 0; w0 < n_windows; w0 += B) {
         const int b = n_windows - w0 < B ? n_windows - w0 : B;
         const dim3 gL(grid1(L), b), gL2(grid1(L2), b), gL4(grid1((L + 3) / 4), b);
@@ -1756,8 +1762,11 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     char* down = nullptr;                                                                        // the three result arrays, one copy (pinned)
     rc = sync_pinned(24 * (size_t)n_windows, &down);
     if (rc != DD_OK) return rc;
+    const double tt_enq = now_us() - tt0;
     DD_HIP_CHECK(hipMemcpyAsync(down, base + o_res, 24 * (size_t)n_windows, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    if (trace) fprintf(stderr, "sync windows host us (%d windows): upload starts %.0f, upload enqueued %.0f, batches enqueued %.0f, synchronised %.0f\n",
+                       n_windows, tt_up0, tt_up1, tt_enq, now_us() - tt0);
     memcpy(peak_host, down, 8 * (size_t)n_windows);
     memcpy(height_host, down + 8 * (size_t)n_windows, 8 * (size_t)n_windows);
     memcpy(tsync_host, down + 16 * (size_t)n_windows, 8 * (size_t)n_windows);

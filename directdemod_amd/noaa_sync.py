@@ -5,6 +5,8 @@ callers (decode_noaa.__audio :600-629, __getAM :631-657, __correlate :659-675,
 __correlateAndFindPeaks :677-767, getCrudeSync :769-806, getAccurateSync :808-880);
 the arithmetic runs in the HIP kernels behind this package's drop-in classes.
 """
+import functools
+
 import numpy as np
 
 from . import _ops, chunker, comm, constants, demod_am, demod_fm, filters
@@ -17,6 +19,24 @@ def sync_needle(sync_bits, samp_rate, positive=True):
     if positive:
         return ((np.repeat(sync_bits, rep) * 233) + 11) / 255
     return np.repeat(sync_bits, rep) - 0.5
+
+
+@functools.lru_cache(maxsize=8)
+def _needles(syncs, samp_rate):
+    """the needles of sync_needle for a tuple of sync words, stacked (float64, C order, read-only: one array per (words, rate))"""
+    a = np.ascontiguousarray(np.stack([sync_needle(np.array(sy), samp_rate) for sy in syncs]), dtype=np.float64)
+    a.setflags(write=False)
+    return a
+
+
+@functools.lru_cache(maxsize=1)
+def _window_taps():
+    """taps of the accurate-sync windows' two zero-phase filters (decode_noaa.py:852, :677)"""
+    bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
+    pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
+    bh.setflags(write=False)
+    pre.setflags(write=False)
+    return bh, pre
 
 
 class noaa_sync:
@@ -163,14 +183,13 @@ class noaa_sync:
         else:
             raw = self._gather_windows(starts, length) if raw is None else raw
             d_raw = DevArray.from_host(raw.reshape(-1), dtype=np.uint8)
-        bh = np.ascontiguousarray(filters.blackmanHarris(151, zeroPhase=True).getB, dtype=np.float64)
-        pre = np.ascontiguousarray(filters.hamming(492, zeroPhase=True).getB, dtype=np.float64)
+        bh, pre = _window_taps()
         pk = np.empty(nw, dtype=np.int64)
         ht = np.empty(nw, dtype=np.float64)
         ts = np.empty(nw, dtype=np.float64)
         dp = C.POINTER(C.c_double)
         if multi:
-            needle = np.ascontiguousarray(np.stack([sync_needle(sy, fs) for sy in syncs]), dtype=np.float64)
+            needle = _needles(tuple(tuple(sy) for sy in syncs), fs)
             _hip.check(_hip.lib().dd_noaa_sync_windows_multi(
                 d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), group.ctypes.data_as(C.POINTER(C.c_int)), nw, int(length),
                 _hip.cycles_q64(self.__offset, fs), bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre),
@@ -178,7 +197,7 @@ class noaa_sync:
                 float(fs), pk.ctypes.data_as(C.POINTER(C.c_int64)), ht.ctypes.data_as(dp), ts.ctypes.data_as(dp), None),
                 "dd_noaa_sync_windows_multi")
         else:
-            needle = np.ascontiguousarray(sync_needle(sync, fs), dtype=np.float64)
+            needle = _needles((tuple(sync),), fs)[0]
             _hip.check(_hip.lib().dd_noaa_sync_windows(
                 d_raw.ptr, 1, st.ctypes.data_as(C.POINTER(C.c_int64)), nw, int(length), _hip.cycles_q64(self.__offset, fs),
                 bh.ctypes.data_as(dp), len(bh), pre.ctypes.data_as(dp), len(pre), needle.ctypes.data_as(dp), len(needle),
@@ -204,12 +223,9 @@ class noaa_sync:
             batched = False         # a foreign source object (only .read): window by window through the drop-in classes
         out, jobs = [], []
         for crude, sync in ((sa, constants.NOAA_SYNCA), (sb, constants.NOAA_SYNCB)):
-            starts = []
-            for c in crude / self.__rate * src.sampFreq:                                  # :828-835
-                startI, endI = int(c) - width, int(c) + width
-                if startI < 0 or endI > src.length:
-                    continue
-                starts.append(startI)
+            ci = (np.asarray(crude, dtype=np.float64) / self.__rate * src.sampFreq).astype(np.int64)   # int(c) of :829 (c >= 0: truncation)
+            keep = (ci - width >= 0) & (ci + width <= src.length)                          # :830-835
+            starts = (ci[keep] - width).tolist()
             if batched:
                 jobs.append((len(out), starts, sync))
                 out.append(None)
