@@ -37,7 +37,7 @@ if "--stages" in sys.argv:
         _hip.sync(); t = time.perf_counter(); r = fn(); _hip.sync()
         print("  %-34s %7.2f ms" % (label, (time.perf_counter() - t) * 1e3)); return r
     obj = noaa_sync.noaa_sync(src, 30000.0)
-    aud = T("audio (fused chain, 2 chunks)", lambda: obj.audio(constants.NOAA_CRUDESYNCSAMPRATE, False))
+    aud = T("audio (fused chunk-list launch)", lambda: obj.audio(constants.NOAA_CRUDESYNCSAMPRATE, False))
     from directdemod_amd import _ops
     needles = [noaa_sync.sync_needle(constants.NOAA_SYNCA, aud.sampRate), noaa_sync.sync_needle(constants.NOAA_SYNCB, aud.sampRate)]
     T("crude tail, ONE call (fused)", lambda: _ops.crude_tail(aud.device_signal, aud.sampRate, needles))
