@@ -88,7 +88,8 @@ int  dd_debug_seam(int withhold_chunk, int spin_log2);
  *   accurate-sync windows takes its prefix-sum form (a[0..3], *Q filled), else 0.
  * dd_debug_sync_envelope -- the envelope stage of dd_noaa_sync_windows alone: X_dev c64 [nwin][L] (device) -> env_dev f64
  *   [nwin][L - 1] = abs(hilbert(angle(X[n+1] conj X[n]))) (decode_noaa.py:852 -> demod_am.py:29).  route 0: the three-launch
- *   512 x 512 transform of csrc/dd_hconv_kernels.h (65 536 < L <= 131 072), route 1: the FFT library's padded real transforms. */
+ *   float64 transform of csrc/dd_hconv_kernels.h (512 x 512 for 65 536 < L <= 131 072, 512 x 256 for 32 768 < L <= 65 536), route 1: the FFT
+ *   library's padded real transforms. */
 int  dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rounds, int* out);
 int  dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out);
 int  dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, int route, double* env_dev, void* stream);
