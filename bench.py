@@ -645,11 +645,28 @@ def run_rank(args):
     eng = (StubStep if stub else HipStep)(args, rank, local_rank)
     device = eng.device
     cdev = torch.device("cpu") if one_device else device       # where the small reduction tensors live
+    rccl_init_s = None
     if dist_on:
+        # one node by contract: the bootstrap sockets stay on loopback (a container hostname may not resolve, and a probe of
+        # every interface of a fresh box is the kind of wait a record cannot explain); the data path is xGMI / shared memory
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        from datetime import timedelta
+        t_init = time.perf_counter()
         if stub or one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=timedelta(seconds=60))
+        t_pg = time.perf_counter()
+        # the communicator itself is built lazily by the first collective: time that too, it is what an 8-GPU record shows first
+        warm = torch.zeros(1, dtype=torch.float32, device=torch.device("cpu") if (stub or one_device) else device)
+        dist.all_reduce(warm)
+        if not (stub or one_device):
+            torch.cuda.synchronize(device)
+        rccl_init_s = time.perf_counter() - t_init
+        sys.stderr.write("[bench] rank %d/%d: init_process_group %.2f s, first collective %.2f s\n" %
+                         (rank, world, t_pg - t_init, rccl_init_s - (t_pg - t_init)))
+        sys.stderr.flush()
     n = eng.n
     step = eng.step
 
@@ -720,6 +737,9 @@ def run_rank(args):
     if dist_on:
         extra["backend"] = dist.get_backend()
         extra["world_size_seen"] = dist.get_world_size()
+        ri = torch.tensor([rccl_init_s], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ri, op=dist.ReduceOp.MAX)
+        extra["rccl_init_s"] = round(float(ri[0]), 3)          # rendezvous + process group + first collective, slowest rank
     if dist_on and not args.no_gather:
         from directdemod_amd import shard
         shard_out, cnt = eng.shard_output()                 # this rank's outputs (a view) and how many are valid

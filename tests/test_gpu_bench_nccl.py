@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(150)
 def test_one_rank_through_the_nccl_branch():
     env = dict(os.environ)
     for k in ("DD_BENCH_STUB", "DD_BENCH_ONE_DEVICE"):
@@ -33,7 +33,8 @@ def test_one_rank_through_the_nccl_branch():
                 "DD_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--log2n", "22", "--steps", "3",
                         "--warmup", "1", "--ramp-ms", "5", "--no-cpu-baseline", "--no-side"],
-                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[bench]")))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -41,6 +42,7 @@ def test_one_rank_through_the_nccl_branch():
     n = 1 << 22
     assert j["n_gpus"] == 1 and j["config"]["samples_per_gpu"] == n
     assert j["extra"]["backend"] == "nccl" and j["extra"]["world_size_seen"] == 1
+    assert 0 <= j["extra"]["rccl_init_s"] < 60                     # rendezvous + communicator set-up, as the 8-GPU record will show it
     assert j["extra"]["gathered_outputs"] == n - 1                 # rank 0 of a stream owns one output fewer (quirk Q3)
     assert j["extra"]["with_all_gather_MSamples_per_s"] > 0 and j["extra"]["all_gather_ms_per_step"] > 0
     assert j["config"]["kernel"] == "k_chain_fft1k" and j["data"] == "synthetic"
