@@ -15,6 +15,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdirectdemod_hip.so")
+# DD_LIB_PATH (diagnostics only: tools/ A/B runs of ablation builds, build/variants/lib_N.so) loads another build of the same
+# C-ABI INSTEAD of the product library and says so on stderr; the product file is never overwritten by a measurement script
+if os.environ.get("DD_LIB_PATH"):
+    LIB_PATH = os.path.abspath(os.environ["DD_LIB_PATH"])
+    import sys as _sys
+    _sys.stderr.write("directdemod_amd: DD_LIB_PATH set, loading %s instead of the product library\n" % LIB_PATH)
 
 DD_OK = 0
 DD_ERR_INVALID = -1
@@ -27,7 +33,7 @@ DD_ERR_TIMEOUT = -6
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
 (DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
- DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI) = range(9)
+ DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS) = range(10)
 # element type of raw interleaved uint8 I,Q pairs held on the device (source.py:117-118 not yet applied): 2 B/sample
 IQ8 = np.dtype([("i", np.uint8), ("q", np.uint8)])
 
@@ -62,6 +68,7 @@ SIGNATURES = {
     "dd_debug_select_kernel": (_int, [C.c_char_p]),
     "dd_debug_seam": (_int, [_int, _int]),
     "dd_debug_fft1k_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int)]),
+    "dd_debug_cos1k_plan": (_int, [_i64, _int, _int, _int, C.POINTER(_int)]),
     "dd_debug_cos_fit": (_int, [C.POINTER(C.c_double), _int, C.POINTER(C.c_double), C.POINTER(_int)]),
     "dd_debug_sync_envelope": (_int, [_p, _i64, _int, _int, _p, _p]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),
@@ -204,7 +211,7 @@ def check(rc, what=""):
 
 
 def select_kernel(name=None):
-    """Tools and tests: force one of the M = 1 chain kernels ("ab", "ws", "fft1k") for every later launch of this process,
+    """Tools and tests: force one of the M = 1 chain kernels ("ab", "ws", "fft1k", "cos1k") for every later launch of this process,
     or go back to the choice by tap class (None / "auto").  Mirrors the choice into os.environ["DD_MFMA_KERNEL"] (which only
     seeds the library's choice, once per process) so that code which looks there sees the same thing."""
     check(lib().dd_debug_select_kernel((name or "auto").encode()), "dd_debug_select_kernel")

@@ -1,0 +1,533 @@
+// Fused M == 1 hot path for cosine-series windows of 255 taps (filters.hamming, filters.py:199; any b[k] = a0 + a1 cos(2 pi k / 254)):
+//
+//     offsetFreq (comm.py:63-78) -> FIR as three RUNNING SUMS (comm.py:80-92, filters.py:64-70) -> demod_fm (demod_fm.py:40-49)
+//
+// Why: k_chain_fft1k runs at the board's power cap -- 0.18 J of switching energy per 2^26-sample
+// launch, of which the two 1024-point transforms per 768 outputs are 0.11 J.  For a cosine-series window the convolution needs no
+// transform: with xt[n] = x[n] e^{-j w n} (the NCO, applied to the samples) and phi = 2 pi / 254,
+//     R[n] = sum_{k<255} xt[n-k]      C[n] = sum_{k<255} cos(phi k) xt[n-k]      S[n] = sum_{k<255} sin(phi k) xt[n-k]
+//     (C, S)[n] = Rot_phi((C, S)[n-1] - (xt[n-255], 0)) + (xt[n], 0)            R[n] = R[n-1] + xt[n] - xt[n-255]
+//     y[n] = a0 R[n] + a1 C[n]
+// i.e. 10 packed multiply-adds per sample where the overlap-save form spends ~44 (tools/ubench/cosfir_arith.hip measured the
+// arithmetic alone: 0.093 ms and 0.064 J per 2^26 samples against 0.123 ms and 0.105 J; profiles/r05_cosfir_ubench.txt).
+//
+// Layout.  A wave walks a contiguous run of ROWS of 1024 samples; lane L owns samples 16 L .. 16 L + 15 of the row, so the
+// recurrence runs serially inside a lane and the 64 lanes are tied together by a two-pass scan:
+//   pass A   lane totals T_L of the un-windowed recurrence started from zero (16 steps)
+//   scan     P_L = sum_{L' <= L} A^{16 (L - L')} T_L'   (Kogge-Stone over the wave through DPP moves, weights = rotations by 16 phi 2^k)
+//   window   V_L = P_L - A^256 P_{L-16} - A^255 (xt[16 (L - 15)], 0): the 255-sample window that ends with lane L, lanes L < 16
+//            taking P_{L-16} from the previous row (kept in a register, moved by one ds_bpermute per component) plus that row's total
+//   pass B   the recurrence again from the true state V_{L-1} at the lane's first sample, subtracting xt[n-255] as it leaves
+// Every quantity is rebuilt from at most the last two rows: no error is carried along the stream (the float32 model
+// tools/sim/cosfir_sim.py: FIR error 4.7e-7 of max|y|, FM median 1.2e-8 rad against the float64 definition).
+// xt[n-255] is lane L-16's sample i+1: the row's samples after the NCO go through LDS once ([16 history + 64 row] groups of 16
+// samples, 144 bytes apart: conflict free for the 16-byte row-major stores and for the lanes' own 16-byte reads), which also
+// turns the coalesced load layout (lane l holds samples 128 j + 2 l, +1) into the lane-contiguous one.  No barrier: a wave owns
+// its LDS image.  Raw u8 input (source.py:117-118) arrives lane-contiguous already (32 bytes per lane and row).
+//
+// Edges.  The row grid is laid by the alignment of `out` (row q covers samples [base + 1024 q, +1024), base in [s - 15, s], so that
+// every lane's 16 angles are one 64-byte line).  A wave first runs the row BEFORE its run without stores (it leaves the LDS
+// history, the previous-row prefixes, the state and y[n-1]); rows that touch the stream start, the chunk end or the carried state
+// (history, last FIR output: DDChainParams) load sample by sample and predicate their stores.  One launch per chunk.
+#include "dd_chain_kernels.h"
+#include "dd_cosfir.h"
+#include "dd_cosfit.h"
+#include "dd_atan.h"
+#include <stdlib.h>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define C1_K 255
+#define C1_ROW 1024
+#define C1_GROUP_BYTES 144                     // 16 samples of 8 bytes + 16 bytes of padding
+#define C1_HIST_GROUPS 16
+#define C1_WAVE_BYTES ((C1_HIST_GROUPS + 64) * C1_GROUP_BYTES)      // 11520
+#define C1_WAVES 4
+#define C1_LDS_BYTES (C1_WAVES * C1_WAVE_BYTES)
+
+struct DDCos1kLane { float b15c, b15s, b31c, b31s; };   // rotation by 16 phi ((lane & 15) + 1) and by 16 phi ((lane & 31) + 1)
+
+struct DDCos1kTabs {
+    float c1, s1;          // rotation by phi
+    float c2, s2;          // rotation by 256 phi (= 2 phi)
+    float a0, a1;          // y = a0 R + a1 C
+    float wc[4], ws[4];    // rotation by 16 phi 2^k, k = 0..3
+    float2 qj[8];          // e^{-j w 128 j}: row-major load layout (complex64 input)
+    float2 e1;             // e^{-j w}
+    float2 ei[16];         // e^{-j w i}: lane-contiguous layout (u8 input)
+    const DDCos1kLane* lane_tab;
+    int base;              // first sample of row 0 (chunk-relative)
+};
+
+__device__ __forceinline__ v2f c1_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f c1_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f){a, a}, b, c); }
+// complex product as one packed multiply and one packed multiply-add
+__device__ __forceinline__ v2f c1_cmul(v2f a, v2f b) { return c1_fma(a.x, b, (v2f){-a.y, a.y} * (v2f){b.y, b.x}); }
+
+template <int CTRL>
+__device__ __forceinline__ float c1_dpp0(float v) {                         // lanes without a source lane read 0 (bound_ctrl)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float c1_dppm(float v) {                         // masked rows read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+// wave_shr:1; lane 0 keeps `first`
+__device__ __forceinline__ float c1_shr1(float v, float first) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ v2f c1_shr1(v2f v, v2f first) { return (v2f){c1_shr1(v.x, first.x), c1_shr1(v.y, first.y)}; }
+__device__ __forceinline__ float c1_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ v2f c1_lane63(v2f v) { return (v2f){c1_lane63(v.x), c1_lane63(v.y)}; }
+__device__ __forceinline__ float c1_bperm(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+__device__ __forceinline__ v2f c1_bperm(int addr, v2f v) { return (v2f){c1_bperm(addr, v.x), c1_bperm(addr, v.y)}; }
+
+struct C1St { v2f C, S, R; };
+
+#define C1_ROW_SHR(n) (0x110 + (n))
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void c1_scan_step(C1St& t, float wc, float ws) {
+    v2f Cs, Ss, Rs;
+    if (ROW_MASK == 0xF) {
+        Cs = (v2f){c1_dpp0<CTRL>(t.C.x), c1_dpp0<CTRL>(t.C.y)};
+        Ss = (v2f){c1_dpp0<CTRL>(t.S.x), c1_dpp0<CTRL>(t.S.y)};
+        Rs = (v2f){c1_dpp0<CTRL>(t.R.x), c1_dpp0<CTRL>(t.R.y)};
+    } else {
+        Cs = (v2f){c1_dppm<CTRL, ROW_MASK>(t.C.x), c1_dppm<CTRL, ROW_MASK>(t.C.y)};
+        Ss = (v2f){c1_dppm<CTRL, ROW_MASK>(t.S.x), c1_dppm<CTRL, ROW_MASK>(t.S.y)};
+        Rs = (v2f){c1_dppm<CTRL, ROW_MASK>(t.R.x), c1_dppm<CTRL, ROW_MASK>(t.R.y)};
+    }
+    t.C = c1_fma(wc, Cs, c1_fma(-ws, Ss, t.C));
+    t.S = c1_fma(ws, Cs, c1_fma(wc, Ss, t.S));
+    t.R += Rs;
+}
+
+// what a wave carries from one row to the next
+struct C1Carry {
+    C1St W;          // P_{L-16} of the previous row as lanes L < 16 need it (lane L holds the previous row's P_{48+L})
+    C1St P63;        // the previous row's P_63 (wave-uniform)
+    C1St V63;        // windowed state at the previous row's last sample (wave-uniform): enters lane 0
+    v2f y63;         // the previous row's last FIR output (wave-uniform): y[n-1] of lane 0's first sample
+};
+
+// Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
+//   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
+//   C1_ABL_NO_LDS    no LDS traffic           C1_ABL_NO_FM     no discriminator         C1_ABL_NO_SCAN    no scan / window stage
+template <bool U8>
+__device__ __forceinline__ void c1_issue_loads(const DDChainParams& P, int64_t S, int lane, v4f (&xin)[8]) {
+#ifdef C1_ABL_NO_LOAD
+    return;
+#endif
+    if (U8) {
+        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const unsigned char*>(P.in) + 2 * (S + 16 * lane));
+        xin[0] = __builtin_nontemporal_load(p);
+        xin[1] = __builtin_nontemporal_load(p + 1);
+    } else {
+        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const float2*>(P.in) + S + 2 * lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xin[j] = __builtin_nontemporal_load(p + 64 * j);
+    }
+}
+
+// One row.  EDGE: sample-by-sample loads (history, chunk end), predicated stores, the carried FIR output.  emit: store angles.
+template <bool U8, bool EDGE>
+__device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs& T, const DDCos1kLane& lt, const int lane, char* const lds,
+                                       const int64_t S, const bool emit, const bool prefetch_next, v4f (&xin)[8], bool& have_xin,
+                                       const v2f ql, C1Carry& cr) {
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    const float c = T.c1, s = T.s1;
+    char* const own = lds + (C1_HIST_GROUPS + lane) * C1_GROUP_BYTES;          // this lane's 16 samples of the row
+    const char* const old = lds + lane * C1_GROUP_BYTES;                       // lane - 16's (previous row's lanes 48.. for L < 16)
+    v2f xt[16];
+    if (EDGE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t n = S + 16 * lane + i;
+            v2f v = (v2f){0.f, 0.f};
+            if (n < 0) {
+                const int64_t ti = n + (C1_K - 1);
+                if (ti >= 0) { const float2 h = P.tail_in[ti]; v = (v2f){h.x, h.y}; }       // (after the NCO already)
+            } else if (n < P.L) {
+                float2 x;
+                if (U8) {
+                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
+                    x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+                } else {
+                    x = reinterpret_cast<const float2*>(P.in)[n];
+                }
+                if (nco) x = dd_cmul(x, dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl));
+                v = (v2f){x.x, x.y};
+            }
+            xt[i] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
+        have_xin = false;
+    } else {
+        if (!have_xin) c1_issue_loads<U8>(P, S, lane, xin);
+        v2f prow = (v2f){1.f, 0.f};
+#ifdef C1_ABL_NO_PHASOR
+        if (nco) prow = c1_cmul((v2f){0.6f, 0.8f}, ql);
+#else
+        if (nco) { const float2 pr = dd_phasor((uint64_t)(P.abs0 + S) * P.cyc, P.nco_tbl); prow = c1_cmul((v2f){pr.x, pr.y}, ql); }
+#endif
+        if (U8) {
+            // 32 bytes = the lane's own 16 samples: (x - 127.5) e^{-j w (S + 16 L + i)}
+            const unsigned* w = reinterpret_cast<const unsigned*>(&xin[0]);
+            unsigned u[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { u[t] = __float_as_uint(xin[0][t]); u[4 + t] = __float_as_uint(xin[1][t]); }
+            (void)w;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned word = u[i >> 1];
+                const float re = (float)((word >> (16 * (i & 1))) & 0xFF) - 127.5f;
+                const float im = (float)((word >> (16 * (i & 1) + 8)) & 0xFF) - 127.5f;
+                v2f x = (v2f){re, im};
+                if (nco) x = c1_cmul(x, i ? c1_cmul(prow, (v2f){T.ei[i].x, T.ei[i].y}) : prow);
+                xt[i] = x;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
+        } else {
+            // row-major registers: xin[j] = samples 128 j + 2 l, + 1  ->  NCO  ->  LDS, group 8 j + (l >> 3), slot l & 7
+            char* const wr = lds + (C1_HIST_GROUPS + (lane >> 3)) * C1_GROUP_BYTES + 16 * (lane & 7);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v2f x0 = (v2f){xin[j].x, xin[j].y}, x1 = (v2f){xin[j].z, xin[j].w};
+                if (nco) {
+                    const v2f pj = j ? c1_cmul(prow, (v2f){T.qj[j].x, T.qj[j].y}) : prow;
+                    const v2f pj1 = c1_cmul(pj, (v2f){T.e1.x, T.e1.y});
+                    x0 = c1_cmul(x0, pj);
+                    x1 = c1_cmul(x1, pj1);
+                }
+#ifdef C1_ABL_NO_LDS
+                xt[2 * j] = x0; xt[2 * j + 1] = x1;
+#else
+                *reinterpret_cast<v4f*>(wr + 8 * j * C1_GROUP_BYTES) = (v4f){x0.x, x0.y, x1.x, x1.y};
+#endif
+            }
+        }
+        have_xin = false;
+    }
+    // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order)
+    if (prefetch_next) { c1_issue_loads<U8>(P, S + C1_ROW, lane, xin); have_xin = true; }
+#ifndef C1_ABL_NO_LDS
+    if (!EDGE && !U8) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const v4f v = *reinterpret_cast<const v4f*>(own + 16 * t);
+            xt[2 * t] = (v2f){v.x, v.y};
+            xt[2 * t + 1] = (v2f){v.z, v.w};
+        }
+    }
+#endif
+    // d[i] = xt[n - 255] = sample i + 1 of the group 16 lanes back
+    v2f d[16];
+#ifdef C1_ABL_NO_LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = xt[(i + 5) & 15] * 0.5f;
+#else
+    d[0] = *reinterpret_cast<const v2f*>(old + 8);
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        const v4f v = *reinterpret_cast<const v4f*>(old + 16 * t);
+        d[2 * t - 1] = (v2f){v.x, v.y};
+        d[2 * t] = (v2f){v.z, v.w};
+    }
+    d[15] = *reinterpret_cast<const v2f*>(old + C1_GROUP_BYTES);
+#endif
+    // ---- pass A: lane totals of the un-windowed recurrence
+    C1St t = {xt[0], (v2f){0.f, 0.f}, xt[0]};
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        const v2f Cn = c1_fma(c, t.C, c1_fma(-s, t.S, xt[i]));
+        t.S = c1_fma(s, t.C, c * t.S);
+        t.C = Cn;
+        t.R += xt[i];
+    }
+    // ---- inclusive weighted scan over the 64 lanes
+#ifndef C1_ABL_NO_SCAN
+    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, T.wc[0], T.ws[0]);
+    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, T.wc[1], T.ws[1]);
+    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, T.wc[2], T.ws[2]);
+    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, T.wc[3], T.ws[3]);
+    c1_scan_step<0x142, 0xA>(t, lt.b15c, lt.b15s);          // row_bcast:15 into rows 1 and 3
+    c1_scan_step<0x143, 0xC>(t, lt.b31c, lt.b31s);          // row_bcast:31 into rows 2 and 3
+#endif
+    // ---- window: V_L = P_L - A^256 P_{L-16} - A^255 (xt[16 (L - 15)], 0); lanes L < 16 continue the previous row's prefix
+    const int back16 = ((lane - 16) & 63) << 2;
+    C1St Wn;                                                 // lane L: this row's P_{L-16} (L >= 16), P_{48+L} (L < 16: the next row's W)
+    Wn.C = c1_bperm(back16, t.C);
+    Wn.S = c1_bperm(back16, t.S);
+    Wn.R = c1_bperm(back16, t.R);
+    const bool low = lane < 16;
+    C1St W;
+    W.C = low ? cr.W.C : Wn.C;
+    W.S = low ? cr.W.S : Wn.S;
+    W.R = low ? cr.W.R : Wn.R;
+    const float uc = low ? lt.b15c : 0.f, us = low ? lt.b15s : 0.f, ur = low ? 1.f : 0.f;      // A^{16 (L + 1)} for L < 16
+    const v2f e = d[15];
+    C1St V;
+    V.C = c1_fma(-T.c2, W.C, c1_fma(T.s2, W.S, c1_fma(-c, e, t.C)));
+    V.S = c1_fma(-T.s2, W.C, c1_fma(-T.c2, W.S, c1_fma(-s, e, t.S)));
+    V.R = t.R - W.R - e;
+    V.C = c1_fma(uc, cr.P63.C, c1_fma(-us, cr.P63.S, V.C));
+    V.S = c1_fma(us, cr.P63.C, c1_fma(uc, cr.P63.S, V.S));
+    V.R = c1_fma(ur, cr.P63.R, V.R);
+    // state at the lane's first sample = V of the lane before (lane 0: the previous row's last)
+    C1St u;
+    u.C = c1_shr1(V.C, cr.V63.C);
+    u.S = c1_shr1(V.S, cr.V63.S);
+    u.R = c1_shr1(V.R, cr.V63.R);
+    cr.W = Wn;
+    cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
+    cr.V63.C = c1_lane63(V.C); cr.V63.S = c1_lane63(V.S); cr.V63.R = c1_lane63(V.R);
+    // ---- pass B: the windowed recurrence; y = a0 R + a1 C (filters.py:199)
+    v2f y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const v2f bC = c1_fma(-c, d[i], xt[i]);
+        const v2f bS = -s * d[i];
+        const v2f Cn = c1_fma(c, u.C, c1_fma(-s, u.S, bC));
+        u.S = c1_fma(s, u.C, c1_fma(c, u.S, bS));
+        u.C = Cn;
+        u.R += xt[i] - d[i];
+        y[i] = c1_fma(T.a0, u.R, T.a1 * u.C);
+    }
+    // the row's last 256 samples are the next row's history
+#ifndef C1_ABL_NO_LDS
+    if (lane >= 48) {
+        char* const h = lds + (lane - 48) * C1_GROUP_BYTES;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) *reinterpret_cast<v4f*>(h + 16 * tt) = (v4f){xt[2 * tt].x, xt[2 * tt].y, xt[2 * tt + 1].x, xt[2 * tt + 1].y};
+    }
+#endif
+    if (EDGE) {
+        // the FIR output before the chunk's first sample is carried state (demod_fm.py:47-49); the chunk's last one becomes it
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t n = S + 16 * lane + i;
+            if (P.s == 0 && n == -1) { const float2 ly = *P.lasty_in; y[i] = (v2f){ly.x, ly.y}; }
+            if (n == P.L - 1 && P.lasty_out) *P.lasty_out = make_float2(y[i].x, y[i].y);
+        }
+    }
+    const v2f yl = c1_shr1(y[15], cr.y63);
+    cr.y63 = c1_lane63(y[15]);
+    if (!emit) return;
+    // ---- demod_fm: angle(y[n] conj(y[n-1])), in four groups of 256 outputs; the small-angle form where a whole group allows it
+    float ang[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float re[4], im[4];
+        float worst = -1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * g + k;
+            const v2f zp = i ? y[i - 1] : yl;
+            re[k] = fmaf(y[i].x, zp.x, y[i].y * zp.y);
+            im[k] = fmaf(y[i].y, zp.x, -y[i].x * zp.y);
+            worst = fmaxf(worst, fmaf(-0.41421356f, re[k], fabsf(im[k])));
+        }
+        // (a product of exactly zero -- digital silence -- takes the full-range form, which returns np.angle(0) = 0)
+#ifdef C1_ABL_NO_FM
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ang[4 * g + k] = re[k] + im[k];
+#else
+        if (__builtin_amdgcn_ballot_w64(worst >= 0.f) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan_small(im[k], re[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan2_poly(im[k], re[k]);
+        }
+#endif
+    }
+    if (EDGE) {
+        float* const o = reinterpret_cast<float*>(P.out) + (S - P.s) + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t n = S + 16 * lane + i;
+            if (n >= P.s && n < P.L) o[i] = ang[i];
+        }
+        return;
+    }
+    // The lane holds 16 consecutive angles (one 64-byte line); a store instruction made of 64 such lines costs four times a
+    // coalesced one in the memory pipeline (measured: the kernel at 0.42 ms with them, 0.14 ms without any store).  So the angles
+    // cross the wave through LDS -- the row's sample image is dead by now -- and leave as four 1 KB row-major stores.
+    // Image: angle m of the row at dword 16 (m >> 4) + 4 (((m >> 2) & 3) ^ ((m >> 5) & 3)) + (m & 3): unpadded, the 16-byte chunks of
+    // a lane's line swizzled by its lane pair, which keeps the eight lanes of a ds_write_b128 group and the sixteen of a
+    // ds_read_b128 group on distinct banks.
+    char* const img = lds + C1_HIST_GROUPS * C1_GROUP_BYTES;
+    {
+        const int sw = (lane >> 1) & 3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<v4f*>(img + 64 * lane + 16 * (t ^ sw)) = (v4f){ang[4 * t], ang[4 * t + 1], ang[4 * t + 2], ang[4 * t + 3]};
+    }
+    float* const o = reinterpret_cast<float*>(P.out) + (S - P.s) + 4 * lane;
+    {
+        const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4f v = *reinterpret_cast<const v4f*>(img + 64 * (16 * g + G) + 16 * ((lane & 3) ^ sw));
+#ifdef C1_ABL_NO_STORE
+            if (v.x + v.y + v.z + v.w == 1234.5f) o[256 * g] = v.x;
+#else
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(o + 256 * g));
+#endif
+        }
+    }
+}
+
+// The whole chunk in one launch.  Row q covers samples [base + 1024 q, base + 1024 (q + 1)); wave gw takes rows
+// [nrows gw / nwaves, nrows (gw + 1) / nwaves), after running the row before them without stores.
+template <bool U8>
+__global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDChainParams P, const DDCos1kTabs T, int nrows, int nwaves) {
+    extern __shared__ __attribute__((aligned(16))) char c1_smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * C1_WAVES + wave;
+    const int q0 = (int)(((int64_t)nrows * gw) / nwaves), q1 = (int)(((int64_t)nrows * (gw + 1)) / nwaves);
+    if (q1 <= q0) return;
+    char* const lds = c1_smem + wave * C1_WAVE_BYTES;
+    const DDCos1kLane lt = T.lane_tab[lane];
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    v2f ql = (v2f){1.f, 0.f};
+    if (nco) { const float2 q = dd_phasor((uint64_t)(U8 ? 16 * lane : 2 * lane) * P.cyc, P.nco_tbl); ql = (v2f){q.x, q.y}; }
+    // the history part of the LDS image starts as zeros (the hardware does not clear LDS; its old contents may be NaN patterns)
+    if (lane < C1_HIST_GROUPS) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<v4f*>(lds + lane * C1_GROUP_BYTES + 16 * t) = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    C1Carry cr;
+    cr.W = cr.P63 = cr.V63 = (C1St){(v2f){0.f, 0.f}, (v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
+    cr.y63 = (v2f){0.f, 0.f};
+    v4f xin[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xin[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    bool have_xin = false;
+    // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end
+    auto edge = [&](int q) { const int64_t lo = (int64_t)T.base + (int64_t)C1_ROW * q; return lo < P.s || lo + C1_ROW > P.L || q == nrows - 1; };
+    for (int q = q0 - 1; q < q1; ++q) {
+        const int64_t S = (int64_t)T.base + (int64_t)C1_ROW * q;
+        const bool emit = q >= q0;
+        const bool pf = q + 1 < q1 && !edge(q + 1);
+        if (edge(q)) c1_row<U8, true>(P, T, lt, lane, lds, S, emit, pf, xin, have_xin, ql, cr);
+        else c1_row<U8, false>(P, T, lt, lane, lds, S, emit, pf, xin, have_xin, ql, cr);
+    }
+    if (gw == nwaves - 1 && P.tail_out) {
+        // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
+        for (int i = lane; i < C1_K - 1; i += 64) {
+            const int64_t n = P.L - (C1_K - 1) + i;
+            float2 v;
+            if (n < 0) {
+                v = P.tail_in[n + (C1_K - 1)];
+            } else {
+                float2 x;
+                if (U8) {
+                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
+                    x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
+                } else {
+                    x = reinterpret_cast<const float2*>(P.in)[n];
+                }
+                v = nco ? dd_cmul(x, dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl)) : x;
+            }
+            P.tail_out[i] = v;
+        }
+    }
+}
+
+// ============================================================================ host side
+struct DDCos1kState {
+    double a0, a1;
+    DDCos1kLane* lane_tab;
+};
+
+int dd_cos1k_supported(const double* taps, int K, int M, int flags) {
+    if (M != 1 || K != C1_K || !(flags & DD_CHAIN_FM)) return 0;
+    DDCosFit f;
+    if (!dd_cos_fit_cached(taps, K, &f)) return 0;
+    return f.Q == 1 ? 1 : 0;                       // a0 + a1 cos(2 pi k / (K-1)): Hamming, Hann and their relatives
+}
+
+int dd_cos1k_create(void** st, const double* taps, int K) {
+    if (K != C1_K) return DD_ERR_UNSUPPORTED;
+    DDCosFit f;
+    if (!dd_cos_fit_cached(taps, K, &f) || f.Q != 1) return DD_ERR_UNSUPPORTED;
+    DDCos1kState* s = new DDCos1kState();
+    s->a0 = f.a[0];
+    s->a1 = f.a[1];
+    s->lane_tab = nullptr;
+    DDCos1kLane h[64];
+    const long double phi16 = 16.0L * 2.0L * 3.14159265358979323846264338327950288L / (long double)(C1_K - 1);
+    for (int l = 0; l < 64; ++l) {
+        h[l].b15c = (float)cosl(phi16 * ((l & 15) + 1)); h[l].b15s = (float)sinl(phi16 * ((l & 15) + 1));
+        h[l].b31c = (float)cosl(phi16 * ((l & 31) + 1)); h[l].b31s = (float)sinl(phi16 * ((l & 31) + 1));
+    }
+    hipError_t e = hipMalloc((void**)&s->lane_tab, sizeof(h));
+    if (e == hipSuccess) e = hipMemcpy(s->lane_tab, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (s->lane_tab) (void)hipFree(s->lane_tab);
+        delete s;
+        dd_set_error("dd_cos1k_create: %s", hipGetErrorString(e));
+        return DD_ERR_HIP;
+    }
+    *st = s;
+    return DD_OK;
+}
+
+void dd_cos1k_destroy(void* stv) {
+    DDCos1kState* s = reinterpret_cast<DDCos1kState*>(stv);
+    if (!s) return;
+    if (s->lane_tab) (void)hipFree(s->lane_tab);
+    delete s;
+}
+
+// where the row grid sits and how many rows and waves a chunk takes (host arithmetic, also reachable without a GPU: dd_debug_cos1k_plan)
+static void cos1k_plan(int64_t L, int s, int out_align_elems, int ncu, int wg_per_cu, int* base, int* nrows, int* grid, int* nwaves) {
+    int b = s - out_align_elems;                                   // out[b - s] starts a 64-byte line
+    while (b > L - 1) b -= 16;                                     // (a chunk of one sample: the last row must hold sample L - 1)
+    const int64_t nr = (L - b + C1_ROW - 1) / C1_ROW;
+    int g = ncu * (wg_per_cu > 0 ? wg_per_cu : 2);
+    if ((int64_t)g * C1_WAVES > nr) g = (int)((nr + C1_WAVES - 1) / C1_WAVES);
+    *base = b; *nrows = (int)nr; *grid = g; *nwaves = g * C1_WAVES;
+}
+extern "C" int dd_debug_cos1k_plan(int64_t L, int s, int out_align_elems, int ncu, int* out) {
+    DD_REQUIRE(L >= 1 && (s == 0 || s == 1) && out_align_elems >= 0 && out_align_elems < 16 && ncu >= 1 && out, "arguments");
+    cos1k_plan(L, s, out_align_elems, ncu, 2, &out[0], &out[1], &out[2], &out[3]);
+    return DD_OK;
+}
+
+int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
+    DDCos1kState* s = reinterpret_cast<DDCos1kState*>(stv);
+    if (P.L < 1) return DD_OK;
+    static DDOncePerDevice attr;
+    if (attr.need()) {
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        attr.mark();
+    }
+    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
+    const long double phi = PI2 / (long double)(C1_K - 1);
+    const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
+    DDCos1kTabs T;
+    T.c1 = (float)cosl(phi); T.s1 = (float)sinl(phi);
+    T.c2 = (float)cosl(256.0L * phi); T.s2 = (float)sinl(256.0L * phi);
+    T.a0 = (float)s->a0; T.a1 = (float)s->a1;
+    for (int k = 0; k < 4; ++k) { T.wc[k] = (float)cosl(16.0L * phi * (1 << k)); T.ws[k] = (float)sinl(16.0L * phi * (1 << k)); }
+    auto ph = [&](int m) { long double p = frac * (long double)m; p -= floorl(p); const long double a = PI2 * p; return make_float2((float)cosl(a), (float)-sinl(a)); };
+    for (int j = 0; j < 8; ++j) T.qj[j] = ph(128 * j);
+    T.e1 = ph(1);
+    for (int i = 0; i < 16; ++i) T.ei[i] = ph(i);
+    T.lane_tab = s->lane_tab;
+    const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
+    static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
+    int nrows, grid, nwaves;
+    cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &T.base, &nrows, &grid, &nwaves);
+    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_cos1k<true>), dim3(grid), dim3(64 * C1_WAVES), C1_LDS_BYTES, stream, P, T, nrows, nwaves);
+    else hipLaunchKernelGGL((k_chain_cos1k<false>), dim3(grid), dim3(64 * C1_WAVES), C1_LDS_BYTES, stream, P, T, nrows, nwaves);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}

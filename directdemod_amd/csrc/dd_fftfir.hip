@@ -21,6 +21,7 @@
 // block, 224 registers, two waves per SIMD: 0.232 ms, vector pipe 47 % busy); k_chain_fft1k below replaced it.
 #include "dd_chain_kernels.h"
 #include "dd_fftfir.h"
+#include "dd_atan.h"
 #include <stdlib.h>
 #include <complex>
 #include <mutex>
@@ -185,36 +186,9 @@ __device__ __forceinline__ void ff_bfly16(v2f (&a)[16]) {
     ff_bfly16<INV, false>(a, none);
 }
 
-__device__ __forceinline__ float ff_atan2(float y, float x) {
-    // odd degree-15 minimax polynomial on [0,1] + octant fix-up (same as dd_mfma.hip's discriminator)
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * __builtin_amdgcn_rcpf(mx);
-    const float z = t * t;
-    float p = -4.054567120e-03f;
-    p = fmaf(p, z, 2.186295773e-02f);
-    p = fmaf(p, z, -5.591232695e-02f);
-    p = fmaf(p, z, 9.642197381e-02f);
-    p = fmaf(p, z, -1.390862959e-01f);
-    p = fmaf(p, z, 1.994656567e-01f);
-    p = fmaf(p, z, -3.332986079e-01f);
-    p = fmaf(p, z, 9.999993356e-01f);
-    float r = p * t;
-    r = (mx == 0.f) ? 0.f : r;
-    r = (ay > ax) ? 1.5707963267948966f - r : r;
-    r = (x < 0.f) ? 3.141592653589793f - r : r;
-    return copysignf(r, y);
-}
-
-// atan(y/x) for x > 0, |y| <= tan(pi/8) x (minimax fit, 2.3e-8 rad evaluated in f32), no octant logic
-__device__ __forceinline__ float ff_atan_small(float y, float x) {
-    const float t = y * __builtin_amdgcn_rcpf(x);
-    const float z = t * t;
-    float p = fmaf(7.902598251e-02f, z, -1.382445378e-01f);
-    p = fmaf(p, z, 1.997187931e-01f);
-    p = fmaf(p, z, -3.333275667e-01f);
-    return fmaf(t, z * p, t);
-}
+// (the arctangents live in dd_atan.h: shared with dd_cosfir.hip)
+__device__ __forceinline__ float ff_atan2(float y, float x) { return dd_atan2_poly(y, x); }
+__device__ __forceinline__ float ff_atan_small(float y, float x) { return dd_atan_small(y, x); }
 
 // ============================================================================
 // k_chain_fft1k: the same convolution with ONE WAVE PER BLOCK -- 1024-point blocks (16 x 16 x 4), 768 outputs each.

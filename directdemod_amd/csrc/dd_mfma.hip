@@ -29,6 +29,7 @@
 //                      per 4-wave workgroup, fully predicated, same MFMA core.
 #include "dd_chain_kernels.h"
 #include "dd_fftfir.h"
+#include "dd_cosfir.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -941,6 +942,8 @@ struct DDMfmaState {
     std::vector<double> taps;
     void* fft;          // overlap-save FFT form of the interior run (dd_fftfir.hip), lazy
     int fft_tried;
+    void* cos;          // running-sum form for cosine-series windows of 255 taps (dd_cosfir.hip), lazy
+    int cos_tried;
 };
 
 static int mfma_nks_for(int K) {
@@ -991,6 +994,8 @@ int dd_mfma_create(void** st, const double* taps, int K) {
     s->taps.assign(taps, taps + K);
     s->fft = nullptr;
     s->fft_tried = 0;
+    s->cos = nullptr;
+    s->cos_tried = 0;
     hipError_t e = hipMalloc((void**)&s->frag, frag.size() * sizeof(_Float16));
     if (e == hipSuccess) e = hipMemcpy(s->frag, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -1007,6 +1012,7 @@ void dd_mfma_destroy(void* st) {
     DDMfmaState* s = reinterpret_cast<DDMfmaState*>(st);
     if (!s) return;
     if (s->fft) dd_fft_destroy(s->fft);
+    if (s->cos) dd_cos1k_destroy(s->cos);
     (void)hipFree(s->frag);
     delete s;
 }
@@ -1016,13 +1022,14 @@ void dd_mfma_destroy(void* st) {
 // Which M = 1 kernel runs: by tap class, unless a tool or test has forced one.  The choice is a process-wide word set
 // through dd_debug_select_kernel (a debug entry like dd_debug_fill_lds); the environment variable DD_MFMA_KERNEL only
 // seeds it, read ONCE when the first chain is launched (no getenv in the launch path).
-enum { DD_KSEL_UNREAD = -1, DD_KSEL_AUTO = 0, DD_KSEL_AB = 1, DD_KSEL_WS = 2, DD_KSEL_FFT1K = 3 };
+enum { DD_KSEL_UNREAD = -1, DD_KSEL_AUTO = 0, DD_KSEL_AB = 1, DD_KSEL_WS = 2, DD_KSEL_FFT1K = 3, DD_KSEL_COS1K = 4 };
 static std::atomic<int> g_kernel_sel{DD_KSEL_UNREAD};
 static int kernel_sel_parse(const char* name) {
     if (!name || !*name || strcmp(name, "auto") == 0) return DD_KSEL_AUTO;
     if (strcmp(name, "ab") == 0) return DD_KSEL_AB;
     if (strcmp(name, "ws") == 0) return DD_KSEL_WS;
     if (strcmp(name, "fft1k") == 0) return DD_KSEL_FFT1K;
+    if (strcmp(name, "cos1k") == 0) return DD_KSEL_COS1K;
     return -2;
 }
 static int kernel_sel() {
@@ -1037,7 +1044,7 @@ static int kernel_sel() {
 extern "C" int dd_debug_select_kernel(const char* name) {
     const int c = kernel_sel_parse(name);
     if (c < 0) {
-        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k)", name);
+        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k, cos1k)", name);
         return DD_ERR_INVALID;
     }
     g_kernel_sel.store(c, std::memory_order_relaxed);
@@ -1109,6 +1116,21 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     // The FFT kernel's time does not depend on the tap count (0.221 ms per 2^26 samples, 0.207 from raw u8); the MFMA
     // kernel's does: 0.227 ms in the 162..257-tap class, 0.20 below.  FM output only.
     const bool fft_class = NKS == 18;
+    // 255 taps of the form a0 + a1 cos(2 pi k / 254) (filters.hamming) with FM output: the running-sum kernel (dd_cosfir.hip),
+    // a third of the overlap-save form's arithmetic.  "cos1k" forces it wherever it applies (it never applies to other taps),
+    // "fft1k" / "ab" / "ws" keep it off.
+    if ((ksel == DD_KSEL_AUTO || ksel == DD_KSEL_COS1K) && st->K == 255 && (P.flags & DD_CHAIN_FM)) {
+        if (!st->cos && !st->cos_tried) {
+            st->cos_tried = 1;
+            if (!dd_cos1k_supported(st->taps.data(), st->K, 1, P.flags) || dd_cos1k_create(&st->cos, st->taps.data(), st->K) != DD_OK) st->cos = nullptr;
+        }
+        if (st->cos) {
+            int rc = dd_cos1k_launch(st->cos, P, s);
+            if (rc != DD_OK) return rc;
+            if (kernel_id) *kernel_id = DD_KERNEL_COS_RS;
+            return DD_OK;
+        }
+    }
     // (any input alignment: its block grid follows the alignment of `out`, dd_fftfir.hip DDFft1kTabs::base)
     if ((force_fft1k || (fft_class && !force_mfma)) && dd_fft1k_supported(st->K, 1, P.flags)) {
         if (!st->fft && !st->fft_tried) {

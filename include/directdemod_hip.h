@@ -72,7 +72,8 @@ int  dd_host_unregister(void* hptr);
  * suite runs the chain kernels after a NaN fill and after a zero fill and requires bit-identical outputs. */
 int  dd_debug_fill_lds(uint32_t pattern, void* stream);
 /* diagnostic: force one of the M = 1 chain kernels for every later launch of this process -- "ab" (k_chain_mfma_ab), "ws"
- * (k_chain_mfma_ws), "fft1k" (k_chain_fft1k, wherever it applies), "auto" / NULL (by tap class, the default).  The parity,
+ * (k_chain_mfma_ws), "fft1k" (k_chain_fft1k, wherever it applies), "cos1k" (k_chain_cos1k where it applies -- 255 taps of a
+ * two-term cosine series, FM output -- and the choice by tap class elsewhere), "auto" / NULL (by tap class, the default).  The parity,
  * full-size and determinism suites run both FM kernels this way; the environment variable DD_MFMA_KERNEL seeds the choice
  * once per process.  No reference counterpart. */
 int  dd_debug_select_kernel(const char* name);
@@ -91,6 +92,9 @@ int  dd_debug_seam(int withhold_chunk, int spin_log2);
  *   float64 transform of csrc/dd_hconv_kernels.h (512 x 512 for 65 536 < L <= 131 072, 512 x 256 for 32 768 < L <= 65 536), route 1: the FFT
  *   library's padded real transforms. */
 int  dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rounds, int* out);
+/* dd_debug_cos1k_plan -- the row grid of a k_chain_cos1k launch (same arguments): out[0..3] = base (first sample of row 0; row q covers
+ *   samples [base + 1024 q, +1024)), rows, workgroups, waves (wave w takes rows [rows w / waves, rows (w + 1) / waves)). */
+int  dd_debug_cos1k_plan(int64_t L, int s, int out_align_elems, int ncu, int* out);
 int  dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out);
 int  dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, int route, double* env_dev, void* stream);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
@@ -251,6 +255,7 @@ int dd_chain_path(const dd_chain* h);
 #define DD_KERNEL_MFMA_AB 6          /* k_chain_mfma_ab: M = 1, FM or complex64 output, two alternating matrix-wave sets + edge tiles in the same launch */
 #define DD_KERNEL_FFT_OS 7           /* k_chain_fft1k: M = 1, FM output, 162..256 taps: f32 overlap-save FFT convolution, one wave per 1024-point block, NCO commuted into the tap spectrum, whole chunk in one launch */
 #define DD_KERNEL_DECIM_MULTI 8      /* k_chain_decim_multi: M > 1, every chunk of a dd_chain_process_chunks call in one launch */
+#define DD_KERNEL_COS_RS 9           /* k_chain_cos1k: M = 1, FM output, 255 taps a0 + a1 cos(2 pi k / 254) (filters.hamming): the FIR as three running sums, one wave per run of 1024-sample rows, whole chunk in one launch */
 int dd_chain_last_kernel(const dd_chain* h);
 int dd_fir_last_kernel(const dd_fir* h);       /* the same for a filter object driven through dd_fused_process (the drop-in classes) */
 /* HIP-event timing of the last dd_chain_process main kernel is up to the caller. */

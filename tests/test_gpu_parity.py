@@ -312,6 +312,55 @@ def test_fft_kernel_block_edges_and_carried_state(dd, K, f_off, select_kernel):
     fm_check(out.signal, ref, np.concatenate(mags))
 
 
+@pytest.mark.parametrize("window", ["hamming", "hann_like"])
+@pytest.mark.parametrize("f_off", [25000.0, -31000.0, 0.0, 700000.0])
+@pytest.mark.parametrize("u8", [False, True])
+def test_cos_kernel_row_edges_and_carried_state(dd, window, f_off, u8, select_kernel):
+    """k_chain_cos1k (round 5: the default M = 1 FM kernel for 255 taps of the form a0 + a1 cos(2 pi k / 254), filters.py:199): the FIR
+    as three running sums, rows of 1024 samples, one lane per 16 consecutive samples.  Chunks of 1, 2, 253, 1023, 1024, 1025,
+    2047, 2048 ... samples with the state carried (history after the NCO, last FIR output), so that the row grid -- laid by the
+    alignment of `out` -- starts anywhere, edge rows (stream start, carried state, chunk end) and interior rows alternate, and a
+    wave's first row follows a row it ran without stores; complex64 and raw u8 chunks; against the float64 oracle."""
+    select_kernel(None)                                          # the choice by tap class must land on it
+    fs = 2400000
+    cuts = np.cumsum([0, 1, 2, 253, 1023, 1024, 1025, 2047, 2048, 5000, 3, 70001, 777, 4096 * 9 + 5])
+    L = int(cuts[-1])
+    raw = O.synth_iq_fm(L, fs, 2900, f_carrier=f_off if f_off else 1000.0, f_mod=700.0, dev=4.0)      # (the NCO brings the carrier to 0 Hz)
+    x = O.grid_c64(raw)
+    if window == "hamming":
+        taps = O.win_hamming(255)
+        flt = dd.filters.hamming(255)
+    else:
+        taps = 0.5 - 0.42 * np.cos(2.0 * np.pi * np.arange(255) / 254.0)
+        flt = dd.filters.filter(taps, [1])
+    fm = dd.demod_fm.demod_fm()
+    ck = dd.chunker.chunker(_Src(L))
+    out = dd.comm.commSignal(fs)
+    fo = O.FilterState(taps)
+    from directdemod_amd import source
+    rec = source.IQarray(raw, fs) if u8 else None
+    last, idx, refs, mags = None, 0, [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        src = rec.read_device_raw(int(a), int(b)) if u8 else x[a:b]
+        s = dd.comm.commSignal(fs, src, ck)
+        if f_off:
+            s.offsetFreq(f_off)
+        s.filter(flt).funcApply(fm.demod)
+        out.extend(s)
+        y = fo.applyOn(O.nco(x[a:b], f_off, fs, idx) if f_off else x[a:b])
+        idx += b - a
+        prv = last
+        r, last = O.fm_demod(y, last)
+        refs.append(r)
+        yy = y if prv is None else np.concatenate([[prv], y])
+        mags.append(np.abs(yy[1:] * np.conj(yy[:-1])))
+    ref = np.concatenate(refs)
+    assert out.length == len(ref) == L - 1
+    got = out.signal
+    assert flt._last_kernel() == dd.hip.DD_KERNEL_COS_RS
+    fm_check(got, ref, np.concatenate(mags))
+
+
 @pytest.mark.parametrize("K", [162, 255, 256])
 @pytest.mark.parametrize("f_off", [25000.0, -700000.0, 0.0])
 @pytest.mark.parametrize("u8", [False, True])

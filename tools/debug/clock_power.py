@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Shader clock and package power (rocm-smi / amd-smi, read-only) sampled while one kernel runs in a loop:
    KERNEL=fft1k|ab  [LIB=build/variants/lib_N.so]  python tools/debug/clock_power.py"""
-import ctypes as C, os, shutil, subprocess, sys, threading, time
+import ctypes as C, os, subprocess, sys, threading, time
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
-if os.environ.get("LIB"):
-    shutil.copy(os.environ["LIB"], os.path.join(root, "directdemod_amd", "libdirectdemod_hip.so"))
+if os.environ.get("LIB"):                      # a variant build is LOADED in place of the product library, never copied over it
+    os.environ["DD_LIB_PATH"] = os.environ["LIB"]
 import torch
 from directdemod_amd import _hip
 import bench

@@ -1,10 +1,9 @@
 #!/bin/bash
 # shader clock and package power (rocm-smi, read-only) while one kernel loops: the two product kernels and every build/variants/lib_N.so
-cp directdemod_amd/libdirectdemod_hip.so /tmp/lib_orig.so
 DUR=4 KERNEL=ab python3 tools/debug/clock_power.py 2>&1 | python3 tools/debug/clock_power_summ.py
 DUR=4 KERNEL=fft1k python3 tools/debug/clock_power.py 2>&1 | python3 tools/debug/clock_power_summ.py
 for f in build/variants/lib_*.so; do
-  i=$(basename $f .so | sed 's/lib_//'); cp $f directdemod_amd/libdirectdemod_hip.so; echo "variant $(sed -n ${i}p build/variants/index.txt)"
-  DUR=4 KERNEL=fft1k python3 tools/debug/clock_power.py 2>&1 | python3 tools/debug/clock_power_summ.py
+  [ -f "$f" ] || continue
+  i=$(basename $f .so | sed 's/lib_//'); echo "variant $(sed -n ${i}p build/variants/index.txt)"
+  DUR=4 KERNEL=fft1k LIB=$f python3 tools/debug/clock_power.py 2>&1 | python3 tools/debug/clock_power_summ.py
 done
-cp /tmp/lib_orig.so directdemod_amd/libdirectdemod_hip.so

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Cycles per phase of k_chain_fft1k's block (library built with -DFF_TRACE: tools/mkvariant.sh N dd_fftfir -DFF_TRACE ...).
 usage: LIB=build/variants/lib_N.so python tools/debug/fft_trace.py"""
-import ctypes as C, os, shutil, sys
+import ctypes as C, os, sys
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
-if os.environ.get("LIB"):
-    shutil.copy(os.environ["LIB"], os.path.join(root, "directdemod_amd", "libdirectdemod_hip.so"))
+if os.environ.get("LIB"):                      # a variant build is LOADED in place of the product library, never copied over it
+    os.environ["DD_LIB_PATH"] = os.environ["LIB"]
 import torch
 from directdemod_amd import _hip
 import bench
