@@ -41,29 +41,42 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define C1_K 255
 #define C1_ROW 1024
 #define C1_GROUP_BYTES 144                     // 16 samples of 8 bytes + 16 bytes of padding
-#define C1_HIST_GROUPS 16
-#define C1_WAVE_BYTES ((C1_HIST_GROUPS + 64) * C1_GROUP_BYTES)      // 11520
+#define C1_BUF_BYTES (64 * C1_GROUP_BYTES)     // one row after the NCO: 9216
+#define C1_WAVE_BYTES (2 * C1_BUF_BYTES)       // this row and the one before it (whose last 16 groups are the samples 255 back of lanes 0..15)
 #define C1_WAVES 4
 #define C1_LDS_BYTES (C1_WAVES * C1_WAVE_BYTES)
 
 struct DDCos1kLane { float b15c, b15s, b31c, b31s; };   // rotation by 16 phi ((lane & 15) + 1) and by 16 phi ((lane & 31) + 1)
 
-struct DDCos1kTabs {
-    float c1, s1;          // rotation by phi
-    float c2, s2;          // rotation by 256 phi (= 2 phi)
-    float a0, a1;          // y = a0 R + a1 C
-    float wc[4], ws[4];    // rotation by 16 phi 2^k, k = 0..3
-    float2 qj[8];          // e^{-j w 128 j}: row-major load layout (complex64 input)
-    float2 e1;             // e^{-j w}
-    float2 ei[16];         // e^{-j w i}: lane-contiguous layout (u8 input)
+// the kernel's only argument
+struct DDCos1kArgs {
+    const void* in;            // complex64 or interleaved u8
+    float* out;                // angles
+    const float2* tail_in;     // 254 samples after the NCO that precede the chunk
+    float2* tail_out;
+    const float2* lasty_in;    // FIR output before the chunk's first sample
+    float2* lasty_out;
+    const float2* nco_tbl;     // 4096-entry phasor table
     const DDCos1kLane* lane_tab;
-    int base;              // first sample of row 0 (chunk-relative)
+    uint64_t cyc;              // frac(f / fs) 2^64
+    int64_t abs0;              // absolute index of in[0]
+    int64_t L;
+    int s;                     // 1: stream start, no angle for sample 0
+    int base;                  // first sample of row 0 (chunk-relative)
+    int nrows, nwaves;
+    float c1, s1;              // rotation by phi
+    float c2, s2;              // rotation by 256 phi (= 2 phi)
+    float a0, a1;              // y = a0 R + a1 C
+    float wc[4], ws[4];        // rotation by 16 phi 2^k, k = 0..3
+    float2 q1, q2, q4;         // e^{-j w 128}, e^{-j w 256}, e^{-j w 512}: row-major load layout (complex64 input)
+    float2 e1, e2, e3, e4, e8; // e^{-j w i}: lane-contiguous layout (u8 input; e1 also pairs the complex64 samples)
 };
 
 __device__ __forceinline__ v2f c1_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f c1_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f){a, a}, b, c); }
 // complex product as one packed multiply and one packed multiply-add
 __device__ __forceinline__ v2f c1_cmul(v2f a, v2f b) { return c1_fma(a.x, b, (v2f){-a.y, a.y} * (v2f){b.y, b.x}); }
+__device__ __forceinline__ v2f c1_v2(float2 a) { return (v2f){a.x, a.y}; }
 
 template <int CTRL>
 __device__ __forceinline__ float c1_dpp0(float v) {                         // lanes without a source lane read 0 (bound_ctrl)
@@ -109,36 +122,50 @@ struct C1Carry {
     C1St P63;        // the previous row's P_63 (wave-uniform)
     C1St V63;        // windowed state at the previous row's last sample (wave-uniform): enters lane 0
     v2f y63;         // the previous row's last FIR output (wave-uniform): y[n-1] of lane 0's first sample
+    v2f prow;        // e^{-j w (abs0 + S)} of the NEXT row times the lane's own factor, looked up a row ahead (the table read is a
+                     // dependent global load: taken at the top of a row it stalls the wave for a memory round trip per row)
+    int cur;         // byte offset of this row's LDS buffer in the wave's image (0 or C1_BUF_BYTES; the other one holds the row before)
 };
 
 // Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
 //   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
 //   C1_ABL_NO_LDS    no LDS traffic           C1_ABL_NO_FM     no discriminator         C1_ABL_NO_SCAN    no scan / window stage
 template <bool U8>
-__device__ __forceinline__ void c1_issue_loads(const DDChainParams& P, int64_t S, int lane, v4f (&xin)[8]) {
+__device__ __forceinline__ void c1_issue_loads(const DDCos1kArgs& A, int64_t S, int lane, v4f (&xin)[8]) {
 #ifdef C1_ABL_NO_LOAD
     return;
 #endif
     if (U8) {
-        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const unsigned char*>(P.in) + 2 * (S + 16 * lane));
+        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const unsigned char*>(A.in) + 2 * (S + 16 * lane));
         xin[0] = __builtin_nontemporal_load(p);
         xin[1] = __builtin_nontemporal_load(p + 1);
     } else {
-        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const float2*>(P.in) + S + 2 * lane);
+        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const float2*>(A.in) + S + 2 * lane);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xin[j] = __builtin_nontemporal_load(p + 64 * j);
     }
 }
 
+template <bool NCO>
+__device__ __forceinline__ v2f c1_row_phasor(const DDCos1kArgs& A, int64_t S, v2f ql) {
+    if (!NCO) return (v2f){1.f, 0.f};
+#ifdef C1_ABL_NO_PHASOR
+    return c1_cmul((v2f){0.6f, 0.8f}, ql);
+#else
+    return c1_cmul(c1_v2(dd_phasor((uint64_t)(A.abs0 + S) * A.cyc, A.nco_tbl)), ql);
+#endif
+}
+
 // One row.  EDGE: sample-by-sample loads (history, chunk end), predicated stores, the carried FIR output.  emit: store angles.
-template <bool U8, bool EDGE>
-__device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs& T, const DDCos1kLane& lt, const int lane, char* const lds,
-                                       const int64_t S, const bool emit, const bool prefetch_next, v4f (&xin)[8], bool& have_xin,
-                                       const v2f ql, C1Carry& cr) {
-    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
-    const float c = T.c1, s = T.s1;
-    char* const own = lds + (C1_HIST_GROUPS + lane) * C1_GROUP_BYTES;          // this lane's 16 samples of the row
-    const char* const old = lds + lane * C1_GROUP_BYTES;                       // lane - 16's (previous row's lanes 48.. for L < 16)
+template <bool U8, bool NCO, bool EDGE>
+__device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds,
+                                       const int64_t S, const bool emit, const bool prefetch_next, const bool next_is_fast,
+                                       v4f (&xin)[8], bool& have_xin, const v2f ql, C1Carry& cr) {
+    const float c = A.c1, s = A.s1;
+    char* const cur = lds + cr.cur;
+    char* const own = cur + lane * C1_GROUP_BYTES;                              // this lane's 16 samples of the row
+    // lane - 16's group: this row's for lanes 16.., the previous row's lanes 48.. for lanes 0..15
+    const char* const old = lane < 16 ? lds + (C1_BUF_BYTES - cr.cur) + (48 + lane) * C1_GROUP_BYTES : cur + (lane - 16) * C1_GROUP_BYTES;
     v2f xt[16];
     if (EDGE) {
 #pragma unroll
@@ -147,17 +174,17 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
             v2f v = (v2f){0.f, 0.f};
             if (n < 0) {
                 const int64_t ti = n + (C1_K - 1);
-                if (ti >= 0) { const float2 h = P.tail_in[ti]; v = (v2f){h.x, h.y}; }       // (after the NCO already)
-            } else if (n < P.L) {
+                if (ti >= 0) v = c1_v2(A.tail_in[ti]);                           // (after the NCO already)
+            } else if (n < A.L) {
                 float2 x;
                 if (U8) {
-                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
+                    const uchar2 u = reinterpret_cast<const uchar2*>(A.in)[n];
                     x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
                 } else {
-                    x = reinterpret_cast<const float2*>(P.in)[n];
+                    x = reinterpret_cast<const float2*>(A.in)[n];
                 }
-                if (nco) x = dd_cmul(x, dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl));
-                v = (v2f){x.x, x.y};
+                if (NCO) x = dd_cmul(x, dd_phasor((uint64_t)(A.abs0 + n) * A.cyc, A.nco_tbl));
+                v = c1_v2(x);
             }
             xt[i] = v;
         }
@@ -165,42 +192,57 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
         for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
         have_xin = false;
     } else {
-        if (!have_xin) c1_issue_loads<U8>(P, S, lane, xin);
-        v2f prow = (v2f){1.f, 0.f};
-#ifdef C1_ABL_NO_PHASOR
-        if (nco) prow = c1_cmul((v2f){0.6f, 0.8f}, ql);
-#else
-        if (nco) { const float2 pr = dd_phasor((uint64_t)(P.abs0 + S) * P.cyc, P.nco_tbl); prow = c1_cmul((v2f){pr.x, pr.y}, ql); }
-#endif
+        if (!have_xin) { c1_issue_loads<U8>(A, S, lane, xin); cr.prow = c1_row_phasor<NCO>(A, S, ql); }
+        const v2f prow = cr.prow;
         if (U8) {
             // 32 bytes = the lane's own 16 samples: (x - 127.5) e^{-j w (S + 16 L + i)}
-            const unsigned* w = reinterpret_cast<const unsigned*>(&xin[0]);
             unsigned u[8];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { u[t] = __float_as_uint(xin[0][t]); u[4 + t] = __float_as_uint(xin[1][t]); }
-            (void)w;
+            v2f p4[4];
+            if (NCO) {
+                p4[0] = prow;
+                p4[1] = c1_cmul(prow, c1_v2(A.e4));
+                p4[2] = c1_cmul(prow, c1_v2(A.e8));
+                p4[3] = c1_cmul(p4[2], c1_v2(A.e4));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const unsigned word = u[i >> 1];
                 const float re = (float)((word >> (16 * (i & 1))) & 0xFF) - 127.5f;
                 const float im = (float)((word >> (16 * (i & 1) + 8)) & 0xFF) - 127.5f;
                 v2f x = (v2f){re, im};
-                if (nco) x = c1_cmul(x, i ? c1_cmul(prow, (v2f){T.ei[i].x, T.ei[i].y}) : prow);
+                if (NCO) {
+                    const v2f pb = p4[i >> 2];
+                    const v2f pi = (i & 3) == 0 ? pb : c1_cmul(pb, c1_v2((i & 3) == 1 ? A.e1 : ((i & 3) == 2 ? A.e2 : A.e3)));
+                    x = c1_cmul(x, pi);
+                }
                 xt[i] = x;
             }
+#ifndef C1_ABL_NO_LDS
 #pragma unroll
             for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
+#endif
         } else {
             // row-major registers: xin[j] = samples 128 j + 2 l, + 1  ->  NCO  ->  LDS, group 8 j + (l >> 3), slot l & 7
-            char* const wr = lds + (C1_HIST_GROUPS + (lane >> 3)) * C1_GROUP_BYTES + 16 * (lane & 7);
+            char* const wr = cur + (lane >> 3) * C1_GROUP_BYTES + 16 * (lane & 7);
+            v2f pj[8];
+            if (NCO) {
+                pj[0] = prow;
+                pj[1] = c1_cmul(prow, c1_v2(A.q1));
+                pj[2] = c1_cmul(prow, c1_v2(A.q2));
+                pj[3] = c1_cmul(pj[2], c1_v2(A.q1));
+                pj[4] = c1_cmul(prow, c1_v2(A.q4));
+                pj[5] = c1_cmul(pj[4], c1_v2(A.q1));
+                pj[6] = c1_cmul(pj[4], c1_v2(A.q2));
+                pj[7] = c1_cmul(pj[6], c1_v2(A.q1));
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v2f x0 = (v2f){xin[j].x, xin[j].y}, x1 = (v2f){xin[j].z, xin[j].w};
-                if (nco) {
-                    const v2f pj = j ? c1_cmul(prow, (v2f){T.qj[j].x, T.qj[j].y}) : prow;
-                    const v2f pj1 = c1_cmul(pj, (v2f){T.e1.x, T.e1.y});
-                    x0 = c1_cmul(x0, pj);
-                    x1 = c1_cmul(x1, pj1);
+                if (NCO) {
+                    x0 = c1_cmul(x0, pj[j]);
+                    x1 = c1_cmul(x1, c1_cmul(pj[j], c1_v2(A.e1)));
                 }
 #ifdef C1_ABL_NO_LDS
                 xt[2 * j] = x0; xt[2 * j + 1] = x1;
@@ -212,7 +254,8 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
         have_xin = false;
     }
     // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order)
-    if (prefetch_next) { c1_issue_loads<U8>(P, S + C1_ROW, lane, xin); have_xin = true; }
+    if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xin); have_xin = true; }
+    if (next_is_fast) cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql);
 #ifndef C1_ABL_NO_LDS
     if (!EDGE && !U8) {
 #pragma unroll
@@ -236,7 +279,8 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
         d[2 * t - 1] = (v2f){v.x, v.y};
         d[2 * t] = (v2f){v.z, v.w};
     }
-    d[15] = *reinterpret_cast<const v2f*>(old + C1_GROUP_BYTES);
+    // (the first sample of the NEXT group: lane 15's is the first sample of this row, in this row's buffer)
+    d[15] = *reinterpret_cast<const v2f*>(lane == 15 ? cur : old + C1_GROUP_BYTES);
 #endif
     // ---- pass A: lane totals of the un-windowed recurrence
     C1St t = {xt[0], (v2f){0.f, 0.f}, xt[0]};
@@ -249,10 +293,10 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
     }
     // ---- inclusive weighted scan over the 64 lanes
 #ifndef C1_ABL_NO_SCAN
-    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, T.wc[0], T.ws[0]);
-    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, T.wc[1], T.ws[1]);
-    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, T.wc[2], T.ws[2]);
-    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, T.wc[3], T.ws[3]);
+    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, A.wc[0], A.ws[0]);
+    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, A.wc[1], A.ws[1]);
+    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, A.wc[2], A.ws[2]);
+    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, A.wc[3], A.ws[3]);
     c1_scan_step<0x142, 0xA>(t, lt.b15c, lt.b15s);          // row_bcast:15 into rows 1 and 3
     c1_scan_step<0x143, 0xC>(t, lt.b31c, lt.b31s);          // row_bcast:31 into rows 2 and 3
 #endif
@@ -270,8 +314,8 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
     const float uc = low ? lt.b15c : 0.f, us = low ? lt.b15s : 0.f, ur = low ? 1.f : 0.f;      // A^{16 (L + 1)} for L < 16
     const v2f e = d[15];
     C1St V;
-    V.C = c1_fma(-T.c2, W.C, c1_fma(T.s2, W.S, c1_fma(-c, e, t.C)));
-    V.S = c1_fma(-T.s2, W.C, c1_fma(-T.c2, W.S, c1_fma(-s, e, t.S)));
+    V.C = c1_fma(-A.c2, W.C, c1_fma(A.s2, W.S, c1_fma(-c, e, t.C)));
+    V.S = c1_fma(-A.s2, W.C, c1_fma(-A.c2, W.S, c1_fma(-s, e, t.S)));
     V.R = t.R - W.R - e;
     V.C = c1_fma(uc, cr.P63.C, c1_fma(-us, cr.P63.S, V.C));
     V.S = c1_fma(us, cr.P63.C, c1_fma(uc, cr.P63.S, V.S));
@@ -294,23 +338,16 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
         u.S = c1_fma(s, u.C, c1_fma(c, u.S, bS));
         u.C = Cn;
         u.R += xt[i] - d[i];
-        y[i] = c1_fma(T.a0, u.R, T.a1 * u.C);
+        y[i] = c1_fma(A.a0, u.R, A.a1 * u.C);
     }
-    // the row's last 256 samples are the next row's history
-#ifndef C1_ABL_NO_LDS
-    if (lane >= 48) {
-        char* const h = lds + (lane - 48) * C1_GROUP_BYTES;
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) *reinterpret_cast<v4f*>(h + 16 * tt) = (v4f){xt[2 * tt].x, xt[2 * tt].y, xt[2 * tt + 1].x, xt[2 * tt + 1].y};
-    }
-#endif
+    cr.cur = C1_BUF_BYTES - cr.cur;                          // this row's buffer is the next row's "row before"
     if (EDGE) {
         // the FIR output before the chunk's first sample is carried state (demod_fm.py:47-49); the chunk's last one becomes it
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t n = S + 16 * lane + i;
-            if (P.s == 0 && n == -1) { const float2 ly = *P.lasty_in; y[i] = (v2f){ly.x, ly.y}; }
-            if (n == P.L - 1 && P.lasty_out) *P.lasty_out = make_float2(y[i].x, y[i].y);
+            if (A.s == 0 && n == -1) y[i] = c1_v2(*A.lasty_in);
+            if (n == A.L - 1 && A.lasty_out) *A.lasty_out = make_float2(y[i].x, y[i].y);
         }
     }
     const v2f yl = c1_shr1(y[15], cr.y63);
@@ -345,28 +382,29 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
 #endif
     }
     if (EDGE) {
-        float* const o = reinterpret_cast<float*>(P.out) + (S - P.s) + 16 * lane;
+        float* const o = A.out + (S - A.s) + 16 * lane;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t n = S + 16 * lane + i;
-            if (n >= P.s && n < P.L) o[i] = ang[i];
+            if (n >= A.s && n < A.L) o[i] = ang[i];
         }
         return;
     }
     // The lane holds 16 consecutive angles (one 64-byte line); a store instruction made of 64 such lines costs four times a
     // coalesced one in the memory pipeline (measured: the kernel at 0.42 ms with them, 0.14 ms without any store).  So the angles
-    // cross the wave through LDS -- the row's sample image is dead by now -- and leave as four 1 KB row-major stores.
+    // cross the wave through LDS -- the first 4 KB of the row's sample image, which nothing reads any more (the next row's lanes
+    // 0..15 look at its LAST 16 groups) -- and leave as four 1 KB row-major stores.
     // Image: angle m of the row at dword 16 (m >> 4) + 4 (((m >> 2) & 3) ^ ((m >> 5) & 3)) + (m & 3): unpadded, the 16-byte chunks of
     // a lane's line swizzled by its lane pair, which keeps the eight lanes of a ds_write_b128 group and the sixteen of a
     // ds_read_b128 group on distinct banks.
-    char* const img = lds + C1_HIST_GROUPS * C1_GROUP_BYTES;
+    char* const img = cur;
     {
         const int sw = (lane >> 1) & 3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             *reinterpret_cast<v4f*>(img + 64 * lane + 16 * (t ^ sw)) = (v4f){ang[4 * t], ang[4 * t + 1], ang[4 * t + 2], ang[4 * t + 3]};
     }
-    float* const o = reinterpret_cast<float*>(P.out) + (S - P.s) + 4 * lane;
+    float* const o = A.out + (S - A.s) + 4 * lane;
     {
         const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
 #pragma unroll
@@ -383,57 +421,60 @@ __device__ __forceinline__ void c1_row(const DDChainParams& P, const DDCos1kTabs
 
 // The whole chunk in one launch.  Row q covers samples [base + 1024 q, base + 1024 (q + 1)); wave gw takes rows
 // [nrows gw / nwaves, nrows (gw + 1) / nwaves), after running the row before them without stores.
-template <bool U8>
-__global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDChainParams P, const DDCos1kTabs T, int nrows, int nwaves) {
+template <bool U8, bool NCO>
+__global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kArgs A) {
     extern __shared__ __attribute__((aligned(16))) char c1_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * C1_WAVES + wave;
+    const int nrows = A.nrows, nwaves = A.nwaves;
     const int q0 = (int)(((int64_t)nrows * gw) / nwaves), q1 = (int)(((int64_t)nrows * (gw + 1)) / nwaves);
     if (q1 <= q0) return;
     char* const lds = c1_smem + wave * C1_WAVE_BYTES;
-    const DDCos1kLane lt = T.lane_tab[lane];
-    const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
+    const DDCos1kLane lt = A.lane_tab[lane];
     v2f ql = (v2f){1.f, 0.f};
-    if (nco) { const float2 q = dd_phasor((uint64_t)(U8 ? 16 * lane : 2 * lane) * P.cyc, P.nco_tbl); ql = (v2f){q.x, q.y}; }
-    // the history part of the LDS image starts as zeros (the hardware does not clear LDS; its old contents may be NaN patterns)
-    if (lane < C1_HIST_GROUPS) {
+    if (NCO) ql = c1_v2(dd_phasor((uint64_t)(U8 ? 16 * lane : 2 * lane) * A.cyc, A.nco_tbl));
+    // the "row before" of the wave's first row starts as zeros where it is read (the hardware does not clear LDS; its old
+    // contents may be NaN patterns): the last 16 groups of the second buffer, plus the word after it that lane 15 of a row never reads
+    if (lane < 16) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) *reinterpret_cast<v4f*>(lds + lane * C1_GROUP_BYTES + 16 * t) = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<v4f*>(lds + C1_BUF_BYTES + (48 + lane) * C1_GROUP_BYTES + 16 * t) = (v4f){0.f, 0.f, 0.f, 0.f};
     }
     C1Carry cr;
     cr.W = cr.P63 = cr.V63 = (C1St){(v2f){0.f, 0.f}, (v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
     cr.y63 = (v2f){0.f, 0.f};
+    cr.prow = (v2f){1.f, 0.f};
+    cr.cur = 0;
     v4f xin[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) xin[j] = (v4f){0.f, 0.f, 0.f, 0.f};
     bool have_xin = false;
     // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end
-    auto edge = [&](int q) { const int64_t lo = (int64_t)T.base + (int64_t)C1_ROW * q; return lo < P.s || lo + C1_ROW > P.L || q == nrows - 1; };
+    auto edge = [&](int q) { const int64_t lo = (int64_t)A.base + (int64_t)C1_ROW * q; return lo < A.s || lo + C1_ROW > A.L || q == nrows - 1; };
     for (int q = q0 - 1; q < q1; ++q) {
-        const int64_t S = (int64_t)T.base + (int64_t)C1_ROW * q;
+        const int64_t S = (int64_t)A.base + (int64_t)C1_ROW * q;
         const bool emit = q >= q0;
         const bool pf = q + 1 < q1 && !edge(q + 1);
-        if (edge(q)) c1_row<U8, true>(P, T, lt, lane, lds, S, emit, pf, xin, have_xin, ql, cr);
-        else c1_row<U8, false>(P, T, lt, lane, lds, S, emit, pf, xin, have_xin, ql, cr);
+        if (edge(q)) c1_row<U8, NCO, true>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
+        else c1_row<U8, NCO, false>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
     }
-    if (gw == nwaves - 1 && P.tail_out) {
+    if (gw == nwaves - 1 && A.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < C1_K - 1; i += 64) {
-            const int64_t n = P.L - (C1_K - 1) + i;
+            const int64_t n = A.L - (C1_K - 1) + i;
             float2 v;
             if (n < 0) {
-                v = P.tail_in[n + (C1_K - 1)];
+                v = A.tail_in[n + (C1_K - 1)];
             } else {
                 float2 x;
                 if (U8) {
-                    const uchar2 u = reinterpret_cast<const uchar2*>(P.in)[n];
+                    const uchar2 u = reinterpret_cast<const uchar2*>(A.in)[n];
                     x = make_float2((float)u.x - 127.5f, (float)u.y - 127.5f);
                 } else {
-                    x = reinterpret_cast<const float2*>(P.in)[n];
+                    x = reinterpret_cast<const float2*>(A.in)[n];
                 }
-                v = nco ? dd_cmul(x, dd_phasor((uint64_t)(P.abs0 + n) * P.cyc, P.nco_tbl)) : x;
+                v = NCO ? dd_cmul(x, dd_phasor((uint64_t)(A.abs0 + n) * A.cyc, A.nco_tbl)) : x;
             }
-            P.tail_out[i] = v;
+            A.tail_out[i] = v;
         }
     }
 }
@@ -504,30 +545,38 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     if (P.L < 1) return DD_OK;
     static DDOncePerDevice attr;
     if (attr.need()) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
         attr.mark();
     }
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
     const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
     const long double phi = PI2 / (long double)(C1_K - 1);
     const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
-    DDCos1kTabs T;
-    T.c1 = (float)cosl(phi); T.s1 = (float)sinl(phi);
-    T.c2 = (float)cosl(256.0L * phi); T.s2 = (float)sinl(256.0L * phi);
-    T.a0 = (float)s->a0; T.a1 = (float)s->a1;
-    for (int k = 0; k < 4; ++k) { T.wc[k] = (float)cosl(16.0L * phi * (1 << k)); T.ws[k] = (float)sinl(16.0L * phi * (1 << k)); }
+    DDCos1kArgs A;
+    A.in = P.in; A.out = reinterpret_cast<float*>(P.out);
+    A.tail_in = P.tail_in; A.tail_out = P.tail_out; A.lasty_in = P.lasty_in; A.lasty_out = P.lasty_out;
+    A.nco_tbl = P.nco_tbl; A.lane_tab = s->lane_tab;
+    A.cyc = P.cyc; A.abs0 = P.abs0; A.L = P.L; A.s = P.s;
+    A.c1 = (float)cosl(phi); A.s1 = (float)sinl(phi);
+    A.c2 = (float)cosl(256.0L * phi); A.s2 = (float)sinl(256.0L * phi);
+    A.a0 = (float)s->a0; A.a1 = (float)s->a1;
+    for (int k = 0; k < 4; ++k) { A.wc[k] = (float)cosl(16.0L * phi * (1 << k)); A.ws[k] = (float)sinl(16.0L * phi * (1 << k)); }
     auto ph = [&](int m) { long double p = frac * (long double)m; p -= floorl(p); const long double a = PI2 * p; return make_float2((float)cosl(a), (float)-sinl(a)); };
-    for (int j = 0; j < 8; ++j) T.qj[j] = ph(128 * j);
-    T.e1 = ph(1);
-    for (int i = 0; i < 16; ++i) T.ei[i] = ph(i);
-    T.lane_tab = s->lane_tab;
+    A.q1 = ph(128); A.q2 = ph(256); A.q4 = ph(512);
+    A.e1 = ph(1); A.e2 = ph(2); A.e3 = ph(3); A.e4 = ph(4); A.e8 = ph(8);
     const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
     static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
-    int nrows, grid, nwaves;
-    cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &T.base, &nrows, &grid, &nwaves);
-    if (P.flags & DD_CHAIN_U8_INPUT) hipLaunchKernelGGL((k_chain_cos1k<true>), dim3(grid), dim3(64 * C1_WAVES), C1_LDS_BYTES, stream, P, T, nrows, nwaves);
-    else hipLaunchKernelGGL((k_chain_cos1k<false>), dim3(grid), dim3(64 * C1_WAVES), C1_LDS_BYTES, stream, P, T, nrows, nwaves);
+    int grid;
+    cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
+    const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
+    const dim3 g(grid), b(64 * C1_WAVES);
+    if (u8 && nco) hipLaunchKernelGGL((k_chain_cos1k<true, true>), g, b, C1_LDS_BYTES, stream, A);
+    else if (u8) hipLaunchKernelGGL((k_chain_cos1k<true, false>), g, b, C1_LDS_BYTES, stream, A);
+    else if (nco) hipLaunchKernelGGL((k_chain_cos1k<false, true>), g, b, C1_LDS_BYTES, stream, A);
+    else hipLaunchKernelGGL((k_chain_cos1k<false, false>), g, b, C1_LDS_BYTES, stream, A);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

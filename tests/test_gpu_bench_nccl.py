@@ -45,5 +45,5 @@ def test_one_rank_through_the_nccl_branch():
     assert 0 <= j["extra"]["rccl_init_s"] < 60                     # rendezvous + communicator set-up, as the 8-GPU record will show it
     assert j["extra"]["gathered_outputs"] == n - 1                 # rank 0 of a stream owns one output fewer (quirk Q3)
     assert j["extra"]["with_all_gather_MSamples_per_s"] > 0 and j["extra"]["all_gather_ms_per_step"] > 0
-    assert j["config"]["kernel"] == "k_chain_fft1k" and j["data"] == "synthetic"
+    assert j["config"]["kernel"] == "k_chain_cos1k" and j["data"] == "synthetic"
     assert 0.005 < j["extra"]["output_rms_rad"] < 0.02             # the demodulated 1 kHz tone (deviation 5 rad)

@@ -31,7 +31,7 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
     j = json.loads(lines[0])
     n = 1 << 22
     assert j["n_gpus"] == 2 and j["config"]["samples_per_gpu"] == n and j["scaling"] == "weak"
-    assert j["config"]["kernel"] == "k_chain_fft1k" and j["data"].startswith("synthetic")
+    assert j["config"]["kernel"] == "k_chain_cos1k" and j["data"].startswith("synthetic")
     assert len(j["extra"]["kernel_ms_per_rank"]) == 2 and all(t > 0 for t in j["extra"]["kernel_ms_per_rank"])
     # the gather leg runs without being asked for
     assert j["extra"]["gathered_outputs"] == 2 * n - 1

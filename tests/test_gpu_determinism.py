@@ -83,13 +83,18 @@ def _hamming(K):
 
 @pytest.mark.parametrize("ntaps", [255, 151, 63])
 @pytest.mark.parametrize("u8", [False, True])
-@pytest.mark.parametrize("kernel", ["auto", "ab", "fft1k"])
+@pytest.mark.parametrize("kernel", ["auto", "ab", "fft1k", "cos1k"])
 def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, select_kernel):
     """NCO + FIR + FM at M = 1: k_chain_fft1k (the 162..256-tap class by default, every class when forced: no atomics, one
     wave per block, LDS image rewritten completely before it is read) and k_chain_mfma_ab (every tap class) with the edge
     tiles riding along."""
     select_kernel(None if kernel == "auto" else kernel)
-    want = g.hip.DD_KERNEL_FFT_OS if (kernel == "fft1k" or (kernel == "auto" and ntaps > 161)) else g.hip.DD_KERNEL_MFMA_AB
+    if ntaps == 255 and kernel in ("auto", "cos1k"):
+        want = g.hip.DD_KERNEL_COS_RS                            # Hamming 255: the running-sum kernel (round 5)
+    elif kernel == "fft1k" or (kernel in ("auto", "cos1k") and ntaps > 161):
+        want = g.hip.DD_KERNEL_FFT_OS
+    else:
+        want = g.hip.DD_KERNEL_MFMA_AB
     t = g.torch
     n = (1 << 23) + 12345
     x = g.bench.make_input(t, n, 0, g.dev, 5 + ntaps)

@@ -36,10 +36,10 @@ def _wrapped_max(torch, a, b, blk=1 << 24):
     return m
 
 
-@pytest.fixture(scope="module", params=["fft1k", "ab"])
+@pytest.fixture(scope="module", params=["cos1k", "fft1k", "ab"])
 def run(request):
-    """every test of this module under both M = 1 FM kernels: k_chain_fft1k (the default for 255 taps) and, forced with
-    dd_debug_select_kernel("ab"), k_chain_mfma_ab"""
+    """every test of this module under the three M = 1 FM kernels: k_chain_cos1k (the default for Hamming 255 since round 5) and,
+    forced with dd_debug_select_kernel, k_chain_fft1k and k_chain_mfma_ab"""
     torch = pytest.importorskip("torch")
     old_env = os.environ.get("DD_MFMA_KERNEL")
     import __graft_entry__ as ge
@@ -47,7 +47,7 @@ def run(request):
         ge.build()
     from directdemod_amd import _hip
     _hip.require_gpu()
-    _hip.select_kernel("ab" if request.param == "ab" else None)
+    _hip.select_kernel(None if request.param == "cos1k" else request.param)   # (cos1k: what the choice by tap class lands on)
     import bench
     n = 1 << LOG2N
     dev = torch.device("cuda", 0)
@@ -72,7 +72,7 @@ def run(request):
     one = torch.empty(n, dtype=torch.float32, device=dev)
     assert process(h, x.data_ptr(), one.data_ptr(), n) == n - 1          # quirk Q3: first chunk is one short
     assert lib.dd_chain_path(h) == 1                                     # the MFMA path ran ...
-    want = _hip.DD_KERNEL_MFMA_AB if request.param == "ab" else _hip.DD_KERNEL_FFT_OS
+    want = {"ab": _hip.DD_KERNEL_MFMA_AB, "fft1k": _hip.DD_KERNEL_FFT_OS, "cos1k": _hip.DD_KERNEL_COS_RS}[request.param]
     assert lib.dd_chain_last_kernel(h) == want                           # ... as the kernel this parametrisation is about
     lib.dd_chain_destroy(h)
     torch.cuda.synchronize()
@@ -166,7 +166,7 @@ def test_oracle_windows_on_input_A_at_full_size(run):
     out = t.empty(n, dtype=t.float32, device=run.dev)
     h = run.chain()
     assert run.process(h, xa.data_ptr(), out.data_ptr(), n) == n - 1
-    assert lib.dd_chain_last_kernel(h) == (hip.DD_KERNEL_FFT_OS if run.kernel == "fft1k" else hip.DD_KERNEL_MFMA_AB)
+    assert lib.dd_chain_last_kernel(h) == {"ab": hip.DD_KERNEL_MFMA_AB, "fft1k": hip.DD_KERNEL_FFT_OS, "cos1k": hip.DD_KERNEL_COS_RS}[run.kernel]
     lib.dd_chain_destroy(h)
     t.cuda.synchronize()
     assert bool(t.isfinite(out[:n - 1]).all())
@@ -350,6 +350,8 @@ def test_complex_output_flavour_at_full_size(run):
     tile seam and the end.  Tolerance: FIR 2e-6 of the peak (4e-6 between the two f32 kernels)."""
     if run.kernel == "ab":
         pytest.skip("complex output always takes k_chain_mfma_ab: run once")
+    if run.kernel == "cos1k":
+        pytest.skip("the running-sum kernel has no complex64-output flavour (the choice by tap class keeps k_chain_fft1k there): run once")
     t, hip, lib = run.torch, run.hip, run.lib
     n = run.n
 
@@ -368,7 +370,7 @@ def test_complex_output_flavour_at_full_size(run):
     assert path == 1
     # (round 4: the overlap-save FFT kernel has a complex64-output flavour and is the default for 162..256 taps; the module's
     # second parametrisation forces k_chain_mfma_ab)
-    assert kern == (hip.DD_KERNEL_FFT_OS if run.kernel == "fft1k" else hip.DD_KERNEL_MFMA_AB)
+    assert kern == {"ab": hip.DD_KERNEL_MFMA_AB, "fft1k": hip.DD_KERNEL_FFT_OS, "cos1k": hip.DD_KERNEL_COS_RS}[run.kernel]
     assert bool(t.isfinite(y).all())
     peak = float(y.abs().max())
     W = 8192

@@ -935,7 +935,8 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm, kern, select_kernel):
         # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
         # (FM output with 255 taps: the overlap-save FFT kernel takes the aligned chunk, whole)
         # (round 4: the FFT kernel lays its block grid by the OUTPUT's alignment and takes any input alignment)
-        want = hip.DD_KERNEL_FFT_OS if kern == "auto" else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
+        # (round 5: FM output through Hamming 255 is the running-sum kernel's; complex64 output stays with the FFT kernel)
+        want = (hip.DD_KERNEL_COS_RS if fm else hip.DD_KERNEL_FFT_OS) if kern == "auto" else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
