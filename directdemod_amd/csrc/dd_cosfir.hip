@@ -74,8 +74,25 @@ struct DDCos1kArgs {
 
 __device__ __forceinline__ v2f c1_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f c1_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f){a, a}, b, c); }
-// complex product as one packed multiply and one packed multiply-add
-__device__ __forceinline__ v2f c1_cmul(v2f a, v2f b) { return c1_fma(a.x, b, (v2f){-a.y, a.y} * (v2f){b.y, b.x}); }
+// A complex product a * w as its two packed instructions with operand selects and sign modifiers spelt out (left to the compiler the
+// swizzled, negated copy of an operand is built with two more instructions).  A packed-f32 result may not be read by the very next
+// VALU instruction on gfx950: callers issue the first halves of a group of products, then the second halves.
+__device__ __forceinline__ v2f c1_mul_lo(v2f a, v2f w) {         // (a.x w.x, a.y w.x)
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+}
+__device__ __forceinline__ v2f c1_fma_hi(v2f a, v2f w, v2f t) {  // t + (-a.y w.y, a.x w.y): completes a * w
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f c1_fma_hic(v2f a, v2f w, v2f t) { // t + (a.y w.y, -a.x w.y): completes a * conj(w)
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f c1_cmul(v2f a, v2f w) { return c1_fma_hi(a, w, c1_mul_lo(a, w)); }
 __device__ __forceinline__ v2f c1_v2(float2 a) { return (v2f){a.x, a.y}; }
 
 template <int CTRL>
@@ -130,6 +147,16 @@ struct C1Carry {
 // Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
 //   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
 //   C1_ABL_NO_LDS    no LDS traffic           C1_ABL_NO_FM     no discriminator         C1_ABL_NO_SCAN    no scan / window stage
+#ifdef C1_TRACE
+// tools/debug/cos_trace.py: cycles per phase of a row (s_memtime stamps; every stamp drains the wave's LDS / scalar counter), summed
+// per wave over its interior rows
+#define C1_NPH 8
+__device__ unsigned long long g_c1_trace[4096 * (C1_NPH + 2)];
+#define C1_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define C1_T(i) do { } while (0)
+#endif
+
 template <bool U8>
 __device__ __forceinline__ void c1_issue_loads(const DDCos1kArgs& A, int64_t S, int lane, v4f (&xin)[8]) {
 #ifdef C1_ABL_NO_LOAD
@@ -152,7 +179,22 @@ __device__ __forceinline__ v2f c1_row_phasor(const DDCos1kArgs& A, int64_t S, v2
 #ifdef C1_ABL_NO_PHASOR
     return c1_cmul((v2f){0.6f, 0.8f}, ql);
 #else
-    return c1_cmul(c1_v2(dd_phasor((uint64_t)(A.abs0 + S) * A.cyc, A.nco_tbl)), ql);
+    // (wave-uniform: the table entry comes through the SCALAR cache -- a vector load here would sit in vmcnt behind the next row's
+    //  eight sample loads, and waiting for it would wait for all of them: a memory round trip exposed per row)
+    const uint64_t phase64 = (uint64_t)(A.abs0 + S) * A.cyc;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(phase64 >> (64 - DD_NCO_TBITS - 32)));
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) float2* c1_const_f2;
+    const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(phase64 >> (64 - DD_NCO_TBITS)));
+    const float2 Tk = ((c1_const_f2)A.nco_tbl)[k];
+#else
+    const float2 Tk = make_float2(1.f, 0.f);
+#endif
+    const float theta = (float)lo * (6.283185307179586f * 5.684341886080802e-14f);   // 2 pi 2^-44 (dd_phasor's residual)
+    const float t2 = theta * theta;
+    const float cc = fmaf(-0.5f, t2, 1.0f), ss = theta * fmaf(-0.16666667f, t2, 1.0f);
+    const v2f pr = (v2f){fmaf(Tk.x, cc, Tk.y * ss), fmaf(Tk.y, cc, -Tk.x * ss)};
+    return c1_cmul(pr, ql);
 #endif
 }
 
@@ -160,7 +202,16 @@ __device__ __forceinline__ v2f c1_row_phasor(const DDCos1kArgs& A, int64_t S, v2
 template <bool U8, bool NCO, bool EDGE>
 __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds,
                                        const int64_t S, const bool emit, const bool prefetch_next, const bool next_is_fast,
-                                       v4f (&xin)[8], bool& have_xin, const v2f ql, C1Carry& cr) {
+                                       v4f (&xin)[8], bool& have_xin, const v2f ql, C1Carry& cr
+#ifdef C1_TRACE
+                                       , unsigned* tr = nullptr
+#endif
+                                       ) {
+#ifdef C1_TRACE
+    unsigned tprev = (unsigned)__builtin_readcyclecounter();
+    unsigned trdummy[C1_NPH];
+    if (!tr) tr = trdummy;
+#endif
     const float c = A.c1, s = A.s1;
     char* const cur = lds + cr.cur;
     char* const own = cur + lane * C1_GROUP_BYTES;                              // this lane's 16 samples of the row
@@ -237,12 +288,22 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
                 pj[6] = c1_cmul(pj[4], c1_v2(A.q2));
                 pj[7] = c1_cmul(pj[6], c1_v2(A.q1));
             }
+            v2f pj1[8], t0[8], t1[8];
+            if (NCO) {
+                const v2f e1 = c1_v2(A.e1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t0[j] = c1_mul_lo(pj[j], e1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pj1[j] = c1_fma_hi(pj[j], e1, t0[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { t0[j] = c1_mul_lo((v2f){xin[j].x, xin[j].y}, pj[j]); t1[j] = c1_mul_lo((v2f){xin[j].z, xin[j].w}, pj1[j]); }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v2f x0 = (v2f){xin[j].x, xin[j].y}, x1 = (v2f){xin[j].z, xin[j].w};
                 if (NCO) {
-                    x0 = c1_cmul(x0, pj[j]);
-                    x1 = c1_cmul(x1, c1_cmul(pj[j], c1_v2(A.e1)));
+                    x0 = c1_fma_hi(x0, pj[j], t0[j]);
+                    x1 = c1_fma_hi(x1, pj1[j], t1[j]);
                 }
 #ifdef C1_ABL_NO_LDS
                 xt[2 * j] = x0; xt[2 * j + 1] = x1;
@@ -253,6 +314,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         }
         have_xin = false;
     }
+    C1_T(0);
     // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order)
     if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xin); have_xin = true; }
     if (next_is_fast) cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql);
@@ -282,15 +344,29 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     // (the first sample of the NEXT group: lane 15's is the first sample of this row, in this row's buffer)
     d[15] = *reinterpret_cast<const v2f*>(lane == 15 ? cur : old + C1_GROUP_BYTES);
 #endif
+    C1_T(1);
     // ---- pass A: lane totals of the un-windowed recurrence
-    C1St t = {xt[0], (v2f){0.f, 0.f}, xt[0]};
+    // T = sum_i A^{15-i} (xt[i], 0) = (sum cos((15-i) phi) xt[i], sum sin((15-i) phi) xt[i]): plain sums with constant weights (phi is
+    // fixed by K = 255), two partial sums each so that consecutive multiply-adds do not wait for one another
+    C1St t;
+    {
+        static constexpr float CW[16] = {1.000000000e+00f, 9.996940573e-01f, 9.987764162e-01f, 9.972476384e-01f, 9.951086592e-01f, 9.923607874e-01f,
+                                         9.890057045e-01f, 9.850454633e-01f, 9.804824871e-01f, 9.753195679e-01f, 9.695598648e-01f, 9.632069021e-01f,
+                                         9.562645670e-01f, 9.487371075e-01f, 9.406291296e-01f, 9.319455943e-01f};
+        static constexpr float SW[16] = {0.000000000e+00f, 2.473442728e-02f, 4.945371992e-02f, 7.414275255e-02f, 9.878641831e-02f, 1.233696381e-01f,
+                                         1.478773698e-01f, 1.722946174e-01f, 1.966064405e-01f, 2.207979630e-01f, 2.448543824e-01f, 2.687609789e-01f,
+                                         2.925031245e-01f, 3.160662917e-01f, 3.394360625e-01f, 3.625981373e-01f};
+        v2f C0 = xt[15], C1 = CW[1] * xt[14], S0 = SW[2] * xt[13], S1 = SW[1] * xt[14], R0 = xt[15] + xt[13], R1 = xt[14];
+        C0 = c1_fma(CW[2], xt[13], C0);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) {
-        const v2f Cn = c1_fma(c, t.C, c1_fma(-s, t.S, xt[i]));
-        t.S = c1_fma(s, t.C, c * t.S);
-        t.C = Cn;
-        t.R += xt[i];
+        for (int i = 12; i >= 0; --i) {
+            const int m = 15 - i;
+            if (i & 1) { C0 = c1_fma(CW[m], xt[i], C0); S0 = c1_fma(SW[m], xt[i], S0); R0 += xt[i]; }
+            else { C1 = c1_fma(CW[m], xt[i], C1); S1 = c1_fma(SW[m], xt[i], S1); R1 += xt[i]; }
+        }
+        t.C = C0 + C1; t.S = S0 + S1; t.R = R0 + R1;
     }
+    C1_T(2);
     // ---- inclusive weighted scan over the 64 lanes
 #ifndef C1_ABL_NO_SCAN
     c1_scan_step<C1_ROW_SHR(1), 0xF>(t, A.wc[0], A.ws[0]);
@@ -328,6 +404,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     cr.W = Wn;
     cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
     cr.V63.C = c1_lane63(V.C); cr.V63.S = c1_lane63(V.S); cr.V63.R = c1_lane63(V.R);
+    C1_T(3);
     // ---- pass B: the windowed recurrence; y = a0 R + a1 C (filters.py:199)
     v2f y[16];
 #pragma unroll
@@ -340,6 +417,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         u.R += xt[i] - d[i];
         y[i] = c1_fma(A.a0, u.R, A.a1 * u.C);
     }
+    C1_T(4);
     cr.cur = C1_BUF_BYTES - cr.cur;                          // this row's buffer is the next row's "row before"
     if (EDGE) {
         // the FIR output before the chunk's first sample is carried state (demod_fm.py:47-49); the chunk's last one becomes it
@@ -353,34 +431,63 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     const v2f yl = c1_shr1(y[15], cr.y63);
     cr.y63 = c1_lane63(y[15]);
     if (!emit) return;
-    // ---- demod_fm: angle(y[n] conj(y[n-1])), in four groups of 256 outputs; the small-angle form where a whole group allows it
+    // ---- demod_fm: angle(y[n] conj(y[n-1])).  Stage by stage over the lane's 16 samples, so that the products, the reciprocals and the
+    // polynomials of different samples fill one another's latencies; the small-angle form where all 256 outputs of a group of four
+    // samples per lane allow it -- decided for the four groups at once, the usual case being "all four".
     float ang[16];
+    {
+        v2f z[16], tz[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float re[4], im[4];
-        float worst = -1.0f;
+        for (int i = 0; i < 16; ++i) tz[i] = c1_mul_lo(y[i], i ? y[i - 1] : yl);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * g + k;
-            const v2f zp = i ? y[i - 1] : yl;
-            re[k] = fmaf(y[i].x, zp.x, y[i].y * zp.y);
-            im[k] = fmaf(y[i].y, zp.x, -y[i].x * zp.y);
-            worst = fmaxf(worst, fmaf(-0.41421356f, re[k], fabsf(im[k])));
+        for (int i = 0; i < 16; ++i) z[i] = c1_fma_hic(y[i], i ? y[i - 1] : yl, tz[i]);          // (re, im) of y[n] conj(y[n-1])
+        float worst[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float w0 = fmaf(-0.41421356f, z[4 * g].x, fabsf(z[4 * g].y)), w1 = fmaf(-0.41421356f, z[4 * g + 1].x, fabsf(z[4 * g + 1].y));
+            const float w2 = fmaf(-0.41421356f, z[4 * g + 2].x, fabsf(z[4 * g + 2].y)), w3 = fmaf(-0.41421356f, z[4 * g + 3].x, fabsf(z[4 * g + 3].y));
+            worst[g] = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
         }
-        // (a product of exactly zero -- digital silence -- takes the full-range form, which returns np.angle(0) = 0)
 #ifdef C1_ABL_NO_FM
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ang[4 * g + k] = re[k] + im[k];
+        for (int i = 0; i < 16; ++i) ang[i] = z[i].x + z[i].y;
 #else
-        if (__builtin_amdgcn_ballot_w64(worst >= 0.f) == 0) {
+        // (a product of exactly zero -- digital silence -- takes the full-range form, which returns np.angle(0) = 0)
+        const float wall = fmaxf(fmaxf(worst[0], worst[1]), fmaxf(worst[2], worst[3]));
+        if (__builtin_amdgcn_ballot_w64(wall >= 0.f) == 0) {
+            float r[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan_small(im[k], re[k]);
+            for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_rcpf(z[i].x);
+            v2f tt[8], zz[8], pp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tt[k] = (v2f){z[2 * k].y * r[2 * k], z[2 * k + 1].y * r[2 * k + 1]};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zz[k] = tt[k] * tt[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pp[k] = c1_fma(7.902598251e-02f, zz[k], (v2f){-1.382445378e-01f, -1.382445378e-01f});
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pp[k] = c1_fma(pp[k], zz[k], (v2f){1.997187931e-01f, 1.997187931e-01f});
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pp[k] = c1_fma(pp[k], zz[k], (v2f){-3.333275667e-01f, -3.333275667e-01f});
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pp[k] = zz[k] * pp[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const v2f a2 = c1_fma(tt[k], pp[k], tt[k]); ang[2 * k] = a2.x; ang[2 * k + 1] = a2.y; }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan2_poly(im[k], re[k]);
+            for (int g = 0; g < 4; ++g) {
+                if (__builtin_amdgcn_ballot_w64(worst[g] >= 0.f) == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan_small(z[4 * g + k].y, z[4 * g + k].x);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan2_poly(z[4 * g + k].y, z[4 * g + k].x);
+                }
+            }
         }
 #endif
     }
+    C1_T(5);
     if (EDGE) {
         float* const o = A.out + (S - A.s) + 16 * lane;
 #pragma unroll
@@ -417,6 +524,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
 #endif
         }
     }
+    C1_T(6);
 }
 
 // The whole chunk in one launch.  Row q covers samples [base + 1024 q, base + 1024 (q + 1)); wave gw takes rows
@@ -448,6 +556,12 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
 #pragma unroll
     for (int j = 0; j < 8; ++j) xin[j] = (v4f){0.f, 0.f, 0.f, 0.f};
     bool have_xin = false;
+#ifdef C1_TRACE
+    unsigned tr[C1_NPH];
+#pragma unroll
+    for (int i = 0; i < C1_NPH; ++i) tr[i] = 0;
+    const unsigned tloop = (unsigned)__builtin_readcyclecounter();
+#endif
     // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end
     auto edge = [&](int q) { const int64_t lo = (int64_t)A.base + (int64_t)C1_ROW * q; return lo < A.s || lo + C1_ROW > A.L || q == nrows - 1; };
     for (int q = q0 - 1; q < q1; ++q) {
@@ -455,8 +569,20 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
         const bool emit = q >= q0;
         const bool pf = q + 1 < q1 && !edge(q + 1);
         if (edge(q)) c1_row<U8, NCO, true>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
+#ifdef C1_TRACE
+        else c1_row<U8, NCO, false>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr, emit ? tr : nullptr);
+#else
         else c1_row<U8, NCO, false>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
+#endif
     }
+#ifdef C1_TRACE
+    tr[7] = (unsigned)__builtin_readcyclecounter() - tloop;
+    if (gw < 4096 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < C1_NPH; ++i) g_c1_trace[gw * (C1_NPH + 2) + i] = tr[i];
+        g_c1_trace[gw * (C1_NPH + 2) + C1_NPH] = (unsigned long long)(q1 - q0);
+    }
+#endif
     if (gw == nwaves - 1 && A.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < C1_K - 1; i += 64) {
@@ -524,6 +650,14 @@ void dd_cos1k_destroy(void* stv) {
     if (s->lane_tab) (void)hipFree(s->lane_tab);
     delete s;
 }
+
+#ifdef C1_TRACE
+extern "C" int dd_debug_cos1k_trace(unsigned long long* out, int nwaves) {
+    DD_HIP_CHECK(hipDeviceSynchronize());
+    DD_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c1_trace), sizeof(unsigned long long) * (size_t)nwaves * (C1_NPH + 2)));
+    return DD_OK;
+}
+#endif
 
 // where the row grid sits and how many rows and waves a chunk takes (host arithmetic, also reachable without a GPU: dd_debug_cos1k_plan)
 static void cos1k_plan(int64_t L, int s, int out_align_elems, int ncu, int wg_per_cu, int* base, int* nrows, int* grid, int* nwaves) {
