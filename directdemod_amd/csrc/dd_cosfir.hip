@@ -201,8 +201,8 @@ __device__ __forceinline__ v2f c1_row_phasor(const DDCos1kArgs& A, int64_t S, v2
 // One row.  EDGE: sample-by-sample loads (history, chunk end), predicated stores, the carried FIR output.  emit: store angles.
 template <bool U8, bool NCO, bool EDGE>
 __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds,
-                                       const int64_t S, const bool emit, const bool prefetch_next, const bool next_is_fast,
-                                       v4f (&xin)[8], bool& have_xin, const v2f ql, C1Carry& cr
+                                       const int64_t S, const bool emit, const bool prefetch_next,
+                                       v4f (&xin)[8], v4f (&xnext)[8], const v2f ql, C1Carry& cr
 #ifdef C1_TRACE
                                        , unsigned* tr = nullptr
 #endif
@@ -241,9 +241,8 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
-        have_xin = false;
     } else {
-        if (!have_xin) { c1_issue_loads<U8>(A, S, lane, xin); cr.prow = c1_row_phasor<NCO>(A, S, ql); }
+        // (xin: this row's samples, requested by the caller or by the row before; cr.prow: this row's phase factor)
         const v2f prow = cr.prow;
         if (U8) {
             // 32 bytes = the lane's own 16 samples: (x - 127.5) e^{-j w (S + 16 L + i)}
@@ -312,12 +311,11 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
 #endif
             }
         }
-        have_xin = false;
     }
     C1_T(0);
-    // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order)
-    if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xin); have_xin = true; }
-    if (next_is_fast) cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql);
+    // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order),
+    // into the OTHER register set: the caller alternates the two, so that nothing is copied -- or waited for -- at the loop's back edge
+    if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xnext); cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql); }
 #ifndef C1_ABL_NO_LDS
     if (!EDGE && !U8) {
 #pragma unroll
@@ -514,13 +512,15 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     float* const o = A.out + (S - A.s) + 4 * lane;
     {
         const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
+        v4f v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const v4f*>(img + 64 * (16 * g + G) + 16 * ((lane & 3) ^ sw));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const v4f v = *reinterpret_cast<const v4f*>(img + 64 * (16 * g + G) + 16 * ((lane & 3) ^ sw));
 #ifdef C1_ABL_NO_STORE
-            if (v.x + v.y + v.z + v.w == 1234.5f) o[256 * g] = v.x;
+            if (v[g].x + v[g].y + v[g].z + v[g].w == 1234.5f) o[256 * g] = v[g].x;
 #else
-            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(o + 256 * g));
+            __builtin_nontemporal_store(v[g], reinterpret_cast<v4f*>(o + 256 * g));
 #endif
         }
     }
@@ -552,29 +552,42 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
     cr.y63 = (v2f){0.f, 0.f};
     cr.prow = (v2f){1.f, 0.f};
     cr.cur = 0;
-    v4f xin[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xin[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    bool have_xin = false;
 #ifdef C1_TRACE
     unsigned tr[C1_NPH];
 #pragma unroll
     for (int i = 0; i < C1_NPH; ++i) tr[i] = 0;
     const unsigned tloop = (unsigned)__builtin_readcyclecounter();
 #endif
-    // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end
+    // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end.  Edge rows sit at
+    // the two ends of a wave's range only: [q0 - 1, f0) edge, [f0, f1) interior, [f1, q1) edge.
     auto edge = [&](int q) { const int64_t lo = (int64_t)A.base + (int64_t)C1_ROW * q; return lo < A.s || lo + C1_ROW > A.L || q == nrows - 1; };
-    for (int q = q0 - 1; q < q1; ++q) {
-        const int64_t S = (int64_t)A.base + (int64_t)C1_ROW * q;
-        const bool emit = q >= q0;
-        const bool pf = q + 1 < q1 && !edge(q + 1);
-        if (edge(q)) c1_row<U8, NCO, true>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
+    int f0 = q0 - 1;
+    while (f0 < q1 && edge(f0)) ++f0;
+    int f1 = f0;
+    while (f1 < q1 && !edge(f1)) ++f1;
+    v4f xa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa[j] = xb[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int q = q0 - 1; q < f0; ++q)
+        c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
+    if (f1 > f0) {
+        const int64_t S0 = (int64_t)A.base + (int64_t)C1_ROW * f0;
+        c1_issue_loads<U8>(A, S0, lane, xa);
+        cr.prow = c1_row_phasor<NCO>(A, S0, ql);
+        // two rows per trip: the sample registers alternate (xa: even rows of the run, xb: odd ones)
+        for (int q = f0; q < f1; q += 2) {
+            const int64_t S = (int64_t)A.base + (int64_t)C1_ROW * q;
 #ifdef C1_TRACE
-        else c1_row<U8, NCO, false>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr, emit ? tr : nullptr);
+            c1_row<U8, NCO, false>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr, q >= q0 ? tr : nullptr);
+            if (q + 1 < f1) c1_row<U8, NCO, false>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr, tr);
 #else
-        else c1_row<U8, NCO, false>(A, lt, lane, lds, S, emit, pf, pf, xin, have_xin, ql, cr);
+            c1_row<U8, NCO, false>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr);
+            if (q + 1 < f1) c1_row<U8, NCO, false>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr);
 #endif
+        }
     }
+    for (int q = f1; q < q1; ++q)
+        c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
 #ifdef C1_TRACE
     tr[7] = (unsigned)__builtin_readcyclecounter() - tloop;
     if (gw < 4096 && lane == 0) {
