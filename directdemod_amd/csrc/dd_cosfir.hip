@@ -141,8 +141,31 @@ struct C1Carry {
     v2f y63;         // the previous row's last FIR output (wave-uniform): y[n-1] of lane 0's first sample
     v2f prow;        // e^{-j w (abs0 + S)} of the NEXT row times the lane's own factor, looked up a row ahead (the table read is a
                      // dependent global load: taken at the top of a row it stalls the wave for a memory round trip per row)
+    int64_t pend_S;  // >= INT64_MIN + 1: the row whose angles wait in the OTHER buffer's first 4 KB for their stores (C1_NO_PEND = none)
     int cur;         // byte offset of this row's LDS buffer in the wave's image (0 or C1_BUF_BYTES; the other one holds the row before)
 };
+
+#define C1_NO_PEND ((int64_t)-4611686018427387904LL)
+// the angles of row S, left in the image at `img` by the row before: four 1 KB row-major stores
+__device__ __forceinline__ void c1_flush_angles(const DDCos1kArgs& A, const char* img, int64_t S, int lane) {
+    float* const o = A.out + (S - A.s) + 4 * lane;
+    const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
+    v4f v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const v4f*>(img + 64 * (16 * g + G) + 16 * ((lane & 3) ^ sw));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#ifdef C1_ABL_NO_STORE
+        if (v[g].x + v[g].y + v[g].z + v[g].w == 1234.5f) o[256 * g] = v[g].x;
+#else
+#ifdef C1_NT_STORE
+        __builtin_nontemporal_store(v[g], reinterpret_cast<v4f*>(o + 256 * g));
+#else
+        *reinterpret_cast<v4f*>(o + 256 * g) = v[g];            // (plain: 0.1514 ms against 0.1633 with the non-temporal hint, same call)
+#endif
+#endif
+    }
+}
 
 // Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
 //   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
@@ -169,7 +192,11 @@ __device__ __forceinline__ void c1_issue_loads(const DDCos1kArgs& A, int64_t S, 
     } else {
         const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const float2*>(A.in) + S + 2 * lane);
 #pragma unroll
+#ifdef C1_PLAIN_LOAD
+        for (int j = 0; j < 8; ++j) xin[j] = p[64 * j];
+#else
         for (int j = 0; j < 8; ++j) xin[j] = __builtin_nontemporal_load(p + 64 * j);
+#endif
     }
 }
 
@@ -316,6 +343,8 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     // the next row's samples fly during this row's arithmetic (requested ahead of every store of this row: vmcnt retires in order),
     // into the OTHER register set: the caller alternates the two, so that nothing is copied -- or waited for -- at the loop's back edge
     if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xnext); cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql); }
+    // the angles of the row before leave now: their LDS round trip and their stores overlap this row's arithmetic
+    if (cr.pend_S != C1_NO_PEND) { c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane); cr.pend_S = C1_NO_PEND; }
 #ifndef C1_ABL_NO_LDS
     if (!EDGE && !U8) {
 #pragma unroll
@@ -509,21 +538,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         for (int t = 0; t < 4; ++t)
             *reinterpret_cast<v4f*>(img + 64 * lane + 16 * (t ^ sw)) = (v4f){ang[4 * t], ang[4 * t + 1], ang[4 * t + 2], ang[4 * t + 3]};
     }
-    float* const o = A.out + (S - A.s) + 4 * lane;
-    {
-        const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
-        v4f v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const v4f*>(img + 64 * (16 * g + G) + 16 * ((lane & 3) ^ sw));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#ifdef C1_ABL_NO_STORE
-            if (v[g].x + v[g].y + v[g].z + v[g].w == 1234.5f) o[256 * g] = v[g].x;
-#else
-            __builtin_nontemporal_store(v[g], reinterpret_cast<v4f*>(o + 256 * g));
-#endif
-        }
-    }
+    cr.pend_S = S;                                           // (stored by the next row, or by the kernel after the wave's last interior row)
     C1_T(6);
 }
 
@@ -552,6 +567,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
     cr.y63 = (v2f){0.f, 0.f};
     cr.prow = (v2f){1.f, 0.f};
     cr.cur = 0;
+    cr.pend_S = C1_NO_PEND;
 #ifdef C1_TRACE
     unsigned tr[C1_NPH];
 #pragma unroll
@@ -586,6 +602,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
 #endif
         }
     }
+    if (cr.pend_S != C1_NO_PEND) { c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane); cr.pend_S = C1_NO_PEND; }
     for (int q = f1; q < q1; ++q)
         c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
 #ifdef C1_TRACE
@@ -718,6 +735,8 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
     int grid;
     cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
+    static const char* grid_env = getenv("DD_COS_GRID");               // tools: a fixed number of workgroups
+    if (grid_env && atoi(grid_env) > 0 && (int64_t)atoi(grid_env) * C1_WAVES <= A.nrows) { grid = atoi(grid_env); A.nwaves = grid * C1_WAVES; }
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
     const dim3 g(grid), b(64 * C1_WAVES);
     if (u8 && nco) hipLaunchKernelGGL((k_chain_cos1k<true, true>), g, b, C1_LDS_BYTES, stream, A);
