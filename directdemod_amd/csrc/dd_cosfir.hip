@@ -116,21 +116,34 @@ __device__ __forceinline__ v2f c1_bperm(int addr, v2f v) { return (v2f){c1_bperm
 struct C1St { v2f C, S, R; };
 
 #define C1_ROW_SHR(n) (0x110 + (n))
+// r += (r of the lane CTRL points at): one instruction (the DPP operand of a VOP2 add); lanes without a source lane, and rows
+// outside ROW_MASK, keep r
+#define C1_STR2(x) #x
+#define C1_STR(x) C1_STR2(x)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float c1_add_dpp(float r) {
+    static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "dpp control");
+    if (CTRL == 0x111) asm("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
+    if (CTRL == 0x112) asm("v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
+    if (CTRL == 0x114) asm("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
+    if (CTRL == 0x118) asm("v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
+    if (CTRL == 0x142) asm("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(r));
+    if (CTRL == 0x143) asm("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(r));
+    return r;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void c1_scan_step(C1St& t, float wc, float ws) {
-    v2f Cs, Ss, Rs;
+    v2f Cs, Ss;
     if (ROW_MASK == 0xF) {
         Cs = (v2f){c1_dpp0<CTRL>(t.C.x), c1_dpp0<CTRL>(t.C.y)};
         Ss = (v2f){c1_dpp0<CTRL>(t.S.x), c1_dpp0<CTRL>(t.S.y)};
-        Rs = (v2f){c1_dpp0<CTRL>(t.R.x), c1_dpp0<CTRL>(t.R.y)};
     } else {
         Cs = (v2f){c1_dppm<CTRL, ROW_MASK>(t.C.x), c1_dppm<CTRL, ROW_MASK>(t.C.y)};
         Ss = (v2f){c1_dppm<CTRL, ROW_MASK>(t.S.x), c1_dppm<CTRL, ROW_MASK>(t.S.y)};
-        Rs = (v2f){c1_dppm<CTRL, ROW_MASK>(t.R.x), c1_dppm<CTRL, ROW_MASK>(t.R.y)};
     }
+    t.R = (v2f){c1_add_dpp<CTRL, ROW_MASK>(t.R.x), c1_add_dpp<CTRL, ROW_MASK>(t.R.y)};
     t.C = c1_fma(wc, Cs, c1_fma(-ws, Ss, t.C));
     t.S = c1_fma(ws, Cs, c1_fma(wc, Ss, t.S));
-    t.R += Rs;
 }
 
 // what a wave carries from one row to the next
@@ -432,17 +445,18 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
     cr.V63.C = c1_lane63(V.C); cr.V63.S = c1_lane63(V.S); cr.V63.R = c1_lane63(V.R);
     C1_T(3);
-    // ---- pass B: the windowed recurrence; y = a0 R + a1 C (filters.py:199)
+    // ---- pass B: the windowed recurrence.  y / a0 = R + (a1 / a0) C (filters.py:199): the discriminator does not see the positive
+    // factor a0 (the edge rows, which hand y to the next chunk, put it back), so an output is one multiply-add
     v2f y[16];
+    const float kap = A.a1 / A.a0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const v2f bC = c1_fma(-c, d[i], xt[i]);
-        const v2f bS = -s * d[i];
-        const v2f Cn = c1_fma(c, u.C, c1_fma(-s, u.S, bC));
-        u.S = c1_fma(s, u.C, c1_fma(c, u.S, bS));
+        const v2f D = u.C - d[i];                                  // the sample 255 back leaves the window (its weight there: cos(254 phi) = 1, sin = 0)
+        const v2f Cn = c1_fma(c, D, c1_fma(-s, u.S, xt[i]));
+        u.S = c1_fma(s, D, c * u.S);
         u.C = Cn;
         u.R += xt[i] - d[i];
-        y[i] = c1_fma(A.a0, u.R, A.a1 * u.C);
+        y[i] = c1_fma(kap, u.C, u.R);
     }
     C1_T(4);
     cr.cur = C1_BUF_BYTES - cr.cur;                          // this row's buffer is the next row's "row before"
@@ -452,7 +466,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         for (int i = 0; i < 16; ++i) {
             const int64_t n = S + 16 * lane + i;
             if (A.s == 0 && n == -1) y[i] = c1_v2(*A.lasty_in);
-            if (n == A.L - 1 && A.lasty_out) *A.lasty_out = make_float2(y[i].x, y[i].y);
+            if (n == A.L - 1 && A.lasty_out) *A.lasty_out = make_float2(A.a0 * y[i].x, A.a0 * y[i].y);
         }
     }
     const v2f yl = c1_shr1(y[15], cr.y63);
@@ -468,26 +482,24 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         for (int i = 0; i < 16; ++i) tz[i] = c1_mul_lo(y[i], i ? y[i - 1] : yl);
 #pragma unroll
         for (int i = 0; i < 16; ++i) z[i] = c1_fma_hic(y[i], i ? y[i - 1] : yl, tz[i]);          // (re, im) of y[n] conj(y[n-1])
-        float worst[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float w0 = fmaf(-0.41421356f, z[4 * g].x, fabsf(z[4 * g].y)), w1 = fmaf(-0.41421356f, z[4 * g + 1].x, fabsf(z[4 * g + 1].y));
-            const float w2 = fmaf(-0.41421356f, z[4 * g + 2].x, fabsf(z[4 * g + 2].y)), w3 = fmaf(-0.41421356f, z[4 * g + 3].x, fabsf(z[4 * g + 3].y));
-            worst[g] = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
-        }
 #ifdef C1_ABL_NO_FM
 #pragma unroll
         for (int i = 0; i < 16; ++i) ang[i] = z[i].x + z[i].y;
 #else
-        // (a product of exactly zero -- digital silence -- takes the full-range form, which returns np.angle(0) = 0)
-        const float wall = fmaxf(fmaxf(worst[0], worst[1]), fmaxf(worst[2], worst[3]));
-        if (__builtin_amdgcn_ballot_w64(wall >= 0.f) == 0) {
-            float r[16];
+        // small-angle form (|angle| <= 22.5 degrees: re > 0 and |im / re| <= tan(pi / 8)) for the whole row when all 1024 outputs allow it
+        // -- the quotients are formed first and the test is made on them; a product of exactly zero (digital silence) fails `re > 0` and
+        // takes the full-range form, which returns np.angle(0) = 0
+        float r[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_rcpf(z[i].x);
-            v2f tt[8], zz[8], pp[8];
+        for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_rcpf(z[i].x);
+        v2f tt[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tt[k] = (v2f){z[2 * k].y * r[2 * k], z[2 * k + 1].y * r[2 * k + 1]};
+        for (int k = 0; k < 8; ++k) tt[k] = (v2f){z[2 * k].y * r[2 * k], z[2 * k + 1].y * r[2 * k + 1]};
+        float tmax = fmaxf(fabsf(tt[0].x), fabsf(tt[0].y)), remin = fminf(z[0].x, z[1].x);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { tmax = fmaxf(tmax, fmaxf(fabsf(tt[k].x), fabsf(tt[k].y))); remin = fminf(remin, fminf(z[2 * k].x, z[2 * k + 1].x)); }
+        if (__builtin_amdgcn_ballot_w64(!(tmax <= 0.41421356f) || !(remin > 0.f)) == 0) {
+            v2f zz[8], pp[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) zz[k] = tt[k] * tt[k];
 #pragma unroll
@@ -501,9 +513,13 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const v2f a2 = c1_fma(tt[k], pp[k], tt[k]); ang[2 * k] = a2.x; ang[2 * k + 1] = a2.y; }
         } else {
+            // rare: per group of four samples (256 outputs), as k_chain_fft1k decides it
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (__builtin_amdgcn_ballot_w64(worst[g] >= 0.f) == 0) {
+                float worst = -1.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) worst = fmaxf(worst, fmaf(-0.41421356f, z[4 * g + k].x, fabsf(z[4 * g + k].y)));
+                if (__builtin_amdgcn_ballot_w64(worst >= 0.f) == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ang[4 * g + k] = dd_atan_small(z[4 * g + k].y, z[4 * g + k].x);
                 } else {
