@@ -260,6 +260,8 @@ class HipStep:
         return self.out[self.first:self.first + self.n], cnt
 
     def path(self):
+        if self.lib.dd_chain_last_kernel(self.h) == 9:
+            return "running-sums-f32"
         if self.lib.dd_chain_last_kernel(self.h) == 7:
             return "fft-f32-overlap-save"
         return {0: "direct-f32", 1: "mfma-f16x3"}.get(self.lib.dd_chain_path(self.h), str(self.lib.dd_chain_path(self.h)))
@@ -448,10 +450,75 @@ def side_configs(eng, steps=10):
                 "kernel": kname, "ms_per_pass_input_A": round(ab["A"], 4), "ms_per_pass_input_B": round(ab["B"], 4),
                 "input_A_over_B": round(ab["A"] / ab["B"], 4), "bytes_per_sample": 12.0,
                 "frac_of_8TBs_input_A": round(n * 12.0 / (ab["A"] * 1e-3) / 8e12, 4), "frac_of_8TBs_input_B": round(n * 12.0 / (ab["B"] * 1e-3) / 8e12, 4)})
+    res.append(side_headline_kernels(eng, steps))
     res.append(side_c3_end_to_end(eng, steps))
     res.append(side_c3_through_classes(eng, steps))
-    res.append(side_c4_end_to_end())
+    res.extend(side_c4_end_to_end())
+    res.append(side_ring_feeder())
     return res
+
+
+def side_headline_kernels(eng, steps=10):
+    """The headline chain through each M = 1 kernel that takes Hamming 255 + FM, same call, back to back (dd_debug_select_kernel):
+    k_chain_cos1k (running sums, the choice by tap class since round 5), k_chain_fft1k (overlap-save FFT, rounds 3-4),
+    k_chain_mfma_ab (f16-limb Toeplitz on the matrix cores, round 2)."""
+    hip, lib = eng._hip, eng.lib
+    n = eng.n
+    ham = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(NTAPS) / (NTAPS - 1)))
+    before = os.environ.get("DD_MFMA_KERNEL")
+    out = {"config": "C2 headline through each M = 1 kernel, same call, 2^26 samples", "bytes_per_sample": 12.0, "kernels": {}}
+    try:
+        for sel in (None, "fft1k", "ab"):
+            hip.select_kernel(sel)
+            h = C.c_void_p()
+            hip.check(lib.dd_chain_create(C.byref(h), ham.ctypes.data_as(C.POINTER(C.c_double)), NTAPS, hip.cycles_q64(F_OFFSET, FS), 1,
+                                          hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM), "dd_chain_create")
+            got = C.c_int64(0)
+
+            def step():
+                hip.check(lib.dd_chain_reset(h, eng.stream), "dd_chain_reset")
+                hip.check(lib.dd_chain_process(h, eng.xin.data_ptr(), eng.out.data_ptr(), n, C.byref(got), eng.stream), "dd_chain_process")
+            for _ in range(300):
+                step()
+            eng.sync()
+            e0, e1 = eng.events()
+            e0.record()
+            for _ in range(20 * steps):
+                step()
+            e1.record()
+            eng.sync()
+            ms = e0.elapsed_time(e1) / (20 * steps)
+            out["kernels"][KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?")] = {
+                "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1), "frac_of_8TBs": round(n * 12.0 / (ms * 1e-3) / 8e12, 4)}
+            lib.dd_chain_destroy(h)
+    finally:
+        hip.select_kernel(before)
+    return out
+
+
+def side_ring_feeder(log2n=28):
+    """source.IQwav-style ingest (source.py:95-118, BASELINE north_star: pinned-host ring buffers, hipMemcpyAsync on a side stream):
+    a host-resident u8 recording through stream.stream_fm_chain -- raw pairs over PCIe into device slots on a copy stream while the
+    previous chunk is decoded (C4 front end: offsetFreq 30 kHz + blackmanHarris151 + bwLim /34 + FM).  Wall time, PCIe inclusive:
+    never `value`."""
+    from directdemod_amd import source, stream as st
+    nraw = 1 << log2n
+    raw = np.random.default_rng(1).integers(0, 256, size=(nraw, 2), dtype=np.uint8)
+    src = source.IQarray(raw, 2048000)
+    k = np.arange(151)
+    bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * k / 150) + 0.14128 * np.cos(4 * np.pi * k / 150) - 0.01168 * np.cos(6 * np.pi * k / 150)
+    st.stream_fm_chain(src, bh, 30000.0, 34, chunk_size=20000000)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st.stream_fm_chain(src, bh, 30000.0, 34, chunk_size=20000000, staging="direct")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    gbps = 2.0 * nraw / best / 1e9
+    return {"config": "ring feeder: host-resident u8 recording over PCIe (hipMemcpyAsync on a copy stream, chunks of 2e7 samples) through "
+                      "the C4 front end (BH151 /34 FM), 2^%d samples" % log2n,
+            "s_per_pass_wall": round(best, 4), "GS_per_s": round(nraw / best / 1e9, 2), "host_to_device_GBps": round(gbps, 1),
+            "frac_of_pcie_63GBps": round(gbps / 63.0, 3), "staging": "direct (from the recording's own memory)"}
 
 
 # ----------------------------------------------------------------------------- one rank
@@ -605,10 +672,32 @@ def side_c4_end_to_end(dur=60.0):
     runs = [one() for _ in range(3)]
     crude = min(r[0] for r in runs)
     accurate = min(r[1] for r in runs)
-    return {"config": "C4 end to end 60 s (crude + accurate sync), 2.048 MS/s synthetic APT, recording resident in HBM as u8",
+    warm = {"config": "C4 end to end 60 s (crude + accurate sync), 2.048 MS/s synthetic APT, recording resident in HBM as u8",
             "iq_samples": int(src.length), "crude_sync_ms": round(crude, 3), "accurate_sync_ms": round(accurate, 3),
             "total_ms": round(crude + accurate, 3), "syncs": [runs[0][2], runs[0][3]], "accurate_windows": runs[0][4],
             "GS_per_s": round(src.length / (crude + accurate) / 1e6, 2)}
+    # the reference decodes one file per process (main.py:208-270): the FIRST call of a fresh process is the call.  A child process
+    # (started, never exec'ed into) loads the same recording from a scratch file and times its first crude + accurate sync.
+    cold = {"config": "C4 end to end 60 s, FIRST call of a fresh process (recording on the host: upload, code objects, tables and plans included)"}
+    import subprocess
+    import tempfile
+    path = None
+    try:
+        fd, path = tempfile.mkstemp(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.close(fd)
+        np.save(path, raw)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_noaa_cold.py"), path], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            cold.update(json.loads(line[-1]))
+        else:
+            cold["error"] = (r.stderr or r.stdout)[-400:]
+    except Exception as e:
+        cold["error"] = repr(e)
+    finally:
+        if path and os.path.exists(path):
+            os.unlink(path)
+    return [warm, cold]
 
 
 def run_rank(args):
@@ -714,8 +803,9 @@ def run_rank(args):
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
-    # the same step for >= 100 ms of device time (20 steps are ~4 ms): consistency check of the short region
-    long_steps = max(args.steps, int(np.ceil(100.0 / max(kern_ms, 1e-3))))
+    # the same step for >= --steady-ms of device time (20 steps are ~3 ms; the default 6 s also makes the run visible to an
+    # activity sampler that looks every few seconds): consistency check of the short region
+    long_steps = max(args.steps, int(np.ceil((min(args.steady_ms, 50.0) if stub else args.steady_ms) / max(kern_ms, 1e-3))))
     l0, l1 = eng.events()
     l0.record()
     for i in range(long_steps):
@@ -780,17 +870,26 @@ def run_rank(args):
         total = world * n * args.steps
         value = total / dt_max / 1e6
         achieved = BYTES_PER_SAMPLE * n / (kern_ms_max * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, power = None, None, None
+        kname = eng.kernel()
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf) and not stub:
             try:
                 tj = json.load(open(tf))
-                traffic = tj.get("bytes_per_launch_log2n_%d" % args.log2n)
-                traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                  "tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
-                                  % (tj.get("kernel", "?"), tj.get("git", "?")))
+                rec = tj.get("kernels", {}).get(kname) or (tj if tj.get("kernel", "").startswith(kname) else None)
+                if rec:
+                    traffic = rec.get("bytes_per_launch_log2n_%d" % args.log2n)
+                    traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                      "tools/pmc_traffic.sh; not measured in this run); kernel %s at git %s"
+                                      % (rec.get("kernel", kname), rec.get("git", "?")))
             except Exception:
                 traffic = None
+        pf = os.path.join(ROOT, "profiles", "power.json")          # rocm-smi clock / package power while the kernel loops, per kernel
+        if os.path.exists(pf) and not stub:
+            try:
+                power = json.load(open(pf)).get("kernels", {}).get(kname)
+            except Exception:
+                power = None
         if world == 1 and not stub and not args.no_side:
             try:
                 extra["side"] = side_configs(eng)
@@ -819,10 +918,7 @@ def run_rank(args):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kern_ms_max, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
-                         "power_note": "not measured in this run: profiles/r04_clock_power.txt (rocm-smi while the kernel loops) -- 1381 W at "
-                                       "2016 MHz against the board's 1400 W cap and 283 W idle; dynamic energy 0.2165 J per 2^26-sample launch "
-                                       "(memory side alone 0.094 J, arithmetic + LDS exchanges 0.141 J), i.e. >= 0.194 ms per launch at the cap "
-                                       "whatever the schedule (DESIGN.md 4.2c)"},
+                         "power": power},      # (profiles/power.json: not measured in this run; says at which git revision it was)
             "extra": extra,
         }
         if not args.no_cpu_baseline and world == 1 and not stub:
@@ -842,6 +938,8 @@ def parse_args(argv=None):
                     help="untimed pre-roll of the same step before the warmup, so the measurement sees the clock the "
                          "chip holds under sustained load (the board's power controller takes ~20 ms to settle on it; "
                          "in between the kernel runs 15-35 %% slower)")
+    ap.add_argument("--steady-ms", type=float, default=6000.0,
+                    help="device time of the steady-state check that follows the timed region (extra.steady_check)")
     ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
     ap.add_argument("--gather", action="store_true", help="(default with more than one rank; kept for old command lines)")
     ap.add_argument("--no-gather", action="store_true", help="more than one rank: skip the RCCL all_gather leg of the decoded output")

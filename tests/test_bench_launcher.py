@@ -102,3 +102,24 @@ def test_launcher_does_not_import_torch_or_hip():
     env.pop("DD_BENCH_STUB", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=60)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_the_drivers_8_gpu_command_line_parses_and_keeps_the_contract():
+    """The scaling record is the driver's to measure (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
+    --steps K --warmup W`); what can be checked here is that this command line parses to the C2 shard per rank, that the
+    launcher would pass every argument through unchanged, and that `extra.rccl_init_s` (rendezvous + first collective) is part
+    of a multi-rank line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert (args.gpus, args.steps, args.warmup, args.log2n) == (8, 20, 5, 26)
+    assert args.steady_ms >= 6000 and not args.no_gather
+    args = bench.parse_args(["--gpus", "8", "--log2n", "26", "--steps", "20", "--warmup", "5", "--no-gather"])
+    assert args.log2n == 26 and args.no_gather
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--gpus", "eight"])
+    r, lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-ms", "2"])
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert 0 <= j["extra"]["rccl_init_s"] < 60 and j["extra"]["world_size_seen"] == 2
+    assert "[bench] rank 0/2: init_process_group" in r.stderr

@@ -32,7 +32,7 @@ def test_one_rank_through_the_nccl_branch():
     env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
                 "DD_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--log2n", "22", "--steps", "3",
-                        "--warmup", "1", "--ramp-ms", "5", "--no-cpu-baseline", "--no-side"],
+                        "--warmup", "1", "--ramp-ms", "5", "--steady-ms", "50", "--no-cpu-baseline", "--no-side"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[bench]")))
     assert r.returncode == 0, r.stderr[-3000:]

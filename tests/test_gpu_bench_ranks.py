@@ -23,7 +23,7 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
         env.pop(k, None)
     env["DD_BENCH_ONE_DEVICE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "22", "--steps", "3",
-                        "--warmup", "1", "--ramp-ms", "5"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+                        "--warmup", "1", "--ramp-ms", "5", "--steady-ms", "50"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[bench]")))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
