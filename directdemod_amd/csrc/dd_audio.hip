@@ -59,6 +59,17 @@ static int get_plan(hipfftHandle* out, hipfftType type, int64_t n, int batch, hi
 
 static inline unsigned grid1(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// An entry point that enqueues kernels on buffers another call may free or reuse (the Hilbert-kernel spectra of g_hilb, the pageable
+// staging vectors of the uploads) and then returns EARLY on an error must not leave that work in flight: this guard synchronises the
+// stream when the function is left without having done so itself.
+struct DDSyncOnExit {
+    hipStream_t s;
+    bool armed;
+    explicit DDSyncOnExit(hipStream_t st) : s(st), armed(true) {}
+    void done() { armed = false; }
+    ~DDSyncOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+};
+
 // ---------------------------------------------------------------- own float64 cyclic convolution of length 2^17 / 2^18 (dd_hconv_kernels.h)
 #include "dd_hconv_kernels.h"
 static std::mutex g_hc_mu;
@@ -1625,6 +1636,7 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
         dd_set_error("NCO table initialisation failed (no GPU?)");
         return DD_ERR_NODEVICE;
     }
+    // (the DD_SYNC_* switches below are read on every call on purpose: the test suite and tools/ change routes inside one process)
     const char* fr_env = getenv("DD_SYNC_FRONT");                     // tools / tests: "kernel" = the front end as a launch of its own
     const bool front_fused = !(fr_env && !strcmp(fr_env, "kernel"));
     int bmax = 64;
@@ -1658,6 +1670,7 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     std::lock_guard<std::mutex> lk(g_sync_mu);
     int rc = sync_scratch(total + 4096, &base);
     if (rc != DD_OK) return rc;
+    DDSyncOnExit sync_guard(s);                       // (an early error return below leaves nothing in flight)
     int64_t* d_starts = (int64_t*)(base + o_starts);
     const int* d_group = needle_of_window_host ? (const int*)(base + o_group) : nullptr;
     double* d_taps1 = (double*)(base + o_taps1);
@@ -1765,6 +1778,8 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     const double tt_enq = now_us() - tt0;
     DD_HIP_CHECK(hipMemcpyAsync(down, base + o_res, 24 * (size_t)n_windows, hipMemcpyDeviceToHost, s));
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    sync_guard.done();
+    { const int sr = dd_seam_poll_all(); if (sr != DD_OK) return sr; }
     if (trace) fprintf(stderr, "sync windows host us (%d windows): upload starts %.0f, upload enqueued %.0f, batches enqueued %.0f, synchronised %.0f\n",
                        n_windows, tt_up0, tt_up1, tt_enq, now_us() - tt0);
     memcpy(peak_host, down, 8 * (size_t)n_windows);
@@ -2255,6 +2270,7 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     char* base = nullptr;
     int rc = sync_scratch(off, &base);
     if (rc != DD_OK) return rc;
+    DDSyncOnExit sync_guard(s);                       // (an early error return below leaves nothing in flight)
     const double* x = audio_is_f32 ? (const double*)(base + o_x) : (const double*)audio;
     double* env = env_out ? env_out : (double*)(base + o_env);
     double2* spec = (double2*)(base + o_spec);
@@ -2340,6 +2356,8 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     DD_HIP_CHECK(hipMemcpyAsync(pin, base + o_head, head_bytes, hipMemcpyDeviceToHost, s));
     tt[3] = now_us() - tt0;
     DD_HIP_CHECK(hipStreamSynchronize(s));
+    sync_guard.done();
+    { const int sr = dd_seam_poll_all(); if (sr != DD_OK) return sr; }        // (the audio may come from a chunk-list launch on this stream)
     tt[4] = now_us() - tt0;
     if (trace) fprintf(stderr, "crude tail host us: blocks enqueued %.0f, remainder %.0f, tail enqueued %.0f, copy enqueued %.0f, synchronised %.0f\n", tt[0], tt[1], tt[2], tt[3], tt[4]);
     const DDCrudeHead* hs = (const DDCrudeHead*)pin;

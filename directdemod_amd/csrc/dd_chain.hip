@@ -771,6 +771,7 @@ static int seam_look(dd_fir* f, bool wait) {
         if (g_seam_pending[i] == f) { g_seam_pending.erase(g_seam_pending.begin() + i); break; }
     const unsigned n = *reinterpret_cast<volatile unsigned int*>(f->seam_err_host);
     if (n == 0) return DD_OK;
+    f->state_invalid = 1;          // (the faulty launch also committed its carried state: nothing may continue from it)
     *f->seam_err_host = 0;
     (void)hipMemset(f->seam_err, 0, sizeof(unsigned int));
     dd_set_error("chunk-list launch: %u in-launch hand-over wait(s) of the carried FIR / FM state timed out; the outputs of that "
@@ -825,6 +826,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->seam_err_host = nullptr;
     f->seam_ev = nullptr;
     f->seam_pending = 0;
+    f->state_invalid = 0;
     const int R = DD_DENSE_R;
     const int K = ntaps;
     // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
@@ -897,6 +899,7 @@ extern "C" int dd_fir_reset(dd_fir* f, int mode, const float* hist_host, void* s
         }
     }
     f->hist_mode = mode;
+    f->state_invalid = 0;
     return dd_fir_reset_f64(f, mode, hist_host, s);
 }
 
@@ -1018,6 +1021,17 @@ static int decim_plan(DDChainParams& P, DDDecimPlan& pl) {
 
 int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out, hipStream_t s) {
     DD_REQUIRE(fir && a.n >= 0 && a.M >= 1 && a.off >= 0 && a.off < a.M, "fused arguments");
+    {
+        // a chunk-list launch whose in-launch hand-over timed out: reported here too, not only by dd_stream_sync, and the
+        // state that launch committed is refused until the filter is reset
+        const int sr = dd_seam_poll_all();
+        if (sr != DD_OK) return sr;
+        if (fir->state_invalid) {
+            dd_set_error("this filter's carried state comes from a chunk-list launch that timed out (DD_ERR_TIMEOUT was reported): reset it "
+                         "(dd_fir_reset / dd_chain_reset / dd_chain_seek) before processing more samples");
+            return DD_ERR_TIMEOUT;
+        }
+    }
     DDChainParams P;
     memset(&P, 0, sizeof(P));
     P.in = a.in;

@@ -30,6 +30,8 @@ struct dd_fir {
     unsigned int* seam_err_host;    // pinned
     hipEvent_t seam_ev;             // recorded behind the mirror copy
     int seam_pending;               // a mirror copy has been enqueued and not looked at yet
+    int state_invalid;              // a chunk-list launch through this filter timed out: the carried history and last FM sample it
+                                    // committed are not to be used -- every fused launch reports DD_ERR_TIMEOUT until dd_fir_reset
 };
 
 // demod_fm object: carried last sample (demod_fm.py:43-49)

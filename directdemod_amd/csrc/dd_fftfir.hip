@@ -23,6 +23,7 @@
 #include "dd_fftfir.h"
 #include "dd_atan.h"
 #include <stdlib.h>
+#include <stddef.h>
 #include <complex>
 #include <mutex>
 
@@ -670,8 +671,12 @@ struct F1KernArgs {
 };
 typedef const __attribute__((address_space(4))) F1KernArgs* F1KernArgsPtr;
 
+// (nothing ties F1KernArgs to k_chain_fft1k's parameter list but these checks: the layout rules of the kernarg segment are the C
+//  struct rules for these members, and the edge block compares the by-value block count it is handed with the one it reads there)
+static_assert(offsetof(F1KernArgs, T) % alignof(DDFft1kTabs) == 0 && offsetof(F1KernArgs, M) % alignof(DDFft1kMap) == 0 &&
+              offsetof(F1KernArgs, nwaves) == offsetof(F1KernArgs, nblk) + sizeof(int), "F1KernArgs must mirror k_chain_fft1k's parameter list");
 template <bool U8, bool CX>
-__device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X, const v2f* const hp, const int lane) {
+__device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X, const v2f* const hp, const int lane, const int nblk_by_value) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const F1KernArgs* const kg = (const F1KernArgs*)ka;        // (address-space cast: device pass only)
 #else
@@ -680,6 +685,7 @@ __device__ __noinline__ void f1_edge_block(F1KernArgsPtr ka, int q, v2f* const X
     const DDChainParams P = kg->P;
     const DDFft1kTabs T = kg->T;
     const int nblk = kg->nblk;
+    if (nblk != nblk_by_value) __builtin_trap();               // the struct above no longer matches the kernel's parameters
     // (its own copy of the twiddles: arrays handed to a function that is not inlined would live in scratch memory for
     // the whole kernel)
     const int tcol = 2 * (lane & 31) + (lane >> 5);
@@ -777,7 +783,7 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
     const v2f* const hp = HP + lane * F1_HP_STRIDE;
     // (the edge blocks are calls: made while no table is live in registers, or everything live is spilled around them)
     F1KernArgsPtr ka = (F1KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    if (gw == 0) f1_edge_block<U8, CX>(ka, 0, X, hp, lane);
+    if (gw == 0) f1_edge_block<U8, CX>(ka, 0, X, hp, lane, nblk);
     // this wave's interior blocks: run k = [1 + start_k, 1 + start_k + len_k)
     const int ni = nblk - 2;
     const int w0 = ni > 0 ? (int)(((int64_t)ni * gw) / nwaves) : 0, w1 = ni > 0 ? (int)(((int64_t)ni * (gw + 1)) / nwaves) : 0;
@@ -871,7 +877,7 @@ __global__ void __launch_bounds__(64 * F1_WAVES, 3) k_chain_fft1k(const DDChainP
 #endif
     }
 #undef F1_RUN
-    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8, CX>(ka, nblk - 1, X, hp, lane);
+    if (gw == nwaves - 1 && nblk > 1) f1_edge_block<U8, CX>(ka, nblk - 1, X, hp, lane, nblk);
 }
 
 // ============================================================================ host side

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the M = 1 FM chain kernels inside one process (DD_MFMA_KERNEL is read per launch): outputs compared against the
-default kernel, HIP-event time per launch.  KERNELS=ab,fft NTAPS=255 N=26 U8=1 INPUT=A|B NORESET=1"""
+"""A/B of the M = 1 FM chain kernels inside one process (switched through dd_debug_select_kernel: auto, ab, ws, fft1k, cos1k): outputs
+compared against the default kernel, HIP-event time per launch.  KERNELS=ab,fft1k,cos1k NTAPS=255 N=26 U8=1 INPUT=A|B NORESET=1"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
