@@ -183,6 +183,7 @@ __device__ __forceinline__ void c1_flush_angles(const DDCos1kArgs& A, const char
 // Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
 //   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
 //   C1_ABL_NO_LDS    no LDS traffic           C1_ABL_NO_FM     no discriminator         C1_ABL_NO_SCAN    no scan / window stage
+//   C1_ABL_MEMONLY   the memory side alone: loads, both LDS transpositions, stores; an "angle" is re + im of the sample
 #ifdef C1_TRACE
 // tools/debug/cos_trace.py: cycles per phase of a row (s_memtime stamps; every stamp drains the wave's LDS / scalar counter), summed
 // per wave over its interior rows
@@ -366,6 +367,20 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
             xt[2 * t] = (v2f){v.x, v.y};
             xt[2 * t + 1] = (v2f){v.z, v.w};
         }
+    }
+#endif
+#ifdef C1_ABL_MEMONLY
+    if (!EDGE) {
+        cr.cur = C1_BUF_BYTES - cr.cur;
+        if (!emit) return;
+        {
+            const int sw = (lane >> 1) & 3;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<v4f*>(cur + 64 * lane + 16 * (t ^ sw)) = (v4f){xt[4 * t].x + xt[4 * t].y, xt[4 * t + 1].x + xt[4 * t + 1].y, xt[4 * t + 2].x + xt[4 * t + 2].y, xt[4 * t + 3].x + xt[4 * t + 3].y};
+        }
+        cr.pend_S = S;
+        return;
     }
 #endif
     // d[i] = xt[n - 255] = sample i + 1 of the group 16 lanes back
