@@ -132,6 +132,7 @@ SIGNATURES = {
     "dd_noaa_sync_windows_multi": (_int, [_p, _int, _pi64, C.POINTER(_int), _int, _i64, C.c_uint64, C.POINTER(C.c_double), _int,
                                           C.POINTER(C.c_double), _int, C.POINTER(C.c_double), _int, _int, C.c_double,
                                           _pi64, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
+    "dd_noaa_prepare": (_int, [_i64, _i64, _p]),
     "dd_noaa_crude_tail": (_int, [_p, _int, _i64, C.c_double, _i64, C.POINTER(C.c_double), _int, _int, _p,
                                   _pi64, _int, C.POINTER(_int), _p]),
     "dd_afsk_binary_filter_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
@@ -232,6 +233,37 @@ def require_gpu():
         raise HipError("directdemod_amd needs an AMD MI355X (gfx950) visible to HIP; none found: %s. "
                        "There is no CPU fallback." % last_error())
     _gpu_checked = True
+    _start_copy_warmup()
+
+
+_warm = None
+
+
+def _start_copy_warmup():
+    """The first host-to-device copy of a process costs ~90 ms inside the HIP runtime whatever its size (tools/debug/first_copy.py: a 4 KB
+    copy 88-93 ms, the 40 MB after it 8 ms).  A 4 KB copy on a thread of its own, started when the GPU is first touched, takes that out
+    of the first real upload: by the time a caller has opened its recording the copy path is up.  (source.read_device_raw waits for it.)"""
+    global _warm
+    if _warm is not None or os.environ.get("DD_NO_COPY_WARMUP"):
+        return
+
+    def run():
+        try:
+            d = _p()
+            if lib().dd_malloc(C.byref(d), 4096) == DD_OK:
+                h = (C.c_char * 4096)()
+                lib().dd_memcpy_h2d(d, h, 4096, None)
+                lib().dd_stream_sync(None)
+                lib().dd_free(d)
+        except Exception:
+            pass
+    _warm = threading.Thread(target=run, name="dd-copy-warmup", daemon=True)
+    _warm.start()
+
+
+def wait_copy_warmup():
+    if _warm is not None and _warm.is_alive():
+        _warm.join()
 
 
 def device_name():

@@ -131,6 +131,14 @@ def find_peaks(cor, samp_rate, needle_len, max_peaks=None):
     return np.array(buf[:n.value], dtype=np.int64)
 
 
+def noaa_prepare(n_audio, block=60000 * 4):
+    """what crude_tail will need for n_audio samples, built ahead (dd_noaa_prepare); errors are left to crude_tail itself"""
+    try:
+        lib().dd_noaa_prepare(int(n_audio), int(block), None)
+    except Exception:
+        pass
+
+
 def crude_tail(audio, samp_rate, needles, block=60000 * 4, want_env=False):
     """getCrudeSync's audio-rate tail in one device call (decode_noaa.py:781-790): envelope in `block`-sample blocks, then
     normalised correlation + peak pick for every needle (same length).  Returns ([peaks per needle], envelope DevArray or

@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <complex>
 
 #define DD_FFT_CHECK(expr)                                                     \
     do {                                                                       \
@@ -1453,44 +1454,73 @@ static double dd_sinpi_frac(int64_t num, int64_t den) {
     return sg * sin(3.14159265358979323846 * (double)r / (double)den);
 }
 
-// hh[n] = imag(ifft(h))[n] = (2/N) sum_{k=1..m} sin(2 pi k n / N), m = the number of doubled bins of scipy's mask
-// ((N-1)/2 for odd N, N/2 - 1 for even N) = (2/N) sin(pi m n/N) sin(pi (m+1) n/N) / sin(pi n/N): a closed form, so no
-// length-N (Bluestein) plan is ever built for it; accurate to a few 1e-17 (checked against a long-double sum).
-static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    auto key = std::make_pair(dev, n);
-    auto it = g_hilb.find(key);
-    if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
-    const int64_t nb = M / 2 + 1, m = (n & 1) ? (n - 1) / 2 : n / 2 - 1;
-    std::vector<double> host((size_t)M, 0.0);                 // buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
-    for (int64_t j = 1; j < n; ++j) {
-        const double v = (2.0 / (double)n) * dd_sinpi_frac(m * j, n) * dd_sinpi_frac((m + 1) * j, n) / dd_sinpi_frac(j, n);
-        host[(size_t)j] = v;
-        host[(size_t)(M - n + j)] = v;
+// In-place radix-2 transform of a power-of-two length on the HOST, float64, twiddles from one table (once per Hilbert-kernel
+// spectrum: 2^18 points take a few milliseconds).  Round 5: the kernel spectra no longer go through the FFT library -- its first plan of
+// a process costs hundreds of milliseconds, and the reference decodes one file per process (main.py:208-270).
+static void host_fft_pow2(std::vector<std::complex<double>>& v) {
+    // (plain arrays and spelt-out complex arithmetic: std::complex's operator* goes through a NaN-checking library call)
+    const size_t n = v.size();
+    double* a = reinterpret_cast<double*>(v.data());
+    std::vector<double> wr(n / 2), wi(n / 2);
+    const double step0 = -6.283185307179586476925286766559 / (double)n;
+    // one octant by the library, the rest by symmetry of the unit circle (k -> n/4 - k, then k -> k + n/4)
+    const size_t q = n / 4;
+    for (size_t k = 0; k <= q / 2 && k < n / 2; ++k) {
+        const double c = cos(step0 * (double)k), sn = sin(step0 * (double)k);
+        wr[k] = c; wi[k] = sn;
+        if (q >= k && q - k < n / 2) { wr[q - k] = -sn; wi[q - k] = -c; }
+    }
+    for (size_t k = 0; k < q && k + q < n / 2; ++k) { wr[k + q] = wi[k]; wi[k + q] = -wr[k]; }
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(a[2 * i], a[2 * j]); std::swap(a[2 * i + 1], a[2 * j + 1]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len / 2, step = n / len;
+        for (size_t i = 0; i < n; i += len) {
+            double* lo = a + 2 * i;
+            double* hi = a + 2 * (i + half);
+            for (size_t k = 0; k < half; ++k) {
+                const double c = wr[k * step], sn = wi[k * step];
+                const double xr = hi[2 * k] * c - hi[2 * k + 1] * sn, xi = hi[2 * k] * sn + hi[2 * k + 1] * c;
+                const double ur = lo[2 * k], ui = lo[2 * k + 1];
+                lo[2 * k] = ur + xr; lo[2 * k + 1] = ui + xi;
+                hi[2 * k] = ur - xr; hi[2 * k + 1] = ui - xi;
+            }
+        }
+    }
+}
+// the spectrum of a real kernel image of length M (divided by M): the M/2 + 1 bins the library's real transforms multiply, and -- for the
+// lengths of dd_hconv_kernels.h -- once more behind them in the order its row pass reads (out[N2 k1 + k2] = bin k1 + 512 k2).  One allocation.
+static int kernel_spectrum_upload(const std::vector<double>& img, int64_t M, double2** out, hipStream_t s) {
+    std::vector<std::complex<double>> v((size_t)M);
+    for (int64_t i = 0; i < M; ++i) v[(size_t)i] = std::complex<double>(img[(size_t)i], 0.0);
+    host_fft_pow2(v);
+    const int64_t nb = M / 2 + 1;
+    const bool own = hc_length_ok(M);
+    std::vector<double2> h((size_t)(nb + (own ? M : 0)));
+    const double sc = 1.0 / (double)M;
+    for (int64_t k = 0; k < nb; ++k) h[(size_t)k] = make_double2(v[(size_t)k].real() * sc, v[(size_t)k].imag() * sc);
+    if (own) {
+        const int lg = M == ((int64_t)1 << 18) ? 9 : 8;
+        for (int64_t i = 0; i < M; ++i) {
+            const int64_t k = (i >> lg) + DD_HC_N * (i & (((int64_t)1 << lg) - 1));
+            h[(size_t)(nb + i)] = make_double2(v[(size_t)k].real() * sc, v[(size_t)k].imag() * sc);
+        }
     }
     double2* HH = nullptr;
-    double* buf = nullptr;
-    DD_HIP_CHECK(hipMalloc((void**)&buf, sizeof(double) * M));
-    // (M = 2^17 / 2^18: the same spectrum once more behind the bins, in the order the row pass reads it -- one allocation, one eviction)
-    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * (nb + (hc_length_ok(M) ? M : 0))));
-    hipfftHandle pm;
-    int rc = get_plan(&pm, HIPFFT_D2Z, M, 1, s);
-    if (rc != DD_OK) { (void)hipFree(buf); (void)hipFree(HH); return rc; }
-    hipError_t e0 = hipMemcpyAsync(buf, host.data(), sizeof(double) * M, hipMemcpyHostToDevice, s);
-    hipfftResult r2 = hipfftExecD2Z(pm, buf, (hipfftDoubleComplex*)HH);
-    hipLaunchKernelGGL(k_scale_f64, dim3(grid1(2 * nb)), dim3(256), 0, s, (double*)HH, 2 * nb, 1.0 / (double)M);
-    if (M == ((int64_t)1 << 18)) hipLaunchKernelGGL(k_hc_perm<9>, dim3((unsigned)(M / 256)), dim3(256), 0, s, HH, HH + nb, 1, 1.0);
-    if (M == ((int64_t)1 << 17)) hipLaunchKernelGGL(k_hc_perm<8>, dim3((unsigned)(M / 256)), dim3(256), 0, s, HH, HH + nb, 1, 1.0);
-    hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(buf);
-    if (e0 != hipSuccess || r2 != HIPFFT_SUCCESS || e != hipSuccess) {
-        (void)hipFree(HH);
-        dd_set_error("Hilbert kernel spectrum: hipfft %d, hip %s", (int)r2, hipGetErrorString(e0 != hipSuccess ? e0 : e));
-        return DD_ERR_HIP;
-    }
+    DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * h.size()));
+    hipError_t e = hipMemcpyAsync(HH, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                          // (the staging vector dies with this call)
+    if (e != hipSuccess) { (void)hipFree(HH); dd_set_error("Hilbert kernel spectrum: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
+    *out = HH;
+    return DD_OK;
+}
+static void hilb_cache_put(std::pair<int, int64_t> key, double2* HH) {
     // (one spectrum per length: up to 8 MB each; a process that walks through recordings of many different lengths keeps the
-    // eight most recently built -- both callers hold g_sync_mu and synchronise before they return, so none is in use now)
+    // eight most recently built -- the callers hold g_sync_mu and leave nothing in flight when they return (DDSyncOnExit))
     g_hilb_order.push_back(key);
     while (g_hilb_order.size() > 8) {
         auto old = g_hilb.find(g_hilb_order.front());
@@ -1498,7 +1528,156 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
         g_hilb_order.erase(g_hilb_order.begin());
     }
     g_hilb[key] = HH;
+}
+
+// hh[n] = imag(ifft(h))[n] = (2/N) sum_{k=1..m} sin(2 pi k n / N), m = the number of doubled bins of scipy's mask
+// ((N-1)/2 for odd N, N/2 - 1 for even N) = (2/N) sin(pi m n/N) sin(pi (m+1) n/N) / sin(pi n/N): a closed form, so no
+// length-N (Bluestein) plan is ever built for it; accurate to a few 1e-17 (checked against a long-double sum).
+static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    int lgM = 0;
+    while (((int64_t)1 << lgM) < M) ++lgM;
+    auto key = std::make_pair(dev, (n << 6) | lgM);            // (length and cyclic length)
+    auto it = g_hilb.find(key);
+    if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
+    const int64_t m = (n & 1) ? (n - 1) / 2 : n / 2 - 1;
+    std::vector<double> host((size_t)M, 0.0);                 // buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
+    for (int64_t j = 1; j < n; ++j) {
+        const double v = (2.0 / (double)n) * dd_sinpi_frac(m * j, n) * dd_sinpi_frac((m + 1) * j, n) / dd_sinpi_frac(j, n);
+        host[(size_t)j] = v;
+        host[(size_t)(M - n + j)] = v;
+    }
+    double2* HH = nullptr;
+    const int rc = kernel_spectrum_upload(host, M, &HH, s);
+    if (rc != DD_OK) return rc;
+    hilb_cache_put(key, HH);
     *out = HH;
+    return DD_OK;
+}
+
+// The Hilbert kernel of an EVEN length N is zero at even lags, hh[2j] = 0, hh[2j+1] = (2/N) cot(pi (2j+1) / N) =: g[j]: the length-N circular
+// convolution falls apart into two of length N/2 with the same kernel,
+//     H(x)[2m+1] = (g (*) x_even)[m]        H(x)[2m] = (g (*) x_odd)[m-1]        (indices mod N/2)
+// and z = x_even + j x_odd carries both through ONE complex convolution.  decode_noaa.py:647-653 takes the envelope in blocks of 240 000
+// samples: two length-120 000 convolutions fit the cyclic length 2^18 of dd_hconv_kernels.h (>= 2 (N/2) - 1), the block itself does not
+// (it would need 2^19).  This is g's spectrum for that image -- g[j mod N/2] at lags j in [-(N/2 - 1), N/2 - 1] -- in row-pass order.
+static int hilbert_split_spectrum(int64_t N, int64_t M, const double2** out_perm, hipStream_t s) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    int lgM = 0;
+    while (((int64_t)1 << lgM) < M) ++lgM;
+    auto key = std::make_pair(dev, -((N << 6) | lgM));         // (negative: the split kernel of length N, beside the full ones)
+    auto it = g_hilb.find(key);
+    if (it != g_hilb.end()) { *out_perm = it->second + (M / 2 + 1); return DD_OK; }
+    const int64_t N2 = N / 2;
+    std::vector<double> host((size_t)M, 0.0);
+    auto g = [&](int64_t j) {                                  // (2/N) cot(pi (2j+1) / N), arguments reduced in integers
+        const int64_t k = 2 * j + 1;
+        return (2.0 / (double)N) * dd_sinpi_frac(2 * k + N, 2 * N) / dd_sinpi_frac(k, N);      // cos(pi k / N) = sin(pi (2k + N) / (2N))
+    };
+    for (int64_t j = 0; j < N2; ++j) {
+        const double v = g(j);
+        host[(size_t)j] = v;                                   // lag +j
+        if (j > 0) host[(size_t)(M - N2 + j)] = v;             // lag j - N/2 (the same circular index)
+    }
+    double2* HH = nullptr;
+    const int rc = kernel_spectrum_upload(host, M, &HH, s);
+    if (rc != DD_OK) return rc;
+    hilb_cache_put(key, HH);
+    *out_perm = HH + (M / 2 + 1);
+    return DD_OK;
+}
+
+// a block of real float64 audio as the source and its envelope as the sink of the three launches; job = block.
+// Split form (even block length N): element n of the image = (x[2n], x[2n+1]), n < N/2; result element m = (H(x)[2m+1], H(x)[2(m+1)]).
+struct HcBlkSplitIO {
+    const double* x;
+    double* env;
+    int64_t N, N2;
+    __device__ int rows(int, int cols) const { return (int)((N2 + cols - 1) / cols); }
+    __device__ double2 at(int job, int64_t n) const {
+        if (n >= N2) return make_double2(0.0, 0.0);
+        const double* p = x + (int64_t)job * N + 2 * n;
+        return make_double2(p[0], p[1]);
+    }
+    __device__ void put(int job, int64_t m, double2 y) const {
+        if (m >= N2) return;
+        const double* p = x + (int64_t)job * N;
+        double* e = env + (int64_t)job * N;
+        e[2 * m + 1] = hypot(p[2 * m + 1], y.x);
+        const int64_t m1 = m + 1 == N2 ? 0 : m + 1;
+        e[2 * m1] = hypot(p[2 * m1], y.y);
+    }
+};
+// Plain form (any length n with 2 n + 2 <= M): element i = (x[i], 0); result element i = (H(x)[i], -)
+struct HcBlkRealIO {
+    const double* x;
+    double* env;
+    int64_t n;
+    __device__ int rows(int, int cols) const { return (int)((n + cols - 1) / cols); }
+    __device__ double2 at(int, int64_t i) const { return i < n ? make_double2(x[i], 0.0) : make_double2(0.0, 0.0); }
+    __device__ void put(int, int64_t i, double2 y) const { if (i < n) env[i] = hypot(x[i], y.x); }
+};
+// envelope of `jobs` blocks of N samples each (x + job N) through dd_hconv_kernels.h; T: [jobs][M] c128 work buffer.  split: the
+// even / odd form above (N even, N - 1 <= M); else the plain form (one block, 2 N + 2 <= M).  DD_ERR_UNSUPPORTED: the caller's other route.
+static int hc_block_envelope(const double* x, double* env, int64_t N, int jobs, bool split, int64_t M, double2* T, hipStream_t s) {
+    if (!hc_length_ok(M)) return DD_ERR_UNSUPPORTED;
+    const int lg = M == ((int64_t)1 << 18) ? 9 : 8;
+    const double2 *TA = nullptr, *TB = nullptr;
+    int rc = hc_tables(lg, &TA, &TB);
+    if (rc != DD_OK) return rc;
+    const double2* HHp = nullptr;
+    if (split) {
+        rc = hilbert_split_spectrum(N, M, &HHp, s);
+        if (rc != DD_OK) return rc;
+        const HcBlkSplitIO io = {x, env, N, N / 2};
+        const HcOneSpec sp = {HHp};
+        if (lg == 9) { rc = hc_ready<9, HcBlkSplitIO, HcBlkSplitIO>(); if (rc == DD_OK) hc_convolve<9>(io, sp, io, T, jobs, TA, TB, s); }
+        else { rc = hc_ready<8, HcBlkSplitIO, HcBlkSplitIO>(); if (rc == DD_OK) hc_convolve<8>(io, sp, io, T, jobs, TA, TB, s); }
+    } else {
+        const double2* HH = nullptr;
+        rc = hilbert_kernel_spectrum(N, M, &HH, s);
+        if (rc != DD_OK) return rc;
+        HHp = HH + (M / 2 + 1);
+        const HcBlkRealIO io = {x, env, N};
+        const HcOneSpec sp = {HHp};
+        if (lg == 9) { rc = hc_ready<9, HcBlkRealIO, HcBlkRealIO>(); if (rc == DD_OK) hc_convolve<9>(io, sp, io, T, 1, TA, TB, s); }
+        else { rc = hc_ready<8, HcBlkRealIO, HcBlkRealIO>(); if (rc == DD_OK) hc_convolve<8>(io, sp, io, T, 1, TA, TB, s); }
+    }
+    return rc;
+}
+
+// cyclic length of dd_hconv_kernels.h for the envelope of a block of N real samples, 0 = not on this route; *split: the even / odd form
+static int64_t hc_block_len(int64_t N, bool* split) {
+    if (N < 2) return 0;
+    if ((N & 1) == 0 && N - 1 <= ((int64_t)1 << 18)) { *split = true; return N - 1 <= ((int64_t)1 << 17) ? (int64_t)1 << 17 : (int64_t)1 << 18; }
+    *split = false;
+    if (2 * N + 2 <= ((int64_t)1 << 17)) return (int64_t)1 << 17;
+    if (2 * N + 2 <= ((int64_t)1 << 18)) return (int64_t)1 << 18;
+    return 0;
+}
+// What dd_noaa_crude_tail will need for `n` audio samples in blocks of `block` -- the Hilbert-kernel spectra of the block and of the ragged
+// last block (host transforms: ~20 ms) and the transform's twiddle tables -- built ahead of time.  noaa_sync calls this from a thread of
+// its own when the decoder object is created, so that it overlaps the upload of the recording and the audio chain; the result sits in the
+// cache the crude tail looks in.  Harmless when the lengths turn out different (the crude tail builds what it needs).
+extern "C" int dd_noaa_prepare(int64_t n, int64_t block, void* stream) {
+    DD_REQUIRE(n >= 1 && block >= 2, "arguments");
+    hipStream_t s = dd_stream(stream);
+    int64_t nfull = 0;
+    while ((nfull + 1) * block < n) ++nfull;
+    const int64_t rem = n - nfull * block;
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    const int64_t lens[2] = {nfull > 0 ? block : 0, rem};
+    for (int i = 0; i < 2; ++i) {
+        bool split = false;
+        const int64_t M = hc_block_len(lens[i], &split);
+        if (!M) continue;
+        const double2 *TA = nullptr, *TB = nullptr, *sp = nullptr;
+        int rc = hc_tables(M == ((int64_t)1 << 18) ? 9 : 8, &TA, &TB);
+        if (rc == DD_OK) rc = split ? hilbert_split_spectrum(lens[i], M, &sp, s) : hilbert_kernel_spectrum(lens[i], M, &sp, s);
+        if (rc != DD_OK) return rc;
+    }
     return DD_OK;
 }
 
@@ -2257,6 +2436,16 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
     const size_t o_spec = take(sizeof(double2) * spec_elems);
     const size_t y_r = (size_t)(Mr ? 2 * Mr : rem);
     const size_t o_y = take(sizeof(double) * ((size_t)(gb * block) > y_r ? (size_t)(gb * block) : y_r));
+    // Round 5: the blocks' envelopes through the own float64 transform (hc_block_envelope: the even / odd split of the Hilbert kernel puts a
+    // 240 000-sample block on the cyclic length 2^18) -- no FFT-library plan on this path, whose creation was 0.9 s of a process's first call.
+    // DD_AM_HILBERT=lib (tools / tests) keeps the library's transforms.
+    static const char* amh_env = getenv("DD_AM_HILBERT");
+    const bool own_ok = !(amh_env && !strcmp(amh_env, "lib"));
+    bool split_b = false, split_r = false;
+    const int64_t Mb_own = (own_ok && nfull > 0) ? hc_block_len(block, &split_b) : 0;
+    const int64_t Mr_own = (own_ok && rem >= 2) ? hc_block_len(rem, &split_r) : 0;
+    const int64_t T_elems = std::max<int64_t>(Mb_own && split_b ? gb * Mb_own : (Mb_own ? Mb_own : 0), Mr_own);
+    const size_t o_T = take(sizeof(double2) * (size_t)T_elems);
     const size_t o_P = take(sizeof(double) * (size_t)(n + 1)), o_Q = take(sizeof(double) * (size_t)(n + 1));
     const size_t o_part = take(sizeof(double2) * (size_t)tiles);
     const size_t o_cor = take(sizeof(double) * (size_t)n * n_needles);
@@ -2299,9 +2488,19 @@ extern "C" int dd_noaa_crude_tail(const void* audio, int audio_is_f32, int64_t n
         hipLaunchKernelGGL(k_env_hypot_flat, dim3(grid1(N * batch)), dim3(256), 0, s, x + first, y, env + first, N * batch, 1.0 / (double)N);
         return DD_OK;
     };
-    for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) rc = env_blocks(b0 * block, block, (int)(nfull - b0 < GB ? nfull - b0 : GB));
+    double2* Tw = (double2*)(base + o_T);
+    if (Mb_own) {
+        // (plain form: one block per call; split form: a batch of blocks, one complex image each)
+        const int per = split_b ? (int)gb : 1;
+        for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += per)
+            rc = hc_block_envelope(x + b0 * block, env + b0 * block, block, (int)(nfull - b0 < per ? nfull - b0 : per), split_b, Mb_own, Tw, s);
+    } else {
+        for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) rc = env_blocks(b0 * block, block, (int)(nfull - b0 < GB ? nfull - b0 : GB));
+    }
     tt[0] = now_us() - tt0;
-    if (rc == DD_OK && Mr) {
+    if (rc == DD_OK && Mr_own) {
+        rc = hc_block_envelope(x + nfull * block, env + nfull * block, rem, 1, split_r, Mr_own, Tw, s);
+    } else if (rc == DD_OK && Mr) {
         const double2* HH = nullptr;
         rc = hilbert_kernel_spectrum(rem, Mr, &HH, s);
         hipfftHandle pf, pb;

@@ -50,6 +50,20 @@ class noaa_sync:
         self.__syncB = None
         self.__rate = None
         self.__useful = 0
+        # the crude sync's envelope stage needs the Hilbert-kernel spectra of its block lengths (host transforms, ~20 ms): built on a
+        # thread of its own from now on, beside the upload of the recording and the audio chain (dd_noaa_prepare)
+        self.__prep = None
+        try:
+            dec = int(sigsrc.sampFreq / self.__bw)                        # bwLim(NOAA_FMBW): 34 at 2.048 MS/s
+            rate1 = int(sigsrc.sampFreq / dec)
+            if dec >= 1 and rate1 >= constants.NOAA_CRUDESYNCSAMPRATE and int(rate1 / constants.NOAA_CRUDESYNCSAMPRATE) == 1:
+                n_audio = -(-int(sigsrc.length) // dec) - 1               # kept samples of the whole stream, one angle fewer (demod_fm.py:43-49)
+                if n_audio > 1:
+                    import threading
+                    self.__prep = threading.Thread(target=_ops.noaa_prepare, args=(n_audio,), daemon=True)
+                    self.__prep.start()
+        except Exception:
+            self.__prep = None
 
     # ---- FM audio in chunks: one fused kernel per chunk (decode_noaa.py:600-629)
     def audio(self, audioFreq=constants.NOAA_CRUDESYNCSAMPRATE, strictness=False, chunkSize=constants.PROC_CHUNKSIZE):
@@ -101,6 +115,9 @@ class noaa_sync:
         if self.__syncA is None or self.__syncB is None:
             audio = self.audio(constants.NOAA_CRUDESYNCSAMPRATE, False)
             res = None
+            if self.__prep is not None:
+                self.__prep.join()
+                self.__prep = None
             if fused:
                 res = _ops.crude_tail(audio.device_signal, audio.sampRate,
                                       [sync_needle(constants.NOAA_SYNCA, audio.sampRate), sync_needle(constants.NOAA_SYNCB, audio.sampRate)])

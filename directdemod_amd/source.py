@@ -99,6 +99,7 @@ class _u8source:
         if 2 * total > int(os.environ.get("DD_RESIDENT_BYTES", str(64 << 30))):
             return None
         if getattr(self, "_res", None) is None:
+            _hip.wait_copy_warmup()
             self._res = DevArray(total, _hip.IQ8)
             self._res_pages = np.zeros((total + self._PAGE - 1) // self._PAGE, dtype=bool)
         for pg in range(a // self._PAGE, (b - 1) // self._PAGE + 1):

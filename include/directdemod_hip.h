@@ -335,6 +335,11 @@ int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int64_t* start
                                const double* needle_host, int needle_len, int n_needles, double samp_rate,
                                int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
 
+/* dd_noaa_prepare -- builds ahead of time what dd_noaa_crude_tail needs for `n` audio samples in blocks of `block` (decode_noaa.py:647-653): the
+ * Hilbert-kernel spectra of the block and of the ragged last block (host transforms, ~20 ms) and the twiddle tables of the float64 transform.
+ * Optional: noaa_sync calls it from a thread of its own when the decoder object is created, so that it overlaps the upload and the audio chain.
+ * No reference counterpart (the reference's scipy.signal.hilbert plans nothing ahead). */
+int  dd_noaa_prepare(int64_t n, int64_t block, void* stream);
 /* P -- getCrudeSync's audio-rate tail (decode_noaa.py:781-790) in one host call: the envelope of `audio` (device float32 or
  *      float64, n samples at samp_rate) in `block`-sample blocks by the chunker rule (__getAM :631-657 -> demod_am.py:29),
  *      then for each of n_needles (1 or 2: sync A and sync B, :786 and :790) piecewise-constant needles of m samples
