@@ -318,7 +318,7 @@ class StubStep:
 
 
 # ----------------------------------------------------------------------------- side configs (N = 1 only)
-def side_configs(eng, steps=10):
+def side_configs(eng, steps=10, only_decim=False):
     """C3 / C4 front ends on the same device-resident buffer: the decimating fused chain,
     chunked with carried state as the reference's chunk loops do (decode_fm.py:54-70, decode_noaa.py:614-624).
     Reported in extra.side, never in `value`."""
@@ -386,6 +386,8 @@ def side_configs(eng, steps=10):
                     "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),
                                   "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4)}})
         lib.dd_chain_destroy(h)
+    if only_decim:                                            # (tools/bench_decim.py)
+        return res
     # the headline chain on RAW u8 input (what source.IQwav reads: 2 B/sample resident instead of 8) and with complex64
     # output (commSignal.filter without demod_fm), same kernel family
     import torch

@@ -195,7 +195,7 @@ __device__ __forceinline__ void dd_seam_wait(unsigned int* flag, unsigned int* e
             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
-        if (!seen && err) __hip_atomic_fetch_add((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!seen && err) __hip_atomic_fetch_add((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (a word of pinned host memory)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -752,7 +752,7 @@ int dd_mfma_launch(void* st, const DDChainParams& P, hipStream_t s, int* kernel_
 // ---------------------------------------------------------------- dd_fir (taps + history)
 // ---- chunk-list launches: hand-overs that timed out (dd_seam_wait) become DD_ERR_TIMEOUT --------------------------------
 static std::mutex g_seam_mu;
-static std::vector<dd_fir*> g_seam_pending;          // filters with a mirror copy of their error count in flight
+static std::vector<dd_fir*> g_seam_pending;          // filters that have made a chunk-list launch (their error word is looked at until they are destroyed)
 static int g_seam_withhold = -1, g_seam_spin_log2 = 0;
 
 extern "C" int dd_debug_seam(int withhold_chunk, int spin_log2) {
@@ -761,19 +761,16 @@ extern "C" int dd_debug_seam(int withhold_chunk, int spin_log2) {
     g_seam_spin_log2 = spin_log2;
     return DD_OK;
 }
-// look at one filter's mirror word if its copy has completed (or wait for it); caller holds g_seam_mu
-static int seam_look(dd_fir* f, bool wait) {
-    if (!f->seam_pending) return DD_OK;
-    if (wait) (void)hipEventSynchronize(f->seam_ev);
-    else if (hipEventQuery(f->seam_ev) != hipSuccess) return DD_OK;          // still running: a later call looks again
-    f->seam_pending = 0;
-    for (size_t i = 0; i < g_seam_pending.size(); ++i)
-        if (g_seam_pending[i] == f) { g_seam_pending.erase(g_seam_pending.begin() + i); break; }
+// look at one filter's error word; caller holds g_seam_mu.  Round 5: the word is pinned host memory the kernel counts into directly
+// (system-scope atomic, taken only by a wait that gives up) -- a chunk-list call used to carry a device-to-host copy of the count and
+// an event behind every launch, two stream operations of ~3 us each around a 100 us kernel.  A look while the launch still runs may be
+// early; the word is final once its stream has been synchronised, and every later fused launch and dd_stream_sync looks again.
+static int seam_look(dd_fir* f, bool) {
+    if (!f->seam_pending || !f->seam_err_host) return DD_OK;
     const unsigned n = *reinterpret_cast<volatile unsigned int*>(f->seam_err_host);
     if (n == 0) return DD_OK;
     f->state_invalid = 1;          // (the faulty launch also committed its carried state: nothing may continue from it)
-    *f->seam_err_host = 0;
-    (void)hipMemset(f->seam_err, 0, sizeof(unsigned int));
+    *reinterpret_cast<volatile unsigned int*>(f->seam_err_host) = 0;
     dd_set_error("chunk-list launch: %u in-launch hand-over wait(s) of the carried FIR / FM state timed out; the outputs of that "
                  "dd_*_process_chunks call are invalid (run the chunks one by one, or raise the bound with dd_debug_seam)", n);
     return DD_ERR_TIMEOUT;
@@ -792,9 +789,7 @@ static void seam_forget(dd_fir* f) {
     std::lock_guard<std::mutex> lk(g_seam_mu);
     for (size_t i = 0; i < g_seam_pending.size(); ++i)
         if (g_seam_pending[i] == f) { g_seam_pending.erase(g_seam_pending.begin() + i); break; }
-    if (f->seam_ev) (void)hipEventDestroy(f->seam_ev);
-    if (f->seam_err_host) (void)hipHostFree(f->seam_err_host);
-    if (f->seam_err) (void)hipFree(f->seam_err);
+    if (f->seam_err_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(f->seam_err_host); }      // (no launch may still count into it)
     f->seam_ev = nullptr; f->seam_err_host = nullptr; f->seam_err = nullptr; f->seam_pending = 0;
 }
 
@@ -1324,11 +1319,10 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
         spin_log2 = g_seam_spin_log2;
     }
     if (!fir->seam_err) {
-        DD_HIP_CHECK(hipMalloc((void**)&fir->seam_err, 2 * sizeof(unsigned int)));
-        DD_HIP_CHECK(hipMemset(fir->seam_err, 0, 2 * sizeof(unsigned int)));
-        DD_HIP_CHECK(hipHostMalloc((void**)&fir->seam_err_host, sizeof(unsigned int), hipHostMallocDefault));
-        *fir->seam_err_host = 0;
-        DD_HIP_CHECK(hipEventCreateWithFlags(&fir->seam_ev, hipEventDisableTiming));
+        // [0]: waits that gave up, counted by the kernel; [1]: where dd_debug_seam sends a withheld flag.  Pinned, mapped host memory.
+        DD_HIP_CHECK(hipHostMalloc((void**)&fir->seam_err_host, 2 * sizeof(unsigned int), hipHostMallocMapped));
+        fir->seam_err_host[0] = fir->seam_err_host[1] = 0;
+        DD_HIP_CHECK(hipHostGetDevicePointer((void**)&fir->seam_err, fir->seam_err_host, 0));
     }
     {
         // (the multi kernels' dynamic LDS limit: a chunk list whose chunks have no interior run never passes through
@@ -1393,11 +1387,11 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     unsigned int* seam_flags = reinterpret_cast<unsigned int*>(fir->multi);
     float2* seam_tail = reinterpret_cast<float2*>(fir->multi + o_tail);
     float2* seam_last = reinterpret_cast<float2*>(fir->multi + o_last);
-    std::vector<char> img(o_tail - o_par, 0);
-    DDChainParams* hP = reinterpret_cast<DDChainParams*>(img.data());
-    DDSeg* hS = reinterpret_cast<DDSeg*>(img.data() + (o_seg - o_par));
-    int* hI = reinterpret_cast<int*>(img.data() + (o_ipre - o_par));
-    int* hE = reinterpret_cast<int*>(img.data() + (o_epre - o_par));
+    std::vector<char> img(o_tail, 0);                         // (from the seam flags, which start as zeros, to the edge prefix: ONE copy)
+    DDChainParams* hP = reinterpret_cast<DDChainParams*>(img.data() + o_par);
+    DDSeg* hS = reinterpret_cast<DDSeg*>(img.data() + o_seg);
+    int* hI = reinterpret_cast<int*>(img.data() + o_ipre);
+    int* hE = reinterpret_cast<int*>(img.data() + o_epre);
     hI[0] = hE[0] = 0;
     size_t lds_p = 0;
     int per_cu = 0;
@@ -1423,8 +1417,8 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     }
     const int n_int = hI[nchunks], n_edge = hE[nchunks];
     if (per_cu < 1) per_cu = 1;
-    DD_HIP_CHECK(hipMemsetAsync(seam_flags, 0, o_par, s));
-    DD_HIP_CHECK(hipMemcpyAsync(fir->multi + o_par, img.data(), img.size(), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    DD_HIP_CHECK(hipMemcpyAsync(fir->multi, img.data(), img.size(), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    (void)seam_flags;
     const int slots = dd_cu_count() * per_cu;
     int grid = n_edge < slots / 2 ? slots - n_edge : slots / 2;
     if (grid > n_int) grid = n_int;
@@ -1438,11 +1432,8 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     else hipLaunchKernelGGL(k_chain_decim_multi<false>, dim3(grid + n_edge), dim3(DD_DECIM_THREADS), lds_p, s, dP, dS, dI, dE, nchunks, grid);
     DD_LAUNCH_CHECK();
     {
-        // mirror the error count behind the launch; looked at by the next chunk-list call through this filter or by dd_stream_sync
+        // the kernel counts waits that gave up into fir->seam_err_host; every later fused launch and dd_stream_sync looks at it
         std::lock_guard<std::mutex> lk(g_seam_mu);
-        if (fir->seam_pending) (void)hipEventSynchronize(fir->seam_ev);       // (one mirror copy in flight per filter)
-        DD_HIP_CHECK(hipMemcpyAsync(fir->seam_err_host, fir->seam_err, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-        DD_HIP_CHECK(hipEventRecord(fir->seam_ev, s));
         if (!fir->seam_pending) g_seam_pending.push_back(fir);
         fir->seam_pending = 1;
     }
