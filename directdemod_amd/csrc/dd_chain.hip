@@ -189,7 +189,10 @@ __device__ __forceinline__ void dd_seam_wait(unsigned int* flag, unsigned int* e
     if (threadIdx.x == 0) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
         gu32* f = (gu32*)flag;
-        const unsigned bound = 1u << (spin_log2 > 0 && spin_log2 < 31 ? spin_log2 : 24);
+        // default bound 2^19 polls of ~0.2 us (s_sleep 8) = ~0.1 s: three orders of magnitude above the ~100 us a producer tile of a
+        // resident launch needs, and short enough that a launch whose producer is NOT resident (a GPU shared with another process)
+        // fails within a second instead of holding the device for seconds per chunk (round 4's bound was 2^24)
+        const unsigned bound = 1u << (spin_log2 > 0 && spin_log2 < 31 ? spin_log2 : 19);
         bool seen = false;
         for (unsigned spins = 0; spins < bound; ++spins) {
             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = true; break; }

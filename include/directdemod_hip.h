@@ -78,7 +78,7 @@ int  dd_debug_fill_lds(uint32_t pattern, void* stream);
  * once per process.  No reference counterpart. */
 int  dd_debug_select_kernel(const char* name);
 /* diagnostic: the NEXT chunk-list launch withholds the hand-over flag of chunk `withhold_chunk` (>= 0; -1: none) and every
- * later one bounds its in-launch waits by 2^spin_log2 polls (0: the default, 2^24 = seconds).  Lets a test see DD_ERR_TIMEOUT
+ * later one bounds its in-launch waits by 2^spin_log2 polls (0: the default, 2^19 = about a tenth of a second per wait).  Lets a test see DD_ERR_TIMEOUT
  * instead of silently wrong samples.  No reference counterpart (the reference's chunk loop is sequential, decode_noaa.py:619-624). */
 int  dd_debug_seam(int withhold_chunk, int spin_log2);
 /* diagnostics that need no GPU (host arithmetic of two launch paths, checked by the CPU test suite):

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from directdemod_amd import _hip, noaa_sync, source
 from oracle import dd_oracle as O
