@@ -64,6 +64,8 @@ struct DDCos1kArgs {
     int s;                     // 1: stream start, no angle for sample 0
     int base;                  // first sample of row 0 (chunk-relative)
     int nrows, nwaves;
+    int run_rows;              // 0: wave w takes ONE run, rows [nrows w / nwaves, nrows (w + 1) / nwaves); R > 0: runs of R rows dealt to the
+                               // waves in turn (run j = rows [jR, jR + R) goes to wave j mod nwaves: the device walks one moving window)
     float c1, s1;              // rotation by phi
     float c2, s2;              // rotation by 256 phi (= 2 phi)
     float a0, a1;              // y = a0 R + a1 C
@@ -581,12 +583,16 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * C1_WAVES + wave;
     const int nrows = A.nrows, nwaves = A.nwaves;
-    const int q0 = (int)(((int64_t)nrows * gw) / nwaves), q1 = (int)(((int64_t)nrows * (gw + 1)) / nwaves);
-    if (q1 <= q0) return;
     char* const lds = c1_smem + wave * C1_WAVE_BYTES;
     const DDCos1kLane lt = A.lane_tab[lane];
     v2f ql = (v2f){1.f, 0.f};
     if (NCO) ql = c1_v2(dd_phasor((uint64_t)(U8 ? 16 * lane : 2 * lane) * A.cyc, A.nco_tbl));
+    const int R = A.run_rows;
+    const int nruns = R > 0 ? (nrows + R - 1) / R : nwaves;
+    for (int run = gw; run < nruns; run += nwaves) {
+    const int q0 = R > 0 ? run * R : (int)(((int64_t)nrows * gw) / nwaves);
+    const int q1 = R > 0 ? (q0 + R < nrows ? q0 + R : nrows) : (int)(((int64_t)nrows * (gw + 1)) / nwaves);
+    if (q1 <= q0) continue;
     // the "row before" of the wave's first row starts as zeros where it is read (the hardware does not clear LDS; its old
     // contents may be NaN patterns): the last 16 groups of the second buffer, plus the word after it that lane 15 of a row never reads
     if (lane < 16) {
@@ -608,14 +614,20 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
     // a row is an edge row when it holds samples before the first output, the carried state or the chunk's end.  Edge rows sit at
     // the two ends of a wave's range only: [q0 - 1, f0) edge, [f0, f1) interior, [f1, q1) edge.
     auto edge = [&](int q) { const int64_t lo = (int64_t)A.base + (int64_t)C1_ROW * q; return lo < A.s || lo + C1_ROW > A.L || q == nrows - 1; };
+#ifdef C1_ABL_MEMONLY
+    int f0 = edge(q0 - 1) ? q0 - 1 : q0;                      // (the memory-only build carries no state: no row before the run)
+    const int qfirst = f0;
+#else
     int f0 = q0 - 1;
+    const int qfirst = q0 - 1;
+#endif
     while (f0 < q1 && edge(f0)) ++f0;
     int f1 = f0;
     while (f1 < q1 && !edge(f1)) ++f1;
     v4f xa[8], xb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) xa[j] = xb[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int q = q0 - 1; q < f0; ++q)
+    for (int q = qfirst; q < f0; ++q)
         c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
     if (f1 > f0) {
         const int64_t S0 = (int64_t)A.base + (int64_t)C1_ROW * f0;
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
         g_c1_trace[gw * (C1_NPH + 2) + C1_NPH] = (unsigned long long)(q1 - q0);
     }
 #endif
-    if (gw == nwaves - 1 && A.tail_out) {
+    if (q1 == nrows && A.tail_out) {
         // the new carried history: the chunk's last K-1 samples after the NCO (older ones from the old history)
         for (int i = lane; i < C1_K - 1; i += 64) {
             const int64_t n = A.L - (C1_K - 1) + i;
@@ -664,6 +676,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
             A.tail_out[i] = v;
         }
     }
+    }   // runs
 }
 
 // ============================================================================ host side
@@ -766,6 +779,8 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
     int grid;
     cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
+    static const char* run_env = getenv("DD_COS_RUN");                 // tools: rows per run of the moving-window map (0 = one run per wave)
+    A.run_rows = run_env ? atoi(run_env) : 0;
     static const char* grid_env = getenv("DD_COS_GRID");               // tools: a fixed number of workgroups
     if (grid_env && atoi(grid_env) > 0 && (int64_t)atoi(grid_env) * C1_WAVES <= A.nrows) { grid = atoi(grid_env); A.nwaves = grid * C1_WAVES; }
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
