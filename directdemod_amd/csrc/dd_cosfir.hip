@@ -575,6 +575,124 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     C1_T(6);
 }
 
+// The row BEFORE a run, cheaply.  What a run needs from it depends on its last 256 samples only: their image in LDS (the samples 255 back of
+// the run's first 16 lanes), the prefixes of lanes 48..63 (as lanes 0..15 will use them: only the sum of the lanes behind matters, so the prefix
+// may start at lane 48), the row total, the windowed state and the FIR output at its last sample -- and that output is a0 R + a1 C of the
+// state itself: no second pass, no discriminator.  A quarter of a row's loads and a third of its instructions; lanes 0..47 work on zeros.
+// (Rows that touch the stream start or the carried state go through c1_row<EDGE> instead.)
+template <bool U8>
+__device__ __forceinline__ void c1_prime_issue(const DDCos1kArgs& A, int64_t S, int lane, v4f (&xp)[2]) {
+    xp[0] = xp[1] = (v4f){0.f, 0.f, 0.f, 0.f};
+#ifdef C1_ABL_NO_LOAD
+    return;
+#endif
+    if (U8) {
+        if (lane >= 48) {
+            const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const unsigned char*>(A.in) + 2 * (S + 16 * lane));
+            xp[0] = __builtin_nontemporal_load(p);
+            xp[1] = __builtin_nontemporal_load(p + 1);
+        }
+    } else {
+        const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const float2*>(A.in) + S + 2 * lane);
+        xp[0] = __builtin_nontemporal_load(p + 64 * 6);
+        xp[1] = __builtin_nontemporal_load(p + 64 * 7);
+    }
+}
+template <bool U8, bool NCO>
+__device__ __forceinline__ void c1_prime_light(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds, const int64_t S,
+                                               const v4f (&xp)[2], const v2f ql, C1Carry& cr) {
+    const float c = A.c1, s = A.s1;
+    char* const cur = lds + cr.cur;
+    char* const own = cur + lane * C1_GROUP_BYTES;
+    const bool act = lane >= 48;
+    const v2f prow = c1_row_phasor<NCO>(A, S, ql);
+    v2f xt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xt[i] = (v2f){0.f, 0.f};
+    if (U8) {
+        if (act) {
+            unsigned u[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { u[t] = __float_as_uint(xp[0][t]); u[4 + t] = __float_as_uint(xp[1][t]); }
+            v2f p4[4];
+            if (NCO) {
+                p4[0] = prow;
+                p4[1] = c1_cmul(prow, c1_v2(A.e4));
+                p4[2] = c1_cmul(prow, c1_v2(A.e8));
+                p4[3] = c1_cmul(p4[2], c1_v2(A.e4));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned word = u[i >> 1];
+                v2f x = (v2f){(float)((word >> (16 * (i & 1))) & 0xFF) - 127.5f, (float)((word >> (16 * (i & 1) + 8)) & 0xFF) - 127.5f};
+                if (NCO) {
+                    const v2f pb = p4[i >> 2];
+                    x = c1_cmul(x, (i & 3) == 0 ? pb : c1_cmul(pb, c1_v2((i & 3) == 1 ? A.e1 : ((i & 3) == 2 ? A.e2 : A.e3))));
+                }
+                xt[i] = x;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<v4f*>(own + 16 * t) = (v4f){xt[2 * t].x, xt[2 * t].y, xt[2 * t + 1].x, xt[2 * t + 1].y};
+        }
+    } else {
+        char* const wr = cur + (lane >> 3) * C1_GROUP_BYTES + 16 * (lane & 7);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 6 + jj;
+            v2f x0 = (v2f){xp[jj].x, xp[jj].y}, x1 = (v2f){xp[jj].z, xp[jj].w};
+            if (NCO) {
+                v2f pj = c1_cmul(c1_cmul(prow, c1_v2(A.q4)), c1_v2(A.q2));
+                if (jj) pj = c1_cmul(pj, c1_v2(A.q1));
+                x0 = c1_cmul(x0, pj);
+                x1 = c1_cmul(x1, c1_cmul(pj, c1_v2(A.e1)));
+            }
+            *reinterpret_cast<v4f*>(wr + 8 * j * C1_GROUP_BYTES) = (v4f){x0.x, x0.y, x1.x, x1.y};
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const v4f v = *reinterpret_cast<const v4f*>(own + 16 * t);
+                xt[2 * t] = (v2f){v.x, v.y};
+                xt[2 * t + 1] = (v2f){v.z, v.w};
+            }
+        }
+    }
+    const v2f e = *reinterpret_cast<const v2f*>(cur + 48 * C1_GROUP_BYTES);          // the first of the 256 samples: it is NOT in the 255-sample window
+    C1St t;
+    {
+        static constexpr float CW[16] = {1.000000000e+00f, 9.996940573e-01f, 9.987764162e-01f, 9.972476384e-01f, 9.951086592e-01f, 9.923607874e-01f,
+                                         9.890057045e-01f, 9.850454633e-01f, 9.804824871e-01f, 9.753195679e-01f, 9.695598648e-01f, 9.632069021e-01f,
+                                         9.562645670e-01f, 9.487371075e-01f, 9.406291296e-01f, 9.319455943e-01f};
+        static constexpr float SW[16] = {0.000000000e+00f, 2.473442728e-02f, 4.945371992e-02f, 7.414275255e-02f, 9.878641831e-02f, 1.233696381e-01f,
+                                         1.478773698e-01f, 1.722946174e-01f, 1.966064405e-01f, 2.207979630e-01f, 2.448543824e-01f, 2.687609789e-01f,
+                                         2.925031245e-01f, 3.160662917e-01f, 3.394360625e-01f, 3.625981373e-01f};
+        v2f C0 = xt[15], C1 = CW[1] * xt[14], S0 = SW[2] * xt[13], S1 = SW[1] * xt[14], R0 = xt[15] + xt[13], R1 = xt[14];
+        C0 = c1_fma(CW[2], xt[13], C0);
+#pragma unroll
+        for (int i = 12; i >= 0; --i) {
+            const int m = 15 - i;
+            if (i & 1) { C0 = c1_fma(CW[m], xt[i], C0); S0 = c1_fma(SW[m], xt[i], S0); R0 += xt[i]; }
+            else { C1 = c1_fma(CW[m], xt[i], C1); S1 = c1_fma(SW[m], xt[i], S1); R1 += xt[i]; }
+        }
+        t.C = C0 + C1; t.S = S0 + S1; t.R = R0 + R1;
+    }
+    // lanes 48..63 are one DPP row: four steps give their prefixes (the lanes before them hold zeros)
+    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, A.wc[0], A.ws[0]);
+    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, A.wc[1], A.ws[1]);
+    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, A.wc[2], A.ws[2]);
+    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, A.wc[3], A.ws[3]);
+    const int back16 = ((lane - 16) & 63) << 2;
+    cr.W.C = c1_bperm(back16, t.C);
+    cr.W.S = c1_bperm(back16, t.S);
+    cr.W.R = c1_bperm(back16, t.R);
+    cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
+    cr.V63.C = c1_fma(-c, e, cr.P63.C);
+    cr.V63.S = c1_fma(-s, e, cr.P63.S);
+    cr.V63.R = cr.P63.R - e;
+    cr.y63 = c1_fma(A.a1 / A.a0, cr.V63.C, cr.V63.R);
+    cr.cur = C1_BUF_BYTES - cr.cur;
+}
+
 // The whole chunk in one launch.  Row q covers samples [base + 1024 q, base + 1024 (q + 1)); wave gw takes rows
 // [nrows gw / nwaves, nrows (gw + 1) / nwaves), after running the row before them without stores.
 template <bool U8, bool NCO>
@@ -631,8 +749,22 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
         c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
     if (f1 > f0) {
         const int64_t S0 = (int64_t)A.base + (int64_t)C1_ROW * f0;
+#if !defined(C1_ABL_MEMONLY) && !defined(C1_FULL_PRIME)
+        if (f0 == q0 - 1 && f1 > q0) {
+            // the row before the run is an interior row: its last 256 samples are all the run needs (c1_prime_light); the run's first row
+            // is requested right behind them
+            v4f xp[2];
+            c1_prime_issue<U8>(A, S0, lane, xp);
+            ++f0;
+            c1_issue_loads<U8>(A, S0 + C1_ROW, lane, xa);
+            c1_prime_light<U8, NCO>(A, lt, lane, lds, S0, xp, ql, cr);
+            cr.prow = c1_row_phasor<NCO>(A, S0 + C1_ROW, ql);
+        } else
+#endif
+        {
         c1_issue_loads<U8>(A, S0, lane, xa);
         cr.prow = c1_row_phasor<NCO>(A, S0, ql);
+        }
         // two rows per trip: the sample registers alternate (xa: even rows of the run, xb: odd ones)
         for (int q = f0; q < f1; q += 2) {
             const int64_t S = (int64_t)A.base + (int64_t)C1_ROW * q;
@@ -780,9 +912,13 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     int grid;
     cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
     static const char* run_env = getenv("DD_COS_RUN");                 // tools: rows per run of the moving-window map (0 = one run per wave)
-    A.run_rows = run_env ? atoi(run_env) : 0;
+    A.run_rows = run_env ? atoi(run_env) : -1;
     static const char* grid_env = getenv("DD_COS_GRID");               // tools: a fixed number of workgroups
     if (grid_env && atoi(grid_env) > 0 && (int64_t)atoi(grid_env) * C1_WAVES <= A.nrows) { grid = atoi(grid_env); A.nwaves = grid * C1_WAVES; }
+    // runs of 8 rows dealt to the waves in turn once every wave gets at least two of them: the device then walks one moving window of
+    // nwaves x 64 KB instead of nwaves streams far apart (memory side alone 5.64 -> 6.05 TB/s, the kernel 0.1455 -> 0.1417 ms in one call,
+    // profiles/r05_cos1k_memory_only.txt; a run start costs c1_prime_light: 2 KB read twice and a third of a row's instructions)
+    if (A.run_rows < 0) A.run_rows = A.nrows >= 16 * A.nwaves ? 8 : 0;
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
     const dim3 g(grid), b(64 * C1_WAVES);
     if (u8 && nco) hipLaunchKernelGGL((k_chain_cos1k<true, true>), g, b, C1_LDS_BYTES, stream, A);
