@@ -39,6 +39,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define C1_K 255
+// rotations by phi = 2 pi / 254, by 256 phi (= 2 phi) and by 16 phi 2^k: fixed by K, so literals -- as kernel arguments they were fourteen of the
+// wave-uniform values the compiler keeps in scalar registers (it holds more than the 102 there are and spills the rest through v_readlane)
+#define C1_C1 9.996940573e-01f
+#define C1_S1 2.473442728e-02f
+#define C1_C2 9.987764162e-01f
+#define C1_S2 4.945371992e-02f
+#define C1_WC0 9.226918151e-01f
+#define C1_WS0 3.855383436e-01f
+#define C1_WC1 7.027203712e-01f
+#define C1_WS1 7.114661481e-01f
+#define C1_WC2 -1.236815966e-02f
+#define C1_WS2 9.999235114e-01f
+#define C1_WC3 -9.996940573e-01f
+#define C1_WS3 -2.473442728e-02f
 #define C1_ROW 1024
 #define C1_GROUP_BYTES 144                     // 16 samples of 8 bytes + 16 bytes of padding
 #define C1_BUF_BYTES (64 * C1_GROUP_BYTES)     // one row after the NCO: 9216
@@ -66,10 +80,7 @@ struct DDCos1kArgs {
     int nrows, nwaves;
     int run_rows;              // 0: wave w takes ONE run, rows [nrows w / nwaves, nrows (w + 1) / nwaves); R > 0: runs of R rows dealt to the
                                // waves in turn (run j = rows [jR, jR + R) goes to wave j mod nwaves: the device walks one moving window)
-    float c1, s1;              // rotation by phi
-    float c2, s2;              // rotation by 256 phi (= 2 phi)
     float a0, a1;              // y = a0 R + a1 C
-    float wc[4], ws[4];        // rotation by 16 phi 2^k, k = 0..3
     float2 q1, q2, q4;         // e^{-j w 128}, e^{-j w 256}, e^{-j w 512}: row-major load layout (complex64 input)
     float2 e1, e2, e3, e4, e8; // e^{-j w i}: lane-contiguous layout (u8 input; e1 also pairs the complex64 samples)
 };
@@ -255,7 +266,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     unsigned trdummy[C1_NPH];
     if (!tr) tr = trdummy;
 #endif
-    const float c = A.c1, s = A.s1;
+    const float c = C1_C1, s = C1_S1;
     char* const cur = lds + cr.cur;
     char* const own = cur + lane * C1_GROUP_BYTES;                              // this lane's 16 samples of the row
     // lane - 16's group: this row's for lanes 16.., the previous row's lanes 48.. for lanes 0..15
@@ -426,10 +437,10 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     C1_T(2);
     // ---- inclusive weighted scan over the 64 lanes
 #ifndef C1_ABL_NO_SCAN
-    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, A.wc[0], A.ws[0]);
-    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, A.wc[1], A.ws[1]);
-    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, A.wc[2], A.ws[2]);
-    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, A.wc[3], A.ws[3]);
+    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, C1_WC0, C1_WS0);
+    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, C1_WC1, C1_WS1);
+    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, C1_WC2, C1_WS2);
+    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, C1_WC3, C1_WS3);
     c1_scan_step<0x142, 0xA>(t, lt.b15c, lt.b15s);          // row_bcast:15 into rows 1 and 3
     c1_scan_step<0x143, 0xC>(t, lt.b31c, lt.b31s);          // row_bcast:31 into rows 2 and 3
 #endif
@@ -447,8 +458,8 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     const float uc = low ? lt.b15c : 0.f, us = low ? lt.b15s : 0.f, ur = low ? 1.f : 0.f;      // A^{16 (L + 1)} for L < 16
     const v2f e = d[15];
     C1St V;
-    V.C = c1_fma(-A.c2, W.C, c1_fma(A.s2, W.S, c1_fma(-c, e, t.C)));
-    V.S = c1_fma(-A.s2, W.C, c1_fma(-A.c2, W.S, c1_fma(-s, e, t.S)));
+    V.C = c1_fma(-C1_C2, W.C, c1_fma(C1_S2, W.S, c1_fma(-c, e, t.C)));
+    V.S = c1_fma(-C1_S2, W.C, c1_fma(-C1_C2, W.S, c1_fma(-s, e, t.S)));
     V.R = t.R - W.R - e;
     V.C = c1_fma(uc, cr.P63.C, c1_fma(-us, cr.P63.S, V.C));
     V.S = c1_fma(us, cr.P63.C, c1_fma(uc, cr.P63.S, V.S));
@@ -601,7 +612,7 @@ __device__ __forceinline__ void c1_prime_issue(const DDCos1kArgs& A, int64_t S, 
 template <bool U8, bool NCO>
 __device__ __forceinline__ void c1_prime_light(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds, const int64_t S,
                                                const v4f (&xp)[2], const v2f ql, C1Carry& cr) {
-    const float c = A.c1, s = A.s1;
+    const float c = C1_C1, s = C1_S1;
     char* const cur = lds + cr.cur;
     char* const own = cur + lane * C1_GROUP_BYTES;
     const bool act = lane >= 48;
@@ -677,10 +688,10 @@ __device__ __forceinline__ void c1_prime_light(const DDCos1kArgs& A, const DDCos
         t.C = C0 + C1; t.S = S0 + S1; t.R = R0 + R1;
     }
     // lanes 48..63 are one DPP row: four steps give their prefixes (the lanes before them hold zeros)
-    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, A.wc[0], A.ws[0]);
-    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, A.wc[1], A.ws[1]);
-    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, A.wc[2], A.ws[2]);
-    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, A.wc[3], A.ws[3]);
+    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, C1_WC0, C1_WS0);
+    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, C1_WC1, C1_WS1);
+    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, C1_WC2, C1_WS2);
+    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, C1_WC3, C1_WS3);
     const int back16 = ((lane - 16) & 63) << 2;
     cr.W.C = c1_bperm(back16, t.C);
     cr.W.S = c1_bperm(back16, t.S);
@@ -893,17 +904,13 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     }
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
     const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
-    const long double phi = PI2 / (long double)(C1_K - 1);
     const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
     DDCos1kArgs A;
     A.in = P.in; A.out = reinterpret_cast<float*>(P.out);
     A.tail_in = P.tail_in; A.tail_out = P.tail_out; A.lasty_in = P.lasty_in; A.lasty_out = P.lasty_out;
     A.nco_tbl = P.nco_tbl; A.lane_tab = s->lane_tab;
     A.cyc = P.cyc; A.abs0 = P.abs0; A.L = P.L; A.s = P.s;
-    A.c1 = (float)cosl(phi); A.s1 = (float)sinl(phi);
-    A.c2 = (float)cosl(256.0L * phi); A.s2 = (float)sinl(256.0L * phi);
     A.a0 = (float)s->a0; A.a1 = (float)s->a1;
-    for (int k = 0; k < 4; ++k) { A.wc[k] = (float)cosl(16.0L * phi * (1 << k)); A.ws[k] = (float)sinl(16.0L * phi * (1 << k)); }
     auto ph = [&](int m) { long double p = frac * (long double)m; p -= floorl(p); const long double a = PI2 * p; return make_float2((float)cosl(a), (float)-sinl(a)); };
     A.q1 = ph(128); A.q2 = ph(256); A.q4 = ph(512);
     A.e1 = ph(1); A.e2 = ph(2); A.e3 = ph(3); A.e4 = ph(4); A.e8 = ph(8);
