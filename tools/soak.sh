@@ -1,13 +1,13 @@
 #!/bin/bash
 # soak: many launches of the persistent kernels (barrier / LDS-counter hand-overs), bounded by timeouts
-timeout 120 python bench.py --no-cpu-baseline --steps 20000 --warmup 10 --ramp-ms 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['kernel'], '20000 steps:', d['value'], d['ms_per_step'], d['extra']['output_rms_rad'])"
+timeout 120 python bench.py --no-cpu-baseline --steps 20000 --warmup 10 --ramp-ms 0 --steady-ms 100 --no-side | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['kernel'], '20000 steps:', d['value'], d['ms_per_step'], d['extra']['output_rms_rad'])"
 timeout 600 python - <<'PY'
-# both M = 1 FM kernels (k_chain_fft1k, the default for 255 taps, and k_chain_mfma_ab): the whole output must be bit-identical
+# the three M = 1 FM kernels (k_chain_cos1k, the default for Hamming 255 since round 5, k_chain_fft1k and k_chain_mfma_ab): the whole output must be bit-identical
 # from launch to launch (no atomics on the data path: a race in the LDS hand-overs -- exchange images, boundary tables, range
 # slots, plane buffers -- would show as a changing checksum)
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import torch
 from directdemod_amd import _hip
 import bench
@@ -17,9 +17,9 @@ dev = torch.device("cuda", 0)
 n = 1 << 26
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(255) / 254))
-for kern, u8 in (("fft1k", False), ("fft1k", True), ("ab", False), ("ab", True)):
+for kern, u8 in (("cos1k", False), ("cos1k", True), ("fft1k", False), ("fft1k", True), ("ab", False), ("ab", True)):
     _hip.select_kernel(kern)
-    want = _hip.DD_KERNEL_FFT_OS if kern == "fft1k" else _hip.DD_KERNEL_MFMA_AB
+    want = {"cos1k": _hip.DD_KERNEL_COS_RS, "fft1k": _hip.DD_KERNEL_FFT_OS, "ab": _hip.DD_KERNEL_MFMA_AB}[kern]
     x = bench.make_input(torch, n, 0, dev, 11)
     if u8:
         x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
@@ -47,7 +47,7 @@ PY
 timeout 120 python - <<'PY'
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import torch
 from directdemod_amd import _hip, shard
 import bench
@@ -78,7 +78,7 @@ timeout 300 python - <<'PY'
 # launch -- 4000 launches of the C3 shape (16 chunks) and of a ragged list, output bit-identical every time and equal to the loop's
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import torch, scipy.signal as ss
 from directdemod_amd import _hip
 import bench
