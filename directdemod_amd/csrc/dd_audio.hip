@@ -175,6 +175,11 @@ __global__ void __launch_bounds__(256) k_cplx_abs_b(const double2* __restrict__ 
     out[(int64_t)blockIdx.y * n + i] = hypot(v.x * inv_n, v.y * inv_n);
 }
 
+// (defined with the accurate-sync code below: the blocks' envelopes through the own float64 transform, no FFT-library plan)
+static std::mutex g_sync_mu;
+static int64_t hc_block_len(int64_t N, bool* split);
+static int hc_block_envelope(const double* x, double* env, int64_t N, int jobs, bool split, int64_t M, double2* T, hipStream_t s);
+
 // `batch` consecutive blocks of n samples each: one batched transform pair
 static int envelope_blocks(const double* in, double* out, int64_t n, int batch, double2* work, hipStream_t s) {
     hipfftHandle plan;
@@ -200,17 +205,40 @@ extern "C" int dd_am_envelope_f64(const double* in, double* out, int64_t n, int6
     while ((nfull + 1) * block < n) ++nfull;
     const int64_t rem = n - nfull * block;                  // 1 .. block
     const int GB = 16;                                       // full blocks per batched transform
-    const int64_t wlen = nfull ? (nfull < GB ? nfull : GB) * block : 0;
+    const int64_t gb = nfull < GB ? nfull : GB;
+    // Round 5: blocks that fit the own float64 transform go through it (hc_block_envelope: a 240 000-sample block by the even / odd split
+    // of the Hilbert kernel) -- no FFT-library plan, whose creation costs a process's first call 0.9 s.  DD_AM_HILBERT=lib: the library.
+    static const char* amh_env = getenv("DD_AM_HILBERT");
+    const bool own_ok = !(amh_env && !strcmp(amh_env, "lib"));
+    bool split_b = false, split_r = false;
+    const int64_t Mb = (own_ok && nfull > 0) ? hc_block_len(block, &split_b) : 0;
+    const int64_t Mr = own_ok ? hc_block_len(rem, &split_r) : 0;
+    const int64_t wlen = nfull ? std::max<int64_t>(Mb ? (split_b ? gb * Mb : Mb) : 0, Mb ? 0 : gb * block) : 0;
+    const int64_t wrem = Mr ? Mr : rem;
     DDScratchLock scr;                      // held until this entry point has enqueued everything
-    int rc = scr.get(sizeof(double2) * (size_t)(wlen > rem ? wlen : rem), s);
+    int rc = scr.get(sizeof(double2) * (size_t)(wlen > wrem ? wlen : wrem), s);
     char* base = scr.ptr;
     if (rc != DD_OK) return rc;
     double2* work = reinterpret_cast<double2*>(base);
-    for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) {
-        const int nbk = (int)(nfull - b0 < GB ? nfull - b0 : GB);
-        rc = envelope_blocks(in + b0 * block, out + b0 * block, block, nbk, work, s);
+    if (Mb) {
+        std::lock_guard<std::mutex> lk(g_sync_mu);           // (the kernel-spectrum cache)
+        const int per = split_b ? (int)gb : 1;
+        for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += per)
+            rc = hc_block_envelope(in + b0 * block, out + b0 * block, block, (int)(nfull - b0 < per ? nfull - b0 : per), split_b, Mb, work, s);
+    } else {
+        for (int64_t b0 = 0; b0 < nfull && rc == DD_OK; b0 += GB) {
+            const int nbk = (int)(nfull - b0 < GB ? nfull - b0 : GB);
+            rc = envelope_blocks(in + b0 * block, out + b0 * block, block, nbk, work, s);
+        }
     }
-    if (rc == DD_OK) rc = envelope_blocks(in + nfull * block, out + nfull * block, rem, 1, work, s);
+    if (rc == DD_OK) {
+        if (Mr) {
+            std::lock_guard<std::mutex> lk(g_sync_mu);
+            rc = hc_block_envelope(in + nfull * block, out + nfull * block, rem, 1, split_r, Mr, work, s);
+        } else {
+            rc = envelope_blocks(in + nfull * block, out + nfull * block, rem, 1, work, s);
+        }
+    }
     return rc;
 }
 
@@ -743,7 +771,6 @@ extern "C" int dd_resample_fft_chunks(const void* in, int in_is_f32, const int64
 
 // grow-only scratch per device for the audio-rate entry points' intermediates (no allocation in the steady state:
 // a hipMalloc/hipFree pair costs 50-100 us, a dozen of them were half of a correlate + peak-pick call)
-static std::mutex g_sync_mu;
 static void* g_sync_scratch[64] = {nullptr};
 static size_t g_sync_scratch_bytes[64] = {0};
 
@@ -1524,7 +1551,7 @@ static void hilb_cache_put(std::pair<int, int64_t> key, double2* HH) {
     g_hilb_order.push_back(key);
     while (g_hilb_order.size() > 8) {
         auto old = g_hilb.find(g_hilb_order.front());
-        if (old != g_hilb.end()) { (void)hipFree(old->second); g_hilb.erase(old); }
+        if (old != g_hilb.end()) { (void)hipDeviceSynchronize(); (void)hipFree(old->second); g_hilb.erase(old); }      // (dd_am_envelope_f64 returns with its kernels in flight)
         g_hilb_order.erase(g_hilb_order.begin());
     }
     g_hilb[key] = HH;

@@ -131,3 +131,41 @@ def test_cos_fit_declines_everything_else():
                  _win("hamming", 2000)):                                          # too long for the kernel's LDS window
         t = np.ascontiguousarray(taps, dtype=np.float64)
         assert lib.dd_debug_cos_fit(t.ctypes.data_as(dp), len(t), a, C.byref(q)) == 0
+
+
+@pytest.mark.parametrize("L,s,align,ncu", [
+    (1 << 26, 1, 0, 256), (1 << 26, 0, 0, 256), (1 << 26, 0, 5, 256), ((1 << 26) + 12345, 1, 15, 256), (1 << 22, 1, 0, 256), (5000000, 0, 3, 256),
+    (3 * 1024 + 5, 1, 0, 256), (1025, 0, 0, 256), (1024, 1, 0, 256), (1, 1, 0, 256), (1, 0, 9, 256), (2, 1, 0, 256), (255, 0, 0, 256), (100000, 1, 7, 4),
+    (40_000_000, 1, 0, 304)])
+def test_cos1k_plan_lays_the_row_grid_by_the_outputs_alignment(L, s, align, ncu):
+    """dd_debug_cos1k_plan (round 5): k_chain_cos1k's rows of 1024 samples.  out[base - s] must start a 64-byte line (`align` = how many
+    elements `out` sits behind one), the rows must hold every sample from the first that has an angle (s) to L - 1 -- the one before it and
+    the carried state belong to the row before the first run, which the kernel runs without stores -- and no wave may be left without a row."""
+    out = (C.c_int * 4)()
+    _hip.check(_hip.lib().dd_debug_cos1k_plan(L, s, align, ncu, out), "dd_debug_cos1k_plan")
+    base, rows, grid, waves = list(out)
+    assert (base - s + align) % 16 == 0 and base <= min(s, L - 1)
+    assert base > min(s, L - 1) - 16                          # (the nearest such line start)
+    assert rows >= 1 and base + 1024 * rows >= L and base + 1024 * (rows - 1) <= L - 1
+    assert waves == 4 * grid and 1 <= grid <= 2 * ncu and waves - 4 < rows or rows < 4
+
+
+def test_a_variant_library_is_loaded_through_dd_lib_path_and_says_so(tmp_path):
+    """measurement scripts no longer copy ablation builds over the product library; DD_LIB_PATH makes _hip load another build of
+    the same C-ABI instead, with a line on stderr.  (Here: a copy of the product library under another name.)"""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "directdemod_amd", "libdirectdemod_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    alt = str(tmp_path / "lib_variant.so")
+    shutil.copy(lib, alt)
+    env = dict(os.environ, DD_LIB_PATH=alt)
+    r = subprocess.run([sys.executable, "-c", "from directdemod_amd import _hip; _hip.load(); print(_hip.LIB_PATH)"], capture_output=True, text=True,
+                       env=env, cwd=root, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip() == alt
+    assert "DD_LIB_PATH set, loading" in r.stderr and alt in r.stderr
