@@ -2,33 +2,37 @@
 //
 //     offsetFreq (comm.py:63-78) -> FIR as three RUNNING SUMS (comm.py:80-92, filters.py:64-70) -> demod_fm (demod_fm.py:40-49)
 //
-// Why: k_chain_fft1k runs at the board's power cap -- 0.18 J of switching energy per 2^26-sample
-// launch, of which the two 1024-point transforms per 768 outputs are 0.11 J.  For a cosine-series window the convolution needs no
+// Why: k_chain_fft1k runs at the board's power cap -- 0.22-0.23 J of switching energy per 2^26-sample
+// launch, half of it for the two 1024-point transforms per 768 outputs.  For a cosine-series window the convolution needs no
 // transform: with xt[n] = x[n] e^{-j w n} (the NCO, applied to the samples) and phi = 2 pi / 254,
 //     R[n] = sum_{k<255} xt[n-k]      C[n] = sum_{k<255} cos(phi k) xt[n-k]      S[n] = sum_{k<255} sin(phi k) xt[n-k]
 //     (C, S)[n] = Rot_phi((C, S)[n-1] - (xt[n-255], 0)) + (xt[n], 0)            R[n] = R[n-1] + xt[n] - xt[n-255]
 //     y[n] = a0 R[n] + a1 C[n]
-// i.e. 10 packed multiply-adds per sample where the overlap-save form spends ~44 (tools/ubench/cosfir_arith.hip measured the
-// arithmetic alone: 0.093 ms and 0.064 J per 2^26 samples against 0.123 ms and 0.105 J; profiles/r05_cosfir_ubench.txt).
+// (tools/ubench/cosfir_arith.hip measured this arithmetic alone before the kernel existed: 0.093 ms and 0.082 J per 2^26 samples against
+// 0.123 ms and 0.129 J for the FFT kernel's; profiles/r05_cosfir_ubench.txt).  The kernel: 0.141-0.148 ms, 0.154-0.162 J per launch.
 //
-// Layout.  A wave walks a contiguous run of ROWS of 1024 samples; lane L owns samples 16 L .. 16 L + 15 of the row, so the
-// recurrence runs serially inside a lane and the 64 lanes are tied together by a two-pass scan:
-//   pass A   lane totals T_L of the un-windowed recurrence started from zero (16 steps)
+// Layout.  A wave walks runs of ROWS of 1024 samples; lane L owns samples 16 L .. 16 L + 15 of the row, so the recurrence runs
+// serially inside a lane and the 64 lanes are tied together by a two-pass scan:
+//   pass A   lane totals T_L = sum_i A^{15-i} (xt_i, 0): plain sums with constant weights (phi is fixed by K = 255)
 //   scan     P_L = sum_{L' <= L} A^{16 (L - L')} T_L'   (Kogge-Stone over the wave through DPP moves, weights = rotations by 16 phi 2^k)
 //   window   V_L = P_L - A^256 P_{L-16} - A^255 (xt[16 (L - 15)], 0): the 255-sample window that ends with lane L, lanes L < 16
 //            taking P_{L-16} from the previous row (kept in a register, moved by one ds_bpermute per component) plus that row's total
-//   pass B   the recurrence again from the true state V_{L-1} at the lane's first sample, subtracting xt[n-255] as it leaves
+//   pass B   the recurrence from the true state V_{L-1} at the lane's first sample, subtracting xt[n-255] as it leaves: 8 packed
+//            instructions per sample; y up to the positive factor a0, which the discriminator does not see
 // Every quantity is rebuilt from at most the last two rows: no error is carried along the stream (the float32 model
 // tools/sim/cosfir_sim.py: FIR error 4.7e-7 of max|y|, FM median 1.2e-8 rad against the float64 definition).
-// xt[n-255] is lane L-16's sample i+1: the row's samples after the NCO go through LDS once ([16 history + 64 row] groups of 16
-// samples, 144 bytes apart: conflict free for the 16-byte row-major stores and for the lanes' own 16-byte reads), which also
-// turns the coalesced load layout (lane l holds samples 128 j + 2 l, +1) into the lane-contiguous one.  No barrier: a wave owns
-// its LDS image.  Raw u8 input (source.py:117-118) arrives lane-contiguous already (32 bytes per lane and row).
+// xt[n-255] is lane L-16's sample i+1: the row's samples after the NCO go through LDS once (two row images per wave -- this row and
+// the one before it, whose last 16 groups are what lanes 0..15 look back at -- of 64 groups of 16 samples, 144 bytes apart: conflict
+// free for the 16-byte row-major stores and for the lanes' own 16-byte reads), which also turns the coalesced load layout (lane l
+// holds samples 128 j + 2 l, +1) into the lane-contiguous one.  No barrier: a wave owns its LDS image.  Raw u8 input (source.py:117-118)
+// arrives lane-contiguous already (32 bytes per lane and row).  The lane's 16 angles go back through the dead part of the row image and
+// leave as four 1 KB row-major stores, issued by the NEXT row behind its loads.
 //
-// Edges.  The row grid is laid by the alignment of `out` (row q covers samples [base + 1024 q, +1024), base in [s - 15, s], so that
-// every lane's 16 angles are one 64-byte line).  A wave first runs the row BEFORE its run without stores (it leaves the LDS
-// history, the previous-row prefixes, the state and y[n-1]); rows that touch the stream start, the chunk end or the carried state
-// (history, last FIR output: DDChainParams) load sample by sample and predicate their stores.  One launch per chunk.
+// Edges and runs.  The row grid is laid by the alignment of `out` (row q covers samples [base + 1024 q, +1024), base in [s - 15, s], so
+// that every lane's 16 angles are one 64-byte line).  Rows come in runs of 8 dealt to the waves in turn (one moving window over the
+// stream; short chunks: one run per wave); a run starts from the last 256 samples of the row before it (c1_prime_light).  Rows that
+// touch the stream start, the chunk end or the carried state (history after the NCO, last FIR output: DDChainParams) load sample by
+// sample with exact phases and predicate their stores.  One launch per chunk.
 #include "dd_chain_kernels.h"
 #include "dd_cosfir.h"
 #include "dd_cosfit.h"
