@@ -257,7 +257,9 @@ def _start_copy_warmup():
                 lib().dd_free(d)
         except Exception:
             pass
-    _warm = threading.Thread(target=run, name="dd-copy-warmup", daemon=True)
+    # (not a daemon: an interpreter that exits right away waits the few milliseconds this takes instead of tearing the HIP runtime
+    #  down under a thread that is inside it)
+    _warm = threading.Thread(target=run, name="dd-copy-warmup", daemon=False)
     _warm.start()
 
 

@@ -60,7 +60,7 @@ class noaa_sync:
                 n_audio = -(-int(sigsrc.length) // dec) - 1               # kept samples of the whole stream, one angle fewer (demod_fm.py:43-49)
                 if n_audio > 1:
                     import threading
-                    self.__prep = threading.Thread(target=_ops.noaa_prepare, args=(n_audio,), daemon=True)
+                    self.__prep = threading.Thread(target=_ops.noaa_prepare, args=(n_audio,), daemon=False)   # (joined by getCrudeSync, or by the interpreter at exit)
                     self.__prep.start()
         except Exception:
             self.__prep = None
