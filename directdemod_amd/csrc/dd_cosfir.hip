@@ -64,7 +64,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define C1_WAVES 4
 #define C1_LDS_BYTES (C1_WAVES * C1_WAVE_BYTES)
 
-struct DDCos1kLane { float b15c, b15s, b31c, b31s; };   // rotation by 16 phi ((lane & 15) + 1) and by 16 phi ((lane & 31) + 1)
+struct DDCos1kLane { float b15c, b15s; };   // rotation by 16 phi ((lane & 15) + 1)
 
 // the kernel's only argument
 struct DDCos1kArgs {
@@ -116,15 +116,14 @@ template <int CTRL>
 __device__ __forceinline__ float c1_dpp0(float v) {                         // lanes without a source lane read 0 (bound_ctrl)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float c1_dppm(float v) {                         // masked rows read 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
-}
 // wave_shr:1; lane 0 keeps `first`
 __device__ __forceinline__ float c1_shr1(float v, float first) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 __device__ __forceinline__ v2f c1_shr1(v2f v, v2f first) { return (v2f){c1_shr1(v.x, first.x), c1_shr1(v.y, first.y)}; }
+// lane 15 of the lane's own DPP row, in every lane of it (row_newbcast:15)
+__device__ __forceinline__ float c1_rowlast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x15F, 0xF, 0xF, false)); }
+__device__ __forceinline__ v2f c1_rowlast(v2f v) { return (v2f){c1_rowlast(v.x), c1_rowlast(v.y)}; }
 __device__ __forceinline__ float c1_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ v2f c1_lane63(v2f v) { return (v2f){c1_lane63(v.x), c1_lane63(v.y)}; }
 __device__ __forceinline__ float c1_bperm(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
@@ -133,40 +132,29 @@ __device__ __forceinline__ v2f c1_bperm(int addr, v2f v) { return (v2f){c1_bperm
 struct C1St { v2f C, S, R; };
 
 #define C1_ROW_SHR(n) (0x110 + (n))
-// r += (r of the lane CTRL points at): one instruction (the DPP operand of a VOP2 add); lanes without a source lane, and rows
-// outside ROW_MASK, keep r
-#define C1_STR2(x) #x
-#define C1_STR(x) C1_STR2(x)
-template <int CTRL, int ROW_MASK>
+// r += (r of the lane n back in the DPP row): one instruction (the DPP operand of a VOP2 add); lanes without a source lane keep r
+template <int CTRL>
 __device__ __forceinline__ float c1_add_dpp(float r) {
-    static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "dpp control");
+    static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118, "dpp control");
     if (CTRL == 0x111) asm("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
     if (CTRL == 0x112) asm("v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
     if (CTRL == 0x114) asm("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
     if (CTRL == 0x118) asm("v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r));
-    if (CTRL == 0x142) asm("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(r));
-    if (CTRL == 0x143) asm("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(r));
     return r;
 }
-template <int CTRL, int ROW_MASK>
+// one Kogge-Stone step of the weighted prefix inside a DPP row of 16 lanes: t += Rot(t of the lane n back)
+template <int CTRL>
 __device__ __forceinline__ void c1_scan_step(C1St& t, float wc, float ws) {
-    v2f Cs, Ss;
-    if (ROW_MASK == 0xF) {
-        Cs = (v2f){c1_dpp0<CTRL>(t.C.x), c1_dpp0<CTRL>(t.C.y)};
-        Ss = (v2f){c1_dpp0<CTRL>(t.S.x), c1_dpp0<CTRL>(t.S.y)};
-    } else {
-        Cs = (v2f){c1_dppm<CTRL, ROW_MASK>(t.C.x), c1_dppm<CTRL, ROW_MASK>(t.C.y)};
-        Ss = (v2f){c1_dppm<CTRL, ROW_MASK>(t.S.x), c1_dppm<CTRL, ROW_MASK>(t.S.y)};
-    }
-    t.R = (v2f){c1_add_dpp<CTRL, ROW_MASK>(t.R.x), c1_add_dpp<CTRL, ROW_MASK>(t.R.y)};
+    const v2f Cs = (v2f){c1_dpp0<CTRL>(t.C.x), c1_dpp0<CTRL>(t.C.y)};
+    const v2f Ss = (v2f){c1_dpp0<CTRL>(t.S.x), c1_dpp0<CTRL>(t.S.y)};
+    t.R = (v2f){c1_add_dpp<CTRL>(t.R.x), c1_add_dpp<CTRL>(t.R.y)};
     t.C = c1_fma(wc, Cs, c1_fma(-ws, Ss, t.C));
     t.S = c1_fma(ws, Cs, c1_fma(wc, Ss, t.S));
 }
 
 // what a wave carries from one row to the next
 struct C1Carry {
-    C1St W;          // P_{L-16} of the previous row as lanes L < 16 need it (lane L holds the previous row's P_{48+L})
-    C1St P63;        // the previous row's P_63 (wave-uniform)
+    C1St W;          // the previous row's prefixes of lanes 48..63 (inside their DPP row) as lanes L < 16 need them (lane L holds lane 48 + L's)
     C1St V63;        // windowed state at the previous row's last sample (wave-uniform): enters lane 0
     v2f y63;         // the previous row's last FIR output (wave-uniform): y[n-1] of lane 0's first sample
     v2f prow;        // e^{-j w (abs0 + S)} of the NEXT row times the lane's own factor, looked up a row ahead (the table read is a
@@ -439,18 +427,20 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
         t.C = C0 + C1; t.S = S0 + S1; t.R = R0 + R1;
     }
     C1_T(2);
-    // ---- inclusive weighted scan over the 64 lanes
+    // ---- inclusive weighted prefix inside each DPP row of 16 lanes
 #ifndef C1_ABL_NO_SCAN
-    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, C1_WC0, C1_WS0);
-    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, C1_WC1, C1_WS1);
-    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, C1_WC2, C1_WS2);
-    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, C1_WC3, C1_WS3);
-    c1_scan_step<0x142, 0xA>(t, lt.b15c, lt.b15s);          // row_bcast:15 into rows 1 and 3
-    c1_scan_step<0x143, 0xC>(t, lt.b31c, lt.b31s);          // row_bcast:31 into rows 2 and 3
+    c1_scan_step<C1_ROW_SHR(1)>(t, C1_WC0, C1_WS0);
+    c1_scan_step<C1_ROW_SHR(2)>(t, C1_WC1, C1_WS1);
+    c1_scan_step<C1_ROW_SHR(4)>(t, C1_WC2, C1_WS2);
+    c1_scan_step<C1_ROW_SHR(8)>(t, C1_WC3, C1_WS3);
 #endif
-    // ---- window: V_L = P_L - A^256 P_{L-16} - A^255 (xt[16 (L - 15)], 0); lanes L < 16 continue the previous row's prefix
+    // ---- window.  t is the prefix INSIDE the lane's DPP row of 16 lanes (l = L & 15); the 256 samples that end with lane L are lanes
+    // 16 rho .. L of its own row and lanes l + 1 .. 15 of the row before, whose sum is A^{16 (l + 1)} (tot' - A^{16 (15 - l)} pre'_l):
+    //     V_L = pre_l + A^{16 (l + 1)} tot' - A^256 pre'_l - A^255 (xt[16 (L - 15)], 0)
+    // pre' = the prefix 16 lanes back (lanes L < 16: the previous wave row's lanes 48.., carried), tot' = its lane 15 (row_newbcast).
+    // No sum here spans more than 32 lanes, and the two wave-wide scan steps (row_bcast 15 / 31) are not needed at all.
     const int back16 = ((lane - 16) & 63) << 2;
-    C1St Wn;                                                 // lane L: this row's P_{L-16} (L >= 16), P_{48+L} (L < 16: the next row's W)
+    C1St Wn;                                                 // lane L: this row's pre of lane L - 16 (L >= 16), of lane 48 + L (L < 16: the next row's W)
     Wn.C = c1_bperm(back16, t.C);
     Wn.S = c1_bperm(back16, t.S);
     Wn.R = c1_bperm(back16, t.R);
@@ -459,22 +449,24 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     W.C = low ? cr.W.C : Wn.C;
     W.S = low ? cr.W.S : Wn.S;
     W.R = low ? cr.W.R : Wn.R;
-    const float uc = low ? lt.b15c : 0.f, us = low ? lt.b15s : 0.f, ur = low ? 1.f : 0.f;      // A^{16 (L + 1)} for L < 16
+    C1St tot;
+    tot.C = c1_rowlast(W.C); tot.S = c1_rowlast(W.S); tot.R = c1_rowlast(W.R);
     const v2f e = d[15];
     C1St V;
     V.C = c1_fma(-C1_C2, W.C, c1_fma(C1_S2, W.S, c1_fma(-c, e, t.C)));
     V.S = c1_fma(-C1_S2, W.C, c1_fma(-C1_C2, W.S, c1_fma(-s, e, t.S)));
     V.R = t.R - W.R - e;
-    V.C = c1_fma(uc, cr.P63.C, c1_fma(-us, cr.P63.S, V.C));
-    V.S = c1_fma(us, cr.P63.C, c1_fma(uc, cr.P63.S, V.S));
-    V.R = c1_fma(ur, cr.P63.R, V.R);
+#ifndef C1_ABL_NO_SCAN
+    V.C = c1_fma(lt.b15c, tot.C, c1_fma(-lt.b15s, tot.S, V.C));
+    V.S = c1_fma(lt.b15s, tot.C, c1_fma(lt.b15c, tot.S, V.S));
+    V.R += tot.R;
+#endif
     // state at the lane's first sample = V of the lane before (lane 0: the previous row's last)
     C1St u;
     u.C = c1_shr1(V.C, cr.V63.C);
     u.S = c1_shr1(V.S, cr.V63.S);
     u.R = c1_shr1(V.R, cr.V63.R);
     cr.W = Wn;
-    cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
     cr.V63.C = c1_lane63(V.C); cr.V63.S = c1_lane63(V.S); cr.V63.R = c1_lane63(V.R);
     C1_T(3);
     // ---- pass B: the windowed recurrence.  y / a0 = R + (a1 / a0) C (filters.py:199): the discriminator does not see the positive
@@ -692,18 +684,18 @@ __device__ __forceinline__ void c1_prime_light(const DDCos1kArgs& A, const DDCos
         t.C = C0 + C1; t.S = S0 + S1; t.R = R0 + R1;
     }
     // lanes 48..63 are one DPP row: four steps give their prefixes (the lanes before them hold zeros)
-    c1_scan_step<C1_ROW_SHR(1), 0xF>(t, C1_WC0, C1_WS0);
-    c1_scan_step<C1_ROW_SHR(2), 0xF>(t, C1_WC1, C1_WS1);
-    c1_scan_step<C1_ROW_SHR(4), 0xF>(t, C1_WC2, C1_WS2);
-    c1_scan_step<C1_ROW_SHR(8), 0xF>(t, C1_WC3, C1_WS3);
+    c1_scan_step<C1_ROW_SHR(1)>(t, C1_WC0, C1_WS0);
+    c1_scan_step<C1_ROW_SHR(2)>(t, C1_WC1, C1_WS1);
+    c1_scan_step<C1_ROW_SHR(4)>(t, C1_WC2, C1_WS2);
+    c1_scan_step<C1_ROW_SHR(8)>(t, C1_WC3, C1_WS3);
     const int back16 = ((lane - 16) & 63) << 2;
     cr.W.C = c1_bperm(back16, t.C);
     cr.W.S = c1_bperm(back16, t.S);
     cr.W.R = c1_bperm(back16, t.R);
-    cr.P63.C = c1_lane63(t.C); cr.P63.S = c1_lane63(t.S); cr.P63.R = c1_lane63(t.R);
-    cr.V63.C = c1_fma(-c, e, cr.P63.C);
-    cr.V63.S = c1_fma(-s, e, cr.P63.S);
-    cr.V63.R = cr.P63.R - e;
+    const C1St P63 = {c1_lane63(t.C), c1_lane63(t.S), c1_lane63(t.R)};
+    cr.V63.C = c1_fma(-c, e, P63.C);
+    cr.V63.S = c1_fma(-s, e, P63.S);
+    cr.V63.R = P63.R - e;
     cr.y63 = c1_fma(A.a1 / A.a0, cr.V63.C, cr.V63.R);
     cr.cur = C1_BUF_BYTES - cr.cur;
 }
@@ -733,7 +725,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
         for (int t = 0; t < 9; ++t) *reinterpret_cast<v4f*>(lds + C1_BUF_BYTES + (48 + lane) * C1_GROUP_BYTES + 16 * t) = (v4f){0.f, 0.f, 0.f, 0.f};
     }
     C1Carry cr;
-    cr.W = cr.P63 = cr.V63 = (C1St){(v2f){0.f, 0.f}, (v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
+    cr.W = cr.V63 = (C1St){(v2f){0.f, 0.f}, (v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
     cr.y63 = (v2f){0.f, 0.f};
     cr.prow = (v2f){1.f, 0.f};
     cr.cur = 0;
@@ -851,7 +843,6 @@ int dd_cos1k_create(void** st, const double* taps, int K) {
     const long double phi16 = 16.0L * 2.0L * 3.14159265358979323846264338327950288L / (long double)(C1_K - 1);
     for (int l = 0; l < 64; ++l) {
         h[l].b15c = (float)cosl(phi16 * ((l & 15) + 1)); h[l].b15s = (float)sinl(phi16 * ((l & 15) + 1));
-        h[l].b31c = (float)cosl(phi16 * ((l & 31) + 1)); h[l].b31s = (float)sinl(phi16 * ((l & 31) + 1));
     }
     hipError_t e = hipMalloc((void**)&s->lane_tab, sizeof(h));
     if (e == hipSuccess) e = hipMemcpy(s->lane_tab, h, sizeof(h), hipMemcpyHostToDevice);
