@@ -14,9 +14,10 @@
 // Layout.  A wave walks runs of ROWS of 1024 samples; lane L owns samples 16 L .. 16 L + 15 of the row, so the recurrence runs
 // serially inside a lane and the 64 lanes are tied together by a two-pass scan:
 //   pass A   lane totals T_L = sum_i A^{15-i} (xt_i, 0): plain sums with constant weights (phi is fixed by K = 255)
-//   scan     P_L = sum_{L' <= L} A^{16 (L - L')} T_L'   (Kogge-Stone over the wave through DPP moves, weights = rotations by 16 phi 2^k)
-//   window   V_L = P_L - A^256 P_{L-16} - A^255 (xt[16 (L - 15)], 0): the 255-sample window that ends with lane L, lanes L < 16
-//            taking P_{L-16} from the previous row (kept in a register, moved by one ds_bpermute per component) plus that row's total
+//   scan     pre_l = sum_{l' <= l} A^{16 (l - l')} T_l' inside each DPP row of 16 lanes (Kogge-Stone through DPP moves, weights = rotations
+//            by 16 phi 2^k)
+//   window   V_L = pre_l + A^{16 (l + 1)} tot' - A^256 pre'_l - A^255 (xt[16 (L - 15)], 0): the 255-sample window that ends with lane L, from
+//            the prefix 16 lanes back (one ds_bpermute per component; lanes L < 16: the previous row's, kept in a register) and its row's total
 //   pass B   the recurrence from the true state V_{L-1} at the lane's first sample, subtracting xt[n-255] as it leaves: 8 packed
 //            instructions per sample; y up to the positive factor a0, which the discriminator does not see
 // Every quantity is rebuilt from at most the last two rows: no error is carried along the stream (the float32 model
@@ -26,7 +27,8 @@
 // free for the 16-byte row-major stores and for the lanes' own 16-byte reads), which also turns the coalesced load layout (lane l
 // holds samples 128 j + 2 l, +1) into the lane-contiguous one.  No barrier: a wave owns its LDS image.  Raw u8 input (source.py:117-118)
 // arrives lane-contiguous already (32 bytes per lane and row).  The lane's 16 angles go back through the dead part of the row image and
-// leave as four 1 KB row-major stores, issued by the NEXT row behind its loads.
+// leave as four 1 KB row-major stores, issued by the NEXT row behind its loads.  Complex64 output (CX: the FIR output itself, commSignal.filter
+// alone) takes the same road through the image of the row before: eight 1 KB stores.
 //
 // Edges and runs.  The row grid is laid by the alignment of `out` (row q covers samples [base + 1024 q, +1024), base in [s - 15, s], so
 // that every lane's 16 angles are one 64-byte line).  Rows come in runs of 8 dealt to the waves in turn (one moving window over the
@@ -69,7 +71,7 @@ struct DDCos1kLane { float b15c, b15s; };   // rotation by 16 phi ((lane & 15) +
 // the kernel's only argument
 struct DDCos1kArgs {
     const void* in;            // complex64 or interleaved u8
-    float* out;                // angles
+    void* out;                 // angles (float), or the FIR output itself (float2: CX)
     const float2* tail_in;     // 254 samples after the NCO that precede the chunk
     float2* tail_out;
     const float2* lasty_in;    // FIR output before the chunk's first sample
@@ -166,7 +168,7 @@ struct C1Carry {
 #define C1_NO_PEND ((int64_t)-4611686018427387904LL)
 // the angles of row S, left in the image at `img` by the row before: four 1 KB row-major stores
 __device__ __forceinline__ void c1_flush_angles(const DDCos1kArgs& A, const char* img, int64_t S, int lane) {
-    float* const o = A.out + (S - A.s) + 4 * lane;
+    float* const o = reinterpret_cast<float*>(A.out) + (S - A.s) + 4 * lane;
     const int G = lane >> 2, sw = (G >> 1) & 3;          // (group 16 g + G: the 16 g part does not reach the swizzle bits)
     v4f v[4];
 #pragma unroll
@@ -185,10 +187,24 @@ __device__ __forceinline__ void c1_flush_angles(const DDCos1kArgs& A, const char
     }
 }
 
+// CX: the 1024 FIR outputs of row S, left in the image at `img` (the padded layout of the sample image) by the row before: eight 16-byte
+// row-major reads per lane, then eight 1 KB stores
+__device__ __forceinline__ void c1_cx_read(const char* img, int lane, v4f (&v)[8]) {
+    const char* const rd = img + (lane >> 3) * C1_GROUP_BYTES + 16 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const v4f*>(rd + 8 * j * C1_GROUP_BYTES);
+}
+__device__ __forceinline__ void c1_cx_store(const DDCos1kArgs& A, int64_t S, int lane, const v4f (&v)[8]) {
+    float2* const o = reinterpret_cast<float2*>(A.out) + S + 2 * lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<v4f*>(o + 128 * j) = v[j];
+}
+
 // Ablation switches for timing experiments (tools/mkvariant.sh N dd_cosfir -DC1_ABL_...; the outputs of such a build are wrong):
 //   C1_ABL_NO_LOAD   no global loads          C1_ABL_NO_STORE  no global stores         C1_ABL_NO_PHASOR  no per-row phase table look-up
 //   C1_ABL_NO_LDS    no LDS traffic           C1_ABL_NO_FM     no discriminator         C1_ABL_NO_SCAN    no scan / window stage
 //   C1_ABL_MEMONLY   the memory side alone: loads, both LDS transpositions, stores; an "angle" is re + im of the sample
+//   C1_CX_IMMEDIATE  (results stay right) complex64 output stored by the row that made it instead of the next one
 #ifdef C1_TRACE
 // tools/debug/cos_trace.py: cycles per phase of a row (s_memtime stamps; every stamp drains the wave's LDS / scalar counter), summed
 // per wave over its interior rows
@@ -244,8 +260,9 @@ __device__ __forceinline__ v2f c1_row_phasor(const DDCos1kArgs& A, int64_t S, v2
 #endif
 }
 
-// One row.  EDGE: sample-by-sample loads (history, chunk end), predicated stores, the carried FIR output.  emit: store angles.
-template <bool U8, bool NCO, bool EDGE>
+// One row.  EDGE: sample-by-sample loads (history, chunk end), predicated stores, the carried FIR output.  emit: store the row's outputs.
+// CX: the output is the FIR output itself (commSignal.filter alone, comm.py:80-92) instead of the discriminator's angles.
+template <bool U8, bool NCO, bool EDGE, bool CX>
 __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& lt, const int lane, char* const lds,
                                        const int64_t S, const bool emit, const bool prefetch_next,
                                        v4f (&xin)[8], v4f (&xnext)[8], const v2f ql, C1Carry& cr
@@ -261,6 +278,11 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     const float c = C1_C1, s = C1_S1;
     char* const cur = lds + cr.cur;
     char* const own = cur + lane * C1_GROUP_BYTES;                              // this lane's 16 samples of the row
+    // CX: the outputs of the row before wait in THIS row's buffer (dead when they were put there); they are read before the samples
+    // overwrite them -- a wave's LDS accesses keep their order -- and stored behind this row's prefetch
+    v4f pv[8];
+    const int64_t cx_pend = CX ? cr.pend_S : C1_NO_PEND;
+    if (CX && cx_pend != C1_NO_PEND) { c1_cx_read(cur, lane, pv); cr.pend_S = C1_NO_PEND; }
     // lane - 16's group: this row's for lanes 16.., the previous row's lanes 48.. for lanes 0..15
     const char* const old = lane < 16 ? lds + (C1_BUF_BYTES - cr.cur) + (48 + lane) * C1_GROUP_BYTES : cur + (lane - 16) * C1_GROUP_BYTES;
     v2f xt[16];
@@ -363,7 +385,8 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     // into the OTHER register set: the caller alternates the two, so that nothing is copied -- or waited for -- at the loop's back edge
     if (prefetch_next) { c1_issue_loads<U8>(A, S + C1_ROW, lane, xnext); cr.prow = c1_row_phasor<NCO>(A, S + C1_ROW, ql); }
     // the angles of the row before leave now: their LDS round trip and their stores overlap this row's arithmetic
-    if (cr.pend_S != C1_NO_PEND) { c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane); cr.pend_S = C1_NO_PEND; }
+    if (CX) { if (cx_pend != C1_NO_PEND) c1_cx_store(A, cx_pend, lane, pv); }
+    else if (cr.pend_S != C1_NO_PEND) { c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane); cr.pend_S = C1_NO_PEND; }
 #ifndef C1_ABL_NO_LDS
     if (!EDGE && !U8) {
 #pragma unroll
@@ -489,9 +512,35 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t n = S + 16 * lane + i;
-            if (A.s == 0 && n == -1) y[i] = c1_v2(*A.lasty_in);
+            if (!CX && A.s == 0 && n == -1) y[i] = c1_v2(*A.lasty_in);
             if (n == A.L - 1 && A.lasty_out) *A.lasty_out = make_float2(A.a0 * y[i].x, A.a0 * y[i].y);
         }
+    }
+    if (CX) {
+        if (!emit) return;
+        const float a0 = A.a0;
+        if (EDGE) {
+            float2* const o = reinterpret_cast<float2*>(A.out);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t n = S + 16 * lane + i;
+                if (n >= 0 && n < A.L) o[n] = make_float2(a0 * y[i].x, a0 * y[i].y);
+            }
+            return;
+        }
+        // The lane holds 16 consecutive outputs (128 bytes); they cross the wave through the image of the row BEFORE (dead: this row has
+        // taken its samples 255 back from it; it is the NEXT row's buffer) in the padded layout of the sample image, and leave as eight
+        // 1 KB row-major stores issued by the next row (or by the kernel after the wave's last interior row).
+        char* const img = lds + cr.cur;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            *reinterpret_cast<v4f*>(img + lane * C1_GROUP_BYTES + 16 * t) = (v4f){a0 * y[2 * t].x, a0 * y[2 * t].y, a0 * y[2 * t + 1].x, a0 * y[2 * t + 1].y};
+#ifdef C1_CX_IMMEDIATE
+        { v4f v[8]; c1_cx_read(img, lane, v); c1_cx_store(A, S, lane, v); }
+#else
+        cr.pend_S = S;
+#endif
+        return;
     }
     const v2f yl = c1_shr1(y[15], cr.y63);
     cr.y63 = c1_lane63(y[15]);
@@ -556,7 +605,7 @@ __device__ __forceinline__ void c1_row(const DDCos1kArgs& A, const DDCos1kLane& 
     }
     C1_T(5);
     if (EDGE) {
-        float* const o = A.out + (S - A.s) + 16 * lane;
+        float* const o = reinterpret_cast<float*>(A.out) + (S - A.s) + 16 * lane;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t n = S + 16 * lane + i;
@@ -702,7 +751,7 @@ __device__ __forceinline__ void c1_prime_light(const DDCos1kArgs& A, const DDCos
 
 // The whole chunk in one launch.  Row q covers samples [base + 1024 q, base + 1024 (q + 1)); wave gw takes rows
 // [nrows gw / nwaves, nrows (gw + 1) / nwaves), after running the row before them without stores.
-template <bool U8, bool NCO>
+template <bool U8, bool NCO, bool CX>
 __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kArgs A) {
     extern __shared__ __attribute__((aligned(16))) char c1_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -753,7 +802,7 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
 #pragma unroll
     for (int j = 0; j < 8; ++j) xa[j] = xb[j] = (v4f){0.f, 0.f, 0.f, 0.f};
     for (int q = qfirst; q < f0; ++q)
-        c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
+        c1_row<U8, NCO, true, CX>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
     if (f1 > f0) {
         const int64_t S0 = (int64_t)A.base + (int64_t)C1_ROW * f0;
 #if !defined(C1_ABL_MEMONLY) && !defined(C1_FULL_PRIME)
@@ -776,17 +825,21 @@ __global__ void __launch_bounds__(64 * C1_WAVES, 2) k_chain_cos1k(const DDCos1kA
         for (int q = f0; q < f1; q += 2) {
             const int64_t S = (int64_t)A.base + (int64_t)C1_ROW * q;
 #ifdef C1_TRACE
-            c1_row<U8, NCO, false>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr, q >= q0 ? tr : nullptr);
-            if (q + 1 < f1) c1_row<U8, NCO, false>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr, tr);
+            c1_row<U8, NCO, false, CX>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr, q >= q0 ? tr : nullptr);
+            if (q + 1 < f1) c1_row<U8, NCO, false, CX>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr, tr);
 #else
-            c1_row<U8, NCO, false>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr);
-            if (q + 1 < f1) c1_row<U8, NCO, false>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr);
+            c1_row<U8, NCO, false, CX>(A, lt, lane, lds, S, q >= q0, q + 1 < f1, xa, xb, ql, cr);
+            if (q + 1 < f1) c1_row<U8, NCO, false, CX>(A, lt, lane, lds, S + C1_ROW, true, q + 2 < f1, xb, xa, ql, cr);
 #endif
         }
     }
-    if (cr.pend_S != C1_NO_PEND) { c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane); cr.pend_S = C1_NO_PEND; }
+    if (cr.pend_S != C1_NO_PEND) {
+        if (CX) { v4f pv[8]; c1_cx_read(lds + cr.cur, lane, pv); c1_cx_store(A, cr.pend_S, lane, pv); }
+        else c1_flush_angles(A, lds + (C1_BUF_BYTES - cr.cur), cr.pend_S, lane);
+        cr.pend_S = C1_NO_PEND;
+    }
     for (int q = f1; q < q1; ++q)
-        c1_row<U8, NCO, true>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
+        c1_row<U8, NCO, true, CX>(A, lt, lane, lds, (int64_t)A.base + (int64_t)C1_ROW * q, q >= q0, false, xa, xb, ql, cr);
 #ifdef C1_TRACE
     tr[7] = (unsigned)__builtin_readcyclecounter() - tloop;
     if (gw < 4096 && lane == 0) {
@@ -825,7 +878,8 @@ struct DDCos1kState {
 };
 
 int dd_cos1k_supported(const double* taps, int K, int M, int flags) {
-    if (M != 1 || K != C1_K || !(flags & DD_CHAIN_FM)) return 0;
+    (void)flags;                                   // FM angles or complex64 output, complex64 or raw u8 input
+    if (M != 1 || K != C1_K) return 0;
     DDCosFit f;
     if (!dd_cos_fit_cached(taps, K, &f)) return 0;
     return f.Q == 1 ? 1 : 0;                       // a0 + a1 cos(2 pi k / (K-1)): Hamming, Hann and their relatives
@@ -886,22 +940,28 @@ extern "C" int dd_debug_cos1k_plan(int64_t L, int s, int out_align_elems, int nc
     return DD_OK;
 }
 
+static const void* cos1k_kernel(bool u8, bool nco, bool cx) {
+    static const void* const k[8] = {
+        (const void*)k_chain_cos1k<false, false, false>, (const void*)k_chain_cos1k<true, false, false>,
+        (const void*)k_chain_cos1k<false, true, false>,  (const void*)k_chain_cos1k<true, true, false>,
+        (const void*)k_chain_cos1k<false, false, true>,  (const void*)k_chain_cos1k<true, false, true>,
+        (const void*)k_chain_cos1k<false, true, true>,   (const void*)k_chain_cos1k<true, true, true>};
+    return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (cx ? 4 : 0)];
+}
+
 int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     DDCos1kState* s = reinterpret_cast<DDCos1kState*>(stv);
     if (P.L < 1) return DD_OK;
     static DDOncePerDevice attr;
     if (attr.need()) {
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
-        DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_cos1k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+        for (int i = 0; i < 8; ++i) DD_HIP_CHECK(hipFuncSetAttribute(cos1k_kernel(i & 1, i & 2, i & 4), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
         attr.mark();
     }
     const bool nco = (P.flags & DD_CHAIN_NCO) != 0;
     const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
     const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
     DDCos1kArgs A;
-    A.in = P.in; A.out = reinterpret_cast<float*>(P.out);
+    A.in = P.in; A.out = P.out;
     A.tail_in = P.tail_in; A.tail_out = P.tail_out; A.lasty_in = P.lasty_in; A.lasty_out = P.lasty_out;
     A.nco_tbl = P.nco_tbl; A.lane_tab = s->lane_tab;
     A.cyc = P.cyc; A.abs0 = P.abs0; A.L = P.L; A.s = P.s;
@@ -909,7 +969,9 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     auto ph = [&](int m) { long double p = frac * (long double)m; p -= floorl(p); const long double a = PI2 * p; return make_float2((float)cosl(a), (float)-sinl(a)); };
     A.q1 = ph(128); A.q2 = ph(256); A.q4 = ph(512);
     A.e1 = ph(1); A.e2 = ph(2); A.e3 = ph(3); A.e4 = ph(4); A.e8 = ph(8);
-    const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
+    const bool cx = !(P.flags & DD_CHAIN_FM);
+    // rows start where `out` starts a line: 16 angles = 64 bytes, 16 complex outputs = 128
+    const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> (cx ? 3 : 2)) & 15);
     static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
     int grid;
     cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
@@ -923,10 +985,7 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     if (A.run_rows < 0) A.run_rows = A.nrows >= 16 * A.nwaves ? 8 : 0;
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0;
     const dim3 g(grid), b(64 * C1_WAVES);
-    if (u8 && nco) hipLaunchKernelGGL((k_chain_cos1k<true, true>), g, b, C1_LDS_BYTES, stream, A);
-    else if (u8) hipLaunchKernelGGL((k_chain_cos1k<true, false>), g, b, C1_LDS_BYTES, stream, A);
-    else if (nco) hipLaunchKernelGGL((k_chain_cos1k<false, true>), g, b, C1_LDS_BYTES, stream, A);
-    else hipLaunchKernelGGL((k_chain_cos1k<false, false>), g, b, C1_LDS_BYTES, stream, A);
-    DD_LAUNCH_CHECK();
+    void* kargs[1] = {&A};
+    DD_HIP_CHECK(hipLaunchKernel(cos1k_kernel(u8, nco, cx), g, b, kargs, C1_LDS_BYTES, stream));
     return DD_OK;
 }

@@ -1116,10 +1116,10 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     // The FFT kernel's time does not depend on the tap count (0.221 ms per 2^26 samples, 0.207 from raw u8); the MFMA
     // kernel's does: 0.227 ms in the 162..257-tap class, 0.20 below.  FM output only.
     const bool fft_class = NKS == 18;
-    // 255 taps of the form a0 + a1 cos(2 pi k / 254) (filters.hamming) with FM output: the running-sum kernel (dd_cosfir.hip),
+    // 255 taps of the form a0 + a1 cos(2 pi k / 254) (filters.hamming), FM or complex64 output: the running-sum kernel (dd_cosfir.hip),
     // a third of the overlap-save form's arithmetic.  "cos1k" forces it wherever it applies (it never applies to other taps),
     // "fft1k" / "ab" / "ws" keep it off.
-    if ((ksel == DD_KSEL_AUTO || ksel == DD_KSEL_COS1K) && st->K == 255 && (P.flags & DD_CHAIN_FM)) {
+    if ((ksel == DD_KSEL_AUTO || ksel == DD_KSEL_COS1K) && st->K == 255) {
         if (!st->cos && !st->cos_tried) {
             st->cos_tried = 1;
             if (!dd_cos1k_supported(st->taps.data(), st->K, 1, P.flags) || dd_cos1k_create(&st->cos, st->taps.data(), st->K) != DD_OK) st->cos = nullptr;

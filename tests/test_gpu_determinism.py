@@ -107,16 +107,16 @@ def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, select_k
     _assert_identical(g, outs, 1)
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ab"])
+@pytest.mark.parametrize("kernel", ["auto", "fft1k", "ab"])
 def test_complex_output_chain_is_bit_reproducible(g, kernel, select_kernel):
-    """NCO + FIR, complex64 out: k_chain_fft1k's complex-output flavour (the default for 255 taps since round 4) and
-    k_chain_mfma_ab's (forced)."""
+    """NCO + FIR, complex64 out: k_chain_cos1k's complex-output flavour (the default for Hamming 255 since round 5), k_chain_fft1k's
+    and k_chain_mfma_ab's (forced)."""
     select_kernel(None if kernel == "auto" else kernel)
     t = g.torch
     n = (1 << 23) + 777
     x = g.bench.make_input(t, n, 0, g.dev, 99)
     outs, kernels = _chain_runs(g, _hamming(255), 1, g.hip.DD_CHAIN_NCO, x, n, 2 * n)
-    assert set(kernels) == {g.hip.DD_KERNEL_FFT_OS if kernel == "auto" else g.hip.DD_KERNEL_MFMA_AB}
+    assert set(kernels) == {{"auto": g.hip.DD_KERNEL_COS_RS, "fft1k": g.hip.DD_KERNEL_FFT_OS, "ab": g.hip.DD_KERNEL_MFMA_AB}[kernel]}
     _assert_identical(g, outs, 2)
 
 

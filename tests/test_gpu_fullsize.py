@@ -345,13 +345,11 @@ def test_oracle_windows_of_the_decimated_runs(run, decim_run, where):
 
 
 def test_complex_output_flavour_at_full_size(run):
-    """NCO + Hamming(255), complex64 out (no FM) over the 2^26-sample input: k_chain_mfma_ab's complex-output flavour
-    against the f32 direct-form path on every output, and against the float64 oracle on windows at the stream start, a
+    """NCO + Hamming(255), complex64 out (no FM) over the 2^26-sample input: the complex-output flavour of k_chain_cos1k (the default
+    since round 5) and of k_chain_fft1k against the f32 direct-form path on every output, and against the float64 oracle on windows at the stream start, a
     tile seam and the end.  Tolerance: FIR 2e-6 of the peak (4e-6 between the two f32 kernels)."""
     if run.kernel == "ab":
         pytest.skip("complex output always takes k_chain_mfma_ab: run once")
-    if run.kernel == "cos1k":
-        pytest.skip("the running-sum kernel has no complex64-output flavour (the choice by tap class keeps k_chain_fft1k there): run once")
     t, hip, lib = run.torch, run.hip, run.lib
     n = run.n
 

@@ -361,6 +361,46 @@ def test_cos_kernel_row_edges_and_carried_state(dd, window, f_off, u8, select_ke
     fm_check(got, ref, np.concatenate(mags))
 
 
+@pytest.mark.parametrize("window", ["hamming", "hann_like"])
+@pytest.mark.parametrize("f_off", [25000.0, 0.0])
+@pytest.mark.parametrize("u8", [False, True])
+def test_cos_kernel_complex_output_row_edges_and_carried_state(dd, window, f_off, u8, select_kernel):
+    """k_chain_cos1k's complex64-output flavour (commSignal.filter alone, comm.py:80-92: the FIR output itself, a0 put back): the same
+    ragged chunk list as the FM test above -- output rows laid by the alignment of the complex64 `out` (128-byte lines), edge rows
+    with predicated stores, interior rows through the LDS transposition -- against the float64 oracle, 2e-6 of the peak."""
+    select_kernel(None)
+    fs = 2400000
+    cuts = np.cumsum([0, 1, 2, 253, 1023, 1024, 1025, 2047, 2048, 5000, 3, 70001, 777, 4096 * 9 + 5])
+    L = int(cuts[-1])
+    raw = O.synth_iq_fm(L, fs, 2901, f_carrier=f_off if f_off else 1000.0, f_mod=700.0, dev=4.0)
+    x = O.grid_c64(raw)
+    if window == "hamming":
+        taps = O.win_hamming(255)
+        flt = dd.filters.hamming(255)
+    else:
+        taps = 0.5 - 0.42 * np.cos(2.0 * np.pi * np.arange(255) / 254.0)
+        flt = dd.filters.filter(taps, [1])
+    ck = dd.chunker.chunker(_Src(L))
+    out = dd.comm.commSignal(fs)
+    fo = O.FilterState(taps)
+    from directdemod_amd import source
+    rec = source.IQarray(raw, fs) if u8 else None
+    idx, refs = 0, []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        src = rec.read_device_raw(int(a), int(b)) if u8 else x[a:b]
+        s = dd.comm.commSignal(fs, src, ck)
+        if f_off:
+            s.offsetFreq(f_off)
+        s.filter(flt)
+        out.extend(s)
+        refs.append(fo.applyOn(O.nco(x[a:b], f_off, fs, idx) if f_off else x[a:b]))
+        idx += b - a
+    ref = np.concatenate(refs)
+    assert out.length == len(ref) == L
+    assert flt._last_kernel() == dd.hip.DD_KERNEL_COS_RS
+    assert rel_err(out.signal, ref) < FIR_TOL
+
+
 def test_cos_kernel_stop_band_signal(dd, select_kernel):
     """What the running-sum form costs in accuracy, stated: a signal that lies ENTIRELY in the stop band (carrier 62 kHz from
     the pass band of Hamming 255 at 2.4 MS/s).  Its running sums R, C carry the rectangular window's side lobes (-13 dB) while their
@@ -962,8 +1002,8 @@ def test_u8_ingest_mfma_interior_tiles(dd, fm, kern, select_kernel):
         # chunk starts on an odd sample (2-byte alignment): tile-per-workgroup kernel
         # (FM output with 255 taps: the overlap-save FFT kernel takes the aligned chunk, whole)
         # (round 4: the FFT kernel lays its block grid by the OUTPUT's alignment and takes any input alignment)
-        # (round 5: FM output through Hamming 255 is the running-sum kernel's; complex64 output stays with the FFT kernel)
-        want = (hip.DD_KERNEL_COS_RS if fm else hip.DD_KERNEL_FFT_OS) if kern == "auto" else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
+        # (round 5: Hamming 255 is the running-sum kernel's, FM or complex64 output)
+        want = hip.DD_KERNEL_COS_RS if kern == "auto" else (hip.DD_KERNEL_MFMA_AB if (2 * pos) % 4 == 0 else hip.DD_KERNEL_MFMA_TILES)
         assert lib.dd_chain_last_kernel(h) == want
         outs.append(o.to_host())
         pos += n
