@@ -204,7 +204,7 @@ def build_once_per_node():
 
 # ----------------------------------------------------------------------------- engines
 KERNEL_NAMES = {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
-                6: "k_chain_mfma_ab", 7: "k_chain_fft1k", 8: "k_chain_decim_multi", 9: "k_chain_cos1k"}
+                6: "k_chain_mfma_ab", 7: "k_chain_fft1k", 8: "k_chain_decim_multi", 9: "k_chain_cos1k", 10: "k_chain_decim_w"}
 
 
 class HipStep:

@@ -33,7 +33,7 @@ DD_ERR_TIMEOUT = -6
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
 (DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
- DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS) = range(10)
+ DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS, DD_KERNEL_DECIM_WAVE) = range(11)
 # element type of raw interleaved uint8 I,Q pairs held on the device (source.py:117-118 not yet applied): 2 B/sample
 IQ8 = np.dtype([("i", np.uint8), ("q", np.uint8)])
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "dd_chain_out_count": (_i64, [_p, _i64]),
     "dd_chain_process": (_int, [_p, _p, _p, _i64, _pi64, _p]),
     "dd_fir_last_kernel": (_int, [_p]),
+    "dd_fir_launch_count": (C.c_longlong, [_p]),
     "dd_fused_process_chunks": (_int, [_p, _p, _p, _p, _pi64, _int, _int, C.c_uint64, _i64, _int, _int, _int, _pi64, _p]),
     "dd_chain_process_chunks": (_int, [_p, _p, _p, _pi64, _int, _pi64, _p]),
     "dd_chain_path": (_int, [_p]),

@@ -11,6 +11,7 @@
 // Taps are wave-uniform and come through the scalar cache (s_load), so the VALU
 // issues only FMAs and LDS reads.
 #include "dd_chain_kernels.h"
+#include "dd_decimw.h"
 #include <mutex>
 
 #define DD_DENSE_R 8
@@ -551,6 +552,30 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, con
     if (t < T) {
         const float2* __restrict__ win = sx + t * M;
         int j = 0;
+#ifdef DD_DECIM_STAPS
+        if ((M & 1) == 0) {
+            // the taps are wave uniform: they come through the scalar cache (a third of the tap loop's LDS reads were theirs), and a
+            // multiply-add handles re and im at once; two partial sums
+            typedef float dd_v2f __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(4))) float* dd_cfp;
+            const dd_cfp Gs = (dd_cfp)(P.taps_rev + (DD_DENSE_R - 1));
+            const float4* __restrict__ win4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(win, 16));
+            dd_v2f a0 = (dd_v2f){0.f, 0.f}, a1 = (dd_v2f){0.f, 0.f};
+            for (; j + 8 <= K; j += 8) {
+                const float4 x0 = win4[j / 2], x1 = win4[j / 2 + 1], x2 = win4[j / 2 + 2], x3 = win4[j / 2 + 3];
+                const float c0 = Gs[j], c1 = Gs[j + 1], c2 = Gs[j + 2], c3 = Gs[j + 3], c4 = Gs[j + 4], c5 = Gs[j + 5], c6 = Gs[j + 6], c7 = Gs[j + 7];
+                a0 = __builtin_elementwise_fma((dd_v2f){c0, c0}, (dd_v2f){x0.x, x0.y}, a0);
+                a1 = __builtin_elementwise_fma((dd_v2f){c1, c1}, (dd_v2f){x0.z, x0.w}, a1);
+                a0 = __builtin_elementwise_fma((dd_v2f){c2, c2}, (dd_v2f){x1.x, x1.y}, a0);
+                a1 = __builtin_elementwise_fma((dd_v2f){c3, c3}, (dd_v2f){x1.z, x1.w}, a1);
+                a0 = __builtin_elementwise_fma((dd_v2f){c4, c4}, (dd_v2f){x2.x, x2.y}, a0);
+                a1 = __builtin_elementwise_fma((dd_v2f){c5, c5}, (dd_v2f){x2.z, x2.w}, a1);
+                a0 = __builtin_elementwise_fma((dd_v2f){c6, c6}, (dd_v2f){x3.x, x3.y}, a0);
+                a1 = __builtin_elementwise_fma((dd_v2f){c7, c7}, (dd_v2f){x3.z, x3.w}, a1);
+            }
+            acc.x = a0.x + a1.x; acc.y = a0.y + a1.y;
+        }
+#else
         if ((M & 1) == 0) {                                // 16-byte aligned windows: conflict-free ds_read_b128 (see k_chain_decim)
             const float4* __restrict__ win4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(win, 16));
             const float4* __restrict__ G4 = reinterpret_cast<const float4*>(__builtin_assume_aligned(gl, 16));
@@ -567,6 +592,7 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, con
                 acc.x = fmaf(c1.w, x3.z, acc.x); acc.y = fmaf(c1.w, x3.w, acc.y);
             }
         }
+#endif
         for (; j + 8 <= K; j += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -747,6 +773,7 @@ __global__ void k_fill_c64(float2* p, int n, float re, float im) {
 // host side
 // ============================================================================
 // MFMA path hooks (dd_mfma.hip)
+int dd_kernel_sel_decimp(void);     // (dd_mfma.hip) dd_debug_select_kernel("decimp"): the tile kernels for M > 1
 int dd_mfma_supported(int K, int M, int flags);
 int dd_mfma_create(void** st, const double* taps, int K);
 void dd_mfma_destroy(void* st);
@@ -818,6 +845,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->hpar = 0;
     f->hist_mode = DD_HIST_ONES;
     f->last_kernel = DD_KERNEL_NONE;
+    f->launches = 0;
     f->multi = nullptr;
     f->multi_bytes = 0;
     f->seam_err = nullptr;
@@ -898,6 +926,7 @@ extern "C" int dd_fir_reset(dd_fir* f, int mode, const float* hist_host, void* s
     }
     f->hist_mode = mode;
     f->state_invalid = 0;
+    f->launches = 0;
     return dd_fir_reset_f64(f, mode, hist_host, s);
 }
 
@@ -1099,6 +1128,11 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         hipLaunchKernelGGL(k_chain_dense, dim3(P.nblocks), dim3(DD_DENSE_THREADS), lds, s, P);
         DD_LAUNCH_CHECK();
         fir->last_kernel = DD_KERNEL_DENSE_F32;
+    } else if (!dd_kernel_sel_decimp() && dd_decimw_supported(P.K, P.M, P.flags, P.in)) {
+        // even M in [8, 64], up to 256 taps: one wave per row of 64 kept outputs on the absolute decimation grid (dd_decimw.hip)
+        int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), s);
+        if (rc != DD_OK) return rc;
+        fir->last_kernel = DD_KERNEL_DECIM_WAVE;
     } else {
         DDDecimPlan pl;
         int rc = decim_plan(P, pl);
@@ -1123,6 +1157,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
             fir->last_kernel = DD_KERNEL_DECIM_TILES;
         }
     }
+    ++fir->launches;
     if (a.commit) {
         fir->parity ^= 1;
         fir->tail_override = nullptr;
@@ -1278,6 +1313,10 @@ extern "C" int dd_fir_last_kernel(const dd_fir* f) {
     return f->last_kernel;
 }
 
+extern "C" long long dd_fir_launch_count(const dd_fir* f) {
+    return f ? f->launches : -1;
+}
+
 extern "C" int dd_chain_last_kernel(const dd_chain* c) {
     if (!c) return DD_ERR_INVALID;
     return c->fir->last_kernel;
@@ -1313,6 +1352,27 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
     const bool u8 = (flags & DD_CHAIN_U8_INPUT) != 0;
     const size_t isz = u8 ? 2 : sizeof(float2), osz = isfm ? sizeof(float) : sizeof(float2);
     if (!(M > 1 && nchunks >= 2 && !(flags & DD_CHAIN_FORCE_DIRECT) && fir->K >= 2)) return 0;
+    if (!dd_kernel_sel_decimp() && dd_decimw_supported(fir->K, M, flags, in)) {
+        // k_chain_decim_w lays its rows on the ABSOLUTE decimation grid, which a chunk list continues from chunk to chunk (comm.py:123-125),
+        // and a sample after the NCO is a pure function of its absolute index: the list is ONE chunk -- same outputs as the loop, bit for
+        // bit, no hand-over inside the launch
+        const int64_t n = bounds_host[nchunks] - bounds_host[0];
+        int has_last = isfm ? fm->has_last : 0, off = off0;
+        for (int i = 0; i < nchunks; ++i) {
+            const int64_t ni = bounds_host[i + 1] - bounds_host[i];
+            const int64_t Ld = kept_count(ni, off, M);
+            if (ni == 0 || Ld == 0) return 0;
+            if (n_out_host) n_out_host[i] = isfm ? Ld - (has_last ? 0 : 1) : Ld;
+            off = (int)((M - (ni - off) % M) % M);
+            if (isfm) has_last = 1;
+        }
+        DDFusedArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in; a.out = out; a.n = n; a.nco = nco; a.cyc = cyc; a.start_index = start_index; a.M = M; a.off = off0;
+        a.u8 = u8 ? 1 : 0; a.commit = 1;
+        const int rc = dd_fused_launch(fir, fm, a, nullptr, s);
+        return rc == DD_OK ? 1 : rc;
+    }
     int withhold = -1, spin_log2 = 0;
     {
         // an earlier chunk-list launch through this filter whose hand-over timed out: say so now, before anything is enqueued
@@ -1443,6 +1503,7 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
         fir->seam_pending = 1;
     }
     fir->last_kernel = DD_KERNEL_DECIM_MULTI;
+    ++fir->launches;
     fir->parity ^= 1;
     fir->tail_override = nullptr;
     if (isfm) {

@@ -22,6 +22,7 @@ struct dd_fir {
     int hpar;
     int hist_mode;
     int last_kernel;        // DD_KERNEL_* of the last fused launch through this filter
+    long long launches;     // fused kernel launches through this filter (dd_fir_launch_count)
     char* multi;            // chunk-list launches: seam flags, per-chunk parameter blocks, prefix tables, seam state (grow-only)
     size_t multi_bytes;
     // chunk-list launches: hand-overs that timed out (dd_seam_wait), counted on the device, mirrored into a pinned word

@@ -1022,7 +1022,7 @@ void dd_mfma_destroy(void* st) {
 // Which M = 1 kernel runs: by tap class, unless a tool or test has forced one.  The choice is a process-wide word set
 // through dd_debug_select_kernel (a debug entry like dd_debug_fill_lds); the environment variable DD_MFMA_KERNEL only
 // seeds it, read ONCE when the first chain is launched (no getenv in the launch path).
-enum { DD_KSEL_UNREAD = -1, DD_KSEL_AUTO = 0, DD_KSEL_AB = 1, DD_KSEL_WS = 2, DD_KSEL_FFT1K = 3, DD_KSEL_COS1K = 4 };
+enum { DD_KSEL_UNREAD = -1, DD_KSEL_AUTO = 0, DD_KSEL_AB = 1, DD_KSEL_WS = 2, DD_KSEL_FFT1K = 3, DD_KSEL_COS1K = 4, DD_KSEL_DECIMP = 5 };
 static std::atomic<int> g_kernel_sel{DD_KSEL_UNREAD};
 static int kernel_sel_parse(const char* name) {
     if (!name || !*name || strcmp(name, "auto") == 0) return DD_KSEL_AUTO;
@@ -1030,6 +1030,7 @@ static int kernel_sel_parse(const char* name) {
     if (strcmp(name, "ws") == 0) return DD_KSEL_WS;
     if (strcmp(name, "fft1k") == 0) return DD_KSEL_FFT1K;
     if (strcmp(name, "cos1k") == 0) return DD_KSEL_COS1K;
+    if (strcmp(name, "decimp") == 0) return DD_KSEL_DECIMP;      // M > 1: the tile kernels of rounds 1-4 instead of k_chain_decim_w (M = 1: as "auto")
     return -2;
 }
 static int kernel_sel() {
@@ -1041,10 +1042,11 @@ static int kernel_sel() {
     }
     return c;
 }
+int dd_kernel_sel_decimp(void) { return kernel_sel() == DD_KSEL_DECIMP ? 1 : 0; }
 extern "C" int dd_debug_select_kernel(const char* name) {
     const int c = kernel_sel_parse(name);
     if (c < 0) {
-        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k, cos1k)", name);
+        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k, cos1k, decimp)", name);
         return DD_ERR_INVALID;
     }
     g_kernel_sel.store(c, std::memory_order_relaxed);

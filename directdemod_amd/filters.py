@@ -100,6 +100,10 @@ class filter:
         """DD_KERNEL_* of the last fused launch through this filter (tests assert the intended kernel ran)"""
         return int(lib().dd_fir_last_kernel(self._handle()))
 
+    def _launch_count(self):
+        """fused kernel launches through this filter since it was created or last reset (a chunk list in one launch counts once)"""
+        return int(lib().dd_fir_launch_count(self._handle()))
+
     def _handle(self):
         if self.__h is None:
             _hip.require_gpu()

@@ -140,11 +140,15 @@ def test_decimating_chain_is_bit_reproducible(g, M, ntaps, fm, u8):
 @pytest.mark.parametrize("shape", ["C3", "C4", "ragged", "tiny_chunks"])
 @pytest.mark.parametrize("fm", [True, False])
 @pytest.mark.parametrize("u8", [False, True])
-def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm, u8):
-    """dd_chain_process_chunks: every chunk of a decimating chunk loop in ONE launch (k_chain_decim_multi; the carried
-    state crosses the chunk seams through device memory inside the launch).  Outputs, per-chunk counts and the state left
-    behind (checked by one more chunk afterwards) must equal those of the dd_chain_process loop as integers; also after
-    LDS fills, and with the seam flags' buffer reused from call to call."""
+@pytest.mark.parametrize("kernel", ["auto", "decimp"])
+def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm, u8, kernel, select_kernel):
+    """dd_chain_process_chunks: every chunk of a decimating chunk loop in ONE launch.  k_chain_decim_w (even M in 8..64, round 5) lays
+    its rows on the absolute decimation grid and rotates every sample by a pure function of its absolute index: the list is one long
+    chunk, no hand-over inside the launch.  k_chain_decim_multi (other M; every M when "decimp" is selected): the carried state crosses
+    the chunk seams through device memory inside the launch.  Outputs, per-chunk counts and the state left behind (checked by one more
+    chunk afterwards) must equal those of the dd_chain_process loop as integers; also after LDS fills, and with the seam flags' buffer
+    reused from call to call."""
+    select_kernel(None if kernel == "auto" else kernel)
     t, lib, hip = g.torch, g.lib, g.hip
     if shape == "C3":
         M, taps, n, cuts = 50, _hamming(127), 1 << 23, [i << 21 for i in range(5)]
@@ -192,7 +196,7 @@ def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm
         lib.dd_chain_reset(h, g.stream)
         out = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
         hip.check(lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), bounds, len(cuts) - 1, nout, g.stream), "chunks")
-        assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_MULTI
+        assert lib.dd_chain_last_kernel(h) == (hip.DD_KERNEL_DECIM_WAVE if kernel == "auto" and shape != "tiny_chunks" else hip.DD_KERNEL_DECIM_MULTI)
         assert list(nout) == counts[:-1]
         p2 = sum(nout)
         hip.check(lib.dd_chain_process(h, x.data_ptr() + isz * n, out.data_ptr() + 4 * per * p2, tail, C.byref(got), g.stream), "process")
@@ -205,12 +209,14 @@ def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm
     lib.dd_chain_destroy(h)
 
 
-def test_withheld_hand_over_is_reported_not_silently_wrong(g):
-    """dd_chain_process_chunks hands the carried FIR / FM state from chunk to chunk INSIDE one launch (agent-scope flags).  A
+def test_withheld_hand_over_is_reported_not_silently_wrong(g, select_kernel):
+    """k_chain_decim_multi (the chunk-list kernel for the decimations k_chain_decim_w does not take; selected here with "decimp"):
+    dd_chain_process_chunks hands the carried FIR / FM state from chunk to chunk INSIDE one launch (agent-scope flags).  A
     consumer whose flag never arrives gives up after a bounded spin and reads whatever the state buffers hold; that used to end
     with DD_OK and wrong samples.  dd_debug_seam withholds one chunk's flag (and shortens the spin bound): the call itself still
     returns (the kernel completes), the error surfaces as DD_ERR_TIMEOUT at dd_stream_sync -- or at the next chunk-list call on
     the filter, whichever comes first -- and a run without the fault afterwards is bit-identical to the chunk loop again."""
+    select_kernel("decimp")
     t, lib, hip = g.torch, g.lib, g.hip
     M, taps, n = 34, np.ascontiguousarray(_hamming(151), dtype=np.float64), 1 << 22
     cuts = [0, 1000000, 2000001, 3000000, n]

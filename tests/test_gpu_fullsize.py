@@ -268,8 +268,14 @@ _DECIM_CASES = {
 @pytest.fixture(scope="module", params=["C4", "C3"])
 def decim_run(run, request):
     """the whole 2^26-sample stream through dd_chain_process chunk by chunk (FIR history, last FM sample, NCO index
-    and decimation phase carried on the device), complex64 input; the persistent kernel must have run for every chunk"""
+    and decimation phase carried on the device), complex64 input.  Under the module's first parametrisation the chunks go
+    through k_chain_decim_w (round 5: one wave per row of 64 kept outputs), under the second through the tile kernels of
+    rounds 1-4 (k_chain_decim_p, "decimp"); the third skips these tests."""
     t, hip, lib = run.torch, run.hip, run.lib
+    old_tiles = run.kernel == "fft1k"
+    if old_tiles:
+        hip.select_kernel("decimp")
+    want = hip.DD_KERNEL_DECIM_PERSISTENT if old_tiles else hip.DD_KERNEL_DECIM_WAVE
     mk, M, fs, f, chunks = _DECIM_CASES[request.param]
     taps = np.ascontiguousarray(mk(), dtype=np.float64)
     h = C.c_void_p()
@@ -281,10 +287,12 @@ def decim_run(run, request):
     bounds = chunks(run.n)
     for a, b in bounds:
         got = run.process(h, run.x.data_ptr() + 8 * a, out.data_ptr() + 4 * pos, b - a)
-        assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_PERSISTENT, (a, b, lib.dd_chain_last_kernel(h))
+        assert lib.dd_chain_last_kernel(h) == want, (a, b, lib.dd_chain_last_kernel(h))
         pos += got
     lib.dd_chain_destroy(h)
     t.cuda.synchronize()
+    if old_tiles:
+        hip.select_kernel(run.kernel)
     assert pos == nd - 1                                                # quirk Q3 once, at the stream start
     assert bool(t.isfinite(out[:pos]).all())
 
