@@ -69,6 +69,7 @@ SIGNATURES = {
     "dd_debug_seam": (_int, [_int, _int]),
     "dd_debug_fft1k_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int)]),
     "dd_debug_cos1k_plan": (_int, [_i64, _int, _int, _int, C.POINTER(_int)]),
+    "dd_debug_decimw_plan": (_int, [_i64, _i64, _int, _int, _int, _int, C.POINTER(_i64)]),
     "dd_debug_cos_fit": (_int, [C.POINTER(C.c_double), _int, C.POINTER(C.c_double), C.POINTER(_int)]),
     "dd_debug_sync_envelope": (_int, [_p, _i64, _int, _int, _p, _p]),
     "dd_memcpy_h2d": (_int, [_p, _p, _sz, _p]),

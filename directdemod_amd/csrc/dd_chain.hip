@@ -1093,7 +1093,13 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
     if (P.Ld == 0) {
         // no kept sample in this chunk: only the FIR history moves on
         if (a.commit && fir->K > 1) {
-            hipLaunchKernelGGL(k_tail_update, dim3(1), dim3(256), 0, s, P);
+            if (a.M > 1 && !dd_kernel_sel_decimp() && dd_decimw_supported(P.K, P.M, P.flags, P.in)) {
+                // (k_chain_decim_w's history is ITS value of a sample after the NCO: the same arithmetic for a chunk without a kept sample)
+                int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), s);
+                if (rc != DD_OK) return rc;
+            } else {
+                hipLaunchKernelGGL(k_tail_update, dim3(1), dim3(256), 0, s, P);
+            }
             DD_LAUNCH_CHECK();
             fir->parity ^= 1;
             fir->tail_override = nullptr;

@@ -213,7 +213,7 @@ __device__ __forceinline__ void dw_stage8_guarded(const DDDecimWArgs& A, float2*
     }
 }
 
-// the K taps over the window that starts at LDS sample `ws` (even): sixteen taps per trip, two partial sums.  The next trip's samples (eight
+// the K taps over the window that starts at LDS sample `ws` (even): sixteen taps per trip, four partial sums.  The next trip's samples (eight
 // 16-byte LDS reads) and taps (one scalar load) are requested before this trip's multiply-adds: with two waves per SIMD nothing else hides
 // their latency (the first version waited for both every eight taps: 0.089 ms for 2^26 raw u8 samples, which move a quarter of the bytes).
 __device__ __forceinline__ void dw_taps_load(const v4f* __restrict__ w4, int j, v4f (&x)[8]) {
@@ -221,27 +221,44 @@ __device__ __forceinline__ void dw_taps_load(const v4f* __restrict__ w4, int j, 
     for (int u = 0; u < 8; ++u) x[u] = w4[j / 2 + u];
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) float* dw_const_f;
+typedef const __attribute__((address_space(4))) v2f* dw_const_f2p;
 #else
-typedef const float* dw_const_f;
+typedef const v2f* dw_const_f2p;
 #endif
-__device__ __forceinline__ void dw_taps_coef(dw_const_f G, int j, float (&c)[16]) {
+__device__ __forceinline__ void dw_taps_coef(dw_const_f2p G, int j, v2f (&c)[8]) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) c[u] = G[j + u];
+    for (int u = 0; u < 8; ++u) c[u] = G[j / 2 + u];
+}
+// acc += (c.x, c.x) * x resp. (c.y, c.y) * x, the tap pair c in a scalar register pair (left to the compiler the odd tap of a pair is first
+// copied into a pair of its own: -DDW_MAC_BUILTIN)
+__device__ __forceinline__ void dw_mac_lo(v2f& acc, v2f c, v2f x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(c), "v"(x));
+}
+__device__ __forceinline__ void dw_mac_hi(v2f& acc, v2f c, v2f x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(c), "v"(x));
 }
 __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf, int ws) {
     const v4f* __restrict__ w4 = reinterpret_cast<const v4f*>(buf + ws);
-    const dw_const_f G = (dw_const_f)A.taps;
-    v2f a0 = (v2f){0.f, 0.f}, a1 = (v2f){0.f, 0.f};
+    const dw_const_f2p G = (dw_const_f2p)A.taps;
+    v2f a0 = (v2f){0.f, 0.f}, a1 = (v2f){0.f, 0.f}, a2 = (v2f){0.f, 0.f}, a3 = (v2f){0.f, 0.f};
     v4f xa[8], xb[8];
-    float ca[16], cb[16];
+    v2f ca[8], cb[8];
     dw_taps_load(w4, 0, xa);
     dw_taps_coef(G, 0, ca);
-    auto mac = [&](const v4f (&x)[8], const float (&c)[16]) {
+    auto mac = [&](const v4f (&x)[8], const v2f (&c)[8]) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a0 = __builtin_elementwise_fma((v2f){c[2 * u], c[2 * u]}, (v2f){x[u].x, x[u].y}, a0);
-            a1 = __builtin_elementwise_fma((v2f){c[2 * u + 1], c[2 * u + 1]}, (v2f){x[u].z, x[u].w}, a1);
+        for (int u = 0; u < 8; u += 2) {
+#ifdef DW_MAC_BUILTIN
+            a0 = __builtin_elementwise_fma((v2f){c[u].x, c[u].x}, (v2f){x[u].x, x[u].y}, a0);
+            a1 = __builtin_elementwise_fma((v2f){c[u].y, c[u].y}, (v2f){x[u].z, x[u].w}, a1);
+            a2 = __builtin_elementwise_fma((v2f){c[u + 1].x, c[u + 1].x}, (v2f){x[u + 1].x, x[u + 1].y}, a2);
+            a3 = __builtin_elementwise_fma((v2f){c[u + 1].y, c[u + 1].y}, (v2f){x[u + 1].z, x[u + 1].w}, a3);
+#else
+            dw_mac_lo(a0, c[u], (v2f){x[u].x, x[u].y});
+            dw_mac_hi(a1, c[u], (v2f){x[u].z, x[u].w});
+            dw_mac_lo(a2, c[u + 1], (v2f){x[u + 1].x, x[u + 1].y});
+            dw_mac_hi(a3, c[u + 1], (v2f){x[u + 1].z, x[u + 1].w});
+#endif
         }
     };
     // (two trips per turn: the two register sets alternate, nothing is copied)
@@ -253,7 +270,9 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
             mac(xb, cb);
         }
     }
-    return a0 + a1;
+    // the four partial sums by TRUE tap index mod 4, whatever the window's alignment (e = 1: the loop's index runs one ahead): the same
+    // additions in the same order for an output wherever its stream's phase puts it -- a chain without NCO counts every chunk from zero
+    return A.e ? (a1 + a2) + (a3 + a0) : (a0 + a1) + (a2 + a3);
 }
 
 // the HP samples before the next row's block: the end of this row's image moves to the front
@@ -468,8 +487,12 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     pl.nruns = (pl.nrows + pl.run_rows - 1) / pl.run_rows;
     pl.nwaves = pl.nruns < slots ? pl.nruns : slots;
 }
-int dd_decimw_plan(int64_t abs0, int64_t L, int64_t Ld, int K, int M, int off, int u8, uintptr_t in_addr, int ncu, int64_t* out) {
-    (void)L; (void)u8; (void)in_addr;
+extern "C" int dd_debug_decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu, int64_t* out) {
+    DD_REQUIRE(out && Ld >= 0 && ncu >= 1 && off >= 0 && off < M, "arguments");
+    if (!dd_decimw_supported(K, M, 0, nullptr)) {
+        dd_set_error("k_chain_decim_w takes even M in [8, 64] and 2 .. 256 taps");
+        return DD_ERR_UNSUPPORTED;
+    }
     DWPlan pl;
     decimw_plan(abs0, Ld, K, M, off, ncu, pl);
     out[0] = pl.R0; out[1] = pl.nrows; out[2] = pl.phi; out[3] = pl.HP; out[4] = pl.e; out[5] = pl.K16; out[6] = pl.wpc; out[7] = pl.run_rows;
@@ -486,7 +509,7 @@ static const void* decimw_kernel(bool u8, bool nco, bool fm) {
 }
 
 int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t stream) {
-    if (P.Ld < 1) return DD_OK;
+    if (P.Ld < 1 && !P.tail_out) return DD_OK;                 // (no kept sample: one wave, for the new history alone)
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0, nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
     DWPlan pl;
     decimw_plan(P.abs0, P.Ld, P.K, P.M, P.off, dd_cu_count(), pl);
@@ -509,6 +532,6 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t s
     A.e = pl.e; A.phi = pl.phi; A.off = P.off; A.s = P.s;
     A.cq = (DW_W - 1) / P.M + 1; A.cr = (DW_W - 1) % P.M;
     void* kargs[1] = {&A};
-    DD_HIP_CHECK(hipLaunchKernel(decimw_kernel(u8, nco, fm), dim3(pl.nwaves), dim3(64), kargs, pl.lds, stream));
+    DD_HIP_CHECK(hipLaunchKernel(decimw_kernel(u8, nco, fm), dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
     return DD_OK;
 }

@@ -638,6 +638,59 @@ def test_fused_chain_vs_oracle_shapes(dd, M, K, chunk):
     fm_check(out.signal, ref, np.abs(yo[1:] * np.conj(yo[:-1])))
 
 
+@pytest.mark.parametrize("M,K", [(8, 2), (8, 255), (10, 15), (12, 256), (34, 151), (50, 127), (62, 150), (64, 64), (64, 256)])
+@pytest.mark.parametrize("fm_on", [True, False])
+@pytest.mark.parametrize("u8", [False, True])
+def test_decimw_kernel_shapes_cuts_and_u8(dd, M, K, fm_on, u8):
+    """k_chain_decim_w (round 5: even M in 8..64, up to 256 taps): one wave per block of 2048 samples of the ABSOLUTE sample grid.  Ragged
+    chunk cuts (1 sample, shorter than the taps, odd lengths, blocks that straddle chunks, chunks without a kept sample) through the
+    chunk-by-chunk C-ABI route against the float64 oracle; the same stream in ONE call equals the chunked outputs bit for bit (a sample
+    after the NCO is a pure function of its absolute index); raw u8 input gives the bits of the same samples as complex64."""
+    import ctypes as C
+    hip = dd.hip
+    lib = hip.lib()
+    fs = 2048000
+    cuts = np.cumsum([0, 1, 2, K - 1, 3, 2047, 2048, 2049, 4096 + 5, 7, 30011, 1, 20000 + M])
+    L = int(cuts[-1])
+    raw = O.synth_iq_fm(L, fs, 300 + M + K, f_carrier=30000.0, f_mod=900.0, dev=3.0)
+    x = O.grid_c64(raw)
+    taps = np.ascontiguousarray(O.firwin_lowpass(K, 0.45 / M) if K > 2 else np.array([0.5, 0.5]))
+    flags = hip.DD_CHAIN_NCO | (hip.DD_CHAIN_FM if fm_on else 0) | (hip.DD_CHAIN_U8_INPUT if u8 else 0)
+    src = hip.DevArray.from_host(raw.reshape(-1)) if u8 else hip.DevArray.from_host(x, dtype=np.complex64)
+    isz = 2 if u8 else 8
+    odt = np.float32 if fm_on else np.complex64
+
+    def run(bounds):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), K, hip.cycles_q64(30000.0, fs), M, flags))
+        outs = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            no = lib.dd_chain_out_count(h, int(b - a))
+            o = hip.DevArray(max(1, no), odt)
+            got = C.c_int64(0)
+            hip.check(lib.dd_chain_process(h, src.ptr + isz * int(a), o.ptr, int(b - a), C.byref(got), None))
+            assert got.value == no
+            if no:
+                assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_WAVE
+            outs.append(o.to_host()[:no])
+        lib.dd_chain_destroy(h)
+        return np.concatenate(outs)
+    got = run(cuts)
+    one = run(np.array([0, L]))
+    assert got.dtype == one.dtype and np.array_equal(got.view(np.uint32), one.view(np.uint32))
+    y = O.FilterState(taps).applyOn(O.nco(x, 30000.0, fs))[::M]
+    if fm_on:
+        ref, _ = O.fm_demod(y, None)
+        fm_check(got, ref, np.abs(y[1:] * np.conj(y[:-1])))
+    else:
+        assert rel_err(got, y) < FIR_TOL
+    if u8:
+        # the same samples as complex64: the same bits
+        src = hip.DevArray.from_host(x, dtype=np.complex64)
+        isz, flags = 8, flags & ~hip.DD_CHAIN_U8_INPUT
+        assert np.array_equal(run(np.array([0, L])).view(np.uint32), one.view(np.uint32))
+
+
 def test_fir_complex_output_decimated_vs_oracle(dd):
     L = 50000
     x = O.grid_c64(O.synth_iq_noise(L, 77))

@@ -150,6 +150,44 @@ def test_cos1k_plan_lays_the_row_grid_by_the_outputs_alignment(L, s, align, ncu)
     assert waves == 4 * grid and 1 <= grid <= 2 * ncu and waves - 4 < rows or rows < 4
 
 
+@pytest.mark.parametrize("abs0,L,off,K,M,ncu", [
+    (0, 1 << 26, 0, 151, 34, 256), (0, 1 << 26, 0, 127, 50, 256), (20000000, 20000000, 12, 151, 34, 256), (4194304 * 3, 1 << 22, 46, 127, 50, 256),
+    (0, 5000, 0, 255, 8, 256), (123457, 70001, 7, 2, 8, 256), (999, 1, 0, 64, 64, 256), (0, 2047, 33, 256, 34, 304), (2047, 3, 1, 15, 10, 4)])
+def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, ncu):
+    """dd_debug_decimw_plan (round 5): k_chain_decim_w's rows are the blocks of 2048 samples of the ABSOLUTE sample index; a chunk's rows run
+    from the block of its first kept sample to the block of its last one; the window of every output starts on an even LDS sample (16-byte
+    reads), one sample early behind a zero tap where the stream's phase makes it odd; and the chunks of a chunk loop (comm.py:123-125: the
+    decimation phase follows on) see the same grid as the concatenation -- which is why a chunk list is one launch."""
+    lib = _hip.lib()
+    out = (C.c_int64 * 8)()
+    Ld = len(range(off, L, M))
+    _hip.check(lib.dd_debug_decimw_plan(abs0, Ld, K, M, off, ncu, out), "dd_debug_decimw_plan")
+    R0, rows, phi, HP, e, K16, wpc, run_rows = list(out)
+    first = abs0 + off
+    assert phi == first % M
+    if Ld == 0:
+        assert rows == 0
+        return
+    last = first + (Ld - 1) * M
+    assert 2048 * R0 <= first < 2048 * (R0 + 1) and 2048 * (R0 + rows - 1) <= last < 2048 * (R0 + rows)
+    assert HP % 2 == 0 and K - 1 <= HP <= K
+    assert e in (0, 1) and (HP - K + 1 + phi - e) % 2 == 0           # (the offset of a kept sample in its block has phi's parity: 2048 and M are even)
+    assert K16 % 16 == 0 and K + e <= K16 < K + e + 16
+    assert 1 <= wpc <= 8 and wpc * 8 * (HP + 2048 + 16 + 32) <= 160 * 1024
+    assert 1 <= run_rows <= 8 or rows < run_rows * ncu * wpc
+    # the next chunk of the loop: same phase, rows that follow on
+    noff = (M - (L - off) % M) % M
+    out2 = (C.c_int64 * 8)()
+    _hip.check(lib.dd_debug_decimw_plan(abs0 + L, len(range(noff, 1 << 20, M)), K, M, noff, ncu, out2), "dd_debug_decimw_plan")
+    assert out2[2] == phi and out2[4] == e and out2[0] in (R0 + rows - 1, R0 + rows) or out2[0] > R0 + rows
+
+
+def test_decimw_plan_refuses_what_the_kernel_does_not_take():
+    out = (C.c_int64 * 8)()
+    for K, M in ((151, 33), (151, 6), (151, 66), (257, 34), (1, 34)):
+        assert _hip.lib().dd_debug_decimw_plan(0, 1000, K, M, 0, 256, out) == _hip.DD_ERR_UNSUPPORTED
+
+
 def test_a_variant_library_is_loaded_through_dd_lib_path_and_says_so(tmp_path):
     """measurement scripts no longer copy ablation builds over the product library; DD_LIB_PATH makes _hip load another build of
     the same C-ABI instead, with a line on stderr.  (Here: a copy of the product library under another name.)"""
