@@ -369,6 +369,7 @@ def side_configs(eng, steps=10, only_decim=False):
             return e0.elapsed_time(e1) / steps, r
         ms_loop, n_out = timed(one_pass)
         ms, n_out_list = timed(one_pass_chunk_list)
+        kern = KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?")
         assert n_out_list == n_out
         # the same 2^26 samples as ONE chunk (one launch): what the kernel does without any chunk seam
         chunked_bounds = bounds
@@ -380,7 +381,8 @@ def side_configs(eng, steps=10, only_decim=False):
         res.append({"config": name, "chunks": len(bounds), "launches_per_pass": 1, "ms_per_pass": round(ms, 4), "outputs": n_out,
                     "GS_per_s": round(n / ms / 1e6, 1), "bytes_per_sample": round(bps, 3),
                     "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4),
-                    "how": "dd_chain_process_chunks: the whole chunk list in one launch, carried state handed over inside it",
+                    "kernel": kern,
+                    "how": "dd_chain_process_chunks: the whole chunk list in one launch (k_chain_decim_w: the list is one chunk on the absolute sample grid)",
                     "chunk_loop": {"launches_per_pass": len(bounds), "ms": round(ms_loop, 4), "GS_per_s": round(n / ms_loop / 1e6, 1),
                                    "frac_of_8TBs": round(n * bps / (ms_loop * 1e-3) / 8e12, 4)},
                     "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),

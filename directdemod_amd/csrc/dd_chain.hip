@@ -857,7 +857,7 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     const int K = ntaps;
     // G[i] = g[i-(R-1)], g[j] = h[K-1-j]; zero padded so every R-block read is in range
     const int niter = (K + R - 1 + R - 1) / R;
-    const int len = niter * R + 2 * R;
+    const int len = niter * R + 6 * R;                    // (k_chain_decim_w reads whole trips of 32 taps: zeros behind the last one)
     std::vector<float> g(len, 0.f);
     for (int j = 0; j < K; ++j) g[j + R - 1] = (float)taps[K - 1 - j];
     const size_t tb = sizeof(float2) * (size_t)(K > 1 ? K - 1 : 1);

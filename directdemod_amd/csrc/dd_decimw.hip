@@ -40,7 +40,10 @@ typedef uint32_t v4u_a2 __attribute__((ext_vector_type(4), aligned(2)));     // 
 #endif
 #define DW_NL (DW_W / 128)   // 16-byte loads per lane and row, complex64
 #define DW_NL8 (DW_W / 512)  // the same, raw u8
-#define DW_PAD 16            // zeros behind the block: the tap loop runs in sixteens
+#ifndef DW_TRIP
+#define DW_TRIP 16            // taps per trip of the tap loop
+#endif
+#define DW_PAD DW_TRIP       // zeros behind the block: the tap loop runs in whole trips
 #define DW_NG (DW_W / 64)    // group phasors e^{-j w 64 g}
 
 struct DDDecimWArgs {
@@ -216,18 +219,18 @@ __device__ __forceinline__ void dw_stage8_guarded(const DDDecimWArgs& A, float2*
 // the K taps over the window that starts at LDS sample `ws` (even): sixteen taps per trip, four partial sums.  The next trip's samples (eight
 // 16-byte LDS reads) and taps (one scalar load) are requested before this trip's multiply-adds: with two waves per SIMD nothing else hides
 // their latency (the first version waited for both every eight taps: 0.089 ms for 2^26 raw u8 samples, which move a quarter of the bytes).
-__device__ __forceinline__ void dw_taps_load(const v4f* __restrict__ w4, int j, v4f (&x)[8]) {
+__device__ __forceinline__ void dw_taps_load(const v4f* __restrict__ w4, int j, v4f (&x)[DW_TRIP / 2]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = w4[j / 2 + u];
+    for (int u = 0; u < DW_TRIP / 2; ++u) x[u] = w4[j / 2 + u];
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) v2f* dw_const_f2p;
 #else
 typedef const v2f* dw_const_f2p;
 #endif
-__device__ __forceinline__ void dw_taps_coef(dw_const_f2p G, int j, v2f (&c)[8]) {
+__device__ __forceinline__ void dw_taps_coef(dw_const_f2p G, int j, v2f (&c)[DW_TRIP / 2]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = G[j / 2 + u];
+    for (int u = 0; u < DW_TRIP / 2; ++u) c[u] = G[j / 2 + u];
 }
 // acc += (c.x, c.x) * x resp. (c.y, c.y) * x, the tap pair c in a scalar register pair (left to the compiler the odd tap of a pair is first
 // copied into a pair of its own: -DDW_MAC_BUILTIN)
@@ -241,13 +244,13 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
     const v4f* __restrict__ w4 = reinterpret_cast<const v4f*>(buf + ws);
     const dw_const_f2p G = (dw_const_f2p)A.taps;
     v2f a0 = (v2f){0.f, 0.f}, a1 = (v2f){0.f, 0.f}, a2 = (v2f){0.f, 0.f}, a3 = (v2f){0.f, 0.f};
-    v4f xa[8], xb[8];
-    v2f ca[8], cb[8];
+    v4f xa[DW_TRIP / 2], xb[DW_TRIP / 2];
+    v2f ca[DW_TRIP / 2], cb[DW_TRIP / 2];
     dw_taps_load(w4, 0, xa);
     dw_taps_coef(G, 0, ca);
-    auto mac = [&](const v4f (&x)[8], const v2f (&c)[8]) {
+    auto mac = [&](const v4f (&x)[DW_TRIP / 2], const v2f (&c)[DW_TRIP / 2]) {
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
+        for (int u = 0; u < DW_TRIP / 2; u += 2) {
 #ifdef DW_MAC_BUILTIN
             a0 = __builtin_elementwise_fma((v2f){c[u].x, c[u].x}, (v2f){x[u].x, x[u].y}, a0);
             a1 = __builtin_elementwise_fma((v2f){c[u].y, c[u].y}, (v2f){x[u].z, x[u].w}, a1);
@@ -262,11 +265,11 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
         }
     };
     // (two trips per turn: the two register sets alternate, nothing is copied)
-    for (int j = 0; j < A.K16; j += 32) {
-        if (j + 16 < A.K16) { dw_taps_load(w4, j + 16, xb); dw_taps_coef(G, j + 16, cb); }
+    for (int j = 0; j < A.K16; j += 2 * DW_TRIP) {
+        if (j + DW_TRIP < A.K16) { dw_taps_load(w4, j + DW_TRIP, xb); dw_taps_coef(G, j + DW_TRIP, cb); }
         mac(xa, ca);
-        if (j + 16 < A.K16) {
-            if (j + 32 < A.K16) { dw_taps_load(w4, j + 32, xa); dw_taps_coef(G, j + 32, ca); }
+        if (j + DW_TRIP < A.K16) {
+            if (j + 2 * DW_TRIP < A.K16) { dw_taps_load(w4, j + 2 * DW_TRIP, xa); dw_taps_coef(G, j + 2 * DW_TRIP, ca); }
             mac(xb, cb);
         }
     }
@@ -275,13 +278,19 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
     return A.e ? (a1 + a2) + (a3 + a0) : (a0 + a1) + (a2 + a3);
 }
 
-// the HP samples before the next row's block: the end of this row's image moves to the front
-__device__ __forceinline__ void dw_halo(const DDDecimWArgs& A, float2* buf, int lane) {
+// the HP samples before the next row's block: the end of this row's image moves to the front (HP <= 256: two 16-byte pieces per lane at
+// most; read before the discriminator, written after it, so that the LDS round trip hides behind it)
+__device__ __forceinline__ void dw_halo_read(const DDDecimWArgs& A, const float2* buf, int lane, v4f (&h)[2]) {
+    const v4f* const b4 = reinterpret_cast<const v4f*>(buf);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < A.HP / 2) h[u] = b4[DW_W / 2 + lane + 64 * u];
+}
+__device__ __forceinline__ void dw_halo_write(const DDDecimWArgs& A, float2* buf, int lane, const v4f (&h)[2]) {
     v4f* const b4 = reinterpret_cast<v4f*>(buf);
-    for (int i = lane; i < A.HP / 2; i += 64) {
-        const v4f t = b4[DW_W / 2 + i];
-        b4[i] = t;
-    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < A.HP / 2) b4[lane + 64 * u] = h[u];
 }
 
 __device__ __forceinline__ float dw_shr1(float v, float first) {       // wave_shr:1; lane 0 keeps `first`
@@ -290,6 +299,15 @@ __device__ __forceinline__ float dw_shr1(float v, float first) {       // wave_s
 __device__ __forceinline__ v2f dw_lane(v2f v, int l) {                  // (l: wave uniform)
     return (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), l))};
 }
+
+#ifdef DW_TRACE
+// tools/debug/decimw_trace.py: cycles per phase of an interior row (every stamp drains the wave's counters), summed per wave
+#define DW_NPH 6
+__device__ unsigned long long g_dw_trace[4096 * (DW_NPH + 2)];
+#define DW_T(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DW_T(i) do { } while (0)
+#endif
 
 // where the outputs of a row sit: r0 = block offset of its first kept sample, cnt of them, p0 = chunk-relative index of the first
 struct DWRow {
@@ -306,14 +324,25 @@ __device__ __forceinline__ void dw_row_next(const DDDecimWArgs& A, DWRow& r) {
 // a staged row: the tap loop over its outputs, 64 per pass; the outputs leave; the halo moves down.  ycarry: the FIR output before the
 // row's first one on entry, the row's last one on exit.  emit false: the row before a run (only ycarry and the halo matter)
 template <bool FM>
-__device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, bool emit, v2f& ycarry, v2f ylast_in) {
-    if (!FM && !emit) { dw_halo(A, buf, lane); return; }        // (complex64 output: no output depends on the one before it)
+__device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, bool emit, v2f& ycarry, v2f ylast_in
+#ifdef DW_TRACE
+                                               , unsigned* tr = nullptr, unsigned tprev = 0
+#endif
+                                               ) {
+#ifdef DW_TRACE
+    unsigned trd[DW_NPH];
+    if (!tr) tr = trd;
+#endif
+    v4f hl[2];
+    if (!FM && !emit) { dw_halo_read(A, buf, lane, hl); dw_halo_write(A, buf, lane, hl); return; }        // (complex64 output: no output depends on the one before it)
     const int ws0 = A.HP - A.K + 1 + r.r0 - A.e;
     const int ng = (r.cnt + 63) >> 6;
     for (int t = emit ? 0 : ng - 1; t < ng; ++t) {
         const int i = 64 * t + lane;
         const int ic = i < r.cnt ? i : r.cnt - 1;
         const v2f y = dw_taps(A, buf, ws0 + ic * A.M);
+        if (t == ng - 1) dw_halo_read(A, buf, lane, hl);
+        DW_T(2);
         if (FM) {
             v2f yp = (v2f){dw_shr1(y.x, ycarry.x), dw_shr1(y.y, ycarry.y)};
             const int last = t == ng - 1 ? (r.cnt - 1) & 63 : 63;
@@ -335,8 +364,10 @@ __device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* bu
                 if (p == A.Ld - 1 && A.lasty_out) *A.lasty_out = make_float2(y.x, y.y);
             }
         }
+        DW_T(3);
     }
-    dw_halo(A, buf, lane);
+    dw_halo_write(A, buf, lane, hl);
+    DW_T(4);
 }
 
 template <bool U8, bool NCO, bool FM>
@@ -389,6 +420,13 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
     const int jlo = (rmin > 0 ? rmin : 0) >> (U8 ? 9 : 7);
     v4f_a8 x[DW_NL];
     v4u_a2 x8[DW_NL8];
+#ifdef DW_TRACE
+    unsigned tr[DW_NPH];
+#pragma unroll
+    for (int i = 0; i < DW_NPH; ++i) tr[i] = 0;
+    unsigned trows = 0;
+    const unsigned tstart = (unsigned)__builtin_readcyclecounter();
+#endif
     for (int run = gw; run < nruns; run += A.nwaves) {
         const int q0 = run * RR, q1 = q0 + RR < A.nrows ? q0 + RR : A.nrows;
         auto brel = [&](int q) { return (A.R0 + q) * (int64_t)DW_W - A.abs0; };
@@ -427,16 +465,27 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
         }
         for (int q = f0; q < f1; ++q) {
+#ifdef DW_TRACE
+            unsigned tprev = (unsigned)__builtin_readcyclecounter();
+#endif
             dw_row_next(A, r);
             DWPh pw;
             dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
+            DW_T(5);
             if constexpr (U8) dw_stage8<NCO>(A, buf, gl, lane, pw, x8);
             else dw_stage<NCO>(A, buf, gl, lane, pw, x);
+            DW_T(0);
             if (q + 1 < f1) {
                 // the next row's samples fly during this row's tap loop
                 if constexpr (U8) dw_issue8(A, brel(q + 1), lane, x8); else dw_issue(A, brel(q + 1), lane, x);
             }
+#ifdef DW_TRACE
+            { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+            ++trows;
+            dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in, tr, tprev);
+#else
             dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
+#endif
         }
         for (int q = f1; q < q1; ++q) {
             dw_row_next(A, r);
@@ -447,7 +496,23 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
         }
     }
+#ifdef DW_TRACE
+    if (gw < 4096 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < DW_NPH; ++i) g_dw_trace[gw * (DW_NPH + 2) + i] = tr[i];
+        g_dw_trace[gw * (DW_NPH + 2) + DW_NPH] = trows;
+        g_dw_trace[gw * (DW_NPH + 2) + DW_NPH + 1] = (unsigned)__builtin_readcyclecounter() - tstart;
+    }
+#endif
 }
+
+#ifdef DW_TRACE
+extern "C" int dd_debug_decimw_trace(unsigned long long* out, int nwaves) {
+    DD_HIP_CHECK(hipDeviceSynchronize());
+    DD_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * (size_t)nwaves * (DW_NPH + 2)));
+    return DD_OK;
+}
+#endif
 
 // ============================================================================ host side
 int dd_decimw_supported(int K, int M, int flags, const void* in) {
@@ -474,7 +539,7 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     // a window starts at LDS sample HP - K + 1 + (offset of its kept sample in the block): the parity of that offset is phi's (W and M are
     // even), so the parity of the start is the launch's -- one sample earlier, behind a zero tap, where it is odd
     pl.e = (int)((pl.HP - K + 1 + phi) & 1);
-    pl.K16 = (K + pl.e + 15) & ~15;
+    pl.K16 = (K + pl.e + DW_TRIP - 1) & ~(DW_TRIP - 1);       // (whole trips)
     pl.lds = sizeof(float2) * (size_t)(pl.HP + DW_W + DW_PAD + DW_NG);
     int wpc = (int)((160 * 1024) / pl.lds);
     pl.wpc = wpc > 4 * DW_WAVES_PER_SIMD ? 4 * DW_WAVES_PER_SIMD : (wpc < 1 ? 1 : wpc);
