@@ -134,17 +134,20 @@ __device__ __forceinline__ v2f dw_sample(const DDDecimWArgs& A, int64_t n, v2f p
 }
 
 // ---- complex64 rows: load j, lane l = samples 128 j + 2 l, + 1 of the block
-__device__ __forceinline__ void dw_issue(const DDDecimWArgs& A, int64_t Brel, int lane, v4f_a8 (&x)[DW_NL]) {
+// (J0, NJ: loads J0 .. J0 + NJ - 1 of the row -- all sixteen, or the last four: what a run needs of the row before it)
+template <int J0, int NJ>
+__device__ __forceinline__ void dw_issue(const DDDecimWArgs& A, int64_t Brel, int lane, v4f_a8 (&x)[NJ]) {
     const v4f_a8* p = reinterpret_cast<const v4f_a8*>(reinterpret_cast<const float2*>(A.in) + Brel + 2 * lane);
 #pragma unroll
-    for (int j = 0; j < DW_NL; ++j) x[j] = __builtin_nontemporal_load(p + 64 * j);
+    for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(p + 64 * (J0 + j));
 }
-template <bool NCO>
-__device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4f_a8 (&x)[DW_NL]) {
+template <bool NCO, int J0, int NJ>
+__device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4f_a8 (&x)[NJ]) {
     float2* const wr = buf + A.HP + 2 * lane;
 #pragma unroll
-    for (int j = 0; j < DW_NL; ++j) {
-        v2f x0 = (v2f){x[j].x, x[j].y}, x1 = (v2f){x[j].z, x[j].w};
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = J0 + jj;
+        v2f x0 = (v2f){x[jj].x, x[jj].y}, x1 = (v2f){x[jj].z, x[jj].w};
         if (NCO) {
             const v2f g = dw_v2(gl[2 * j + (lane >> 5)]);
             x0 = dw_cmul(x0, dw_cmul(pw.w[0], g));
@@ -171,19 +174,21 @@ __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* 
 }
 
 // ---- raw u8 rows (source.py:117-118): load j, lane l = samples 512 j + 8 l .. + 7 of the block
-__device__ __forceinline__ void dw_issue8(const DDDecimWArgs& A, int64_t Brel, int lane, v4u_a2 (&x)[DW_NL8]) {
+template <int J0, int NJ>
+__device__ __forceinline__ void dw_issue8(const DDDecimWArgs& A, int64_t Brel, int lane, v4u_a2 (&x)[NJ]) {
     const unsigned char* p = reinterpret_cast<const unsigned char*>(A.in) + 2 * (Brel + 8 * lane);
 #pragma unroll
-    for (int j = 0; j < DW_NL8; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u_a2*>(p + 1024 * j));
+    for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u_a2*>(p + 1024 * (J0 + j)));
 }
-template <bool NCO>
-__device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4u_a2 (&x)[DW_NL8]) {
+template <bool NCO, int J0, int NJ>
+__device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4u_a2 (&x)[NJ]) {
     float2* const wr = buf + A.HP + 8 * lane;
 #pragma unroll
-    for (int j = 0; j < DW_NL8; ++j) {
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = J0 + jj;
         v2f g = (v2f){1.f, 0.f};
         if (NCO) g = dw_v2(gl[8 * j + (lane >> 3)]);
-        const uint32_t d[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+        const uint32_t d[4] = {x[jj].x, x[jj].y, x[jj].z, x[jj].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v2f xa = (v2f){(float)(d[k] & 0xff) - 127.5f, (float)((d[k] >> 8) & 0xff) - 127.5f};
@@ -418,6 +423,7 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
     // one) and everything after it
     const int rmin = DW_W - M - A.K;
     const int jlo = (rmin > 0 ? rmin : 0) >> (U8 ? 9 : 7);
+    static_assert(DW_W - 512 >= 0 && DW_NL >= 4 && DW_NL8 >= 1, "the last 512 samples of a row hold K + M <= 320");
     v4f_a8 x[DW_NL];
     v4u_a2 x8[DW_NL8];
 #ifdef DW_TRACE
@@ -437,8 +443,16 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
         while (f0 < q1 && !inside(f0)) ++f0;
         int f1 = f0;
         while (f1 < q1 && inside(f1)) ++f1;
+        // the row before the run: its last K + M samples (<= 320) are all the run needs -- the last four loads of the row (u8: the last one)
+        // when it lies inside the chunk, requested ahead of the run's first row
+        const bool pin = inside(q0 - 1);
+        v4f_a8 xp[4];
+        v4u_a2 xp8[1];
+        if (pin) {
+            if constexpr (U8) dw_issue8<DW_NL8 - 1, 1>(A, brel(q0 - 1), lane, xp8); else dw_issue<DW_NL - 4, 4>(A, brel(q0 - 1), lane, xp);
+        }
         if (f1 > f0) {
-            if constexpr (U8) dw_issue8(A, brel(f0), lane, x8); else dw_issue(A, brel(f0), lane, x);
+            if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(f0), lane, x8); else dw_issue<0, DW_NL>(A, brel(f0), lane, x);
         }
         // the row before the run
         DWRow r;
@@ -451,8 +465,13 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             r.p0 = (B + r.r0 - A.abs0 - A.off) / M;                  // (exact: B + r0 is a kept sample's absolute index)
             DWPh pw;
             dw_row_ph<U8, NCO>(row_phasor(q0 - 1), ph, pw);
-            if constexpr (U8) dw_stage8_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
-            else dw_stage_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
+            if (pin) {
+                if constexpr (U8) dw_stage8<NCO, DW_NL8 - 1, 1>(A, buf, gl, lane, pw, xp8);
+                else dw_stage<NCO, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp);
+            } else {
+                if constexpr (U8) dw_stage8_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
+                else dw_stage_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
+            }
         }
         v2f ycarry = (v2f){0.f, 0.f};
         dw_row_outputs<FM>(A, buf, lane, r, false, ycarry, ylast_in);
@@ -472,12 +491,12 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             DWPh pw;
             dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
             DW_T(5);
-            if constexpr (U8) dw_stage8<NCO>(A, buf, gl, lane, pw, x8);
-            else dw_stage<NCO>(A, buf, gl, lane, pw, x);
+            if constexpr (U8) dw_stage8<NCO, 0, DW_NL8>(A, buf, gl, lane, pw, x8);
+            else dw_stage<NCO, 0, DW_NL>(A, buf, gl, lane, pw, x);
             DW_T(0);
             if (q + 1 < f1) {
                 // the next row's samples fly during this row's tap loop
-                if constexpr (U8) dw_issue8(A, brel(q + 1), lane, x8); else dw_issue(A, brel(q + 1), lane, x);
+                if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
             }
 #ifdef DW_TRACE
             { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
