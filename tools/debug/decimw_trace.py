@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cycles per phase of an interior row of k_chain_decim_w (library built with -DDW_TRACE: tools/mkvariant.sh N dd_decimw -DDW_TRACE).
-usage: LIB=build/variants/lib_N.so python tools/debug/decimw_trace.py [u8]"""
+usage: [M=34] LIB=build/variants/lib_N.so python tools/debug/decimw_trace.py [u8]"""
 import ctypes as C, os, sys
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,14 +15,15 @@ lib = _hip.lib()
 dev = torch.device("cuda", 0)
 n = 1 << 26
 u8 = "u8" in sys.argv[1:]
+M = int(os.environ.get("M", "34"))
 x = bench.make_input(torch, n, 0, dev, 3)
 if u8:
     x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
 k = np.arange(151)
 taps = np.ascontiguousarray(0.35875 - 0.48829 * np.cos(2 * np.pi * k / 150) + 0.14128 * np.cos(4 * np.pi * k / 150) - 0.01168 * np.cos(6 * np.pi * k / 150))
-out = torch.zeros(n // 34 + 8, dtype=torch.float32, device=dev)
+out = torch.zeros(n // M + 8, dtype=torch.float32, device=dev)
 h = C.c_void_p()
-_hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 151, _hip.cycles_q64(30000.0, 2048000), 34,
+_hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 151, _hip.cycles_q64(30000.0, 2048000), M,
                                _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_U8_INPUT if u8 else 0)), "create")
 for _ in range(100):
     lib.dd_chain_reset(h, None)
@@ -43,7 +44,7 @@ _hip.check(f(buf, NW), "trace")
 a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NPH + 2).astype(np.float64)
 rows = a[:, NPH].sum()
 names = ["wait for the loads, NCO, LDS writes", "issue the next row's loads", "tap loop", "discriminator, stores", "halo copy", "row geometry, row phasor"]
-print("%s %s: %.4f ms per launch (with stamps); cycles per interior row and wave, %d rows; whole kernel %.0f cycles per wave" %
+print("M = %d  " % M + "%s %s: %.4f ms per launch (with stamps); cycles per interior row and wave, %d rows; whole kernel %.0f cycles per wave" %
       (os.environ.get("LIB", "default"), "u8" if u8 else "c64", ms, rows, a[:, NPH + 1].mean()))
 tot = a[:, :NPH].sum() / rows
 for i, nm in enumerate(names):
