@@ -846,6 +846,8 @@ extern "C" int dd_fir_create(dd_fir** h, const double* taps, int ntaps) {
     f->hist_mode = DD_HIST_ONES;
     f->last_kernel = DD_KERNEL_NONE;
     f->launches = 0;
+    f->dw_taps.dev = nullptr;
+    f->dw_taps.key = -1;
     f->multi = nullptr;
     f->multi_bytes = 0;
     f->seam_err = nullptr;
@@ -893,6 +895,7 @@ extern "C" int dd_fir_destroy(dd_fir* f) {
     if (f->mfma) dd_mfma_destroy(f->mfma);
     seam_forget(f);
     (void)hipFree(f->multi);
+    (void)hipFree(f->dw_taps.dev);
     (void)hipFree(f->taps_rev);
     (void)hipFree(f->tail[0]);
     (void)hipFree(f->tail[1]);
@@ -1095,7 +1098,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         if (a.commit && fir->K > 1) {
             if (a.M > 1 && !dd_kernel_sel_decimp() && dd_decimw_supported(P.K, P.M, P.flags, P.in)) {
                 // (k_chain_decim_w's history is ITS value of a sample after the NCO: the same arithmetic for a chunk without a kept sample)
-                int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), s);
+                int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), fir->taps.data(), &fir->dw_taps, s);
                 if (rc != DD_OK) return rc;
             } else {
                 hipLaunchKernelGGL(k_tail_update, dim3(1), dim3(256), 0, s, P);
@@ -1136,7 +1139,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         fir->last_kernel = DD_KERNEL_DENSE_F32;
     } else if (!dd_kernel_sel_decimp() && dd_decimw_supported(P.K, P.M, P.flags, P.in)) {
         // even M in [8, 64], up to 256 taps: one wave per row of 64 kept outputs on the absolute decimation grid (dd_decimw.hip)
-        int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), s);
+        int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), fir->taps.data(), &fir->dw_taps, s);
         if (rc != DD_OK) return rc;
         fir->last_kernel = DD_KERNEL_DECIM_WAVE;
     } else {

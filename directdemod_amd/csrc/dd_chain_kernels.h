@@ -2,6 +2,7 @@
 // FM kernels (direct-form f32 and f16-split MFMA variants).  Internal.
 #pragma once
 #include "dd_common.h"
+#include "dd_decimw.h"
 #include <vector>
 
 // ---- handles (host side) ------------------------------------------------------
@@ -23,6 +24,7 @@ struct dd_fir {
     int hist_mode;
     int last_kernel;        // DD_KERNEL_* of the last fused launch through this filter
     long long launches;     // fused kernel launches through this filter (dd_fir_launch_count)
+    DDDecimWTaps dw_taps;   // k_chain_decim_w's padded taps (M = 0 mod 4), lazy
     char* multi;            // chunk-list launches: seam flags, per-chunk parameter blocks, prefix tables, seam state (grow-only)
     size_t multi_bytes;
     // chunk-list launches: hand-overs that timed out (dd_seam_wait), counted on the device, mirrored into a pinned word

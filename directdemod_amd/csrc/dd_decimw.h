@@ -1,9 +1,15 @@
 // Wave-autonomous decimating chain kernel (dd_decimw.hip).  Internal.
 #pragma once
-#include "dd_chain_kernels.h"
+#include "dd_common.h"
 
+struct DDChainParams;
+// kept with a filter: the taps as a PAD launch meets them (zeros over the gaps of the padded LDS image), for one (M, tap shift) at a time
+struct DDDecimWTaps {
+    float* dev;
+    int key;
+};
 // even M in [8, 64], 2 <= K <= 256, complex64 (8-byte aligned) or raw u8 (2-byte aligned) input, FM or complex64 output
 int dd_decimw_supported(int K, int M, int flags, const void* in);
 // the WHOLE chunk in one launch (stream start, chunk end and the carried state included): P as dd_fused_launch fills it;
-// taps_g0 = the reversed taps g[j] = h[K-1-j] on the device, at least one zero in front of g[0] and 22 behind g[K-1]
-int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t stream);
+// taps_g0 = the reversed taps g[j] = h[K-1-j] on the device, at least one zero in front of g[0] and 38 behind g[K-1]; taps_host = h[0 .. K-1]
+int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream);

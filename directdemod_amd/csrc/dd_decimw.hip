@@ -26,6 +26,7 @@
 #include "dd_decimw.h"
 #include "dd_atan.h"
 #include <stdlib.h>
+#include <vector>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -64,6 +65,8 @@ struct DDDecimWArgs {
     int phi;                   // (abs0 + off) mod M
     int off;
     int cq, cr;                // (W - 1) / M + 1, (W - 1) % M
+    uint32_t minv;             // PAD: 2^32 / M + 1
+    int img;                   // samples of the LDS image (halo, block, gaps, zeros behind)
     int s;                     // 1: stream start, no angle for output 0
 };
 
@@ -133,6 +136,21 @@ __device__ __forceinline__ v2f dw_sample(const DDDecimWArgs& A, int64_t n, v2f p
     return NCO ? dw_cmul(x, ph) : x;
 }
 
+// ---- where a staged sample sits in LDS.  Plain: sample r of [halo | block] at position r.  PAD (M = 0 mod 8): the lanes' windows start M
+// samples = a multiple of 16 banks apart -- every 16-byte read of the tap loop a bank conflict (M = 32: all lanes on the same banks).  There the
+// image carries two samples of gap after every M, counted from the first window's start: lane i's window starts (M + 2) i further on (= 2 mod 4:
+// conflict free), every window meets the gaps at the same places, and the taps carry zeros there (padded taps, built on the host).  The layout follows the row's own
+// phase: the halo moves down from the row before's layout into this row's (dw_halo_*).
+struct DWMap {
+    int c0m;           // (first window's start) mod M, minus M
+    uint32_t minv;     // 2^32 / M + 1: x / M = umulhi(x, minv) for the x met here
+};
+template <bool PAD>
+__device__ __forceinline__ int dw_pos(const DWMap& mp, int r) {
+    if (!PAD) return r;
+    return r + 2 * (int)__umulhi((uint32_t)(r - mp.c0m), mp.minv);
+}
+
 // ---- complex64 rows: load j, lane l = samples 128 j + 2 l, + 1 of the block
 // (J0, NJ: loads J0 .. J0 + NJ - 1 of the row -- all sixteen, or the last four: what a run needs of the row before it)
 template <int J0, int NJ>
@@ -141,9 +159,8 @@ __device__ __forceinline__ void dw_issue(const DDDecimWArgs& A, int64_t Brel, in
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(p + 64 * (J0 + j));
 }
-template <bool NCO, int J0, int NJ>
-__device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4f_a8 (&x)[NJ]) {
-    float2* const wr = buf + A.HP + 2 * lane;
+template <bool NCO, bool PAD, int J0, int NJ>
+__device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4f_a8 (&x)[NJ], const DWMap& mp) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int j = J0 + jj;
@@ -153,13 +170,13 @@ __device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, con
             x0 = dw_cmul(x0, dw_cmul(pw.w[0], g));
             x1 = dw_cmul(x1, dw_cmul(pw.w[1], g));
         }
-        *reinterpret_cast<v4f*>(wr + 128 * j) = (v4f){x0.x, x0.y, x1.x, x1.y};
+        const int r = A.HP + 128 * j + 2 * lane;
+        *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){x0.x, x0.y, x1.x, x1.y};
     }
 }
 // the same through guarded sample-by-sample loads, loads jlo .. 15
-template <bool NCO>
-__device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw) {
-    float2* const wr = buf + A.HP + 2 * lane;
+template <bool NCO, bool PAD>
+__device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw, const DWMap& mp) {
     for (int j = jlo; j < DW_NL; ++j) {
         v2f pj = (v2f){1.f, 0.f}, pj1 = (v2f){1.f, 0.f};
         if (NCO) {
@@ -169,7 +186,7 @@ __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* 
         }
         const int64_t n = Brel + 128 * j + 2 * lane;
         const v2f x0 = dw_sample<false, NCO>(A, n, pj), x1 = dw_sample<false, NCO>(A, n + 1, pj1);
-        *reinterpret_cast<v4f*>(wr + 128 * j) = (v4f){x0.x, x0.y, x1.x, x1.y};
+        *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, A.HP + 128 * j + 2 * lane)) = (v4f){x0.x, x0.y, x1.x, x1.y};
     }
 }
 
@@ -180,9 +197,8 @@ __device__ __forceinline__ void dw_issue8(const DDDecimWArgs& A, int64_t Brel, i
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u_a2*>(p + 1024 * (J0 + j)));
 }
-template <bool NCO, int J0, int NJ>
-__device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4u_a2 (&x)[NJ]) {
-    float2* const wr = buf + A.HP + 8 * lane;
+template <bool NCO, bool PAD, int J0, int NJ>
+__device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4u_a2 (&x)[NJ], const DWMap& mp) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int j = J0 + jj;
@@ -197,13 +213,13 @@ __device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, co
                 xa = dw_cmul(xa, dw_cmul(pw.w[2 * k], g));
                 xb = dw_cmul(xb, dw_cmul(pw.w[2 * k + 1], g));
             }
-            *reinterpret_cast<v4f*>(wr + 512 * j + 2 * k) = (v4f){xa.x, xa.y, xb.x, xb.y};
+            const int r = A.HP + 512 * j + 8 * lane + 2 * k;
+            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){xa.x, xa.y, xb.x, xb.y};
         }
     }
 }
-template <bool NCO>
-__device__ __forceinline__ void dw_stage8_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw) {
-    float2* const wr = buf + A.HP + 8 * lane;
+template <bool NCO, bool PAD>
+__device__ __forceinline__ void dw_stage8_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw, const DWMap& mp) {
     for (int j = jlo; j < DW_NL8; ++j) {
         v2f g = (v2f){1.f, 0.f};
         if (NCO) g = dw_v2(gl[8 * j + (lane >> 3)]);
@@ -216,7 +232,7 @@ __device__ __forceinline__ void dw_stage8_guarded(const DDDecimWArgs& A, float2*
                 pb = dw_cmul(pw.w[2 * k + 1], g);
             }
             const v2f xa = dw_sample<true, NCO>(A, n + 2 * k, pa), xb = dw_sample<true, NCO>(A, n + 2 * k + 1, pb);
-            *reinterpret_cast<v4f*>(wr + 512 * j + 2 * k) = (v4f){xa.x, xa.y, xb.x, xb.y};
+            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, A.HP + 512 * j + 8 * lane + 2 * k)) = (v4f){xa.x, xa.y, xb.x, xb.y};
         }
     }
 }
@@ -245,6 +261,7 @@ __device__ __forceinline__ void dw_mac_lo(v2f& acc, v2f c, v2f x) {
 __device__ __forceinline__ void dw_mac_hi(v2f& acc, v2f c, v2f x) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(c), "v"(x));
 }
+template <bool PAD>
 __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf, int ws) {
     const v4f* __restrict__ w4 = reinterpret_cast<const v4f*>(buf + ws);
     const dw_const_f2p G = (dw_const_f2p)A.taps;
@@ -264,8 +281,8 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
 #else
             dw_mac_lo(a0, c[u], (v2f){x[u].x, x[u].y});
             dw_mac_hi(a1, c[u], (v2f){x[u].z, x[u].w});
-            dw_mac_lo(a2, c[u + 1], (v2f){x[u + 1].x, x[u + 1].y});
-            dw_mac_hi(a3, c[u + 1], (v2f){x[u + 1].z, x[u + 1].w});
+            dw_mac_lo(PAD ? a0 : a2, c[u + 1], (v2f){x[u + 1].x, x[u + 1].y});
+            dw_mac_hi(PAD ? a1 : a3, c[u + 1], (v2f){x[u + 1].z, x[u + 1].w});
 #endif
         }
     };
@@ -280,22 +297,25 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
     }
     // the four partial sums by TRUE tap index mod 4, whatever the window's alignment (e = 1: the loop's index runs one ahead): the same
     // additions in the same order for an output wherever its stream's phase puts it -- a chain without NCO counts every chunk from zero
+    // (PAD: two partial sums, even and odd taps -- the gaps of the padded image move with e against the taps, but they are two samples wide)
+    if (PAD) return A.e ? a1 + a0 : a0 + a1;
     return A.e ? (a1 + a2) + (a3 + a0) : (a0 + a1) + (a2 + a3);
 }
 
 // the HP samples before the next row's block: the end of this row's image moves to the front (HP <= 256: two 16-byte pieces per lane at
-// most; read before the discriminator, written after it, so that the LDS round trip hides behind it)
-__device__ __forceinline__ void dw_halo_read(const DDDecimWArgs& A, const float2* buf, int lane, v4f (&h)[2]) {
-    const v4f* const b4 = reinterpret_cast<const v4f*>(buf);
+// most; read before the discriminator, written after it, so that the LDS round trip hides behind it).  PAD: out of this row's layout into the
+// next row's.
+template <bool PAD>
+__device__ __forceinline__ void dw_halo_read(const DDDecimWArgs& A, const float2* buf, int lane, v4f (&h)[2], const DWMap& mp) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (lane + 64 * u < A.HP / 2) h[u] = b4[DW_W / 2 + lane + 64 * u];
+        if (lane + 64 * u < A.HP / 2) h[u] = *reinterpret_cast<const v4f*>(buf + dw_pos<PAD>(mp, DW_W + 2 * (lane + 64 * u)));
 }
-__device__ __forceinline__ void dw_halo_write(const DDDecimWArgs& A, float2* buf, int lane, const v4f (&h)[2]) {
-    v4f* const b4 = reinterpret_cast<v4f*>(buf);
+template <bool PAD>
+__device__ __forceinline__ void dw_halo_write(const DDDecimWArgs& A, float2* buf, int lane, const v4f (&h)[2], const DWMap& mp) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (lane + 64 * u < A.HP / 2) b4[lane + 64 * u] = h[u];
+        if (lane + 64 * u < A.HP / 2) *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, 2 * (lane + 64 * u))) = h[u];
 }
 
 __device__ __forceinline__ float dw_shr1(float v, float first) {       // wave_shr:1; lane 0 keeps `first`
@@ -328,8 +348,15 @@ __device__ __forceinline__ void dw_row_next(const DDDecimWArgs& A, DWRow& r) {
 
 // a staged row: the tap loop over its outputs, 64 per pass; the outputs leave; the halo moves down.  ycarry: the FIR output before the
 // row's first one on entry, the row's last one on exit.  emit false: the row before a run (only ycarry and the halo matter)
-template <bool FM>
-__device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, bool emit, v2f& ycarry, v2f ylast_in
+// the LDS layout of a PAD row: gaps counted from its first window's start
+__device__ __forceinline__ DWMap dw_row_map(const DDDecimWArgs& A, const DWRow& r) {
+    const int ws0 = A.HP - A.K + 1 + r.r0 - A.e;
+    const int k = (int)__umulhi((uint32_t)ws0, A.minv);
+    return DWMap{ws0 - k * A.M - A.M, A.minv};
+}
+
+template <bool FM, bool PAD>
+__device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, const DWMap& mp, bool emit, v2f& ycarry, v2f ylast_in
 #ifdef DW_TRACE
                                                , unsigned* tr = nullptr, unsigned tprev = 0
 #endif
@@ -339,14 +366,27 @@ __device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* bu
     if (!tr) tr = trd;
 #endif
     v4f hl[2];
-    if (!FM && !emit) { dw_halo_read(A, buf, lane, hl); dw_halo_write(A, buf, lane, hl); return; }        // (complex64 output: no output depends on the one before it)
+    DWMap mpn = mp;                                           // the NEXT row's layout: where the halo goes
+    if (PAD) {
+        DWRow rn = r;
+        dw_row_next(A, rn);
+        mpn = dw_row_map(A, rn);
+    }
+    if (!FM && !emit) {                                       // (complex64 output: no output depends on the one before it)
+        dw_halo_read<PAD>(A, buf, lane, hl, mp);
+        dw_halo_write<PAD>(A, buf, lane, hl, mpn);
+        return;
+    }
     const int ws0 = A.HP - A.K + 1 + r.r0 - A.e;
+    // PAD: the first window starts behind floor(ws0 / M) + 1 gaps, every further one M + 2 samples on
+    const int wsp = PAD ? ws0 + 2 * ((int)__umulhi((uint32_t)ws0, A.minv) + 1) : ws0;
+    const int wstep = PAD ? A.M + 2 : A.M;
     const int ng = (r.cnt + 63) >> 6;
     for (int t = emit ? 0 : ng - 1; t < ng; ++t) {
         const int i = 64 * t + lane;
         const int ic = i < r.cnt ? i : r.cnt - 1;
-        const v2f y = dw_taps(A, buf, ws0 + ic * A.M);
-        if (t == ng - 1) dw_halo_read(A, buf, lane, hl);
+        const v2f y = dw_taps<PAD>(A, buf, wsp + ic * wstep);
+        if (t == ng - 1) dw_halo_read<PAD>(A, buf, lane, hl, mp);
         DW_T(2);
         if (FM) {
             v2f yp = (v2f){dw_shr1(y.x, ycarry.x), dw_shr1(y.y, ycarry.y)};
@@ -371,19 +411,24 @@ __device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* bu
         }
         DW_T(3);
     }
-    dw_halo_write(A, buf, lane, hl);
+    dw_halo_write<PAD>(A, buf, lane, hl, mpn);
     DW_T(4);
 }
 
-template <bool U8, bool NCO, bool FM>
+template <bool U8, bool NCO, bool FM, bool PAD>
 __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const DDDecimWArgs A) {
     extern __shared__ __attribute__((aligned(16))) char dw_smem[];
     float2* const buf = reinterpret_cast<float2*>(dw_smem);
-    float2* const gl = buf + A.HP + DW_W + DW_PAD;
+    float2* const gl = buf + A.img;
     const int lane = threadIdx.x;
     const int gw = blockIdx.x;
     const int M = A.M;
-    if (lane < DW_PAD) buf[A.HP + DW_W + lane] = make_float2(0.f, 0.f);
+    if (PAD) {
+        // (the gaps are never written: they start as zeros -- whatever a later row's layout leaves in a gap is finite and meets a zero tap)
+        for (int i = lane; i < A.img / 2; i += 64) reinterpret_cast<v4f*>(buf)[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    } else if (lane < DW_PAD) {
+        buf[A.HP + DW_W + lane] = make_float2(0.f, 0.f);
+    }
     DWPh ph;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ph.w[k] = (v2f){1.f, 0.f};
@@ -456,6 +501,7 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
         }
         // the row before the run
         DWRow r;
+        DWMap mp = DWMap{0, A.minv};
         {
             const int64_t B = (A.R0 + q0 - 1) * (int64_t)DW_W;
             int64_t m = ((int64_t)A.phi - B) % M;
@@ -463,56 +509,49 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             r.r0 = (int)m;
             r.cnt = (DW_W - 1 - r.r0) / M + 1;
             r.p0 = (B + r.r0 - A.abs0 - A.off) / M;                  // (exact: B + r0 is a kept sample's absolute index)
+            if (PAD) mp = dw_row_map(A, r);
             DWPh pw;
             dw_row_ph<U8, NCO>(row_phasor(q0 - 1), ph, pw);
             if (pin) {
-                if constexpr (U8) dw_stage8<NCO, DW_NL8 - 1, 1>(A, buf, gl, lane, pw, xp8);
-                else dw_stage<NCO, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp);
+                if constexpr (U8) dw_stage8<NCO, PAD, DW_NL8 - 1, 1>(A, buf, gl, lane, pw, xp8, mp);
+                else dw_stage<NCO, PAD, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp, mp);
             } else {
-                if constexpr (U8) dw_stage8_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
-                else dw_stage_guarded<NCO>(A, buf, gl, lane, jlo, brel(q0 - 1), pw);
+                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
+                else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
             }
         }
         v2f ycarry = (v2f){0.f, 0.f};
-        dw_row_outputs<FM>(A, buf, lane, r, false, ycarry, ylast_in);
-        for (int q = q0; q < f0; ++q) {
-            dw_row_next(A, r);
-            DWPh pw;
-            dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
-            if constexpr (U8) dw_stage8_guarded<NCO>(A, buf, gl, lane, 0, brel(q), pw);
-            else dw_stage_guarded<NCO>(A, buf, gl, lane, 0, brel(q), pw);
-            dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
-        }
-        for (int q = f0; q < f1; ++q) {
+        dw_row_outputs<FM, PAD>(A, buf, lane, r, mp, false, ycarry, ylast_in);
+        for (int q = q0; q < q1; ++q) {
 #ifdef DW_TRACE
             unsigned tprev = (unsigned)__builtin_readcyclecounter();
 #endif
+            const bool fast = q >= f0 && q < f1;
             dw_row_next(A, r);
+            if (PAD) mp = dw_row_map(A, r);
             DWPh pw;
             dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
             DW_T(5);
-            if constexpr (U8) dw_stage8<NCO, 0, DW_NL8>(A, buf, gl, lane, pw, x8);
-            else dw_stage<NCO, 0, DW_NL>(A, buf, gl, lane, pw, x);
-            DW_T(0);
-            if (q + 1 < f1) {
-                // the next row's samples fly during this row's tap loop
-                if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
+            if (fast) {
+                if constexpr (U8) dw_stage8<NCO, PAD, 0, DW_NL8>(A, buf, gl, lane, pw, x8, mp);
+                else dw_stage<NCO, PAD, 0, DW_NL>(A, buf, gl, lane, pw, x, mp);
+                DW_T(0);
+                if (q + 1 < f1) {
+                    // the next row's samples fly during this row's tap loop
+                    if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
+                }
+            } else {
+                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
+                else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
             }
 #ifdef DW_TRACE
-            { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
-            ++trows;
-            dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in, tr, tprev);
-#else
-            dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
+            if (fast) {
+                { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+                ++trows;
+                dw_row_outputs<FM, PAD>(A, buf, lane, r, mp, true, ycarry, ylast_in, tr, tprev);
+            } else
 #endif
-        }
-        for (int q = f1; q < q1; ++q) {
-            dw_row_next(A, r);
-            DWPh pw;
-            dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
-            if constexpr (U8) dw_stage8_guarded<NCO>(A, buf, gl, lane, 0, brel(q), pw);
-            else dw_stage_guarded<NCO>(A, buf, gl, lane, 0, brel(q), pw);
-            dw_row_outputs<FM>(A, buf, lane, r, true, ycarry, ylast_in);
+            dw_row_outputs<FM, PAD>(A, buf, lane, r, mp, true, ycarry, ylast_in);
         }
     }
 #ifdef DW_TRACE
@@ -542,10 +581,16 @@ int dd_decimw_supported(int K, int M, int flags, const void* in) {
 
 struct DWPlan {
     int64_t R0;
-    int nrows, phi, HP, e, K16, wpc, run_rows, nwaves, nruns;
+    int nrows, phi, HP, e, K16, wpc, run_rows, nwaves, nruns, pad, img;
     size_t lds;
 };
 static int64_t dw_floordiv(int64_t a, int64_t b) { int64_t q = a / b; if (a - q * b < 0) --q; return q; }
+// taps as the tap loop meets them: e leading zeros, and in a PAD image two zeros after every M
+static int dw_padded_taps_len(int K, int M, int e, int pad) {
+    const int Ke = K + e;
+    const int raw = pad ? Ke + 2 * ((Ke - 1) / M) : Ke;
+    return (raw + DW_TRIP - 1) & ~(DW_TRIP - 1);
+}
 static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu, DWPlan& pl) {
     const int64_t first = abs0 + off;                          // absolute index of the chunk's first kept sample
     int64_t phi = first % M;
@@ -558,8 +603,13 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     // a window starts at LDS sample HP - K + 1 + (offset of its kept sample in the block): the parity of that offset is phi's (W and M are
     // even), so the parity of the start is the launch's -- one sample earlier, behind a zero tap, where it is odd
     pl.e = (int)((pl.HP - K + 1 + phi) & 1);
-    pl.K16 = (K + pl.e + DW_TRIP - 1) & ~(DW_TRIP - 1);       // (whole trips)
-    pl.lds = sizeof(float2) * (size_t)(pl.HP + DW_W + DW_PAD + DW_NG);
+    // lane stride M samples = M / 2 sixteen-byte bank groups of sixteen: conflict free for odd M / 2, two-way for M = 4 mod 8 (cheaper than the
+    // padded image's longer tap loop: M = 12 0.158 against 0.183 ms, M = 20 0.128 / 0.132), four-way and worse for M = 0 mod 8: the padded image
+    pl.pad = (M % 8) == 0 ? 1 : 0;
+    pl.K16 = dw_padded_taps_len(K, M, pl.e, pl.pad);
+    const int span = pl.HP + DW_W;
+    pl.img = pl.pad ? (span + 2 * (span / M + 4) + 2 * DW_TRIP + 8) & ~1 : span + DW_PAD;
+    pl.lds = sizeof(float2) * (size_t)(pl.img + DW_NG);
     int wpc = (int)((160 * 1024) / pl.lds);
     pl.wpc = wpc > 4 * DW_WAVES_PER_SIMD ? 4 * DW_WAVES_PER_SIMD : (wpc < 1 ? 1 : wpc);
     // runs of about 8 rows dealt to the waves in turn, every wave the same number of them where the chunk is long enough
@@ -583,16 +633,20 @@ extern "C" int dd_debug_decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int 
     return DD_OK;
 }
 
-static const void* decimw_kernel(bool u8, bool nco, bool fm) {
-    static const void* const k[8] = {
-        (const void*)k_chain_decim_w<false, false, false>, (const void*)k_chain_decim_w<true, false, false>,
-        (const void*)k_chain_decim_w<false, true, false>,  (const void*)k_chain_decim_w<true, true, false>,
-        (const void*)k_chain_decim_w<false, false, true>,  (const void*)k_chain_decim_w<true, false, true>,
-        (const void*)k_chain_decim_w<false, true, true>,   (const void*)k_chain_decim_w<true, true, true>};
-    return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (fm ? 4 : 0)];
+static const void* decimw_kernel(bool u8, bool nco, bool fm, bool pad) {
+    static const void* const k[16] = {
+        (const void*)k_chain_decim_w<false, false, false, false>, (const void*)k_chain_decim_w<true, false, false, false>,
+        (const void*)k_chain_decim_w<false, true, false, false>,  (const void*)k_chain_decim_w<true, true, false, false>,
+        (const void*)k_chain_decim_w<false, false, true, false>,  (const void*)k_chain_decim_w<true, false, true, false>,
+        (const void*)k_chain_decim_w<false, true, true, false>,   (const void*)k_chain_decim_w<true, true, true, false>,
+        (const void*)k_chain_decim_w<false, false, false, true>,  (const void*)k_chain_decim_w<true, false, false, true>,
+        (const void*)k_chain_decim_w<false, true, false, true>,   (const void*)k_chain_decim_w<true, true, false, true>,
+        (const void*)k_chain_decim_w<false, false, true, true>,   (const void*)k_chain_decim_w<true, false, true, true>,
+        (const void*)k_chain_decim_w<false, true, true, true>,    (const void*)k_chain_decim_w<true, true, true, true>};
+    return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (fm ? 4 : 0) | (pad ? 8 : 0)];
 }
 
-int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t stream) {
+int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream) {
     if (P.Ld < 1 && !P.tail_out) return DD_OK;                 // (no kept sample: one wave, for the new history alone)
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0, nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
     DWPlan pl;
@@ -604,10 +658,27 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t s
         const int slots = dd_cu_count() * pl.wpc;
         pl.nwaves = pl.nruns < slots ? pl.nruns : slots;
     }
+    const float* taps = taps_g0 - pl.e;
+    if (pl.pad) {
+        // the padded taps of (M, e): a small device buffer kept with the filter, rewritten in stream order when the key changes
+        const int key = (P.M << 1) | pl.e;
+        const int cap = 256 + 1 + 2 * 32 + 2 * DW_TRIP;
+        if (!cache->dev) DD_HIP_CHECK(hipMalloc((void**)&cache->dev, sizeof(float) * cap));
+        if (cache->key != key) {
+            std::vector<float> t(cap, 0.f);
+            for (int j = 0; j < P.K; ++j) {                    // g[j] = h[K-1-j] at logical window sample j + e
+                const int w = j + pl.e;
+                t[w + 2 * (w / P.M)] = (float)taps_host[P.K - 1 - j];
+            }
+            DD_HIP_CHECK(hipMemcpyAsync(cache->dev, t.data(), sizeof(float) * cap, hipMemcpyHostToDevice, stream));   // (pageable: staged before the call returns)
+            cache->key = key;
+        }
+        taps = cache->dev;
+    }
     DDDecimWArgs A;
     A.in = P.in; A.out = P.out;
     A.tail_in = P.tail_in; A.tail_out = P.tail_out; A.lasty_in = P.lasty_in; A.lasty_out = P.lasty_out;
-    A.taps = taps_g0 - pl.e;
+    A.taps = taps;
     A.nco_tbl = P.nco_tbl;
     A.cyc = P.cyc; A.abs0 = P.abs0; A.L = P.L; A.Ld = P.Ld;
     A.R0 = pl.R0;
@@ -615,7 +686,9 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, hipStream_t s
     A.K = P.K; A.K16 = pl.K16; A.M = P.M; A.HP = pl.HP;
     A.e = pl.e; A.phi = pl.phi; A.off = P.off; A.s = P.s;
     A.cq = (DW_W - 1) / P.M + 1; A.cr = (DW_W - 1) % P.M;
+    A.minv = (uint32_t)(0x100000000ull / (uint64_t)P.M) + 1u;
+    A.img = pl.img;
     void* kargs[1] = {&A};
-    DD_HIP_CHECK(hipLaunchKernel(decimw_kernel(u8, nco, fm), dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
+    DD_HIP_CHECK(hipLaunchKernel(decimw_kernel(u8, nco, fm, pl.pad != 0), dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
     return DD_OK;
 }
