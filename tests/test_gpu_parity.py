@@ -638,11 +638,12 @@ def test_fused_chain_vs_oracle_shapes(dd, M, K, chunk):
     fm_check(out.signal, ref, np.abs(yo[1:] * np.conj(yo[:-1])))
 
 
-@pytest.mark.parametrize("M,K", [(8, 2), (8, 255), (10, 15), (12, 256), (34, 151), (50, 127), (62, 150), (64, 64), (64, 256)])
+@pytest.mark.parametrize("M,K", [(8, 2), (8, 255), (10, 15), (12, 256), (16, 33), (32, 151), (34, 151), (40, 127), (50, 127), (62, 150), (64, 64), (64, 256)])
 @pytest.mark.parametrize("fm_on", [True, False])
 @pytest.mark.parametrize("u8", [False, True])
 def test_decimw_kernel_shapes_cuts_and_u8(dd, M, K, fm_on, u8):
-    """k_chain_decim_w (round 5: even M in 8..64, up to 256 taps): one wave per block of 2048 samples of the ABSOLUTE sample grid.  Ragged
+    """k_chain_decim_w (round 5: even M in 8..64, up to 256 taps): one wave per block of 2048 samples of the ABSOLUTE sample grid; M = 0 mod 8
+    through the padded LDS image (gaps of two samples, zero taps over them).  Ragged
     chunk cuts (1 sample, shorter than the taps, odd lengths, blocks that straddle chunks, chunks without a kept sample) through the
     chunk-by-chunk C-ABI route against the float64 oracle; the same stream in ONE call equals the chunked outputs bit for bit (a sample
     after the NCO is a pure function of its absolute index); raw u8 input gives the bits of the same samples as complex64."""
