@@ -18,8 +18,8 @@
 // from chunk to chunk, IS one long chunk -- dd_chain_process_chunks makes ONE launch of this kernel, no hand-over inside it, and the outputs
 // equal the chunk loop's bit for bit; raw u8 input gives the bits of the same samples as complex64.
 //
-// A lane runs the K taps over its output's window (LDS reads 16 bytes wide, conflict free for M = 2 mod 4; the taps are wave uniform and come
-// through the scalar cache; one packed multiply-add handles re and im).  Rows that reach outside the chunk (stream start: the carried history;
+// A lane runs the K taps over its output's window (LDS reads 16 bytes wide, conflict free for M = 2 mod 4, two-way for M = 4 mod 8; M = 0 mod 8
+// through a padded image, DWMap; the taps are wave uniform and come through the scalar cache in pairs; one packed multiply-add handles re and im).  Rows that reach outside the chunk (stream start: the carried history;
 // chunk end) take guarded sample-by-sample loads with the same phasors; rows come in runs dealt to the waves in turn (one moving window over
 // the stream), a run starts from the last K + M samples of the row before it (halo, and the FIR output the discriminator needs).
 #include "dd_chain_kernels.h"
@@ -254,7 +254,7 @@ __device__ __forceinline__ void dw_taps_coef(dw_const_f2p G, int j, v2f (&c)[DW_
     for (int u = 0; u < DW_TRIP / 2; ++u) c[u] = G[j / 2 + u];
 }
 // acc += (c.x, c.x) * x resp. (c.y, c.y) * x, the tap pair c in a scalar register pair (left to the compiler the odd tap of a pair is first
-// copied into a pair of its own: -DDW_MAC_BUILTIN)
+// copied into a pair of its own)
 __device__ __forceinline__ void dw_mac_lo(v2f& acc, v2f c, v2f x) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(c), "v"(x));
 }
@@ -273,17 +273,10 @@ __device__ __forceinline__ v2f dw_taps(const DDDecimWArgs& A, const float2* buf,
     auto mac = [&](const v4f (&x)[DW_TRIP / 2], const v2f (&c)[DW_TRIP / 2]) {
 #pragma unroll
         for (int u = 0; u < DW_TRIP / 2; u += 2) {
-#ifdef DW_MAC_BUILTIN
-            a0 = __builtin_elementwise_fma((v2f){c[u].x, c[u].x}, (v2f){x[u].x, x[u].y}, a0);
-            a1 = __builtin_elementwise_fma((v2f){c[u].y, c[u].y}, (v2f){x[u].z, x[u].w}, a1);
-            a2 = __builtin_elementwise_fma((v2f){c[u + 1].x, c[u + 1].x}, (v2f){x[u + 1].x, x[u + 1].y}, a2);
-            a3 = __builtin_elementwise_fma((v2f){c[u + 1].y, c[u + 1].y}, (v2f){x[u + 1].z, x[u + 1].w}, a3);
-#else
             dw_mac_lo(a0, c[u], (v2f){x[u].x, x[u].y});
             dw_mac_hi(a1, c[u], (v2f){x[u].z, x[u].w});
             dw_mac_lo(PAD ? a0 : a2, c[u + 1], (v2f){x[u + 1].x, x[u + 1].y});
             dw_mac_hi(PAD ? a1 : a3, c[u + 1], (v2f){x[u + 1].z, x[u + 1].w});
-#endif
         }
     };
     // (two trips per turn: the two register sets alternate, nothing is copied)
