@@ -156,7 +156,7 @@ def test_cos1k_plan_lays_the_row_grid_by_the_outputs_alignment(L, s, align, ncu)
 def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, ncu):
     """dd_debug_decimw_plan (round 5): k_chain_decim_w's rows are the blocks of 2048 samples of the ABSOLUTE sample index; a chunk's rows run
     from the block of its first kept sample to the block of its last one; the window of every output starts on an even LDS sample (16-byte
-    reads), one sample early behind a zero tap where the stream's phase makes it odd; and the chunks of a chunk loop (comm.py:123-125: the
+    reads), one sample early behind a zero tap where the stream's phase makes it odd; decimations that are multiples of 8 get the padded image; and the chunks of a chunk loop (comm.py:123-125: the
     decimation phase follows on) see the same grid as the concatenation -- which is why a chunk list is one launch."""
     lib = _hip.lib()
     out = (C.c_int64 * 8)()
@@ -172,8 +172,13 @@ def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, n
     assert 2048 * R0 <= first < 2048 * (R0 + 1) and 2048 * (R0 + rows - 1) <= last < 2048 * (R0 + rows)
     assert HP % 2 == 0 and K - 1 <= HP <= K
     assert e in (0, 1) and (HP - K + 1 + phi - e) % 2 == 0           # (the offset of a kept sample in its block has phi's parity: 2048 and M are even)
-    assert K16 % 16 == 0 and K + e <= K16 < K + e + 16
-    assert 1 <= wpc <= 8 and wpc * 8 * (HP + 2048 + 16 + 32) <= 160 * 1024
+    # M = 0 mod 8: the padded LDS image -- two samples of gap after every M of a window, zero taps over them
+    pad = M % 8 == 0
+    taps = K + e + (2 * ((K + e - 1) // M) if pad else 0)
+    assert K16 % 16 == 0 and taps <= K16 < taps + 16
+    span = HP + 2048
+    img = ((span + 2 * (span // M + 4) + 2 * 16 + 8) & ~1) if pad else span + 16
+    assert 1 <= wpc <= 8 and wpc * 8 * (img + 32) <= 160 * 1024 and (wpc == 8 or (wpc + 1) * 8 * (img + 32) > 160 * 1024)
     assert 1 <= run_rows <= 8 or rows < run_rows * ncu * wpc
     # the next chunk of the loop: same phase, rows that follow on
     noff = (M - (L - off) % M) % M
