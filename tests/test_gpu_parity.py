@@ -692,6 +692,64 @@ def test_decimw_kernel_shapes_cuts_and_u8(dd, M, K, fm_on, u8):
         assert np.array_equal(run(np.array([0, L])).view(np.uint32), one.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_decimw_kernel_fuzz(dd, seed):
+    """seeded random shapes of k_chain_decim_w: even decimation 8..64 (plain and padded LDS images), 2..256 taps, NCO on / off (a chain without
+    NCO counts every chunk from zero: the decimation phase, and with it the window alignment, then changes from chunk to chunk), FM or complex64
+    output, complex64 or raw u8 input, random ragged cuts, a stream that does not start at sample 0 of the NCO's count (dd_chain_seek): the
+    chunked run equals the one-call run bit for bit, and both agree with the float64 oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(7000 + seed)
+    hip = dd.hip
+    lib = hip.lib()
+    fs = 2048000
+    M = int(rng.choice(np.arange(8, 66, 2)))
+    K = int(rng.integers(2, 257))
+    nco, fm_on, u8 = bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    L = int(rng.integers(20000, 120000))
+    ncut = int(rng.integers(2, 9))
+    cuts = np.unique(np.concatenate([[0, L], rng.integers(1, L, size=ncut)]))
+    start = int(rng.choice([0, 0, 1, 2047, 2048, 123457, 5 * 10 ** 9 + 1]))
+    f_off = float(rng.choice([30000.0, -25000.0, 250000.0]))
+    raw = O.synth_iq_fm(L, fs, 400 + seed, f_carrier=f_off if nco else 2000.0, f_mod=900.0, dev=3.0)
+    x = O.grid_c64(raw)
+    taps = np.ascontiguousarray(O.firwin_lowpass(K, 0.45 / M) if K > 2 else np.array([0.5, 0.5]))
+    flags = (hip.DD_CHAIN_NCO if nco else 0) | (hip.DD_CHAIN_FM if fm_on else 0) | (hip.DD_CHAIN_U8_INPUT if u8 else 0)
+    src = hip.DevArray.from_host(raw.reshape(-1)) if u8 else hip.DevArray.from_host(x, dtype=np.complex64)
+    isz = 2 if u8 else 8
+    odt = np.float32 if fm_on else np.complex64
+    case = dict(seed=seed, M=M, K=K, nco=nco, fm=fm_on, u8=u8, L=L, cuts=cuts.tolist(), start=start)
+
+    def run(bounds):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), K, hip.cycles_q64(f_off, fs), M, flags))
+        if start:
+            hip.check(lib.dd_chain_seek(h, start, None))
+        outs = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            no = lib.dd_chain_out_count(h, int(b - a))
+            o = hip.DevArray(max(1, no), odt)
+            got = C.c_int64(0)
+            hip.check(lib.dd_chain_process(h, src.ptr + isz * int(a), o.ptr, int(b - a), C.byref(got), None))
+            assert got.value == no, case
+            if no:
+                assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_WAVE, case
+            outs.append(o.to_host()[:no])
+        lib.dd_chain_destroy(h)
+        return np.concatenate(outs)
+    got, one = run(cuts), run(np.array([0, L]))
+    assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), case
+    xin = O.nco(x, f_off, fs, start) if nco else x
+    hist = None if start == 0 else np.zeros(K - 1, dtype=np.complex128)       # dd_chain_seek: ones at the stream start (Q1), zeros elsewhere
+    y = O.FilterState(taps).applyOn(xin) if hist is None else O.lfilter_fir(taps, np.concatenate([hist, xin]), None)[K - 1:]
+    y = y[(M - start % M) % M::M]                             # kept global indices are the multiples of M (comm.py:123-127, Q4)
+    if fm_on:
+        ref, _ = O.fm_demod(y, None)
+        fm_check(got, ref, np.abs(y[1:] * np.conj(y[:-1])))
+    else:
+        assert rel_err(got, y) < FIR_TOL, case
+
+
 def test_fir_complex_output_decimated_vs_oracle(dd):
     L = 50000
     x = O.grid_c64(O.synth_iq_noise(L, 77))
