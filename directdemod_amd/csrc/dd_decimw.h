@@ -4,9 +4,11 @@
 
 struct DDChainParams;
 // kept with a filter: the taps as a PAD launch meets them (zeros over the gaps of the padded LDS image), for one (M, tap shift) at a time
+#define DD_DECIMW_TAPS_CAP 416
 struct DDDecimWTaps {
     float* dev;
     int key;
+    float host[DD_DECIMW_TAPS_CAP];      // the copy's source: lives as long as the filter (the copy is asynchronous)
 };
 // even M in [8, 64], 2 <= K <= 256, complex64 (8-byte aligned) or raw u8 (2-byte aligned) input, FM or complex64 output
 int dd_decimw_supported(int K, int M, int flags, const void* in);

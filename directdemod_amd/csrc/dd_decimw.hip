@@ -26,7 +26,6 @@
 #include "dd_decimw.h"
 #include "dd_atan.h"
 #include <stdlib.h>
-#include <vector>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -601,7 +600,7 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     pl.pad = (M % 8) == 0 ? 1 : 0;
     pl.K16 = dw_padded_taps_len(K, M, pl.e, pl.pad);
     const int span = pl.HP + DW_W;
-    pl.img = pl.pad ? (span + 2 * (span / M + 4) + 2 * DW_TRIP + 8) & ~1 : span + DW_PAD;
+    pl.img = pl.pad ? (span + 2 * (span / M + 4) + 2 * DW_TRIP + 40) & ~1 : span + DW_PAD;
     pl.lds = sizeof(float2) * (size_t)(pl.img + DW_NG);
     int wpc = (int)((160 * 1024) / pl.lds);
     pl.wpc = wpc > 4 * DW_WAVES_PER_SIMD ? 4 * DW_WAVES_PER_SIMD : (wpc < 1 ? 1 : wpc);
@@ -655,15 +654,19 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     if (pl.pad) {
         // the padded taps of (M, e): a small device buffer kept with the filter, rewritten in stream order when the key changes
         const int key = (P.M << 1) | pl.e;
-        const int cap = 256 + 1 + 2 * 32 + 2 * DW_TRIP;
+        const int cap = DD_DECIMW_TAPS_CAP;
+        static_assert(256 + 1 + 2 * 32 + 2 * DW_TRIP <= DD_DECIMW_TAPS_CAP, "padded taps");
         if (!cache->dev) DD_HIP_CHECK(hipMalloc((void**)&cache->dev, sizeof(float) * cap));
         if (cache->key != key) {
-            std::vector<float> t(cap, 0.f);
+            // (an earlier copy out of this array -- another key -- may still be queued on another stream: one caller thread and one stream per
+            //  filter is the contract; on the same stream the runtime has staged pageable memory by the time the call returns)
+            float* const t = cache->host;
+            for (int j = 0; j < cap; ++j) t[j] = 0.f;
             for (int j = 0; j < P.K; ++j) {                    // g[j] = h[K-1-j] at logical window sample j + e
                 const int w = j + pl.e;
                 t[w + 2 * (w / P.M)] = (float)taps_host[P.K - 1 - j];
             }
-            DD_HIP_CHECK(hipMemcpyAsync(cache->dev, t.data(), sizeof(float) * cap, hipMemcpyHostToDevice, stream));   // (pageable: staged before the call returns)
+            DD_HIP_CHECK(hipMemcpyAsync(cache->dev, t, sizeof(float) * cap, hipMemcpyHostToDevice, stream));
             cache->key = key;
         }
         taps = cache->dev;

@@ -177,7 +177,7 @@ def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, n
     taps = K + e + (2 * ((K + e - 1) // M) if pad else 0)
     assert K16 % 16 == 0 and taps <= K16 < taps + 16
     span = HP + 2048
-    img = ((span + 2 * (span // M + 4) + 2 * 16 + 8) & ~1) if pad else span + 16
+    img = ((span + 2 * (span // M + 4) + 2 * 16 + 40) & ~1) if pad else span + 16
     assert 1 <= wpc <= 8 and wpc * 8 * (img + 32) <= 160 * 1024 and (wpc == 8 or (wpc + 1) * 8 * (img + 32) > 160 * 1024)
     assert 1 <= run_rows <= 8 or rows < run_rows * ncu * wpc
     # the next chunk of the loop: same phase, rows that follow on
