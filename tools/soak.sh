@@ -71,11 +71,11 @@ for i in range(5000):
         assert ref is None or s == ref, (i, s, ref)
         ref = s
 torch.cuda.synchronize()
-print("decim persistent 5000 launches ok, checksum stable, %.1f s" % (time.time() - t0))
+print("decimating chain (BH151 /34: k_chain_decim_w) 5000 launches ok, checksum stable, %.1f s" % (time.time() - t0))
 PY
 timeout 300 python - <<'PY'
-# the chunk-list launch (k_chain_decim_multi): carried state handed from chunk to chunk through device memory and flags inside ONE
-# launch -- 4000 launches of the C3 shape (16 chunks) and of a ragged list, output bit-identical every time and equal to the loop's
+# the chunk-list launch (k_chain_decim_w: the list as one chunk on the absolute sample grid; DD_MFMA_KERNEL=decimp: k_chain_decim_multi, carried state
+# handed from chunk to chunk through device memory and flags inside ONE launch) -- 4000 launches of the C3 shape (16 chunks) and of a ragged list, output bit-identical every time and equal to the loop's
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
@@ -110,7 +110,7 @@ for name, bounds in (("16 x 2^22", [i << 22 for i in range(17)]), ("ragged", [0,
         _hip.check(lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), cb, nch, cn, stream), "chunks")
         if i % 500 == 0:
             torch.cuda.synchronize()
-            assert lib.dd_chain_last_kernel(h) == _hip.DD_KERNEL_DECIM_MULTI and sum(cn) == pos
+            assert lib.dd_chain_last_kernel(h) in (_hip.DD_KERNEL_DECIM_WAVE, _hip.DD_KERNEL_DECIM_MULTI) and sum(cn) == pos
             assert torch.equal(out.view(torch.int32), loop.view(torch.int32)), (name, i)
     torch.cuda.synchronize()
     lib.dd_chain_destroy(h)
