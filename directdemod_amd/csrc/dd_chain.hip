@@ -552,7 +552,7 @@ __device__ __forceinline__ void dd_decim_tile(const DDChainParams& P, int b, con
     if (t < T) {
         const float2* __restrict__ win = sx + t * M;
         int j = 0;
-#ifdef DD_DECIM_STAPS
+#ifndef DD_DECIM_LDS_TAPS                                  // (-DDD_DECIM_LDS_TAPS: the taps from LDS, one multiply-add per component, as in rounds 1-4)
         if ((M & 1) == 0) {
             // the taps are wave uniform: they come through the scalar cache (a third of the tap loop's LDS reads were theirs), and a
             // multiply-add handles re and im at once; two partial sums
