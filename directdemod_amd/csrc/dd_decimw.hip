@@ -44,6 +44,9 @@ typedef uint32_t v4u_a2 __attribute__((ext_vector_type(4), aligned(2)));     // 
 #define DW_TRIP 16            // taps per trip of the tap loop
 #endif
 #define DW_PAD DW_TRIP       // zeros behind the block: the tap loop runs in whole trips
+#ifndef DW_MAX_M
+#define DW_MAX_M 64
+#endif
 #define DW_NG (DW_W / 64)    // group phasors e^{-j w 64 g}
 
 struct DDDecimWArgs {
@@ -566,7 +569,7 @@ extern "C" int dd_debug_decimw_trace(unsigned long long* out, int nwaves) {
 
 // ============================================================================ host side
 int dd_decimw_supported(int K, int M, int flags, const void* in) {
-    if (M < 8 || M > 64 || (M & 1) || K < 2 || K > 256) return 0;
+    if (M < 8 || M > DW_MAX_M || (M & 1) || K < 2 || K > 256) return 0;
     const uintptr_t a = reinterpret_cast<uintptr_t>(in);
     return (a & ((flags & DD_CHAIN_U8_INPUT) ? 1 : 7)) == 0 ? 1 : 0;
 }
