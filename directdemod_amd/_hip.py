@@ -56,6 +56,8 @@ SIGNATURES = {
     "dd_version": (C.c_char_p, []),
     "dd_device_count": (_int, [C.POINTER(_int)]),
     "dd_set_device": (_int, [_int]),
+    "dd_get_device": (_int, [C.POINTER(_int)]),
+    "dd_copy_warmup": (_int, []),
     "dd_device_name": (_int, [C.c_char_p, _int]),
     "dd_malloc": (_int, [_pp, _sz]),
     "dd_free": (_int, [_p]),
@@ -241,6 +243,24 @@ def require_gpu():
 _warm = None
 
 
+def current_device():
+    """The calling thread's HIP device ordinal (dd_get_device)."""
+    d = _int(0)
+    check(lib().dd_get_device(C.byref(d)), "dd_get_device")
+    return d.value
+
+
+def on_callers_device(fn):
+    """`fn` wrapped for a helper thread: the thread first takes the device that is current on the thread that calls THIS function (HIP's
+    current device is per host thread and starts at 0 -- a helper of rank k of a multi-GPU job would otherwise work on GPU 0)."""
+    dev = current_device()
+
+    def run(*a, **kw):
+        check(lib().dd_set_device(dev), "dd_set_device")
+        return fn(*a, **kw)
+    return run
+
+
 def _start_copy_warmup():
     """The first host-to-device copy of a process costs ~90 ms inside the HIP runtime whatever its size (tools/debug/first_copy.py: a 4 KB
     copy 88-93 ms, the 40 MB after it 8 ms).  A 4 KB copy on a thread of its own, started when the GPU is first touched, takes that out
@@ -249,14 +269,14 @@ def _start_copy_warmup():
     if _warm is not None or os.environ.get("DD_NO_COPY_WARMUP"):
         return
 
+    dev = current_device()
+
     def run():
+        # (HIP keeps the current device per host thread, default 0: take the caller's -- under bench.py --gpus N every rank's main
+        #  thread has chosen its own GPU -- and make a plain synchronous copy: no stream of the library is touched, no seam word looked at)
         try:
-            d = _p()
-            if lib().dd_malloc(C.byref(d), 4096) == DD_OK:
-                h = (C.c_char * 4096)()
-                lib().dd_memcpy_h2d(d, h, 4096, None)
-                lib().dd_stream_sync(None)
-                lib().dd_free(d)
+            if lib().dd_set_device(dev) == DD_OK:
+                lib().dd_copy_warmup()
         except Exception:
             pass
     # (not a daemon: an interpreter that exits right away waits the few milliseconds this takes instead of tearing the HIP runtime

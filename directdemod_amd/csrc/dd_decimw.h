@@ -4,7 +4,7 @@
 
 struct DDChainParams;
 // kept with a filter: the taps as a PAD launch meets them (zeros over the gaps of the padded LDS image), for one (M, tap shift) at a time
-#define DD_DECIMW_TAPS_CAP 416
+#define DD_DECIMW_TAPS_CAP 640
 struct DDDecimWTaps {
     float* dev;
     int key;

@@ -70,6 +70,9 @@ struct DDDecimWArgs {
     uint32_t minv;             // PAD: 2^32 / M + 1
     int img;                   // samples of the LDS image (halo, block, gaps, zeros behind)
     int s;                     // 1: stream start, no angle for output 0
+    // block-sum form (k_chain_decim_b): taps = the MFMA operand table, e = the block starts one sample early (on an even LDS sample)
+    int NI;                    // partial sums per output, ceil(K / M) <= 8
+    int nh, h1lo;              // steps of eight samples per block; first step with a non-zero tap among partial sums 4 .. 7
 };
 
 // a * w as one packed multiply and one packed multiply-add with the operand selects and sign modifiers spelt out (left to the compiler the
@@ -323,7 +326,8 @@ __device__ __forceinline__ v2f dw_lane(v2f v, int l) {                  // (l: w
 #ifdef DW_TRACE
 // tools/debug/decimw_trace.py: cycles per phase of an interior row (every stamp drains the wave's counters), summed per wave
 #define DW_NPH 6
-__device__ unsigned long long g_dw_trace[4096 * (DW_NPH + 2)];
+#define DW_NTR (DW_NPH + 6)     // + rows, whole kernel, kernel start -> first run, run start -> row before staged, the row before's outputs, runs
+__device__ unsigned long long g_dw_trace[4096 * DW_NTR];
 #define DW_T(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DW_T(i) do { } while (0)
@@ -410,6 +414,27 @@ __device__ __forceinline__ void dw_row_outputs(const DDDecimWArgs& A, float2* bu
     DW_T(4);
 }
 
+// the new carried history (the chunk's last K-1 samples after the NCO, older ones from the old history): the value a row gives a sample,
+// recomputed -- its row, its group of 64 and its place in the group follow from its absolute index
+template <bool U8, bool NCO>
+__device__ __forceinline__ void dw_new_tail(const DDDecimWArgs& A, int lane) {
+    for (int i = lane; i < A.K - 1; i += 64) {
+        const int64_t n = A.L - (A.K - 1) + i;
+        v2f p = (v2f){1.f, 0.f};
+        if (NCO && n >= 0) {
+            const int64_t na = A.abs0 + n;
+            int64_t R = na / DW_W;
+            if (na - R * DW_W < 0) --R;
+            const int r = (int)(na - R * DW_W);
+            const v2f prow = dw_phasor_v((uint64_t)(R * DW_W) * A.cyc, A.nco_tbl);
+            const v2f pw = dw_cmul(prow, dw_phasor_v((uint64_t)(r & 63) * A.cyc, A.nco_tbl));
+            p = dw_cmul(pw, dw_phasor_v((uint64_t)(64 * (r >> 6)) * A.cyc, A.nco_tbl));
+        }
+        const v2f v = dw_sample<U8, NCO>(A, n, p);
+        A.tail_out[i] = make_float2(v.x, v.y);
+    }
+}
+
 template <bool U8, bool NCO, bool FM, bool PAD>
 __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const DDDecimWArgs A) {
     extern __shared__ __attribute__((aligned(16))) char dw_smem[];
@@ -435,25 +460,7 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
             gl[lane] = make_float2(g.x, g.y);
         }
     }
-    // the new carried history (the chunk's last K-1 samples after the NCO, older ones from the old history): the value a row gives a sample,
-    // recomputed -- its row, its group of 64 and its place in the group follow from its absolute index
-    if (gw == 0 && A.tail_out) {
-        for (int i = lane; i < A.K - 1; i += 64) {
-            const int64_t n = A.L - (A.K - 1) + i;
-            v2f p = (v2f){1.f, 0.f};
-            if (NCO && n >= 0) {
-                const int64_t na = A.abs0 + n;
-                int64_t R = na / DW_W;
-                if (na - R * DW_W < 0) --R;
-                const int r = (int)(na - R * DW_W);
-                const v2f prow = dw_phasor_v((uint64_t)(R * DW_W) * A.cyc, A.nco_tbl);
-                const v2f pw = dw_cmul(prow, dw_phasor_v((uint64_t)(r & 63) * A.cyc, A.nco_tbl));
-                p = dw_cmul(pw, dw_phasor_v((uint64_t)(64 * (r >> 6)) * A.cyc, A.nco_tbl));
-            }
-            const v2f v = dw_sample<U8, NCO>(A, n, p);
-            A.tail_out[i] = make_float2(v.x, v.y);
-        }
-    }
+    if (gw == 0 && A.tail_out) dw_new_tail<U8, NCO>(A, lane);
     // the FIR output before the chunk (demod_fm.py:47-49), fetched once: a load inside a row would wait for the row's prefetch
     v2f ylast_in = (v2f){0.f, 0.f};
     if (FM && A.s == 0) ylast_in = dw_v2(*A.lasty_in);
@@ -552,9 +559,9 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
 #ifdef DW_TRACE
     if (gw < 4096 && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < DW_NPH; ++i) g_dw_trace[gw * (DW_NPH + 2) + i] = tr[i];
-        g_dw_trace[gw * (DW_NPH + 2) + DW_NPH] = trows;
-        g_dw_trace[gw * (DW_NPH + 2) + DW_NPH + 1] = (unsigned)__builtin_readcyclecounter() - tstart;
+        for (int i = 0; i < DW_NPH; ++i) g_dw_trace[gw * DW_NTR + i] = tr[i];
+        g_dw_trace[gw * DW_NTR + DW_NPH] = trows;
+        g_dw_trace[gw * DW_NTR + DW_NPH + 1] = (unsigned)__builtin_readcyclecounter() - tstart;
     }
 #endif
 }
@@ -562,10 +569,426 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_w(const D
 #ifdef DW_TRACE
 extern "C" int dd_debug_decimw_trace(unsigned long long* out, int nwaves) {
     DD_HIP_CHECK(hipDeviceSynchronize());
-    DD_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * (size_t)nwaves * (DW_NPH + 2)));
+    DD_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * (size_t)nwaves * DW_NTR));
     return DD_OK;
 }
 #endif
+
+// ============================================================================ block-sum form (round 6)
+// k_chain_decim_w's tap loop reads every staged sample K / M times (2.5-4.4 for the reference's /34 and /50): 80 sixteen-byte LDS reads and one
+// scalar tap load per sixteen taps, each trip waiting for both -- a wave alone on its SIMD spends 2400 cycles per row in it where its 160 packed
+// multiply-adds need 640 (profiles/r05_decim_taps_ubench.txt).  Here every staged sample is read ONCE: the M samples that end at a kept sample
+// form the BLOCK of its lane, and the FIR output is a sum of block sums,
+//
+//     y[g] = sum_i P_i[g - i],   P_i[b] = sum_j h[M i + (M - 1 - j)] x_b[j]        (i < NI = ceil(K / M), h = 0 beyond K - 1)
+//
+// -- output g takes its newest M taps from its own block, the next M from the block before it, and so on.  A lane forms the NI sums of ITS block
+// (the same samples against NI different tap sets) and the sums travel up the lanes: H = P_{NI-1}; H = P_s + (H of the lane below), s = NI-2 .. 0
+// (DPP wave_shr:1; lane 0 takes the values the last lane of the row before left behind, kept in scalar registers; a run of rows starts by
+// forming them from the last outputs of the row before it).  The block sums are v_mfma_f32_4x4x1_16b_f32: sixteen 4 x 4 outer products
+// D_t[m][n] += A_t[m] B_t[n] per instruction, B = the lanes' samples (lane 4 t + n: its own block's sample j, re or im), A broadcast from ONE of
+// the sixteen A blocks (cbsz = 4, abid = j mod 16: lane 4 (j mod 16) + m of tap register j / 16 holds h[M m + (M - 1 - j)]) -- so register m of
+// a lane accumulates P_m of its block, four partial sums per instruction, one exact fmaf per element (tools/ubench/mfma4x4_layout.hip: layout,
+// broadcast and rounding checked against fmaf bit for bit), and the taps of a whole block sit in at most ten registers for the whole launch:
+// no tap traffic at all, LDS reads a fifth of the window form's, and the matrix pipe -- idle in every other phase -- does the multiply-adds
+// beside the other wave's vector work.  Partial sums 4 .. 7 (K > 4 M) take a second accumulator set, over the samples whose taps there are
+// not zero.  The order of the additions of an output depends on (K, M) only -- blocks are counted from the output, not from the row -- so
+// chunked and one-call runs and raw u8 / complex64 input agree bit for bit as before.  Where the block would start on an odd LDS sample
+// (phi even) it starts one sample early: the reads then cover [kept - M, kept - 1] (the first one under a zero tap) and one more read fetches
+// the kept sample.  LDS image: [M samples of halo | 2048 | zeros]; M = 0 mod 4: two samples of gap after every block (lane stride M + 2
+// samples: conflict-free 16-byte reads), the gaps are never read.
+struct DWCarry {
+    v2f h[7];                  // H_{s+1} of the output before the pass's first one, s = 0 .. 6
+};
+
+template <int NG>
+struct DWAcc {
+    v4f r[NG], i[NG];          // [group][m]: P_{4 group + m}, re / im
+};
+
+// the block sums of the lane's block (blk: its first sample, even), eight samples (four 16-byte reads) per step, straight-line code for up to
+// nine steps: the reads of the step after next are requested before a step's products (the LDS answers after ~300 cycles when eight waves
+// stage and read at once; a step's 16-32 products cover 130-270).  The reads are inline asm with the waits placed by hand: as plain loads the
+// compiler sinks each one behind the wave-uniform exit in front of its first use -- read, wait, use, nine times the LDS latency per row.  A
+// wait for "at most n reads outstanding" with n = the reads requested AFTER the ones needed is safe whatever else the compiler has in
+// flight on the same counter (LDS answers in order: while a needed read is out, so are the n behind it).  No read is left in flight when
+// the function returns (its register would be free for reuse), none runs past the block.
+template <bool PAD>
+struct DWOct {
+    v4f x[4];
+};
+template <int OFF>
+__device__ __forceinline__ v4f dw_lds_read16(uint32_t addr) {
+    v4f r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <bool PAD, int H>
+__device__ __forceinline__ void dw_bo_load(uint32_t addr, int M, DWOct<PAD>& d) {
+    if constexpr (PAD) {
+        // (the kept sample of a block that starts one sample early, j = M, sits behind the gap: sixteen bytes further on)
+        d.x[0] = dw_lds_read16<64 * H>(addr + (8 * H >= M ? 16u : 0u));
+        d.x[1] = dw_lds_read16<64 * H + 16>(addr + (8 * H + 2 >= M ? 16u : 0u));
+        d.x[2] = dw_lds_read16<64 * H + 32>(addr + (8 * H + 4 >= M ? 16u : 0u));
+        d.x[3] = dw_lds_read16<64 * H + 48>(addr + (8 * H + 6 >= M ? 16u : 0u));
+    } else {
+        d.x[0] = dw_lds_read16<64 * H>(addr);
+        d.x[1] = dw_lds_read16<64 * H + 16>(addr);
+        d.x[2] = dw_lds_read16<64 * H + 32>(addr);
+        d.x[3] = dw_lds_read16<64 * H + 48>(addr);
+    }
+}
+template <int N, bool PAD>
+__device__ __forceinline__ void dw_bo_wait(DWOct<PAD>& d) {           // the step's samples have arrived once at most N younger reads are out
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d.x[0]), "+v"(d.x[1]), "+v"(d.x[2]), "+v"(d.x[3]) : "n"(N));
+}
+// two samples (one 16-byte read) into accumulator set S: block samples j0, j0 + 1 = A blocks J0, J0 + 1 of the tap register
+template <int NG, int S, int J0>
+__device__ __forceinline__ void dw_bo_mac2(DWAcc<NG>& a, float t, v4f x) {
+    a.r[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.x, a.r[S], 4, J0, 0);
+    a.i[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.y, a.i[S], 4, J0, 0);
+    a.r[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.z, a.r[S], 4, J0 + 1, 0);
+    a.i[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.w, a.i[S], 4, J0 + 1, 0);
+}
+template <int NG, int H, bool PAD>
+__device__ __forceinline__ void dw_bo_mac(DWAcc<NG>& a, const DWOct<PAD>& d, float ta, float tb, bool g1) {
+    constexpr int J = (8 * H) & 15;
+    dw_bo_mac2<NG, 0, J>(a, ta, d.x[0]);
+    dw_bo_mac2<NG, 0, J + 2>(a, ta, d.x[1]);
+    dw_bo_mac2<NG, 0, J + 4>(a, ta, d.x[2]);
+    dw_bo_mac2<NG, 0, J + 6>(a, ta, d.x[3]);
+    if constexpr (NG == 2) {
+        if (g1) {
+            dw_bo_mac2<NG, 1, J>(a, tb, d.x[0]);
+            dw_bo_mac2<NG, 1, J + 2>(a, tb, d.x[1]);
+            dw_bo_mac2<NG, 1, J + 4>(a, tb, d.x[2]);
+            dw_bo_mac2<NG, 1, J + 6>(a, tb, d.x[3]);
+        }
+    }
+}
+template <bool PAD, int NG>
+__device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __restrict__ blk, const float (&ta)[5], const float (&tb)[5], DWAcc<NG>& acc) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc.r[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+        acc.i[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    // (through an empty asm: left visible as launch constants the comparisons are hoisted out of the row loop into scalar registers that spill)
+    int nh = A.nh, h1lo = A.h1lo, M = A.M;
+    asm volatile("" : "+s"(nh), "+s"(h1lo), "+s"(M));
+    const uint32_t addr = (uint32_t)(uintptr_t)blk;            // (LDS: the low 32 bits of the generic address are the byte offset)
+    // every step requests a later one without asking whether the block has it (reads past the block's end -- two steps at most -- stay inside
+    // the image and are never used): one wait per step, the same on every path.  Two accumulator sets: a step's 32 products cover the LDS
+    // latency, the next step's reads are enough (32 registers); one set: the step after next (48)
+    if constexpr (NG == 2) {
+        DWOct<PAD> b0, b1;
+        dw_bo_load<PAD, 0>(addr, M, b0);
+#define DW_BSTEP(H, CUR, NXT)                                                        \
+        dw_bo_load<PAD, (H) + 1>(addr, M, NXT);                                      \
+        dw_bo_wait<4, PAD>(CUR);                                                     \
+        dw_bo_mac<NG, H, PAD>(acc, CUR, ta[(H) >> 1], tb[(H) >> 1], (H) >= h1lo);    \
+        if ((H) + 1 >= nh) break;
+        do {
+            DW_BSTEP(0, b0, b1)
+            DW_BSTEP(1, b1, b0)
+            DW_BSTEP(2, b0, b1)
+            DW_BSTEP(3, b1, b0)
+            DW_BSTEP(4, b0, b1)
+            DW_BSTEP(5, b1, b0)
+            DW_BSTEP(6, b0, b1)
+            DW_BSTEP(7, b1, b0)
+            DW_BSTEP(8, b0, b1)
+        } while (0);
+#undef DW_BSTEP
+        // the request past the last step lands in registers nobody reads: held until it has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(b0.x[0]), "v"(b0.x[1]), "v"(b0.x[2]), "v"(b0.x[3]), "v"(b1.x[0]), "v"(b1.x[1]), "v"(b1.x[2]), "v"(b1.x[3]));
+    } else {
+        DWOct<PAD> b0, b1, b2;
+        dw_bo_load<PAD, 0>(addr, M, b0);
+        dw_bo_load<PAD, 1>(addr, M, b1);
+#define DW_BSTEP(H, CUR, NXT)                                                        \
+        dw_bo_load<PAD, (H) + 2>(addr, M, NXT);                                      \
+        dw_bo_wait<8, PAD>(CUR);                                                     \
+        dw_bo_mac<NG, H, PAD>(acc, CUR, ta[(H) >> 1], tb[(H) >> 1], (H) >= h1lo);    \
+        if ((H) + 1 >= nh) break;
+        do {
+            DW_BSTEP(0, b0, b2)
+            DW_BSTEP(1, b1, b0)
+            DW_BSTEP(2, b2, b1)
+            DW_BSTEP(3, b0, b2)
+            DW_BSTEP(4, b1, b0)
+            DW_BSTEP(5, b2, b1)
+            DW_BSTEP(6, b0, b2)
+            DW_BSTEP(7, b1, b0)
+            DW_BSTEP(8, b2, b1)
+        } while (0);
+#undef DW_BSTEP
+        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(b0.x[0]), "v"(b0.x[1]), "v"(b0.x[2]), "v"(b0.x[3]), "v"(b1.x[0]), "v"(b1.x[1]), "v"(b1.x[2]), "v"(b1.x[3]),
+                     "v"(b2.x[0]), "v"(b2.x[1]), "v"(b2.x[2]), "v"(b2.x[3]));
+    }
+}
+
+// the LDS layout of a PAD row of the block-sum form: gaps counted from its first block's start
+__device__ __forceinline__ int dw_b_first(const DDDecimWArgs& A, const DWRow& r) { return A.HP + r.r0 - A.M + 1 - A.e; }
+__device__ __forceinline__ DWMap dw_b_row_map(const DDDecimWArgs& A, const DWRow& r) {
+    const int bs0 = dw_b_first(A, r);
+    const int k = (int)__umulhi((uint32_t)bs0, A.minv);
+    return DWMap{bs0 - k * A.M - A.M, A.minv};
+}
+
+// a staged row of the block-sum form: block sums, the sums travel up the lanes, the outputs leave, the halo moves down.  cy: the partial
+// sums the row before left for this row's first outputs (in), this row's for the next (out); ycarry as in dw_row_outputs.  emit false: the
+// row before a run -- one pass over its LAST 64 outputs, for cy, ycarry and the halo.
+template <bool FM, bool PAD, int NG>
+__device__ __forceinline__ void dw_b_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, const DWMap& mp, bool emit, v2f& ycarry,
+                                                 DWCarry& cy, v2f ylast_in, const float (&ta)[5], const float (&tb)[5]
+#ifdef DW_TRACE
+                                                 , unsigned* tr = nullptr, unsigned tprev = 0
+#endif
+                                                 ) {
+#ifdef DW_TRACE
+    unsigned trd[DW_NPH];
+    if (!tr) tr = trd;
+#endif
+    v4f hl[2];
+    DWMap mpn = mp;
+    if (PAD) {
+        DWRow rn = r;
+        dw_row_next(A, rn);
+        mpn = dw_b_row_map(A, rn);
+    }
+    const int bs0 = dw_b_first(A, r);
+    const int bsp = PAD ? bs0 + 2 * ((int)__umulhi((uint32_t)bs0, A.minv) + 1) : bs0;
+    const int bstep = PAD ? A.M + 2 : A.M;
+    const int ng = emit ? (r.cnt + 63) >> 6 : 1;
+    for (int t = 0; t < ng; ++t) {
+        const int i = emit ? 64 * t + lane : r.cnt - 64 + lane;
+        const int ic = i < 0 ? 0 : (i < r.cnt ? i : r.cnt - 1);
+        DWAcc<NG> acc;
+        dw_bsums<PAD, NG>(A, buf + bsp + ic * bstep, ta, tb, acc);
+        if (t == ng - 1) dw_halo_read<PAD>(A, buf, lane, hl, mp);
+        const int last = (emit && t == ng - 1) ? (r.cnt - 1) & 63 : 63;
+        // y = P_0 + (P_1[lane - 1] + (P_2[lane - 2] + ...)): the sums move up one lane per step
+        v2f y = (v2f){0.f, 0.f};
+        int NI = A.NI;
+        asm volatile("" : "+s"(NI));
+#pragma unroll
+        for (int s = 4 * NG - 1; s >= 0; --s) {
+            if (s < NI) {
+                const v2f P = (v2f){acc.r[s >> 2][s & 3], acc.i[s >> 2][s & 3]};
+                if (s + 1 < NI) {
+                    const v2f cin = cy.h[s];
+                    cy.h[s] = dw_lane(y, last);
+                    y = (v2f){P.x + dw_shr1(y.x, cin.x), P.y + dw_shr1(y.y, cin.y)};
+                } else {
+                    y = P;
+                }
+            }
+        }
+        DW_T(2);
+        const int64_t p = r.p0 + i;
+        if (FM) {
+            v2f yp = (v2f){dw_shr1(y.x, ycarry.x), dw_shr1(y.y, ycarry.y)};
+            ycarry = dw_lane(y, last);
+            if (emit && i < r.cnt && p >= 0 && p < A.Ld) {
+                if (p == 0 && A.s == 0) yp = ylast_in;
+                if (p >= A.s) {
+                    const float re = fmaf(y.x, yp.x, y.y * yp.y), im = fmaf(y.y, yp.x, -y.x * yp.y);
+                    reinterpret_cast<float*>(A.out)[p - A.s] = dd_atan2_poly(im, re);
+                }
+                if (p == A.Ld - 1 && A.lasty_out) *A.lasty_out = make_float2(y.x, y.y);
+            }
+        } else {
+            if (emit && i < r.cnt && p >= 0 && p < A.Ld) {
+                reinterpret_cast<float2*>(A.out)[p] = make_float2(y.x, y.y);
+                if (p == A.Ld - 1 && A.lasty_out) *A.lasty_out = make_float2(y.x, y.y);
+            }
+        }
+        DW_T(3);
+    }
+    dw_halo_write<PAD>(A, buf, lane, hl, mpn);
+    DW_T(4);
+}
+
+template <bool U8, bool NCO, bool FM, bool PAD, int NG>
+__global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const DDDecimWArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+    float2* const buf = reinterpret_cast<float2*>(dw_smem);
+    float2* const gl = buf + A.img;
+    const int lane = threadIdx.x;
+    const int gw = blockIdx.x;
+    const int M = A.M;
+#ifdef DW_TRACE
+    const unsigned tstart = (unsigned)__builtin_readcyclecounter();
+#endif
+    const int RR = A.run_rows;
+    const int nruns = (A.nrows + RR - 1) / RR;
+    v4f_a8 x[DW_NL];
+    v4u_a2 x8[DW_NL8];
+    auto brel = [&](int q) { return (A.R0 + q) * (int64_t)DW_W - A.abs0; };
+    auto inside = [&](int q) { const int64_t b = brel(q); return b >= 0 && b + DW_W <= A.L; };
+    auto row_phasor = [&](int q) { return NCO ? dw_phasor_u((uint64_t)((A.R0 + q) * (int64_t)DW_W) * A.cyc, A.nco_tbl) : (v2f){1.f, 0.f}; };
+    // rows [q0, f0) and [f1, q1) of a run reach outside the chunk, [f0, f1) lie inside it; pin: so does the row before the run
+    struct Run { int q0, q1, f0, f1; bool pin; };
+    auto run_of = [&](int run) {
+        Run u;
+        u.q0 = run * RR;
+        u.q1 = u.q0 + RR < A.nrows ? u.q0 + RR : A.nrows;
+        u.f0 = u.q0;
+        while (u.f0 < u.q1 && !inside(u.f0)) ++u.f0;
+        u.f1 = u.f0;
+        while (u.f1 < u.q1 && inside(u.f1)) ++u.f1;
+        u.pin = inside(u.q0 - 1);
+        return u;
+    };
+    v4f_a8 xp[4];
+    v4u_a2 xp8[1];
+    // what a run starts from: the end of the row before it (the last four loads of that row, u8: the last one) and its first row
+    auto issue_start = [&](const Run& u) {
+        if (u.pin) {
+            if constexpr (U8) dw_issue8<DW_NL8 - 1, 1>(A, brel(u.q0 - 1), lane, xp8); else dw_issue<DW_NL - 4, 4>(A, brel(u.q0 - 1), lane, xp);
+        }
+        if (u.f1 > u.f0) {
+            if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(u.f0), lane, x8); else dw_issue<0, DW_NL>(A, brel(u.f0), lane, x);
+        }
+    };
+    if (gw < nruns) issue_start(run_of(gw));                   // (first thing: the tables below are built while these fly)
+    // (nothing outside the staged samples is ever read with a non-zero tap, and the gaps of a PAD image not at all; the zeros behind the block
+    //  are what a block that starts one sample early reads behind the row's last kept sample)
+    if (lane < 2 * DW_PAD) buf[A.img - 2 * DW_PAD + lane] = make_float2(0.f, 0.f);
+    // the taps of a block as the matrix instruction takes them (host: dd_decimw_launch): register g, lane 4 t + m = the tap of block sample
+    // 16 g + t in partial sum m (ta) resp. 4 + m (tb) -- the instruction broadcasts the A block t = j mod 16 it is told to; for the whole launch
+    float ta[5], tb[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        ta[g] = A.taps[64 * g + lane];
+        tb[g] = NG == 2 ? A.taps[320 + 64 * g + lane] : 0.f;
+    }
+    DWPh ph;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ph.w[k] = (v2f){1.f, 0.f};
+    if (NCO) {
+#pragma unroll
+        for (int k = 0; k < (U8 ? 8 : 2); ++k) ph.w[k] = dw_phasor_v((uint64_t)(((U8 ? 8 * lane : 2 * lane) & 63) + k) * A.cyc, A.nco_tbl);
+        if (lane < DW_NG) {
+            const v2f g = dw_phasor_v((uint64_t)(64 * lane) * A.cyc, A.nco_tbl);
+            gl[lane] = make_float2(g.x, g.y);
+        }
+    }
+    if (gw == 0 && A.tail_out) dw_new_tail<U8, NCO>(A, lane);
+    v2f ylast_in = (v2f){0.f, 0.f};
+    if (FM && A.s == 0) ylast_in = dw_v2(*A.lasty_in);
+    // the part of the row before a run that the run needs: the blocks of its last NI outputs (NI M < K + M samples back from the last kept one)
+    const int rmin = DW_W - M - A.NI * M - 2;
+    const int jlo = (rmin > 0 ? rmin : 0) >> (U8 ? 9 : 7);
+#ifdef DW_TRACE
+    unsigned tr[DW_NPH];
+#pragma unroll
+    for (int i = 0; i < DW_NPH; ++i) tr[i] = 0;
+    unsigned trows = 0;
+#endif
+#ifdef DW_TRACE
+    unsigned tx[4] = {0, 0, 0, 0};
+    tx[0] = (unsigned)__builtin_readcyclecounter() - tstart;
+#endif
+    for (int run = gw; run < nruns; run += A.nwaves) {
+#ifdef DW_TRACE
+        const unsigned trun = (unsigned)__builtin_readcyclecounter();
+#endif
+        const Run cur = run_of(run);
+        const int q0 = cur.q0, q1 = cur.q1, f0 = cur.f0, f1 = cur.f1;
+        const bool pin = cur.pin;
+#ifdef DW_XRUN
+        // (tried: the next run's first samples requested while this run works on its last row -- 5-10 % SLOWER, two far-apart address
+        //  streams per wave; profiles/r06_decimb_notes.txt)
+        const bool more = run + A.nwaves < nruns;
+#else
+        const bool more = false;
+        if (run != gw) issue_start(cur);
+#endif
+        const Run nxt = run_of(more ? run + A.nwaves : run);
+        DWRow r;
+        DWMap mp = DWMap{0, A.minv};
+        {
+            const int64_t B = (A.R0 + q0 - 1) * (int64_t)DW_W;
+            int64_t m = ((int64_t)A.phi - B) % M;
+            if (m < 0) m += M;
+            r.r0 = (int)m;
+            r.cnt = (DW_W - 1 - r.r0) / M + 1;
+            r.p0 = (B + r.r0 - A.abs0 - A.off) / M;
+            if (PAD) mp = dw_b_row_map(A, r);
+            DWPh pw;
+            dw_row_ph<U8, NCO>(row_phasor(q0 - 1), ph, pw);
+            if (pin) {
+                if constexpr (U8) dw_stage8<NCO, PAD, DW_NL8 - 1, 1>(A, buf, gl, lane, pw, xp8, mp);
+                else dw_stage<NCO, PAD, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp, mp);
+            } else {
+                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
+                else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
+            }
+        }
+        v2f ycarry = (v2f){0.f, 0.f};
+        DWCarry cy;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) cy.h[s] = (v2f){0.f, 0.f};
+#ifdef DW_TRACE
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // (lgkmcnt(0) only: the staged samples are in LDS; the loads stay in flight)
+        const unsigned tpre = (unsigned)__builtin_readcyclecounter();
+        tx[1] += tpre - trun;
+#endif
+        dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, false, ycarry, cy, ylast_in, ta, tb);
+#ifdef DW_TRACE
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        tx[2] += (unsigned)__builtin_readcyclecounter() - tpre;
+        ++tx[3];
+#endif
+        for (int q = q0; q < q1; ++q) {
+#ifdef DW_TRACE
+            unsigned tprev = (unsigned)__builtin_readcyclecounter();
+#endif
+            const bool fast = q >= f0 && q < f1;
+            dw_row_next(A, r);
+            if (PAD) mp = dw_b_row_map(A, r);
+            DWPh pw;
+            dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
+            DW_T(5);
+            if (fast) {
+                if constexpr (U8) dw_stage8<NCO, PAD, 0, DW_NL8>(A, buf, gl, lane, pw, x8, mp);
+                else dw_stage<NCO, PAD, 0, DW_NL>(A, buf, gl, lane, pw, x, mp);
+                DW_T(0);
+                if (q + 1 < f1) {
+                    // the next row's samples fly during this row's block sums
+                    if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
+                } else if (q + 1 == q1 && more) {
+                    issue_start(nxt);                                 // ... or this wave's next run's
+                }
+            } else {
+                // (a row at the chunk's edge: the sample registers are free by now -- the rows inside the chunk lie behind or ahead)
+                if (q + 1 == q1 && more) issue_start(nxt);
+                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
+                else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
+            }
+#ifdef DW_TRACE
+            if (fast) {
+                { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+                ++trows;
+                dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb, tr, tprev);
+            } else
+#endif
+            dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb);
+        }
+    }
+#ifdef DW_TRACE
+    if (gw < 4096 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < DW_NPH; ++i) g_dw_trace[gw * DW_NTR + i] = tr[i];
+        g_dw_trace[gw * DW_NTR + DW_NPH] = trows;
+        g_dw_trace[gw * DW_NTR + DW_NPH + 1] = (unsigned)__builtin_readcyclecounter() - tstart;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_dw_trace[gw * DW_NTR + DW_NPH + 2 + i] = tx[i];
+    }
+#endif
+}
 
 // ============================================================================ host side
 int dd_decimw_supported(int K, int M, int flags, const void* in) {
@@ -577,6 +1000,7 @@ int dd_decimw_supported(int K, int M, int flags, const void* in) {
 struct DWPlan {
     int64_t R0;
     int nrows, phi, HP, e, K16, wpc, run_rows, nwaves, nruns, pad, img;
+    int bsum, NI, j1lo, nh;    // block-sum form (k_chain_decim_b): partial sums per output, first block sample of the second accumulator set, steps of eight samples per block
     size_t lds;
 };
 static int64_t dw_floordiv(int64_t a, int64_t b) { int64_t q = a / b; if (a - q * b < 0) --q; return q; }
@@ -594,6 +1018,27 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     pl.R0 = dw_floordiv(first, DW_W);
     const int64_t Rl = Ld > 0 ? dw_floordiv(first + (Ld - 1) * M, DW_W) : pl.R0 - 1;
     pl.nrows = (int)(Rl - pl.R0 + 1);
+    // block sums (k_chain_decim_b) where an output needs at most eight of them: K <= 8 M -- every K for M >= 32, the reference's /34 and /50
+    pl.NI = (K + M - 1) / M;
+#ifdef DW_NO_BSUM
+    pl.bsum = 0;
+#else
+    pl.bsum = pl.NI <= 8 ? 1 : 0;
+#endif
+    pl.j1lo = 0;
+    pl.nh = 0;
+    if (pl.bsum) {
+        pl.HP = M;                                             // a block reaches at most M samples back from its row's first sample
+        // a block starts at LDS sample HP + (offset of its kept sample) - M + 1: on an odd one when phi is even -- one sample earlier then
+        pl.e = (int)((phi + 1) & 1);
+        // lane stride M samples: conflict-free 16-byte reads for odd M / 2; else two samples of gap between the blocks (never read)
+        pl.pad = (M % 4) == 0 ? 1 : 0;
+        pl.K16 = 0;
+        pl.j1lo = 5 * M + pl.e - K > 0 ? 5 * M + pl.e - K : 0;
+        pl.nh = (M + pl.e + 7) >> 3;                           // block samples [0, M - 1 + e] in steps of eight
+        const int span = pl.HP + DW_W;
+        pl.img = pl.pad ? (span + 2 * (span / M + 4) + 2 * DW_PAD) & ~1 : span + 2 * DW_PAD;      // (a block's reads run up to two steps past it)
+    } else {
     pl.HP = K & ~1;                                            // K - 1 rounded up to even
     // a window starts at LDS sample HP - K + 1 + (offset of its kept sample in the block): the parity of that offset is phi's (W and M are
     // even), so the parity of the start is the launch's -- one sample earlier, behind a zero tap, where it is odd
@@ -604,6 +1049,7 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     pl.K16 = dw_padded_taps_len(K, M, pl.e, pl.pad);
     const int span = pl.HP + DW_W;
     pl.img = pl.pad ? (span + 2 * (span / M + 4) + 2 * DW_TRIP + 40) & ~1 : span + DW_PAD;
+    }
     pl.lds = sizeof(float2) * (size_t)(pl.img + DW_NG);
     int wpc = (int)((160 * 1024) / pl.lds);
     pl.wpc = wpc > 4 * DW_WAVES_PER_SIMD ? 4 * DW_WAVES_PER_SIMD : (wpc < 1 ? 1 : wpc);
@@ -625,6 +1071,7 @@ extern "C" int dd_debug_decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int 
     DWPlan pl;
     decimw_plan(abs0, Ld, K, M, off, ncu, pl);
     out[0] = pl.R0; out[1] = pl.nrows; out[2] = pl.phi; out[3] = pl.HP; out[4] = pl.e; out[5] = pl.K16; out[6] = pl.wpc; out[7] = pl.run_rows;
+    out[8] = pl.bsum; out[9] = pl.NI; out[10] = pl.j1lo; out[11] = pl.img;
     return DD_OK;
 }
 
@@ -641,6 +1088,20 @@ static const void* decimw_kernel(bool u8, bool nco, bool fm, bool pad) {
     return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (fm ? 4 : 0) | (pad ? 8 : 0)];
 }
 
+template <int NG>
+static const void* decimb_kernel(bool u8, bool nco, bool fm, bool pad) {
+    static const void* const k[16] = {
+        (const void*)k_chain_decim_b<false, false, false, false, NG>, (const void*)k_chain_decim_b<true, false, false, false, NG>,
+        (const void*)k_chain_decim_b<false, true, false, false, NG>,  (const void*)k_chain_decim_b<true, true, false, false, NG>,
+        (const void*)k_chain_decim_b<false, false, true, false, NG>,  (const void*)k_chain_decim_b<true, false, true, false, NG>,
+        (const void*)k_chain_decim_b<false, true, true, false, NG>,   (const void*)k_chain_decim_b<true, true, true, false, NG>,
+        (const void*)k_chain_decim_b<false, false, false, true, NG>,  (const void*)k_chain_decim_b<true, false, false, true, NG>,
+        (const void*)k_chain_decim_b<false, true, false, true, NG>,   (const void*)k_chain_decim_b<true, true, false, true, NG>,
+        (const void*)k_chain_decim_b<false, false, true, true, NG>,   (const void*)k_chain_decim_b<true, false, true, true, NG>,
+        (const void*)k_chain_decim_b<false, true, true, true, NG>,    (const void*)k_chain_decim_b<true, true, true, true, NG>};
+    return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (fm ? 4 : 0) | (pad ? 8 : 0)];
+}
+
 int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream) {
     if (P.Ld < 1 && !P.tail_out) return DD_OK;                 // (no kept sample: one wave, for the new history alone)
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0, nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
@@ -654,7 +1115,26 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
         pl.nwaves = pl.nruns < slots ? pl.nruns : slots;
     }
     const float* taps = taps_g0 - pl.e;
-    if (pl.pad) {
+    if (pl.bsum) {
+        // the taps as the matrix instruction takes them, for (M, e): [set][register g][lane 4 t + m] = h[M (4 set + m) + d], d = M - 1 + e - j the
+        // distance of block sample j = 16 g + t from the block's kept sample (0 outside the block and beyond h[K - 1]); kept with the filter
+        const int key = 0x10000 | (P.M << 1) | pl.e;
+        static_assert(640 <= DD_DECIMW_TAPS_CAP, "block-sum taps");
+        if (!cache->dev) DD_HIP_CHECK(hipMalloc((void**)&cache->dev, sizeof(float) * DD_DECIMW_TAPS_CAP));
+        if (cache->key != key) {
+            float* const t = cache->host;
+            for (int j = 0; j < DD_DECIMW_TAPS_CAP; ++j) t[j] = 0.f;
+            for (int j = 0; j < 80; ++j)
+                for (int i = 0; i < 8; ++i) {
+                    const int d = P.M - 1 + pl.e - j;
+                    if (d < 0 || d > P.M - 1 || P.M * i + d >= P.K) continue;
+                    t[320 * (i >> 2) + 64 * (j >> 4) + 4 * (j & 15) + (i & 3)] = (float)taps_host[P.M * i + d];
+                }
+            DD_HIP_CHECK(hipMemcpyAsync(cache->dev, t, sizeof(float) * DD_DECIMW_TAPS_CAP, hipMemcpyHostToDevice, stream));
+            cache->key = key;
+        }
+        taps = cache->dev;
+    } else if (pl.pad) {
         // the padded taps of (M, e): a small device buffer kept with the filter, rewritten in stream order when the key changes
         const int key = (P.M << 1) | pl.e;
         const int cap = DD_DECIMW_TAPS_CAP;
@@ -687,7 +1167,10 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     A.cq = (DW_W - 1) / P.M + 1; A.cr = (DW_W - 1) % P.M;
     A.minv = (uint32_t)(0x100000000ull / (uint64_t)P.M) + 1u;
     A.img = pl.img;
+    A.NI = pl.NI; A.nh = pl.nh; A.h1lo = pl.j1lo >> 3;
     void* kargs[1] = {&A};
-    DD_HIP_CHECK(hipLaunchKernel(decimw_kernel(u8, nco, fm, pl.pad != 0), dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
+    const void* kern = !pl.bsum ? decimw_kernel(u8, nco, fm, pl.pad != 0)
+                                : (pl.NI > 4 ? decimb_kernel<2>(u8, nco, fm, pl.pad != 0) : decimb_kernel<1>(u8, nco, fm, pl.pad != 0));
+    DD_HIP_CHECK(hipLaunchKernel(kern, dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
     return DD_OK;
 }

@@ -38,6 +38,12 @@ extern "C" int dd_set_device(int device) {
     return DD_OK;
 }
 
+extern "C" int dd_get_device(int* device) {
+    DD_REQUIRE(device, "device");
+    DD_HIP_CHECK(hipGetDevice(device));
+    return DD_OK;
+}
+
 extern "C" int dd_device_name(char* buf, int buflen) {
     DD_REQUIRE(buf && buflen > 0, "buf");
     int dev = 0;
@@ -203,6 +209,18 @@ extern "C" int dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void
 }
 extern "C" int dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dd_stream(stream)));
+    return DD_OK;
+}
+// the first host-to-device copy of a process costs ~90 ms inside the runtime whatever its size (tools/debug/first_copy.py): a 4 KB synchronous
+// copy on the CALLING thread's device, for a helper thread to make while the caller opens its recording.  Touches no stream of the
+// library and looks at no seam word (dd_stream_sync does).
+extern "C" int dd_copy_warmup(void) {
+    void* d = nullptr;
+    DD_HIP_CHECK(hipMalloc(&d, 4096));
+    static const char zeros[4096] = {0};
+    hipError_t e = hipMemcpy(d, zeros, sizeof(zeros), hipMemcpyHostToDevice);
+    (void)hipFree(d);
+    DD_HIP_CHECK(e);
     return DD_OK;
 }
 extern "C" int dd_stream_create(void** stream) {

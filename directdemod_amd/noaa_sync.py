@@ -60,7 +60,8 @@ class noaa_sync:
                 n_audio = -(-int(sigsrc.length) // dec) - 1               # kept samples of the whole stream, one angle fewer (demod_fm.py:43-49)
                 if n_audio > 1:
                     import threading
-                    self.__prep = threading.Thread(target=_ops.noaa_prepare, args=(n_audio,), daemon=False)   # (joined by getCrudeSync, or by the interpreter at exit)
+                    from . import _hip
+                    self.__prep = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(n_audio,), daemon=False)   # (joined by getCrudeSync, or by the interpreter at exit)
                     self.__prep.start()
         except Exception:
             self.__prep = None
@@ -273,6 +274,7 @@ class noaa_sync:
                 if not st:
                     return None
                 return DevArray.from_host(self._gather_windows(st, 2 * width), dtype=np.uint8, stream=up)
+            feed = _hip.on_callers_device(feed)            # (the worker thread: this thread's GPU, not HIP's per-thread default)
             parts = [(slot, st[i:i + 64], sync) for slot, st, sync in jobs for i in range(0, max(1, len(st)), 64)]
             res = {slot: ([], [], []) for slot, _, _ in jobs}
             with ThreadPoolExecutor(max_workers=1) as ex:

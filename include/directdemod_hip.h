@@ -57,6 +57,9 @@ const char* dd_last_error(void);
 const char* dd_version(void);
 int  dd_device_count(int* count);
 int  dd_set_device(int device);
+/* the calling thread's current device (HIP keeps one per host thread, default 0): a helper thread started on behalf of a caller
+ * takes the caller's device with dd_set_device(dd_get_device()) before it touches the GPU */
+int  dd_get_device(int* device);
 int  dd_device_name(char* buf, int buflen);
 int  dd_malloc(void** dptr, size_t bytes);
 int  dd_free(void* dptr);
@@ -95,16 +98,21 @@ int  dd_debug_fft1k_plan(int64_t L, int s, int out_align_elems, int ncu, int rou
 /* dd_debug_cos1k_plan -- the row grid of a k_chain_cos1k launch (same arguments): out[0..3] = base (first sample of row 0; row q covers
  *   samples [base + 1024 q, +1024)), rows, workgroups, waves (wave w takes rows [rows w / waves, rows (w + 1) / waves)). */
 int  dd_debug_cos1k_plan(int64_t L, int s, int out_align_elems, int ncu, int* out);
-/* dd_debug_decimw_plan -- the row grid of a k_chain_decim_w launch over a chunk that starts at absolute sample abs0 with decimation phase
- *   off and keeps Ld samples: out[0..7] = R0 (absolute index of the first row: row R is the block of 2048 samples [2048 R, 2048 (R + 1))),
- *   rows, phi = (abs0 + off) mod M, samples kept in LDS in front of a block, tap shift (0 / 1), taps per lane rounded up to 16, waves per CU,
- *   rows per run.  DD_ERR_UNSUPPORTED when the kernel does not take (K, M). */
+/* dd_debug_decimw_plan -- the row grid of a k_chain_decim_w / k_chain_decim_b launch over a chunk that starts at absolute sample abs0 with
+ *   decimation phase off and keeps Ld samples: out[0..11] = R0 (absolute index of the first row: row R is the block of 2048 samples
+ *   [2048 R, 2048 (R + 1))), rows, phi = (abs0 + off) mod M, samples kept in LDS in front of a block, start shift (0 / 1), taps per lane
+ *   rounded up to 16 (window form), waves per CU, rows per run, form (1: block sums, k_chain_decim_b, K <= 8 M; 0: one window per lane,
+ *   k_chain_decim_w), partial sums per output ceil(K / M), first block sample of the second accumulator set, samples of the LDS image.
+ *   DD_ERR_UNSUPPORTED when the kernels do not take (K, M). */
 int  dd_debug_decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu, int64_t* out);
 int  dd_debug_cos_fit(const double* taps_host, int K, double* a_out, int* Q_out);
 int  dd_debug_sync_envelope(const void* X_dev, int64_t L, int nwin, int route, double* env_dev, void* stream);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* one small synchronous host-to-device copy on the calling thread's device (the process's first copy pays ~90 ms of runtime set-up
+ * whatever its size): _hip.py makes it on a helper thread when the GPU is first touched.  No reference counterpart. */
+int  dd_copy_warmup(void);
 int  dd_stream_create(void** stream);
 int  dd_stream_destroy(void* stream);
 int  dd_stream_sync(void* stream);

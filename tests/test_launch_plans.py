@@ -159,10 +159,10 @@ def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, n
     reads), one sample early behind a zero tap where the stream's phase makes it odd; decimations that are multiples of 8 get the padded image; and the chunks of a chunk loop (comm.py:123-125: the
     decimation phase follows on) see the same grid as the concatenation -- which is why a chunk list is one launch."""
     lib = _hip.lib()
-    out = (C.c_int64 * 8)()
+    out = (C.c_int64 * 12)()
     Ld = len(range(off, L, M))
     _hip.check(lib.dd_debug_decimw_plan(abs0, Ld, K, M, off, ncu, out), "dd_debug_decimw_plan")
-    R0, rows, phi, HP, e, K16, wpc, run_rows = list(out)
+    R0, rows, phi, HP, e, K16, wpc, run_rows, bsum, NI, j1lo, img_got = list(out)
     first = abs0 + off
     assert phi == first % M
     if Ld == 0:
@@ -170,25 +170,37 @@ def test_decimw_plan_lays_rows_on_the_absolute_sample_grid(abs0, L, off, K, M, n
         return
     last = first + (Ld - 1) * M
     assert 2048 * R0 <= first < 2048 * (R0 + 1) and 2048 * (R0 + rows - 1) <= last < 2048 * (R0 + rows)
-    assert HP % 2 == 0 and K - 1 <= HP <= K
-    assert e in (0, 1) and (HP - K + 1 + phi - e) % 2 == 0           # (the offset of a kept sample in its block has phi's parity: 2048 and M are even)
-    # M = 0 mod 8: the padded LDS image -- two samples of gap after every M of a window, zero taps over them
-    pad = M % 8 == 0
-    taps = K + e + (2 * ((K + e - 1) // M) if pad else 0)
-    assert K16 % 16 == 0 and taps <= K16 < taps + 16
+    assert NI == -(-K // M) and bsum == (1 if NI <= 8 else 0)
     span = HP + 2048
-    img = ((span + 2 * (span // M + 4) + 2 * 16 + 40) & ~1) if pad else span + 16
+    if bsum:
+        # block sums (round 6, k_chain_decim_b): an output is the sum of NI <= 8 sums over blocks of M samples, a lane forms those of the
+        # block that ends at its kept sample.  M samples in front of a row; a block starts on an even LDS sample (16-byte reads), one sample
+        # early where the stream's phase makes it odd; M = 0 mod 4: two samples of gap between the blocks; partial sums 4 .. 7 have
+        # non-zero taps from block sample j1lo on
+        assert HP == M and e in (0, 1) and (HP + phi - M + 1 - e) % 2 == 0
+        pad = M % 4 == 0
+        img = ((span + 2 * (span // M + 4) + 32) & ~1) if pad else span + 32
+        assert j1lo == max(0, 5 * M + e - K)
+    else:
+        assert HP % 2 == 0 and K - 1 <= HP <= K
+        assert e in (0, 1) and (HP - K + 1 + phi - e) % 2 == 0           # (the offset of a kept sample in its block has phi's parity: 2048 and M are even)
+        # M = 0 mod 8: the padded LDS image -- two samples of gap after every M of a window, zero taps over them
+        pad = M % 8 == 0
+        taps = K + e + (2 * ((K + e - 1) // M) if pad else 0)
+        assert K16 % 16 == 0 and taps <= K16 < taps + 16
+        img = ((span + 2 * (span // M + 4) + 2 * 16 + 40) & ~1) if pad else span + 16
+    assert img == img_got
     assert 1 <= wpc <= 8 and wpc * 8 * (img + 32) <= 160 * 1024 and (wpc == 8 or (wpc + 1) * 8 * (img + 32) > 160 * 1024)
     assert 1 <= run_rows <= 8 or rows < run_rows * ncu * wpc
     # the next chunk of the loop: same phase, rows that follow on
     noff = (M - (L - off) % M) % M
-    out2 = (C.c_int64 * 8)()
+    out2 = (C.c_int64 * 12)()
     _hip.check(lib.dd_debug_decimw_plan(abs0 + L, len(range(noff, 1 << 20, M)), K, M, noff, ncu, out2), "dd_debug_decimw_plan")
     assert out2[2] == phi and out2[4] == e and out2[0] in (R0 + rows - 1, R0 + rows) or out2[0] > R0 + rows
 
 
 def test_decimw_plan_refuses_what_the_kernel_does_not_take():
-    out = (C.c_int64 * 8)()
+    out = (C.c_int64 * 12)()
     for K, M in ((151, 33), (151, 6), (151, 66), (257, 34), (1, 34)):
         assert _hip.lib().dd_debug_decimw_plan(0, 1000, K, M, 0, 256, out) == _hip.DD_ERR_UNSUPPORTED
 

@@ -36,12 +36,13 @@ for _ in range(50):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 50
 NW, NPH = 2048, 6
-buf = (C.c_ulonglong * (NW * (NPH + 2)))()
+NTR = NPH + 6
+buf = (C.c_ulonglong * (NW * NTR))()
 f = C.CDLL(_hip.LIB_PATH).dd_debug_decimw_trace
 f.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 f.restype = C.c_int
 _hip.check(f(buf, NW), "trace")
-a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NPH + 2).astype(np.float64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NTR).astype(np.float64)
 rows = a[:, NPH].sum()
 names = ["wait for the loads, NCO, LDS writes", "issue the next row's loads", "tap loop", "discriminator, stores", "halo copy", "row geometry, row phasor"]
 print("M = %d  " % M + "%s %s: %.4f ms per launch (with stamps); cycles per interior row and wave, %d rows; whole kernel %.0f cycles per wave" %
@@ -50,3 +51,7 @@ tot = a[:, :NPH].sum() / rows
 for i, nm in enumerate(names):
     v = a[:, i].sum() / rows
     print("  %-40s %9.1f  %5.1f %%" % (nm, v, 100 * v / tot))
+if a[:, NPH + 5].sum() > 0:
+    runs = a[:, NPH + 5].mean()
+    print("  per wave: %.1f rows in %.1f runs; kernel start -> first run %.0f cycles; per run: start -> the row before it staged %.0f, its block sums %.0f; rows %.0f of %.0f cycles" %
+          (rows / NW, runs, a[:, NPH + 2].mean(), a[:, NPH + 3].sum() / a[:, NPH + 5].sum(), a[:, NPH + 4].sum() / a[:, NPH + 5].sum(), tot * rows / NW, a[:, NPH + 1].mean()))
