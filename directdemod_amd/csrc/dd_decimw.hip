@@ -73,6 +73,9 @@ struct DDDecimWArgs {
     // block-sum form (k_chain_decim_b): taps = the MFMA operand table, e = the block starts one sample early (on an even LDS sample)
     int NI;                    // partial sums per output, ceil(K / M) <= 8
     int nh, h1lo;              // steps of eight samples per block; first step with a non-zero tap among partial sums 4 .. 7
+    int F0, F1;                // rows [F0, F1) of the launch lie inside the chunk (whole 16-byte loads), the others reach past its ends
+    int c0, d0, wm;            // (phi - R0 W) mod M; R0 W - (abs0 + off); W mod M: a row's first kept sample and output index without 64-bit divisions
+    int small;                 // 1: fewer than 2^19 rows -- that arithmetic fits 32 bits
 };
 
 // a * w as one packed multiply and one packed multiply-add with the operand selects and sign modifiers spelt out (left to the compiler the
@@ -83,6 +86,27 @@ __device__ __forceinline__ v2f dw_cmul(v2f a, v2f w) {
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
+}
+// the two halves of dw_cmul, for code that runs several products side by side (a dependent packed operation issued right behind the one it
+// waits for costs a wait state: the staging loops run eight products in step)
+__device__ __forceinline__ v2f dw_cmul_a(v2f a, v2f w) {
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+}
+__device__ __forceinline__ v2f dw_cmul_b(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// n products a[i] * w[i] in step (same two roundings per product as dw_cmul)
+template <int N>
+__device__ __forceinline__ void dw_cmul_n(v2f (&a)[N], const v2f (&w)[N]) {
+    v2f t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = dw_cmul_a(a[i], w[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = dw_cmul_b(a[i], w[i], t[i]);
 }
 __device__ __forceinline__ v2f dw_v2(float2 a) { return (v2f){a.x, a.y}; }
 
@@ -161,26 +185,54 @@ __device__ __forceinline__ int dw_pos(const DWMap& mp, int r) {
 template <int J0, int NJ>
 __device__ __forceinline__ void dw_issue(const DDDecimWArgs& A, int64_t Brel, int lane, v4f_a8 (&x)[NJ]) {
     const v4f_a8* p = reinterpret_cast<const v4f_a8*>(reinterpret_cast<const float2*>(A.in) + Brel + 2 * lane);
+#ifdef DW_NO_LOADS      // (diagnostic: the kernel without its sample loads -- wrong outputs, the time of everything else)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x[j] = (v4f_a8){(float)lane, 1.f, 2.f, (float)(J0 + j)};
+#else
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(p + 64 * (J0 + j));
+#endif
 }
 template <bool NCO, bool PAD, int J0, int NJ>
 __device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4f_a8 (&x)[NJ], const DWMap& mp) {
+    // (the group phasors of all the row's loads first, in one batch: read one by one, each LDS read waits behind the 16-byte write in front
+    //  of it and the staging of a row is sixteen LDS round trips -- 3400 of a row's 8100 cycles, profiles/r06_decimb_notes.txt)
+    v2f g[NJ];
+    if (NCO) {
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int j = J0 + jj;
-        v2f x0 = (v2f){x[jj].x, x[jj].y}, x1 = (v2f){x[jj].z, x[jj].w};
-        if (NCO) {
-            const v2f g = dw_v2(gl[2 * j + (lane >> 5)]);
-            x0 = dw_cmul(x0, dw_cmul(pw.w[0], g));
-            x1 = dw_cmul(x1, dw_cmul(pw.w[1], g));
+        for (int jj = 0; jj < NJ; ++jj) g[jj] = dw_v2(gl[2 * (J0 + jj) + (lane >> 5)]);
+    }
+    // four loads = eight samples at a time: their phasors (pw.w x g) in step, then the rotations in step, then the four 16-byte writes
+    constexpr int NB = NJ < 4 ? NJ : 4;
+    static_assert(NJ % NB == 0, "loads per staging batch");
+#pragma unroll
+    for (int j0 = 0; j0 < NJ; j0 += NB) {
+        v2f v[2 * NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            v[2 * u] = (v2f){x[j0 + u].x, x[j0 + u].y};
+            v[2 * u + 1] = (v2f){x[j0 + u].z, x[j0 + u].w};
         }
-        const int r = A.HP + 128 * j + 2 * lane;
-        *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){x0.x, x0.y, x1.x, x1.y};
+        if (NCO) {
+            v2f p[2 * NB], gg[2 * NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                p[2 * u] = pw.w[0];
+                p[2 * u + 1] = pw.w[1];
+                gg[2 * u] = gg[2 * u + 1] = g[j0 + u];
+            }
+            dw_cmul_n<2 * NB>(p, gg);
+            dw_cmul_n<2 * NB>(v, p);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int r = A.HP + 128 * (J0 + j0 + u) + 2 * lane;
+            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){v[2 * u].x, v[2 * u].y, v[2 * u + 1].x, v[2 * u + 1].y};
+        }
     }
 }
 // the same through guarded sample-by-sample loads, loads jlo .. 15
-template <bool NCO, bool PAD>
+template <bool NCO, bool PAD, bool U8 = false>
 __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw, const DWMap& mp) {
     for (int j = jlo; j < DW_NL; ++j) {
         v2f pj = (v2f){1.f, 0.f}, pj1 = (v2f){1.f, 0.f};
@@ -190,8 +242,61 @@ __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* 
             pj1 = dw_cmul(pw.w[1], g);
         }
         const int64_t n = Brel + 128 * j + 2 * lane;
-        const v2f x0 = dw_sample<false, NCO>(A, n, pj), x1 = dw_sample<false, NCO>(A, n + 1, pj1);
+        const v2f x0 = dw_sample<U8, NCO>(A, n, pj), x1 = dw_sample<U8, NCO>(A, n + 1, pj1);
         *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, A.HP + 128 * j + 2 * lane)) = (v4f){x0.x, x0.y, x1.x, x1.y};
+    }
+}
+
+// ---- raw u8 rows of the block-sum kernel (source.py:117-118), four bytes per lane: load j, lane l = samples 128 j + 2 l, + 1 of the block -- the
+// complex64 rows' layout, so the 16-byte LDS writes of a load cover 1 KB in lane order.  (Sixteen bytes per lane, dw_issue8: lane l writes
+// its eight samples 64 bytes from lane l + 1's -- every write a four-way bank conflict, 60 % of the LDS cycles of the launch;
+// profiles/r06_decimb_notes.txt)
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+template <int J0, int NJ>
+__device__ __forceinline__ void dw_issue4(const DDDecimWArgs& A, int64_t Brel, int lane, uint32_t (&x)[NJ]) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(A.in) + 2 * (Brel + 2 * lane);
+#ifdef DW_NO_LOADS
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x[j] = (uint32_t)lane * 0x01010101u + (uint32_t)(J0 + j);
+#else
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const u32_a2*>(p + 256 * (J0 + j)));
+#endif
+}
+template <bool NCO, bool PAD, int J0, int NJ>
+__device__ __forceinline__ void dw_stage4(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const uint32_t (&x)[NJ], const DWMap& mp) {
+    v2f g[NJ];
+    if (NCO) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) g[jj] = dw_v2(gl[2 * (J0 + jj) + (lane >> 5)]);
+    }
+    constexpr int NB = NJ < 4 ? NJ : 4;
+    static_assert(NJ % NB == 0, "loads per staging batch");
+#pragma unroll
+    for (int j0 = 0; j0 < NJ; j0 += NB) {
+        v2f v[2 * NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const uint32_t d = x[j0 + u];
+            v[2 * u] = (v2f){(float)(d & 0xff) - 127.5f, (float)((d >> 8) & 0xff) - 127.5f};
+            v[2 * u + 1] = (v2f){(float)((d >> 16) & 0xff) - 127.5f, (float)(d >> 24) - 127.5f};
+        }
+        if (NCO) {
+            v2f p[2 * NB], gg[2 * NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                p[2 * u] = pw.w[0];
+                p[2 * u + 1] = pw.w[1];
+                gg[2 * u] = gg[2 * u + 1] = g[j0 + u];
+            }
+            dw_cmul_n<2 * NB>(p, gg);
+            dw_cmul_n<2 * NB>(v, p);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int r = A.HP + 128 * (J0 + j0 + u) + 2 * lane;
+            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){v[2 * u].x, v[2 * u].y, v[2 * u + 1].x, v[2 * u + 1].y};
+        }
     }
 }
 
@@ -199,27 +304,44 @@ __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* 
 template <int J0, int NJ>
 __device__ __forceinline__ void dw_issue8(const DDDecimWArgs& A, int64_t Brel, int lane, v4u_a2 (&x)[NJ]) {
     const unsigned char* p = reinterpret_cast<const unsigned char*>(A.in) + 2 * (Brel + 8 * lane);
+#ifdef DW_NO_LOADS
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x[j] = (v4u_a2){(uint32_t)lane * 0x01010101u, 0x80807f7fu, 0x7f808180u, (uint32_t)(J0 + j)};
+#else
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u_a2*>(p + 1024 * (J0 + j)));
+#endif
 }
 template <bool NCO, bool PAD, int J0, int NJ>
 __device__ __forceinline__ void dw_stage8(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, const DWPh& pw, const v4u_a2 (&x)[NJ], const DWMap& mp) {
+    v2f gs[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) gs[jj] = NCO ? dw_v2(gl[8 * (J0 + jj) + (lane >> 3)]) : (v2f){1.f, 0.f};
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int j = J0 + jj;
-        v2f g = (v2f){1.f, 0.f};
-        if (NCO) g = dw_v2(gl[8 * j + (lane >> 3)]);
+        const v2f g = gs[jj];
         const uint32_t d[4] = {x[jj].x, x[jj].y, x[jj].z, x[jj].w};
+        v2f v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v2f xa = (v2f){(float)(d[k] & 0xff) - 127.5f, (float)((d[k] >> 8) & 0xff) - 127.5f};
-            v2f xb = (v2f){(float)((d[k] >> 16) & 0xff) - 127.5f, (float)(d[k] >> 24) - 127.5f};
-            if (NCO) {
-                xa = dw_cmul(xa, dw_cmul(pw.w[2 * k], g));
-                xb = dw_cmul(xb, dw_cmul(pw.w[2 * k + 1], g));
+            v[2 * k] = (v2f){(float)(d[k] & 0xff) - 127.5f, (float)((d[k] >> 8) & 0xff) - 127.5f};
+            v[2 * k + 1] = (v2f){(float)((d[k] >> 16) & 0xff) - 127.5f, (float)(d[k] >> 24) - 127.5f};
+        }
+        if (NCO) {
+            v2f p[8], gg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                p[k] = pw.w[k];
+                gg[k] = g;
             }
+            dw_cmul_n<8>(p, gg);
+            dw_cmul_n<8>(v, p);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             const int r = A.HP + 512 * j + 8 * lane + 2 * k;
-            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){xa.x, xa.y, xb.x, xb.y};
+            *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, r)) = (v4f){v[2 * k].x, v[2 * k].y, v[2 * k + 1].x, v[2 * k + 1].y};
         }
     }
 }
@@ -325,7 +447,7 @@ __device__ __forceinline__ v2f dw_lane(v2f v, int l) {                  // (l: w
 
 #ifdef DW_TRACE
 // tools/debug/decimw_trace.py: cycles per phase of an interior row (every stamp drains the wave's counters), summed per wave
-#define DW_NPH 6
+#define DW_NPH 7
 #define DW_NTR (DW_NPH + 6)     // + rows, whole kernel, kernel start -> first run, run start -> row before staged, the row before's outputs, runs
 __device__ unsigned long long g_dw_trace[4096 * DW_NTR];
 #define DW_T(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -666,8 +788,22 @@ __device__ __forceinline__ void dw_bo_mac(DWAcc<NG>& a, const DWOct<PAD>& d, flo
         }
     }
 }
+// the first reads of a block's sums, requested ahead of time (k_chain_decim_b: before it issues the next row's global loads -- the reads
+// queue behind the row's sixteen LDS writes and need ~400 cycles, the address arithmetic of the loads hides them)
 template <bool PAD, int NG>
-__device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __restrict__ blk, const float (&ta)[5], const float (&tb)[5], DWAcc<NG>& acc) {
+struct DWPre {
+    DWOct<PAD> b0, b1;
+};
+template <bool PAD, int NG>
+__device__ __forceinline__ void dw_bsums_begin(const DDDecimWArgs& A, const float2* __restrict__ blk, DWPre<PAD, NG>& pre) {
+    int M = A.M;
+    asm volatile("" : "+s"(M));
+    const uint32_t addr = (uint32_t)(uintptr_t)blk;            // (LDS: the low 32 bits of the generic address are the byte offset)
+    dw_bo_load<PAD, 0>(addr, M, pre.b0);
+    if constexpr (NG == 1) dw_bo_load<PAD, 1>(addr, M, pre.b1);
+}
+template <bool PAD, int NG>
+__device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __restrict__ blk, DWPre<PAD, NG>& pre, const float (&ta)[5], const float (&tb)[5], DWAcc<NG>& acc) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         acc.r[g] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -676,13 +812,13 @@ __device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __
     // (through an empty asm: left visible as launch constants the comparisons are hoisted out of the row loop into scalar registers that spill)
     int nh = A.nh, h1lo = A.h1lo, M = A.M;
     asm volatile("" : "+s"(nh), "+s"(h1lo), "+s"(M));
-    const uint32_t addr = (uint32_t)(uintptr_t)blk;            // (LDS: the low 32 bits of the generic address are the byte offset)
+    const uint32_t addr = (uint32_t)(uintptr_t)blk;
     // every step requests a later one without asking whether the block has it (reads past the block's end -- two steps at most -- stay inside
     // the image and are never used): one wait per step, the same on every path.  Two accumulator sets: a step's 32 products cover the LDS
     // latency, the next step's reads are enough (32 registers); one set: the step after next (48)
     if constexpr (NG == 2) {
-        DWOct<PAD> b0, b1;
-        dw_bo_load<PAD, 0>(addr, M, b0);
+        DWOct<PAD>& b0 = pre.b0;
+        DWOct<PAD>& b1 = pre.b1;
 #define DW_BSTEP(H, CUR, NXT)                                                        \
         dw_bo_load<PAD, (H) + 1>(addr, M, NXT);                                      \
         dw_bo_wait<4, PAD>(CUR);                                                     \
@@ -703,9 +839,9 @@ __device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __
         // the request past the last step lands in registers nobody reads: held until it has landed
         asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(b0.x[0]), "v"(b0.x[1]), "v"(b0.x[2]), "v"(b0.x[3]), "v"(b1.x[0]), "v"(b1.x[1]), "v"(b1.x[2]), "v"(b1.x[3]));
     } else {
-        DWOct<PAD> b0, b1, b2;
-        dw_bo_load<PAD, 0>(addr, M, b0);
-        dw_bo_load<PAD, 1>(addr, M, b1);
+        DWOct<PAD>& b0 = pre.b0;
+        DWOct<PAD>& b1 = pre.b1;
+        DWOct<PAD> b2;
 #define DW_BSTEP(H, CUR, NXT)                                                        \
         dw_bo_load<PAD, (H) + 2>(addr, M, NXT);                                      \
         dw_bo_wait<8, PAD>(CUR);                                                     \
@@ -739,9 +875,20 @@ __device__ __forceinline__ DWMap dw_b_row_map(const DDDecimWArgs& A, const DWRow
 // a staged row of the block-sum form: block sums, the sums travel up the lanes, the outputs leave, the halo moves down.  cy: the partial
 // sums the row before left for this row's first outputs (in), this row's for the next (out); ycarry as in dw_row_outputs.  emit false: the
 // row before a run -- one pass over its LAST 64 outputs, for cy, ycarry and the halo.
+// the block of the lane's output in pass t of a row (emit false: the one pass over the row's last 64 outputs)
+template <bool PAD>
+__device__ __forceinline__ const float2* dw_b_block(const DDDecimWArgs& A, const float2* buf, int lane, const DWRow& r, bool emit, int t) {
+    const int bs0 = dw_b_first(A, r);
+    const int bsp = PAD ? bs0 + 2 * ((int)__umulhi((uint32_t)bs0, A.minv) + 1) : bs0;
+    const int bstep = PAD ? A.M + 2 : A.M;
+    const int i = emit ? 64 * t + lane : r.cnt - 64 + lane;
+    const int ic = i < 0 ? 0 : (i < r.cnt ? i : r.cnt - 1);
+    return buf + bsp + ic * bstep;
+}
+// pre0: the first pass's first reads have been requested (dw_bsums_begin on dw_b_block(.., 0))
 template <bool FM, bool PAD, int NG>
 __device__ __forceinline__ void dw_b_row_outputs(const DDDecimWArgs& A, float2* buf, int lane, const DWRow& r, const DWMap& mp, bool emit, v2f& ycarry,
-                                                 DWCarry& cy, v2f ylast_in, const float (&ta)[5], const float (&tb)[5]
+                                                 DWCarry& cy, v2f ylast_in, const float (&ta)[5], const float (&tb)[5], DWPre<PAD, NG>& pre0
 #ifdef DW_TRACE
                                                  , unsigned* tr = nullptr, unsigned tprev = 0
 #endif
@@ -757,15 +904,14 @@ __device__ __forceinline__ void dw_b_row_outputs(const DDDecimWArgs& A, float2* 
         dw_row_next(A, rn);
         mpn = dw_b_row_map(A, rn);
     }
-    const int bs0 = dw_b_first(A, r);
-    const int bsp = PAD ? bs0 + 2 * ((int)__umulhi((uint32_t)bs0, A.minv) + 1) : bs0;
-    const int bstep = PAD ? A.M + 2 : A.M;
     const int ng = emit ? (r.cnt + 63) >> 6 : 1;
     for (int t = 0; t < ng; ++t) {
         const int i = emit ? 64 * t + lane : r.cnt - 64 + lane;
-        const int ic = i < 0 ? 0 : (i < r.cnt ? i : r.cnt - 1);
+        const float2* const blk = dw_b_block<PAD>(A, buf, lane, r, emit, t);
         DWAcc<NG> acc;
-        dw_bsums<PAD, NG>(A, buf + bsp + ic * bstep, ta, tb, acc);
+        if (t > 0) dw_bsums_begin<PAD, NG>(A, blk, pre0);
+        dw_bsums<PAD, NG>(A, blk, pre0, ta, tb, acc);
+        DW_T(6);
         if (t == ng - 1) dw_halo_read<PAD>(A, buf, lane, hl, mp);
         const int last = (emit && t == ng - 1) ? (r.cnt - 1) & 63 : 63;
         // y = P_0 + (P_1[lane - 1] + (P_2[lane - 2] + ...)): the sums move up one lane per step
@@ -824,9 +970,9 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
     const int RR = A.run_rows;
     const int nruns = (A.nrows + RR - 1) / RR;
     v4f_a8 x[DW_NL];
-    v4u_a2 x8[DW_NL8];
+    uint32_t x8[DW_NL];
     auto brel = [&](int q) { return (A.R0 + q) * (int64_t)DW_W - A.abs0; };
-    auto inside = [&](int q) { const int64_t b = brel(q); return b >= 0 && b + DW_W <= A.L; };
+    auto inside = [&](int q) { return q >= A.F0 && q < A.F1; };
     auto row_phasor = [&](int q) { return NCO ? dw_phasor_u((uint64_t)((A.R0 + q) * (int64_t)DW_W) * A.cyc, A.nco_tbl) : (v2f){1.f, 0.f}; };
     // rows [q0, f0) and [f1, q1) of a run reach outside the chunk, [f0, f1) lie inside it; pin: so does the row before the run
     struct Run { int q0, q1, f0, f1; bool pin; };
@@ -834,22 +980,24 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
         Run u;
         u.q0 = run * RR;
         u.q1 = u.q0 + RR < A.nrows ? u.q0 + RR : A.nrows;
-        u.f0 = u.q0;
-        while (u.f0 < u.q1 && !inside(u.f0)) ++u.f0;
-        u.f1 = u.f0;
-        while (u.f1 < u.q1 && inside(u.f1)) ++u.f1;
+        u.f0 = u.q0 > A.F0 ? u.q0 : A.F0;
+        if (u.f0 > u.q1) u.f0 = u.q1;
+        u.f1 = u.q1 < A.F1 ? u.q1 : A.F1;
+        if (u.f1 < u.f0) u.f1 = u.f0;
         u.pin = inside(u.q0 - 1);
         return u;
     };
     v4f_a8 xp[4];
-    v4u_a2 xp8[1];
-    // what a run starts from: the end of the row before it (the last four loads of that row, u8: the last one) and its first row
+    uint32_t xp8[4];
+    // what a run starts from: the end of the row before it (the last four loads of that row, u8: the last one) and its first row inside the
+    // chunk.  (Tried: requested while the wave's run BEFORE works on its last row -- 5-10 % slower, two far-apart
+    // address streams per wave; profiles/r06_decimb_notes.txt)
     auto issue_start = [&](const Run& u) {
         if (u.pin) {
-            if constexpr (U8) dw_issue8<DW_NL8 - 1, 1>(A, brel(u.q0 - 1), lane, xp8); else dw_issue<DW_NL - 4, 4>(A, brel(u.q0 - 1), lane, xp);
+            if constexpr (U8) dw_issue4<DW_NL - 4, 4>(A, brel(u.q0 - 1), lane, xp8); else dw_issue<DW_NL - 4, 4>(A, brel(u.q0 - 1), lane, xp);
         }
         if (u.f1 > u.f0) {
-            if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(u.f0), lane, x8); else dw_issue<0, DW_NL>(A, brel(u.f0), lane, x);
+            if constexpr (U8) dw_issue4<0, DW_NL>(A, brel(u.f0), lane, x8); else dw_issue<0, DW_NL>(A, brel(u.f0), lane, x);
         }
     };
     if (gw < nruns) issue_start(run_of(gw));                   // (first thing: the tables below are built while these fly)
@@ -869,7 +1017,7 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
     for (int k = 0; k < 8; ++k) ph.w[k] = (v2f){1.f, 0.f};
     if (NCO) {
 #pragma unroll
-        for (int k = 0; k < (U8 ? 8 : 2); ++k) ph.w[k] = dw_phasor_v((uint64_t)(((U8 ? 8 * lane : 2 * lane) & 63) + k) * A.cyc, A.nco_tbl);
+        for (int k = 0; k < 2; ++k) ph.w[k] = dw_phasor_v((uint64_t)(((2 * lane) & 63) + k) * A.cyc, A.nco_tbl);
         if (lane < DW_NG) {
             const v2f g = dw_phasor_v((uint64_t)(64 * lane) * A.cyc, A.nco_tbl);
             gl[lane] = make_float2(g.x, g.y);
@@ -880,7 +1028,7 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
     if (FM && A.s == 0) ylast_in = dw_v2(*A.lasty_in);
     // the part of the row before a run that the run needs: the blocks of its last NI outputs (NI M < K + M samples back from the last kept one)
     const int rmin = DW_W - M - A.NI * M - 2;
-    const int jlo = (rmin > 0 ? rmin : 0) >> (U8 ? 9 : 7);
+    const int jlo = (rmin > 0 ? rmin : 0) >> 7;
 #ifdef DW_TRACE
     unsigned tr[DW_NPH];
 #pragma unroll
@@ -898,32 +1046,36 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
         const Run cur = run_of(run);
         const int q0 = cur.q0, q1 = cur.q1, f0 = cur.f0, f1 = cur.f1;
         const bool pin = cur.pin;
-#ifdef DW_XRUN
-        // (tried: the next run's first samples requested while this run works on its last row -- 5-10 % SLOWER, two far-apart address
-        //  streams per wave; profiles/r06_decimb_notes.txt)
-        const bool more = run + A.nwaves < nruns;
-#else
-        const bool more = false;
         if (run != gw) issue_start(cur);
-#endif
-        const Run nxt = run_of(more ? run + A.nwaves : run);
         DWRow r;
         DWMap mp = DWMap{0, A.minv};
         {
-            const int64_t B = (A.R0 + q0 - 1) * (int64_t)DW_W;
-            int64_t m = ((int64_t)A.phi - B) % M;
-            if (m < 0) m += M;
-            r.r0 = (int)m;
-            r.cnt = (DW_W - 1 - r.r0) / M + 1;
-            r.p0 = (B + r.r0 - A.abs0 - A.off) / M;
+            // the row before the run, q = q0 - 1 >= -1: offset of its first kept sample, outputs before it (a 64-bit remainder and quotient
+            // cost ~1000 cycles at every run start; with the launch's row 0 as the origin 32 bits do for 2^19 rows)
+            if (A.small) {
+                const uint32_t u = ((uint32_t)q0 * (uint32_t)A.wm) % (uint32_t)M;
+                int m = A.c0 + A.wm - (int)u;                        // in (-M, 2 M)
+                if (m >= M) m -= M;
+                if (m < 0) m += M;
+                r.r0 = m;
+                r.cnt = (DW_W - 1 - r.r0) / M + 1;
+                r.p0 = ((q0 - 1) * DW_W + A.d0 + r.r0) / M;          // (exact: a kept sample's distance from the chunk's first one)
+            } else {
+                const int64_t B = (A.R0 + q0 - 1) * (int64_t)DW_W;
+                int64_t m = ((int64_t)A.phi - B) % M;
+                if (m < 0) m += M;
+                r.r0 = (int)m;
+                r.cnt = (DW_W - 1 - r.r0) / M + 1;
+                r.p0 = (B + r.r0 - A.abs0 - A.off) / M;
+            }
             if (PAD) mp = dw_b_row_map(A, r);
             DWPh pw;
-            dw_row_ph<U8, NCO>(row_phasor(q0 - 1), ph, pw);
+            dw_row_ph<false, NCO>(row_phasor(q0 - 1), ph, pw);
             if (pin) {
-                if constexpr (U8) dw_stage8<NCO, PAD, DW_NL8 - 1, 1>(A, buf, gl, lane, pw, xp8, mp);
+                if constexpr (U8) dw_stage4<NCO, PAD, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp8, mp);
                 else dw_stage<NCO, PAD, DW_NL - 4, 4>(A, buf, gl, lane, pw, xp, mp);
             } else {
-                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
+                if constexpr (U8) dw_stage_guarded<NCO, PAD, true>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
                 else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, jlo, brel(q0 - 1), pw, mp);
             }
         }
@@ -936,7 +1088,9 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
         const unsigned tpre = (unsigned)__builtin_readcyclecounter();
         tx[1] += tpre - trun;
 #endif
-        dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, false, ycarry, cy, ylast_in, ta, tb);
+        DWPre<PAD, NG> pre;
+        dw_bsums_begin<PAD, NG>(A, dw_b_block<PAD>(A, buf, lane, r, false, 0), pre);
+        dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, false, ycarry, cy, ylast_in, ta, tb, pre);
 #ifdef DW_TRACE
         __builtin_amdgcn_s_waitcnt(0xc07f);
         tx[2] += (unsigned)__builtin_readcyclecounter() - tpre;
@@ -950,32 +1104,33 @@ __global__ void __launch_bounds__(64, DW_WAVES_PER_SIMD) k_chain_decim_b(const D
             dw_row_next(A, r);
             if (PAD) mp = dw_b_row_map(A, r);
             DWPh pw;
-            dw_row_ph<U8, NCO>(row_phasor(q), ph, pw);
+            dw_row_ph<false, NCO>(row_phasor(q), ph, pw);
             DW_T(5);
             if (fast) {
-                if constexpr (U8) dw_stage8<NCO, PAD, 0, DW_NL8>(A, buf, gl, lane, pw, x8, mp);
+                // (tried: a second set of sample registers, the next row requested BEFORE this one is staged so that the wave always has a
+                //  request in flight -- no gain, the launch sits on the memory system's rate, not on the bytes in flight; r06_decimb_notes.txt)
+                if constexpr (U8) dw_stage4<NCO, PAD, 0, DW_NL>(A, buf, gl, lane, pw, x8, mp);
                 else dw_stage<NCO, PAD, 0, DW_NL>(A, buf, gl, lane, pw, x, mp);
                 DW_T(0);
+                // (the block sums' first LDS reads ahead of the loads' address arithmetic)
+                dw_bsums_begin<PAD, NG>(A, dw_b_block<PAD>(A, buf, lane, r, true, 0), pre);
                 if (q + 1 < f1) {
                     // the next row's samples fly during this row's block sums
-                    if constexpr (U8) dw_issue8<0, DW_NL8>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
-                } else if (q + 1 == q1 && more) {
-                    issue_start(nxt);                                 // ... or this wave's next run's
+                    if constexpr (U8) dw_issue4<0, DW_NL>(A, brel(q + 1), lane, x8); else dw_issue<0, DW_NL>(A, brel(q + 1), lane, x);
                 }
             } else {
-                // (a row at the chunk's edge: the sample registers are free by now -- the rows inside the chunk lie behind or ahead)
-                if (q + 1 == q1 && more) issue_start(nxt);
-                if constexpr (U8) dw_stage8_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
+                if constexpr (U8) dw_stage_guarded<NCO, PAD, true>(A, buf, gl, lane, 0, brel(q), pw, mp);
                 else dw_stage_guarded<NCO, PAD>(A, buf, gl, lane, 0, brel(q), pw, mp);
+                dw_bsums_begin<PAD, NG>(A, dw_b_block<PAD>(A, buf, lane, r, true, 0), pre);
             }
 #ifdef DW_TRACE
             if (fast) {
                 { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tr[1] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); }
                 ++trows;
-                dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb, tr, tprev);
+                dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb, pre, tr, tprev);
             } else
 #endif
-            dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb);
+            dw_b_row_outputs<FM, PAD, NG>(A, buf, lane, r, mp, true, ycarry, cy, ylast_in, ta, tb, pre);
         }
     }
 #ifdef DW_TRACE
@@ -1168,6 +1323,18 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     A.minv = (uint32_t)(0x100000000ull / (uint64_t)P.M) + 1u;
     A.img = pl.img;
     A.NI = pl.NI; A.nh = pl.nh; A.h1lo = pl.j1lo >> 3;
+    {
+        // rows of the launch that lie inside the chunk: abs0 <= (R0 + q) W and (R0 + q + 1) W <= abs0 + L
+        const int64_t lo = dw_floordiv(P.abs0 - pl.R0 * DW_W + DW_W - 1, DW_W), hi = dw_floordiv(P.abs0 + P.L - pl.R0 * DW_W, DW_W);
+        const int64_t f0 = lo < -1 ? -1 : (lo > pl.nrows ? pl.nrows : lo), f1 = hi < f0 ? f0 : (hi > pl.nrows ? pl.nrows : hi);
+        A.F0 = (int)f0; A.F1 = (int)f1;
+        int64_t c0 = ((int64_t)pl.phi - pl.R0 * DW_W) % P.M;
+        if (c0 < 0) c0 += P.M;
+        A.c0 = (int)c0;
+        A.d0 = (int)(pl.R0 * DW_W - (P.abs0 + P.off));
+        A.wm = DW_W % P.M;
+        A.small = pl.nrows < (1 << 19) ? 1 : 0;
+    }
     void* kargs[1] = {&A};
     const void* kern = !pl.bsum ? decimw_kernel(u8, nco, fm, pl.pad != 0)
                                 : (pl.NI > 4 ? decimb_kernel<2>(u8, nco, fm, pl.pad != 0) : decimb_kernel<1>(u8, nco, fm, pl.pad != 0));

@@ -35,7 +35,7 @@ for _ in range(50):
     _hip.check(lib.dd_chain_process(h, x.data_ptr(), out.data_ptr(), n, None, None), "process")
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 50
-NW, NPH = 2048, 6
+NW, NPH = 2048, 7
 NTR = NPH + 6
 buf = (C.c_ulonglong * (NW * NTR))()
 f = C.CDLL(_hip.LIB_PATH).dd_debug_decimw_trace
@@ -44,7 +44,8 @@ f.restype = C.c_int
 _hip.check(f(buf, NW), "trace")
 a = np.frombuffer(buf, dtype=np.uint64).reshape(NW, NTR).astype(np.float64)
 rows = a[:, NPH].sum()
-names = ["wait for the loads, NCO, LDS writes", "issue the next row's loads", "tap loop", "discriminator, stores", "halo copy", "row geometry, row phasor"]
+names = ["wait for the loads, NCO, LDS writes", "issue the next row's loads", "tap loop (block-sum form: the sums up the lanes)", "discriminator, stores", "halo copy", "row geometry, row phasor",
+         "block sums (block-sum form)"]
 print("M = %d  " % M + "%s %s: %.4f ms per launch (with stamps); cycles per interior row and wave, %d rows; whole kernel %.0f cycles per wave" %
       (os.environ.get("LIB", "default"), "u8" if u8 else "c64", ms, rows, a[:, NPH + 1].mean()))
 tot = a[:, :NPH].sum() / rows
