@@ -21,8 +21,9 @@ args>` as a child and relays its output (rank 0's JSON line); the launcher itsel
 imports torch and never touches the GPU.
 
 Timing.  `value` and `ms_per_step` are wall clock around the K timed steps (barrier +
-device sync on both sides, max over ranks).  `roofline.kernel_ms` is HIP-event time on the
-launch stream around the same K launches / K (one kernel launch per step).  20 steps are
+device sync on both sides, max over ranks), and `roofline.achieved` / `roofline.frac` are computed from that
+same interval (one basis for the whole line).  `roofline.kernel_ms_events` is HIP-event time on the
+launch stream around the same K launches / K (one kernel launch per step), kept beside it.  20 steps are
 only ~4 ms of device time, so the same step is also run for >= 100 ms right after the
 timed region (`extra.steady_check`); the process's first step (one-off costs) and the 19 after it,
 before the pre-roll, are reported in `extra.first_step_ms` / `extra.cold_ms_per_step`.
@@ -204,7 +205,7 @@ def build_once_per_node():
 
 # ----------------------------------------------------------------------------- engines
 KERNEL_NAMES = {1: "k_chain_dense", 2: "k_chain_decim", 3: "k_chain_decim_p", 4: "k_chain_mfma_ws", 5: "k_chain_mfma_edge",
-                6: "k_chain_mfma_ab", 7: "k_chain_fft1k", 8: "k_chain_decim_multi", 9: "k_chain_cos1k", 10: "k_chain_decim_w"}
+                6: "k_chain_mfma_ab", 7: "k_chain_fft1k", 8: "k_chain_decim_multi", 9: "k_chain_cos1k", 10: "k_chain_decim_w", 11: "k_chain_decim_b"}
 
 
 class HipStep:
@@ -318,6 +319,25 @@ class StubStep:
 
 
 # ----------------------------------------------------------------------------- side configs (N = 1 only)
+def side_roofline(key, alg_bytes, ms, bound="hbm", note=None):
+    """The roofline block of a side entry: algorithmic bytes per launch / the measured time against the 8 TB/s HBM peak, with the HBM traffic
+    of the same launch from profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_decimw_traffic.sh;
+    not measured in this run) where a record exists."""
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "basis": "HIP events around the timed launches"}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("kernels", {}).get(key)
+        if rec:
+            r["traffic"] = rec.get("bytes_per_launch_log2n_26")
+            r["traffic_source"] = "profiles/hbm_traffic.json, %s at git %s" % (rec.get("kernel", key), rec.get("git", "?"))
+    except Exception:
+        pass
+    if note:
+        r["note"] = note
+    return r
+
+
 def side_configs(eng, steps=10, only_decim=False):
     """C3 / C4 front ends on the same device-resident buffer: the decimating fused chain,
     chunked with carried state as the reference's chunk loops do (decode_fm.py:54-70, decode_noaa.py:614-624).
@@ -378,15 +398,44 @@ def side_configs(eng, steps=10, only_decim=False):
         bounds = chunked_bounds
         assert n_out1 == n_out
         bps = 8.0 + 4.0 / M
+        case = "C3" if M == 50 else "C4"
+        alg = 8.0 * n + 4.0 * n_out
+        u8 = None
+        if case == "C4":
+            # the same front end from RAW u8 pairs (what source.IQwav holds: 2 B per sample resident), one chunk
+            import torch
+            x8 = (xin[:n] + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+            h8 = C.c_void_p()
+            hip.check(lib.dd_chain_create(C.byref(h8), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps), hip.cycles_q64(f, fs), M,
+                                          hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM | hip.DD_CHAIN_U8_INPUT), "dd_chain_create")
+
+            def one_pass_u8():
+                hip.check(lib.dd_chain_reset(h8, eng.stream), "dd_chain_reset")
+                hip.check(lib.dd_chain_process(h8, x8.data_ptr(), out.data_ptr(), n, C.byref(got), eng.stream), "dd_chain_process")
+                return got.value
+            ms8, n8 = timed(one_pass_u8)
+            assert n8 == n_out
+            u8 = {"ms": round(ms8, 4), "GS_per_s": round(n / ms8 / 1e6, 1), "bytes_per_sample": round(2.0 + 4.0 / M, 3),
+                  "kernel": KERNEL_NAMES.get(lib.dd_chain_last_kernel(h8), "?"),
+                  "roofline": side_roofline("k_chain_decim_b:C4u8", 2.0 * n + 4.0 * n_out, ms8, bound="issue",
+                                            note="a quarter of the bytes: not memory bound -- the wave's own instruction stream (rotation and staging of a row, its "
+                                                 "block sums on the matrix pipe, the discriminator) sets the time; the same launch WITHOUT its sample loads takes "
+                                                 "the same time (profiles/r06_decimb_notes.txt)")}
+            lib.dd_chain_destroy(h8)
+            del x8
         res.append({"config": name, "chunks": len(bounds), "launches_per_pass": 1, "ms_per_pass": round(ms, 4), "outputs": n_out,
+                    "roofline": side_roofline("k_chain_decim_b:" + case, alg, ms,
+                                              note="reads every sample once, writes one angle per %d samples; what separates it from the peak: profiles/r06_decimb_notes.txt" % M),
+                    "raw_u8_one_chunk": u8,
                     "GS_per_s": round(n / ms / 1e6, 1), "bytes_per_sample": round(bps, 3),
                     "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4),
                     "kernel": kern,
-                    "how": "dd_chain_process_chunks: the whole chunk list in one launch (k_chain_decim_w: the list is one chunk on the absolute sample grid)",
+                    "how": "dd_chain_process_chunks: the whole chunk list in one launch (k_chain_decim_b: the list is one chunk on the absolute sample grid)",
                     "chunk_loop": {"launches_per_pass": len(bounds), "ms": round(ms_loop, 4), "GS_per_s": round(n / ms_loop / 1e6, 1),
                                    "frac_of_8TBs": round(n * bps / (ms_loop * 1e-3) / 8e12, 4)},
                     "one_chunk": {"ms": round(ms1, 4), "GS_per_s": round(n / ms1 / 1e6, 1),
-                                  "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4)}})
+                                  "frac_of_8TBs": round(n * bps / (ms1 * 1e-3) / 8e12, 4),
+                                  "roofline": side_roofline("k_chain_decim_b:" + case, alg, ms1)}})
         lib.dd_chain_destroy(h)
     if only_decim:                                            # (tools/bench_decim.py)
         return res
@@ -455,11 +504,41 @@ def side_configs(eng, steps=10, only_decim=False):
                 "input_A_over_B": round(ab["A"] / ab["B"], 4), "bytes_per_sample": 12.0,
                 "frac_of_8TBs_input_A": round(n * 12.0 / (ab["A"] * 1e-3) / 8e12, 4), "frac_of_8TBs_input_B": round(n * 12.0 / (ab["B"] * 1e-3) / 8e12, 4)})
     res.append(side_headline_kernels(eng, steps))
+    try:
+        res.append(side_iir_iq(eng))
+    except Exception as e:
+        res.append({"config": "butter at IQ rate", "error": repr(e)})
     res.append(side_c3_end_to_end(eng, steps))
     res.append(side_c3_through_classes(eng, steps))
     res.extend(side_c4_end_to_end())
     res.append(side_ring_feeder())
     return res
+
+
+def side_iir_iq(eng, steps=5):
+    """filters.butter over full-rate IQ (decode_funcube.py:160,230: the Funcube / Meteor front ends low-pass the complex stream before they
+    decimate): a 6th-order Butterworth low-pass, butter(2 048 000, 20 000), over the 2^26 resident complex64 samples through the drop-in class
+    -- complex128 out like the reference's lfilter (csrc/dd_fir.hip: block end states, scan of the block start states, blocks
+    re-run from their true states)."""
+    from directdemod_amd import _hip, filters
+    import torch
+    n = eng.n
+    f = filters.butter(2048000, 20000.0, storeState=False)
+    src = _hip.DevArray(n, np.complex64, ptr=eng.xin.data_ptr())      # (a view of the bench's resident input: nothing is copied)
+    y = f.applyOn(src)
+    _hip.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = f.applyOn(src)
+    _hip.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    alg = 24.0 * n                                            # 8 B read (complex64) + 16 B written (complex128) per sample
+    del y
+    return {"config": "filters.butter(2 048 000, 20 000), order 6, over 2^26 complex64 IQ samples (decode_funcube.py:160 shape), complex128 out, through the class",
+            "ms_per_pass": round(ms, 3), "GS_per_s": round(n / ms / 1e6, 2), "bytes_per_sample": 24.0,
+            "roofline": side_roofline("dd_iir_f64:iq", alg, ms, note="float64 recurrence in three passes over the samples (block end states from zero, the scan of "
+                                      "the block start states, the blocks again from their true states): the passes re-read the input, so ~2.3 x the algorithmic bytes move; "
+                                      "wall clock around the class calls, host side included")}
 
 
 def side_headline_kernels(eng, steps=10):
@@ -873,7 +952,9 @@ def run_rank(args):
     if rank == 0 or args.simulate_rank is not None:
         total = world * n * args.steps
         value = total / dt_max / 1e6
-        achieved = BYTES_PER_SAMPLE * n / (kern_ms_max * 1e-3) / 1e9
+        # (one basis for the whole line: `achieved` / `frac` from the interval `value` and `ms_per_step` come from -- barrier-to-barrier wall
+        #  clock over the timed steps, max over ranks; the HIP-event time of the same launches is kept beside it as kernel_ms_events)
+        achieved = BYTES_PER_SAMPLE * n / (dt_max / args.steps) / 1e9
         traffic, traffic_source, power = None, None, None
         kname = eng.kernel()
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -920,7 +1001,8 @@ def run_rank(args):
                        "sharding": "contiguous sample ranges, absolute-index state, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": round(kern_ms_max, 4),
+                         "basis": "ms_per_step (wall clock between the barriers; VERDICT r5: one basis for value and frac)",
+                         "kernel_ms_events": round(kern_ms_max, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
                          "power": power},      # (profiles/power.json: not measured in this run; says at which git revision it was)
             "extra": extra,

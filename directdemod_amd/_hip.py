@@ -33,7 +33,14 @@ DD_ERR_TIMEOUT = -6
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
 DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
 (DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
- DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS, DD_KERNEL_DECIM_WAVE) = range(11)
+ DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS, DD_KERNEL_DECIM_WAVE,
+ DD_KERNEL_DECIM_BLOCKS) = range(12)
+
+
+def decim_wave_kernel(K, M):
+    """Which of the two wave-per-row decimating kernels takes (K taps, even decimation M in 8..64): block sums where an output needs at most
+    eight of them (dd_decimw.hip, round 6), else one window per lane."""
+    return DD_KERNEL_DECIM_BLOCKS if -(-K // M) <= 8 else DD_KERNEL_DECIM_WAVE
 # element type of raw interleaved uint8 I,Q pairs held on the device (source.py:117-118 not yet applied): 2 B/sample
 IQ8 = np.dtype([("i", np.uint8), ("q", np.uint8)])
 

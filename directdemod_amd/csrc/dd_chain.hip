@@ -1139,9 +1139,10 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
         fir->last_kernel = DD_KERNEL_DENSE_F32;
     } else if (!dd_kernel_sel_decimp() && dd_decimw_supported(P.K, P.M, P.flags, P.in)) {
         // even M in [8, 64], up to 256 taps: one wave per row of 64 kept outputs on the absolute decimation grid (dd_decimw.hip)
-        int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), fir->taps.data(), &fir->dw_taps, s);
+        int kid = DD_KERNEL_DECIM_WAVE;
+        int rc = dd_decimw_launch(P, fir->taps_rev + (DD_DENSE_R - 1), fir->taps.data(), &fir->dw_taps, s, &kid);
         if (rc != DD_OK) return rc;
-        fir->last_kernel = DD_KERNEL_DECIM_WAVE;
+        fir->last_kernel = kid;
     } else {
         DDDecimPlan pl;
         int rc = decim_plan(P, pl);

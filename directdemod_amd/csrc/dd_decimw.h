@@ -14,4 +14,5 @@ struct DDDecimWTaps {
 int dd_decimw_supported(int K, int M, int flags, const void* in);
 // the WHOLE chunk in one launch (stream start, chunk end and the carried state included): P as dd_fused_launch fills it;
 // taps_g0 = the reversed taps g[j] = h[K-1-j] on the device, at least one zero in front of g[0] and 38 behind g[K-1]; taps_host = h[0 .. K-1]
-int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream);
+// *kernel_id (may be null): DD_KERNEL_DECIM_BLOCKS (k_chain_decim_b, K <= 8 M) or DD_KERNEL_DECIM_WAVE (k_chain_decim_w)
+int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream, int* kernel_id = nullptr);

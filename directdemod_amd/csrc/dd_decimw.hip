@@ -1257,7 +1257,7 @@ static const void* decimb_kernel(bool u8, bool nco, bool fm, bool pad) {
     return k[(u8 ? 1 : 0) | (nco ? 2 : 0) | (fm ? 4 : 0) | (pad ? 8 : 0)];
 }
 
-int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream) {
+int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double* taps_host, DDDecimWTaps* cache, hipStream_t stream, int* kernel_id) {
     if (P.Ld < 1 && !P.tail_out) return DD_OK;                 // (no kept sample: one wave, for the new history alone)
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0, nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
     DWPlan pl;
@@ -1339,5 +1339,6 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     const void* kern = !pl.bsum ? decimw_kernel(u8, nco, fm, pl.pad != 0)
                                 : (pl.NI > 4 ? decimb_kernel<2>(u8, nco, fm, pl.pad != 0) : decimb_kernel<1>(u8, nco, fm, pl.pad != 0));
     DD_HIP_CHECK(hipLaunchKernel(kern, dim3(pl.nwaves > 0 ? pl.nwaves : 1), dim3(64), kargs, pl.lds, stream));
+    if (kernel_id) *kernel_id = pl.bsum ? DD_KERNEL_DECIM_BLOCKS : DD_KERNEL_DECIM_WAVE;
     return DD_OK;
 }

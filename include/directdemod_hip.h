@@ -269,7 +269,8 @@ int dd_chain_path(const dd_chain* h);
 #define DD_KERNEL_FFT_OS 7           /* k_chain_fft1k: M = 1, FM output, 162..256 taps: f32 overlap-save FFT convolution, one wave per 1024-point block, NCO commuted into the tap spectrum, whole chunk in one launch */
 #define DD_KERNEL_DECIM_MULTI 8      /* k_chain_decim_multi: M > 1, every chunk of a dd_chain_process_chunks call in one launch */
 #define DD_KERNEL_COS_RS 9           /* k_chain_cos1k: M = 1, FM or complex64 output, 255 taps a0 + a1 cos(2 pi k / 254) (filters.hamming): the FIR as three running sums, one wave per run of 1024-sample rows, whole chunk in one launch */
-#define DD_KERNEL_DECIM_WAVE 10      /* k_chain_decim_w: M > 1 (even, 8..64), up to 256 taps, FM or complex64 output, complex64 or raw u8 input: one wave per row of 64 kept outputs on the absolute decimation grid, no barrier; a chunk list is ONE launch of it */
+#define DD_KERNEL_DECIM_WAVE 10      /* k_chain_decim_w: M > 1 (even, 8..64), up to 256 taps, FM or complex64 output, complex64 or raw u8 input: one wave per row of 64 kept outputs on the absolute decimation grid, no barrier; a chunk list is ONE launch of it.  Since round 6 only where K > 8 M */
+#define DD_KERNEL_DECIM_BLOCKS 11    /* k_chain_decim_b (round 6): the same rows and grids for K <= 8 M (every K for M >= 32: the reference's /34 and /50) -- every staged sample is read once: a lane forms the ceil(K / M) block sums of the M samples that end at its kept sample on the matrix pipe (v_mfma_f32_4x4x1, exact f32), the sums travel up the lanes */
 int dd_chain_last_kernel(const dd_chain* h);
 int dd_fir_last_kernel(const dd_fir* h);       /* the same for a filter object driven through dd_fused_process (the drop-in classes) */
 long long dd_fir_launch_count(const dd_fir* h); /* fused kernel launches through this filter since it was created or last reset (a chunk list in one launch counts once): tests tell "one launch" from "a launch per chunk" by it */

@@ -350,7 +350,7 @@ def test_class_chunk_loop_over_a_resident_recording_is_one_launch(dd, case):
     g = got.signal
     nchunks = len(O.chunk_list(L, chunk))
     # ONE launch for the whole list: k_chain_decim_w over the list as one chunk (even M in 8..64, round 5)
-    assert filt._last_kernel() == dd.hip.DD_KERNEL_DECIM_WAVE and filt._launch_count() == 1
+    assert filt._last_kernel() == dd.hip.DD_KERNEL_DECIM_BLOCKS and filt._launch_count() == 1
     ref, f2 = _class_chunk_loop(dd, rate, L, chunk, one, taps, M, f_off, fm_on, strict, out_rate)
     r = ref.signal
     assert f2._launch_count() == nchunks                   # (private copies: a launch per chunk)
@@ -524,7 +524,7 @@ def test_class_chunk_loop_random_shapes_three_ways(dd, seed):
     case = dict(seed=seed, rate=rate, M=M, K=K, L=L, chunk=chunk, nco=f_off, fm=fm_on, strict=strict, u8=u8, nchunks=nchunks)
     if nchunks >= 2:
         wave = M % 2 == 0 and 8 <= M <= 64 and 2 <= K <= 256           # k_chain_decim_w's decimations; the others: k_chain_decim_multi
-        assert f1._last_kernel() == (dd.hip.DD_KERNEL_DECIM_WAVE if wave else dd.hip.DD_KERNEL_DECIM_MULTI), case
+        assert f1._last_kernel() == (dd.hip.decim_wave_kernel(K, M) if wave else dd.hip.DD_KERNEL_DECIM_MULTI), case
         assert f1._launch_count() == 1 and f2._launch_count() == nchunks, case
     assert got.length == ref.length == len(g) and g.dtype == r.dtype and np.array_equal(g, r), case
     assert len(pv) == len(g) and np.max(np.abs(pv - g)) < (1e-5 if fm_on else 1e-4 * np.max(np.abs(g))), case

@@ -196,7 +196,7 @@ def test_chunk_list_in_one_launch_equals_the_chunk_loop_bit_for_bit(g, shape, fm
         lib.dd_chain_reset(h, g.stream)
         out = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
         hip.check(lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), bounds, len(cuts) - 1, nout, g.stream), "chunks")
-        assert lib.dd_chain_last_kernel(h) == (hip.DD_KERNEL_DECIM_WAVE if kernel == "auto" and shape != "tiny_chunks" else hip.DD_KERNEL_DECIM_MULTI)
+        assert lib.dd_chain_last_kernel(h) == (hip.decim_wave_kernel(len(taps), M) if kernel == "auto" and shape != "tiny_chunks" else hip.DD_KERNEL_DECIM_MULTI)
         assert list(nout) == counts[:-1]
         p2 = sum(nout)
         hip.check(lib.dd_chain_process(h, x.data_ptr() + isz * n, out.data_ptr() + 4 * per * p2, tail, C.byref(got), g.stream), "process")

@@ -275,7 +275,7 @@ def decim_run(run, request):
     old_tiles = run.kernel == "fft1k"
     if old_tiles:
         hip.select_kernel("decimp")
-    want = hip.DD_KERNEL_DECIM_PERSISTENT if old_tiles else hip.DD_KERNEL_DECIM_WAVE
+    want = hip.DD_KERNEL_DECIM_PERSISTENT if old_tiles else hip.DD_KERNEL_DECIM_BLOCKS
     mk, M, fs, f, chunks = _DECIM_CASES[request.param]
     taps = np.ascontiguousarray(mk(), dtype=np.float64)
     h = C.c_void_p()

@@ -672,7 +672,7 @@ def test_decimw_kernel_shapes_cuts_and_u8(dd, M, K, fm_on, u8):
             hip.check(lib.dd_chain_process(h, src.ptr + isz * int(a), o.ptr, int(b - a), C.byref(got), None))
             assert got.value == no
             if no:
-                assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_WAVE
+                assert lib.dd_chain_last_kernel(h) == hip.decim_wave_kernel(K, M)
             outs.append(o.to_host()[:no])
         lib.dd_chain_destroy(h)
         return np.concatenate(outs)
@@ -733,7 +733,7 @@ def test_decimw_kernel_fuzz(dd, seed):
             hip.check(lib.dd_chain_process(h, src.ptr + isz * int(a), o.ptr, int(b - a), C.byref(got), None))
             assert got.value == no, case
             if no:
-                assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_WAVE, case
+                assert lib.dd_chain_last_kernel(h) == hip.decim_wave_kernel(K, M), case
             outs.append(o.to_host()[:no])
         lib.dd_chain_destroy(h)
         return np.concatenate(outs)

@@ -6,6 +6,6 @@ for k in ${@:-auto fft1k}; do
     DD_MFMA_KERNEL=$k python bench.py --no-cpu-baseline --no-side --steady-ms 300 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$k', d['config']['kernel'], 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'frac', d['roofline']['frac'], 'steady', d['extra']['steady_check']['kernel_ms'], 'rms', round(d['extra']['output_rms_rad'], 5))"
+print('$k', d['config']['kernel'], 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms_events'], 'frac', d['roofline']['frac'], 'steady', d['extra']['steady_check']['kernel_ms'], 'rms', round(d['extra']['output_rms_rad'], 5))"
   done
 done

@@ -110,7 +110,7 @@ for name, bounds in (("16 x 2^22", [i << 22 for i in range(17)]), ("ragged", [0,
         _hip.check(lib.dd_chain_process_chunks(h, x.data_ptr(), out.data_ptr(), cb, nch, cn, stream), "chunks")
         if i % 500 == 0:
             torch.cuda.synchronize()
-            assert lib.dd_chain_last_kernel(h) in (_hip.DD_KERNEL_DECIM_WAVE, _hip.DD_KERNEL_DECIM_MULTI) and sum(cn) == pos
+            assert lib.dd_chain_last_kernel(h) in (_hip.DD_KERNEL_DECIM_WAVE, _hip.DD_KERNEL_DECIM_BLOCKS, _hip.DD_KERNEL_DECIM_MULTI) and sum(cn) == pos
             assert torch.equal(out.view(torch.int32), loop.view(torch.int32)), (name, i)
     torch.cuda.synchronize()
     lib.dd_chain_destroy(h)
