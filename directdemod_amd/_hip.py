@@ -31,7 +31,7 @@ DD_ERR_NODEVICE = -5
 DD_ERR_TIMEOUT = -6
 
 DD_HIST_ZEROS, DD_HIST_ONES, DD_HIST_GIVEN = 0, 1, 2
-DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT = 1, 2, 4, 8
+DD_CHAIN_NCO, DD_CHAIN_FM, DD_CHAIN_U8_INPUT, DD_CHAIN_FORCE_DIRECT, DD_CHAIN_TIGHT = 1, 2, 4, 8, 16
 (DD_KERNEL_NONE, DD_KERNEL_DENSE_F32, DD_KERNEL_DECIM_TILES, DD_KERNEL_DECIM_PERSISTENT, DD_KERNEL_MFMA_WS,
  DD_KERNEL_MFMA_TILES, DD_KERNEL_MFMA_AB, DD_KERNEL_FFT_OS, DD_KERNEL_DECIM_MULTI, DD_KERNEL_COS_RS, DD_KERNEL_DECIM_WAVE,
  DD_KERNEL_DECIM_BLOCKS) = range(12)

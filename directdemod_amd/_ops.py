@@ -56,6 +56,8 @@ def fused(x, filt, nco_op, decim, fm):
     flags = _hip.DD_CHAIN_FORCE_DIRECT if FORCE_DIRECT else 0
     if x.dtype == _hip.IQ8:
         flags |= _hip.DD_CHAIN_U8_INPUT
+    if getattr(filt, "tight", False):
+        flags |= _hip.DD_CHAIN_TIGHT
     check(lib().dd_fused_process(fir_h, fm_h, x.ptr, out.ptr, x.n,
                                  1 if nco_op is not None else 0,
                                  nco_op[1] if nco_op is not None else 0,

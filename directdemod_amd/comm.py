@@ -136,7 +136,8 @@ def _run_batch(sigs):
         off = (M - (n - off) % M) % M
     x0 = sigs[0]._dev
     out = DevArray(max(1, sum(expect)), _F32 if fm is not None else _C64)
-    flags = (_hip.DD_CHAIN_FORCE_DIRECT if _ops.FORCE_DIRECT else 0) | (_hip.DD_CHAIN_U8_INPUT if x0.dtype == _IQ8 else 0)
+    flags = (_hip.DD_CHAIN_FORCE_DIRECT if _ops.FORCE_DIRECT else 0) | (_hip.DD_CHAIN_U8_INPUT if x0.dtype == _IQ8 else 0) | \
+            (_hip.DD_CHAIN_TIGHT if getattr(filt, "tight", False) else 0)
     nout = (C.c_int64 * k)()
     _hip.check(_hip.lib().dd_fused_process_chunks(fir_h, fm_h, x0.ptr, out.ptr, (C.c_int64 * (k + 1))(*bounds), k,
                                                   1 if nco0 is not None else 0, nco0[1] if nco0 is not None else 0,

@@ -1079,7 +1079,7 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
     P.M = a.M;
     P.off = a.off;
     P.Ld = kept_count(a.n, a.off, a.M);
-    P.flags = (a.nco ? DD_CHAIN_NCO : 0) | (fm ? DD_CHAIN_FM : 0) | (a.u8 ? DD_CHAIN_U8_INPUT : 0);
+    P.flags = (a.nco ? DD_CHAIN_NCO : 0) | (fm ? DD_CHAIN_FM : 0) | (a.u8 ? DD_CHAIN_U8_INPUT : 0) | (a.tight ? DD_CHAIN_TIGHT : 0);
     const bool isfm = fm != nullptr;
     P.s = (isfm && !fm->has_last) ? 1 : 0;
     if (isfm) {
@@ -1196,6 +1196,7 @@ extern "C" int dd_fused_process(dd_fir* fir, dd_fm* fm, const void* in, void* ou
     a.u8 = (flags & DD_CHAIN_U8_INPUT) ? 1 : 0;
     a.commit = carry;
     a.force_direct = (flags & DD_CHAIN_FORCE_DIRECT) ? 1 : 0;
+    a.tight = (flags & DD_CHAIN_TIGHT) ? 1 : 0;
     return dd_fused_launch(fir, fm, a, n_out, dd_stream(stream));
 }
 
@@ -1347,6 +1348,7 @@ extern "C" int dd_chain_process(dd_chain* c, const void* in, void* out, int64_t 
     a.u8 = (c->flags & DD_CHAIN_U8_INPUT) ? 1 : 0;
     a.commit = 1;
     a.force_direct = (c->flags & DD_CHAIN_FORCE_DIRECT) ? 1 : 0;
+    a.tight = (c->flags & DD_CHAIN_TIGHT) ? 1 : 0;
     int rc = dd_fused_launch(c->fir, c->fm, a, n_out, dd_stream(stream));
     if (rc == DD_OK) c->abs_index += n;
     return rc;

@@ -57,6 +57,7 @@ struct DDFusedArgs {
     int u8;                 // input is interleaved u8 I,Q
     int commit;             // carry the state forward (storeState)
     int force_direct;
+    int tight;              // DD_CHAIN_TIGHT: no running-sum kernel
 };
 int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out, hipStream_t s);
 int64_t dd_fused_out_count(const dd_fm* fm, int64_t n, int M, int off);

@@ -888,13 +888,16 @@ int dd_cos1k_supported(const double* taps, int K, int M, int flags) {
     if (M != 1 || K != C1_K) return 0;
     DDCosFit f;
     if (!dd_cos_fit_cached(taps, K, &f)) return 0;
-    return f.Q == 1 ? 1 : 0;                       // a0 + a1 cos(2 pi k / (K-1)): Hamming, Hann and their relatives
+    if (f.Q != 1) return 0;                        // a0 + a1 cos(2 pi k / (K-1)): Hamming, Hann and their relatives
+    // the kernel works with y / a0 (the discriminator does not see a positive factor) and forms a1 / a0: a (near) pure cosine has no a0
+    // to divide by -- such taps take the transform kernel
+    return (isfinite(f.a[0]) && isfinite(f.a[1]) && fabs(f.a[0]) >= 1e-3 * fabs(f.a[1]) && f.a[0] != 0.0) ? 1 : 0;
 }
 
 int dd_cos1k_create(void** st, const double* taps, int K) {
     if (K != C1_K) return DD_ERR_UNSUPPORTED;
     DDCosFit f;
-    if (!dd_cos_fit_cached(taps, K, &f) || f.Q != 1) return DD_ERR_UNSUPPORTED;
+    if (!dd_cos_fit_cached(taps, K, &f) || f.Q != 1 || !dd_cos1k_supported(taps, K, 1, 0)) return DD_ERR_UNSUPPORTED;
     DDCos1kState* s = new DDCos1kState();
     s->a0 = f.a[0];
     s->a1 = f.a[1];

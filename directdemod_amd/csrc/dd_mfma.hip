@@ -1121,7 +1121,8 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     // 255 taps of the form a0 + a1 cos(2 pi k / 254) (filters.hamming), FM or complex64 output: the running-sum kernel (dd_cosfir.hip),
     // a third of the overlap-save form's arithmetic.  "cos1k" forces it wherever it applies (it never applies to other taps),
     // "fft1k" / "ab" / "ws" keep it off.
-    if ((ksel == DD_KSEL_AUTO || ksel == DD_KSEL_COS1K) && st->K == 255) {
+    // (DD_CHAIN_TIGHT: the caller asks for the transform kernel's stop-band error bound)
+    if ((ksel == DD_KSEL_AUTO || ksel == DD_KSEL_COS1K) && st->K == 255 && !(P.flags & DD_CHAIN_TIGHT)) {
         if (!st->cos && !st->cos_tried) {
             st->cos_tried = 1;
             if (!dd_cos1k_supported(st->taps.data(), st->K, 1, P.flags) || dd_cos1k_create(&st->cos, st->taps.data(), st->K) != DD_OK) st->cos = nullptr;

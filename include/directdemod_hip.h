@@ -51,6 +51,11 @@ extern "C" {
 #define DD_CHAIN_FM         2   /* apply demod_fm.demod on the output (demod_fm.py:29-51) */
 #define DD_CHAIN_U8_INPUT   4   /* input is interleaved u8 I,Q; source.read fused (source.py:117-118) */
 #define DD_CHAIN_FORCE_DIRECT 8 /* disable the MFMA fast path (f32 direct form only) */
+#define DD_CHAIN_TIGHT       16 /* M = 1 chains: keep the running-sum kernel (k_chain_cos1k, filters.hamming(255)) off -- its FIR output is
+                                 * a0 R + a1 C with R, C the rectangular-window sums, which cancel to the window's -50 dB in the stop band: FM
+                                 * angles of a signal the filter rejects are good to 1e-3 rad there, against 3e-4 for the transform kernel
+                                 * this flag selects instead (1.4 x the time).  Also a flag of dd_fused_process(_chunks);
+                                 * Python: filters.filter.tight = True.  No reference counterpart (float64 there, filters.py:64-70) */
 
 /* ---- runtime ---------------------------------------------------------------- */
 const char* dd_last_error(void);

@@ -350,7 +350,7 @@ def test_class_chunk_loop_over_a_resident_recording_is_one_launch(dd, case):
     g = got.signal
     nchunks = len(O.chunk_list(L, chunk))
     # ONE launch for the whole list: k_chain_decim_w over the list as one chunk (even M in 8..64, round 5)
-    assert filt._last_kernel() == dd.hip.DD_KERNEL_DECIM_BLOCKS and filt._launch_count() == 1
+    assert filt._last_kernel() == dd.hip.decim_wave_kernel(K, M) and filt._launch_count() == 1
     ref, f2 = _class_chunk_loop(dd, rate, L, chunk, one, taps, M, f_off, fm_on, strict, out_rate)
     r = ref.signal
     assert f2._launch_count() == nchunks                   # (private copies: a launch per chunk)

@@ -428,6 +428,93 @@ def test_cos_kernel_stop_band_signal(dd, select_kernel):
     assert res["fft1k"][0] <= FM_MED and res["fft1k"][1] <= FM_WELL and res["fft1k"][2] <= 3e-4, res
 
 
+def test_cos_kernel_complex_output_stop_band_signal(dd, select_kernel):
+    """the FIR bound of commSignal.filter(hamming(255)) ALONE (complex64 out, no demodulator) on the stop-band input of the test
+    above (max|y| is 2 % of max|x| sum|b| there), the three M = 1 kernels side by side.  Stated two ways: relative to what goes in,
+    max|x| sum|b| -- each kernel <= 1e-7 (measured: k_chain_cos1k 3.9e-8, k_chain_fft1k 1.4e-8, k_chain_mfma_ab 2.7e-8; the float32 direct form's
+    own level is 3.1e-7 of max|y| on pass-band signals) -- and relative to max|y|: k_chain_cos1k <= 4e-6 (measured 1.8e-6: its
+    sums R, C sit 37 dB above their combination), k_chain_fft1k <= 2e-6 (6.6e-7), k_chain_mfma_ab <= 3e-6 (1.2e-6).  So the complex-output flavour
+    keeps about FIR_TOL even here; what the stop band costs shows in the ANGLES at the deep nulls only (test above)."""
+    fs, f_off = 2400000, -31000.0
+    L = 120000
+    raw = O.synth_iq_fm(L, fs, 2900, f_carrier=31000.0, f_mod=700.0, dev=4.0)
+    x = O.grid_c64(raw)
+    taps = O.win_hamming(255)
+    y = O.FilterState(taps).applyOn(O.nco(x, f_off, fs, 0))
+    scale_in = np.max(np.abs(x)) * np.sum(np.abs(taps))
+    res = {}
+    for kern, want in ((None, dd.hip.DD_KERNEL_COS_RS), ("fft1k", dd.hip.DD_KERNEL_FFT_OS), ("ab", dd.hip.DD_KERNEL_MFMA_AB)):
+        select_kernel(kern)
+        flt = dd.filters.hamming(255)
+        got = np.asarray(dd.comm.commSignal(fs, x).offsetFreq(f_off).filter(flt).signal)
+        assert flt._last_kernel() == want, (kern, flt._last_kernel())
+        e = np.max(np.abs(got[255:] - y[255:]))                 # (behind the ones history: its step is a pass-band signal)
+        res[kern or "cos1k"] = (e / scale_in, e / np.max(np.abs(y[255:])))
+    assert np.max(np.abs(y[255:])) < 5e-2 * scale_in, "the input is supposed to lie in the stop band"
+    print("stop-band FIR error (of max|x| sum|b|, of max|y|):", {k: ("%.3g" % a, "%.3g" % b) for k, (a, b) in res.items()})
+    for k, (ein, _) in res.items():
+        assert ein <= 1e-7, res
+    assert res["cos1k"][1] <= 4e-6 and res["fft1k"][1] <= 2e-6 and res["ab"][1] <= 3e-6, res
+
+
+def test_tight_flag_keeps_the_running_sum_kernel_off(dd, select_kernel):
+    """DD_CHAIN_TIGHT / filters.filter.tight (round 6): a caller who needs the transform kernel's stop-band bound asks for
+    it in public -- hamming(255) without decimation then runs k_chain_fft1k (FM output: 3e-4 rad at |z| >= 1e-3 median on the stop-band
+    input instead of 1e-3), through the classes and through dd_chain_create's flags; pass-band results agree with the default kernel's
+    to the FM tolerance.  (Carrying the running sums' scan state in float64 does not close the gap -- the float32 model of the kernel's
+    exact operation order, tools/sim/cosfir_sim.py: 4.2e-4 -> 3.7e-4 rad on this input; profiles/r06_cos1k_stopband.txt.)"""
+    import ctypes as C
+    hip = dd.hip
+    lib = hip.lib()
+    select_kernel(None)
+    fs, f_off = 2400000, -31000.0
+    L = 120000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 2900, f_carrier=31000.0, f_mod=700.0, dev=4.0))
+    y = O.FilterState(O.win_hamming(255)).applyOn(O.nco(x, f_off, fs, 0))
+    ref, _ = O.fm_demod(y, None)
+    mag = np.abs(y[1:] * np.conj(y[:-1]))
+    flt = dd.filters.hamming(255)
+    flt.tight = True
+    got = np.asarray(dd.comm.commSignal(fs, x).offsetFreq(f_off).filter(flt).funcApply(dd.demod_fm.demod_fm().demod).signal, dtype=np.float64)
+    assert flt._last_kernel() == hip.DD_KERNEL_FFT_OS
+    d = np.abs(np.angle(np.exp(1j * (got - ref))))
+    assert np.median(d) <= FM_MED and np.max(d[mag >= 1e-3 * np.median(mag)]) <= 3e-4
+    # the C-ABI: the flag of dd_chain_create
+    taps = np.ascontiguousarray(O.win_hamming(255))
+    src = hip.DevArray.from_host(x, dtype=np.complex64)
+    for fl, want in ((0, hip.DD_KERNEL_COS_RS), (hip.DD_CHAIN_TIGHT, hip.DD_KERNEL_FFT_OS)):
+        h = C.c_void_p()
+        hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, hip.cycles_q64(f_off, fs), 1,
+                                      hip.DD_CHAIN_NCO | hip.DD_CHAIN_FM | fl))
+        o = hip.DevArray(L, np.float32)
+        n = C.c_int64(0)
+        hip.check(lib.dd_chain_process(h, src.ptr, o.ptr, L, C.byref(n), None))
+        assert lib.dd_chain_last_kernel(h) == want and n.value == L - 1
+        dk = np.abs(np.angle(np.exp(1j * (o.to_host()[:L - 1].astype(np.float64) - ref))))
+        assert np.max(dk[mag >= 1e-3 * np.median(mag)]) <= (3e-4 if fl else 1e-3)
+        lib.dd_chain_destroy(h)
+
+
+def test_cos_kernel_is_not_taken_for_a_near_pure_cosine_tap_set(dd, select_kernel):
+    """k_chain_cos1k forms a1 / a0 -- a 255-tap set a0 + a1 cos(2 pi k / 254) with a0 ~ 0 (a pure cosine) fits the cosine series
+    but must not take the running-sum kernel (the quotient overflows, the discriminator returns NaN): such taps fall through to the
+    transform kernel.  A Hann window (a0 = a1 = 0.5) still takes it."""
+    select_kernel(None)
+    fs = 2400000
+    L = 60000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 2903, f_carrier=25000.0, f_mod=700.0, dev=4.0))
+    k = np.arange(255)
+    for name, taps, cos in (("pure cosine", np.cos(2 * np.pi * k / 254.0), False), ("tiny a0", 1e-9 + np.cos(2 * np.pi * k / 254.0), False),
+                            ("hann", 0.5 - 0.5 * np.cos(2 * np.pi * k / 254.0), True)):
+        flt = dd.filters.filter(taps, [1])
+        got = np.asarray(dd.comm.commSignal(fs, x).offsetFreq(25000.0).filter(flt).funcApply(dd.demod_fm.demod_fm().demod).signal, dtype=np.float64)
+        assert np.all(np.isfinite(got)), name
+        assert (flt._last_kernel() == dd.hip.DD_KERNEL_COS_RS) == cos, (name, flt._last_kernel())
+        y = O.FilterState(taps).applyOn(O.nco(x, 25000.0, fs, 0))
+        ref, _ = O.fm_demod(y, None)
+        fm_check(got, ref, np.abs(y[1:] * np.conj(y[:-1])))
+
+
 @pytest.mark.parametrize("K", [162, 255, 256])
 @pytest.mark.parametrize("f_off", [25000.0, -700000.0, 0.0])
 @pytest.mark.parametrize("u8", [False, True])
