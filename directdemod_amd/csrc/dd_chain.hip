@@ -1056,7 +1056,13 @@ int dd_fused_launch(dd_fir* fir, dd_fm* fm, const DDFusedArgs& a, int64_t* n_out
     {
         // a chunk-list launch whose in-launch hand-over timed out: reported here too, not only by dd_stream_sync, and the
         // state that launch committed is refused until the filter is reset
-        const int sr = dd_seam_poll_all();
+        // (only THIS filter's word decides this call -- a timeout on another filter marks that filter, whose next call, or
+        //  dd_stream_sync, reports it)
+        int sr = DD_OK;
+        {
+            std::lock_guard<std::mutex> lk(g_seam_mu);
+            sr = seam_look(fir, false);
+        }
         if (sr != DD_OK) return sr;
         if (fir->state_invalid) {
             dd_set_error("this filter's carried state comes from a chunk-list launch that timed out (DD_ERR_TIMEOUT was reported): reset it "
@@ -1391,6 +1397,13 @@ static int fused_chunks_one_launch(dd_fir* fir, dd_fm* fm, const void* in, void*
         std::lock_guard<std::mutex> lk(g_seam_mu);
         const int rc0 = seam_look(fir, false);
         if (rc0 != DD_OK) return rc0;
+        if (fir->state_invalid) {
+            // (the look above zeroes the word when it reports -- a SECOND chunk-list call without a reset must not go on from the
+            //  state the faulty launch committed)
+            dd_set_error("this filter's carried state comes from a chunk-list launch that timed out (DD_ERR_TIMEOUT was reported): reset it "
+                         "(dd_fir_reset / dd_chain_reset / dd_chain_seek) before processing more samples");
+            return DD_ERR_TIMEOUT;
+        }
         withhold = g_seam_withhold;
         g_seam_withhold = -1;                  // (one launch)
         spin_log2 = g_seam_spin_log2;

@@ -81,7 +81,7 @@ def _hamming(K):
     return 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(K) / (K - 1))
 
 
-@pytest.mark.parametrize("ntaps", [255, 151, 63])
+@pytest.mark.parametrize("ntaps", [255, 151, 127, 63])
 @pytest.mark.parametrize("u8", [False, True])
 @pytest.mark.parametrize("kernel", ["auto", "ab", "fft1k", "cos1k"])
 def test_fm_chain_undecimated_is_bit_reproducible(g, ntaps, u8, kernel, select_kernel):
@@ -253,6 +253,11 @@ def test_withheld_hand_over_is_reported_not_silently_wrong(g, select_kernel):
     assert rc == hip.DD_ERR_TIMEOUT, rc
     with pytest.raises(hip.HipError):
         hip.check(rc, "dd_chain_process_chunks")
+    #  the report zeroes the error word -- a further chunk-list call WITHOUT a reset must still refuse to go on from the state
+    # the faulty launch committed
+    out2 = t.full((nfl,), float("nan"), dtype=t.float32, device=g.dev)
+    assert lib.dd_chain_process_chunks(h, x.data_ptr(), out2.data_ptr(), bounds, len(cuts) - 1, nout, g.stream) == hip.DD_ERR_TIMEOUT
+    assert b"reset" in lib.dd_last_error()
     # and without the fault everything is as before
     hip.check(lib.dd_debug_seam(-1, 0), "dd_debug_seam")
     rc, again = one_launch()
