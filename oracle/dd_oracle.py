@@ -744,8 +744,9 @@ def afsk_edges(binary_filter, spb):
     return np.correlate(np.sign(binary_filter), kernel, mode="same") / spb
 
 
-def synth_afsk_iq(n_bits, fs, seed, bw=22050, baud=1200, mark=1200, space=2200, dev=3000.0, amp=60.0, sigma=2.0):
-    """FM-modulated AFSK1200 (random NRZI bits) as u8 IQ at `fs` (a multiple of bw)."""
+def synth_afsk_iq(n_bits, fs, seed, bw=22050, baud=1200, mark=1200, space=2200, dev=3000.0, amp=60.0, sigma=2.0, f_carrier=0.0):
+    """FM-modulated AFSK1200 (random NRZI bits) as u8 IQ at `fs` (a multiple of bw); f_carrier: where the signal sits in the recording
+    (config 1: 10 kHz above the centre frequency the file name carries)."""
     rng = np.random.default_rng(seed)
     bits = rng.integers(0, 2, n_bits)
     spb_fs = fs / baud
@@ -755,6 +756,8 @@ def synth_afsk_iq(n_bits, fs, seed, bw=22050, baud=1200, mark=1200, space=2200, 
     audio_phase = 2 * np.pi * np.cumsum(tone) / fs
     audio = np.cos(audio_phase)
     rf_phase = 2 * np.pi * dev * np.cumsum(audio) / fs
+    if f_carrier:
+        rf_phase = rf_phase + 2 * np.pi * ((f_carrier / fs * t) % 1.0)
     s = amp * np.exp(1j * rf_phase) + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     raw = np.empty((n, 2), dtype=np.uint8)
     raw[:, 0] = np.clip(np.round(s.real + 127.5), 0, 255).astype(np.uint8)

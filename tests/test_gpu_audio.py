@@ -563,6 +563,48 @@ def test_source_readers(dd, tmp_path):
     assert dd.source.IQwavAlt(str(w), 1234567).sampFreq == 1234567
 
 
+@pytest.mark.parametrize("how", ["host_read_default_chunk", "host_read_chunks_1e6", "device_raw_chunks_1e6"])
+def test_config1_afsk_front_end_from_a_wav_golden(dd, golden_dir, tmp_path, how):
+    """SURVEY 8d C1 in its stated shape (VERDICT r5 "what's missing" 3): a 2.4 MS/s 8-bit stereo IQ.wav whose NAME carries the centre
+    frequency (main.py:167-173 takes the offset from it) -> source.IQwav -> chunker -> offsetFreq -> blackmanHarris(151) -> bwLim(22050)
+    [M = 108: the tile kernels' path, above k_chain_decim_b's 64] -> extend; demod_fm over the whole (decode_afsk1200.py:67-94) -- against
+    the FM output the REFERENCE produced from the same file (tests/golden/c1_afsk_front.npz, tools/gen_golden.py --c1).  The reference's
+    one chunk (PROC_CHUNKSIZE = 2e7 > the file), chunks of 10^6 samples (its result does not depend on the chunking: carried state), and the
+    same chunks as raw u8 pairs read in place on the device (widened inside the fused kernel)."""
+    from _wav import write_iq_wav
+    g = _load(golden_dir, "c1_afsk_front.npz")
+    fs = int(g["fs"])
+    name = "synth_20180101_120000Z_145825000Hz_IQ.wav"
+    raw = O.synth_afsk_iq(int(g["n_bits"]), fs, int(g["seed"]), f_carrier=float(g["offset"]))
+    path = tmp_path / name
+    write_iq_wav(path, raw, fs)
+    # what main.py does with the file name and -f 145835000 (main.py:167-173)
+    centre = int([i for i in name.split("_") if i[-2:] == "Hz"][0][:-2])
+    offset = 145835000 - centre
+    assert offset == int(g["offset"])
+    src = dd.source.IQwav(str(path))
+    assert src.sampFreq == fs and src.length == raw.shape[0]
+    ck = dd.chunker.chunker(src) if how == "host_read_default_chunk" else dd.chunker.chunker(src, 1000000)
+    sig = dd.comm.commSignal(src.sampFreq)
+    bh = dd.filters.blackmanHarris(151)
+    fm = dd.demod_fm.demod_fm()
+    for i in ck.getChunks:
+        chunk = src.read_device_raw(*i) if how.startswith("device_raw") else src.read(*i)
+        c = dd.comm.commSignal(src.sampFreq, chunk, ck)
+        c.offsetFreq(offset)
+        c.filter(bh)
+        c.bwLim(int(g["bw"]))
+        sig.extend(c)
+    sig.funcApply(fm.demod)
+    assert sig.sampRate == int(g["rate_out"]) and sig.length == int(g["n_out"])
+    assert bh._last_kernel() in (dd.hip.DD_KERNEL_DECIM_PERSISTENT, dd.hip.DD_KERNEL_DECIM_TILES, dd.hip.DD_KERNEL_DECIM_MULTI)
+    got = np.asarray(sig.signal, dtype=np.float64)
+    # two-tier FM tolerance against the reference's float64 angles (every 4th, and the first and last 2048 in full)
+    for a, b in ((got[:2048], g["head"]), (got[-2048:], g["tail"]), (got[::4], g["every4"])):
+        d = np.abs(np.angle(np.exp(1j * (a - b))))
+        assert np.max(d) < 2e-5 and np.median(d) < 2e-6, (how, float(np.max(d)), float(np.median(d)))
+
+
 def test_streaming_ring_feeder_equals_one_shot(dd):
     """u8 source -> pinned ring -> side-stream H2D -> fused u8 chain, chunked == one shot"""
     from directdemod_amd import stream

@@ -252,3 +252,21 @@ def test_afsk_correlators_match_reference_run(golden_dir):
     # the generator in the oracle reproduces the recording the golden run used
     raw = O.synth_afsk_iq(int(g["n_bits"]), int(g["fs_iq"]), int(g["seed"]))
     assert raw.shape == (int(g["n_bits"]) * int(g["fs_iq"]) // 1200, 2)
+
+
+def test_config1_afsk_front_end_from_a_wav_golden(golden_dir):
+    """SURVEY 8d C1 in its stated shape: the fixture was captured from the reference's own run (tools/gen_golden.py --c1: source.IQwav on a
+    2.4 MS/s 8-bit stereo IQ.wav named ..._145825000Hz_IQ.wav, decode_afsk1200.getMsg's front end, decode_afsk1200.py:67-94).  The oracle's
+    restatement -- read (source.py:117-118), offsetFreq 10 kHz, blackmanHarris(151) with the ones history, bwLim [::108], demod_fm --
+    reproduces the reference's FM output to 1e-9 rad."""
+    g = np.load(os.path.join(golden_dir, "c1_afsk_front.npz"))
+    fs, M = int(g["fs"]), int(g["fs"]) // int(g["bw"])
+    raw = O.synth_afsk_iq(int(g["n_bits"]), fs, int(g["seed"]), f_carrier=float(g["offset"]))
+    x = O.read_iq_u8(raw, 0, raw.shape[0])
+    y = O.FilterState(O.win_blackmanharris(151)).applyOn(O.nco(x, float(g["offset"]), fs, 0))[::M]
+    fm, _ = O.fm_demod(y, None)
+    assert M == 108 and len(fm) == int(g["n_out"])
+
+    def dphi(a, b):
+        return np.max(np.abs(np.angle(np.exp(1j * (a - b)))))
+    assert dphi(fm[:2048], g["head"]) < 1e-9 and dphi(fm[-2048:], g["tail"]) < 1e-9 and dphi(fm[::4], g["every4"]) < 1e-9

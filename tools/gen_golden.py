@@ -133,9 +133,64 @@ def gen_c4_60s():
     print("noaa_c4_60s: crude A %d B %d, accurate A %d B %d, useful %d" % (len(sa), len(sb), len(acc[0]), len(acc[4]), nobj.useful))
 
 
+C1_NAME = "synth_20180101_120000Z_145825000Hz_IQ.wav"       # (the name pattern lets main.py:167-173 parse the centre frequency)
+C1_FREQ = 145835000                                         # what a user would pass as -f: the signal sits 10 kHz above the centre
+
+
+def gen_c1():
+    """config 1 in its stated shape (VERDICT r5 "what's missing" 3): a synthetic 8-bit stereo IQ.wav at 2.4 MS/s whose NAME
+    carries the centre frequency, read by the reference's own source.IQwav, through the reference's AFSK front end exactly as getMsg runs it
+    (decode_afsk1200.py:67-94: chunker -> offsetFreq -> blackmanHarris(151) -> bwLim(22050) [M = 108] -> extend; demod_fm over the whole).
+    Captured: what getMsg hands to its Butterworth band-pass, i.e. the FM output.  Stored: seed and shape, the first and last 2048 angles,
+    every 4th angle in between (float64) -- ~110 KB.   gen_golden.py --c1"""
+    install_shim()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tempfile
+    from directdemod import decode_afsk1200 as dafsk, filters, source
+    from oracle import dd_oracle as O
+    from _wav import write_iq_wav
+    fs, nbits, seed = 2400000, 2400, 11                      # 2 s of AFSK1200
+    # the offset main.py would hand to the decoder: -f minus the "...Hz" field of the file name (main.py:167-173)
+    centre = int([i for i in C1_NAME.split("_") if i[-2:] == "Hz"][0][:-2])
+    offset = C1_FREQ - centre
+    raw = O.synth_afsk_iq(nbits, fs, seed, f_carrier=float(offset))
+    cap = {}
+
+    class _Stop(Exception):
+        pass
+
+    def _butter_tap(self, x):
+        cap["fm"] = np.array(x, dtype=np.float64)
+        raise _Stop()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, C1_NAME)
+        write_iq_wav(path, raw, fs)
+        src = source.IQwav(path)
+        assert src.sampFreq == fs and src.length == raw.shape[0]
+        filters.butter.applyOn = _butter_tap
+        try:
+            dafsk.decode_afsk1200(src, offset, 22050).getMsg
+        except _Stop:
+            pass
+        finally:
+            del filters.butter.applyOn
+    fm = cap["fm"]
+    M = int(fs / 22050)
+    assert M == 108 and len(fm) == len(range(0, raw.shape[0], M)) - 1
+    g = {"fs": np.int64(fs), "n_bits": np.int64(nbits), "seed": np.int64(seed), "offset": np.int64(offset), "bw": np.int64(22050),
+         "n_out": np.int64(len(fm)), "rate_out": np.int64(int(fs / M)), "head": fm[:2048], "tail": fm[-2048:], "every4": fm[::4]}
+    np.savez_compressed(os.path.join(OUT, "c1_afsk_front.npz"), **g)
+    print("c1: %d samples @%d -> %d angles @%d S/s (M = %d), offset %d Hz, fixture %d bytes" %
+          (raw.shape[0], fs, len(fm), int(fs / M), M, offset, os.path.getsize(os.path.join(OUT, "c1_afsk_front.npz"))))
+
+
 def main():
     if "--c4-60s" in sys.argv:
         return gen_c4_60s()
+    if "--c1" in sys.argv:
+        return gen_c1()
     only_afsk = "--afsk-only" in sys.argv
     install_shim()
     sys.path.insert(0, REF)
