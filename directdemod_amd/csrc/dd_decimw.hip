@@ -725,7 +725,10 @@ struct DWCarry {
 
 template <int NG>
 struct DWAcc {
-    v4f r[NG], i[NG];          // [group][m]: P_{4 group + m}, re / im
+    // [group][m]: P_{4 group + m}, re / im -- each as TWO chains, the block's even and odd samples (r, i and r1, i1), added at the end: a
+    // chain of M / 2 multiply-adds rounds less than one of M (the whole 2^26-sample C3 run against float64: 1.3e-4 -> see
+    // tests/test_gpu_fullsize.py), and four to eight independent chains need no wait state between dependent matrix instructions
+    v4f r[NG], i[NG], r1[NG], i1[NG];
 };
 
 // the block sums of the lane's block (blk: its first sample, even), eight samples (four 16-byte reads) per step, straight-line code for up to
@@ -769,8 +772,8 @@ template <int NG, int S, int J0>
 __device__ __forceinline__ void dw_bo_mac2(DWAcc<NG>& a, float t, v4f x) {
     a.r[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.x, a.r[S], 4, J0, 0);
     a.i[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.y, a.i[S], 4, J0, 0);
-    a.r[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.z, a.r[S], 4, J0 + 1, 0);
-    a.i[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.w, a.i[S], 4, J0 + 1, 0);
+    a.r1[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.z, a.r1[S], 4, J0 + 1, 0);
+    a.i1[S] = __builtin_amdgcn_mfma_f32_4x4x1f32(t, x.w, a.i1[S], 4, J0 + 1, 0);
 }
 template <int NG, int H, bool PAD>
 __device__ __forceinline__ void dw_bo_mac(DWAcc<NG>& a, const DWOct<PAD>& d, float ta, float tb, bool g1) {
@@ -808,6 +811,8 @@ __device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __
     for (int g = 0; g < NG; ++g) {
         acc.r[g] = (v4f){0.f, 0.f, 0.f, 0.f};
         acc.i[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+        acc.r1[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+        acc.i1[g] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
     // (through an empty asm: left visible as launch constants the comparisons are hoisted out of the row loop into scalar registers that spill)
     int nh = A.nh, h1lo = A.h1lo, M = A.M;
@@ -921,7 +926,7 @@ __device__ __forceinline__ void dw_b_row_outputs(const DDDecimWArgs& A, float2* 
 #pragma unroll
         for (int s = 4 * NG - 1; s >= 0; --s) {
             if (s < NI) {
-                const v2f P = (v2f){acc.r[s >> 2][s & 3], acc.i[s >> 2][s & 3]};
+                const v2f P = (v2f){acc.r[s >> 2][s & 3] + acc.r1[s >> 2][s & 3], acc.i[s >> 2][s & 3] + acc.i1[s >> 2][s & 3]};
                 if (s + 1 < NI) {
                     const v2f cin = cy.h[s];
                     cy.h[s] = dw_lane(y, last);

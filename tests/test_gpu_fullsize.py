@@ -36,6 +36,49 @@ def _wrapped_max(torch, a, b, blk=1 << 24):
     return m
 
 
+def _f64_fir_on_device(torch, x, taps, f_off, fs):
+    """The whole chain's FIR output in float64 ON THE DEVICE, for every sample (the full-size runs were compared with the
+    float64 oracle on windows only).  Test infrastructure, plain torch: the NCO as the reference forms it (comm.py:77: the phase
+    2 pi f n / fs and its exponential in float64, the product rounded once to complex64), the FIR with the ones history (filters.py:45) as
+    an overlap-save convolution through float64 transforms of 2^23 points (error ~1e-13 of the peak); checked against the numpy oracle on
+    a window by its caller.  Returns complex128 [n]."""
+    n = x.shape[0]
+    K = len(taps)
+    dev = x.device
+    out = torch.empty(n, dtype=torch.complex128, device=dev)
+    B, NF = 1 << 22, 1 << 23
+    tp = torch.zeros(NF, dtype=torch.complex128, device=dev)
+    tp[:K] = torch.from_numpy(np.asarray(taps, dtype=np.float64)).to(dev).to(torch.complex128)
+    TP = torch.fft.fft(tp)
+    carry = torch.ones(K - 1, dtype=torch.complex128, device=dev)       # quirk Q1: the delay line starts as ones
+    for s0 in range(0, n, B):
+        s1 = min(n, s0 + B)
+        idx = torch.arange(s0, s1, dtype=torch.float64, device=dev)
+        ph = (-2.0 * np.pi * f_off / fs) * idx                          # (float64 product, as np.exp(-1j*2*pi*f*arange/fs) forms it)
+        xc = torch.complex(x[s0:s1, 0].double(), x[s0:s1, 1].double())
+        xt = (xc * torch.complex(torch.cos(ph), torch.sin(ph))).to(torch.complex64).to(torch.complex128)
+        seg = torch.zeros(NF, dtype=torch.complex128, device=dev)
+        seg[:K - 1] = carry
+        seg[K - 1:K - 1 + (s1 - s0)] = xt
+        y = torch.fft.ifft(torch.fft.fft(seg) * TP)
+        out[s0:s1] = y[K - 1:K - 1 + (s1 - s0)]
+        carry = seg[s1 - s0:s1 - s0 + K - 1].clone()
+        del seg, y, xt, xc, ph, idx
+    return out
+
+
+def _wrapped_err_stats(torch, got, ref, mag=None, blk=1 << 24):
+    """max wrapped |got - ref| over all elements (and over those with mag >= thr, for (thr_name, thr) pairs), median by sampling"""
+    m = 0.0
+    for s in range(0, got.numel(), blk):
+        d = got[s:s + blk].double() - ref[s:s + blk]
+        d = (torch.remainder(d + np.pi, 2 * np.pi) - np.pi).abs()
+        if mag is not None:
+            d = torch.where(mag[s:s + blk], d, torch.zeros_like(d))
+        m = max(m, float(d.max()))
+    return m
+
+
 @pytest.fixture(scope="module", params=["cos1k", "fft1k", "ab"])
 def run(request):
     """every test of this module under the three M = 1 FM kernels: k_chain_cos1k (the default for Hamming 255 since round 5) and,
@@ -129,6 +172,25 @@ def test_eight_primed_shards_equal_one_shot(run):
     t.cuda.synchronize()
     assert pos == run.n - 1
     assert _wrapped_max(t, out[:pos], run.one[:pos]) < TOL
+
+
+def test_every_output_against_a_float64_reference_on_the_device(run):
+    """All 2^26 - 1 angles of the full-size run against a float64 evaluation of the same chain on the device (_f64_fir_on_device; itself
+    pinned to the numpy oracle on a window here, 1e-9 rad): max wrapped error under TOL on EVERY output -- no inference from windows or from
+    the agreement of two float32 kernels."""
+    t = run.torch
+    y = _f64_fir_on_device(t, run.x, run.taps, F_OFF, FS)
+    ref = t.angle(y[1:] * t.conj(y[:-1]))
+    # the device reference against the oracle (numpy, float64) on a window in the middle of the stream
+    w0, W = run.n // 2 + 777, 4096
+    h0 = w0 - (NTAPS - 1)
+    xs = run.x[h0:w0 + W].cpu().numpy().astype(np.float32)
+    yo = O.lfilter_fir(run.taps, O.nco((xs[:, 0] + 1j * xs[:, 1]).astype(np.complex64), F_OFF, FS, h0), None)[NTAPS - 1:]
+    ao, _ = O.fm_demod(yo, None)
+    assert np.max(np.abs(y[w0:w0 + W].cpu().numpy() - yo)) < 1e-9 * np.max(np.abs(yo))
+    assert np.max(np.abs(np.angle(np.exp(1j * (ref[w0:w0 + W - 1].cpu().numpy() - ao))))) < 1e-9
+    del y
+    assert _wrapped_err_stats(t, run.one[:run.n - 1], ref) < TOL
 
 
 @pytest.mark.parametrize("where", ["start", "seam", "middle", "end"])
@@ -350,6 +412,28 @@ def test_oracle_windows_of_the_decimated_runs(run, decim_run, where):
         (d.name, where, np.max(err[well]), np.max(err[strong]), np.median(err))
     if where == "end":
         assert k_first - 1 + len(a_ref) == d.nout                       # the window really reaches the last output
+
+
+def test_every_decimated_output_against_a_float64_reference_on_the_device(run, decim_run):
+    """The C3 / C4 front ends at full size (k_chain_decim_b since round 6; the tile kernels under "decimp"): EVERY angle against the float64
+    evaluation on the device.  Two tiers as in the window test (the C3 filter rejects the bench tone: where the product of neighbouring
+    outputs nearly cancels, its angle amplifies the FIR's float32 error by median / |z|): 2e-5 rad where |z| >= 0.1 median, and 2e-4 where
+    |z| >= 1e-3 median -- the maximum over ALL 1.3 million C3 outputs (measured: k_chain_decim_b 1.2e-4, the tile kernels 8.0e-5; C4, whose
+    filter passes the tone: 3.7e-7 / 6.4e-7 everywhere), where the 400-output windows keep 1e-4."""
+    if run.kernel == "ab":
+        pytest.skip("the decimating kernels do not depend on the M = 1 FM kernel: run once")
+    t, d = run.torch, decim_run
+    y = _f64_fir_on_device(t, run.x, d.taps, d.f, d.fs)[::d.M].contiguous()
+    z = y[1:] * t.conj(y[:-1])
+    ref = t.angle(z)
+    mag = z.abs()
+    med = float(mag[:: max(1, mag.numel() // (1 << 20))].median())
+    del y, z
+    assert ref.numel() == d.nout
+    got = d.out[:d.nout]
+    e_well, e_strong = _wrapped_err_stats(t, got, ref, mag >= 0.1 * med), _wrapped_err_stats(t, got, ref, mag >= 1e-3 * med)
+    print("full-size %s: max wrapped error %.3g rad where |z| >= 0.1 median, %.3g where |z| >= 1e-3 median, %d outputs" % (d.name, e_well, e_strong, d.nout))
+    assert e_well < 2e-5 and e_strong < 2e-4, (d.name, e_well, e_strong)
 
 
 def test_complex_output_flavour_at_full_size(run):
