@@ -466,9 +466,28 @@ def side_configs(eng, steps=10, only_decim=False):
         e1.record()
         eng.sync()
         ms = e0.elapsed_time(e1) / (10 * steps)
-        res.append({"config": name + ", 2^26 samples, one chunk", "kernel": KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?"),
-                    "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
-                    "bytes_per_sample": bps, "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)})
+        kname = KERNEL_NAMES.get(lib.dd_chain_last_kernel(h), "?")
+        entry = {"config": name + ", 2^26 samples, one chunk", "kernel": kname,
+                 "ms_per_pass": round(ms, 4), "GS_per_s": round(n / ms / 1e6, 1),
+                 "bytes_per_sample": bps, "frac_of_8TBs": round(n * bps / (ms * 1e-3) / 8e12, 4)}
+        # which bound, from the records under profiles/ (not measured in this run)
+        try:
+            pw = json.load(open(os.path.join(ROOT, "profiles", "power.json"))).get("kernels", {}).get(kname + (":u8" if bps == 6.0 else ":cx"))
+        except Exception:
+            pw = None
+        if bps == 6.0:
+            entry["bound"] = {"name": "package power (and the arithmetic itself)", "power": pw,
+                              "ms_floor_at_the_1400W_cap": pw.get("ms_floor_at_the_cap") if pw else None,
+                              "ms_arithmetic_only": [0.0887, 0.0932],
+                              "note": "6 B per sample: a third of the HBM rate the FM flavour needs, so memory does not bind; the running sums alone take 0.089-0.093 ms "
+                                      "(tools/ubench/cosfir_arith.hip, profiles/r05_cosfir_ubench.txt) and the launch draws the board's cap: its dynamic energy over "
+                                      "(1400 W - idle) is the floor quoted here (profiles/power.json) -- the measured time is within ~5 % of it"}
+        else:
+            entry["bound"] = {"name": "HBM, 1 : 1 read : write", "power": pw, "copy_ceiling_TBs": 5.61,
+                              "frac_of_copy_ceiling": round(n * bps / (ms * 1e-3) / 5.61e12, 3),
+                              "note": "16 B per sample (8 in, 8 out): a float4 copy kernel reaches 5.61 TB/s of read + written bytes on this part (profiles/r04_stream_2to1.txt, "
+                                      "first rows; the guide: 6.29); the clock stays at its maximum and the package below the cap (profiles/power.json)"}
+        res.append(entry)
         lib.dd_chain_destroy(h)
         del out
     # SURVEY 8(d) defines two C2 inputs: B (FM tone + noise, the headline above) and A, what source.py:117-118 hands out on a dead
@@ -759,6 +778,26 @@ def side_c4_end_to_end(dur=60.0):
             "iq_samples": int(src.length), "crude_sync_ms": round(crude, 3), "accurate_sync_ms": round(accurate, 3),
             "total_ms": round(crude + accurate, 3), "syncs": [runs[0][2], runs[0][3]], "accurate_windows": runs[0][4],
             "GS_per_s": round(src.length / (crude + accurate) / 1e6, 2)}
+    # what bounds the two calls.  Not measured in this run: byte counts per kernel from profiles/r04_side_traffic.txt (PMC), arithmetic
+    # from the stage definitions, launches from profiles/r05_bench_kernel_stats.csv.
+    nwin = runs[0][4]
+    hbm_mb_per_win = 24.3        # fetched + written by the nine kernels of a batch / windows of the batch (1452 MB per 59.75 windows)
+    f32_mflop_per_win = 288.0    # the zero-phase blackmanHarris(151) pre-filter at IQ rate: 2 passes x (118 152 + 6 x 151) samples x 151 taps x 8 flop
+    f64_mflop_per_win = 60.0     # Hilbert envelope as one 2^18-point float64 cyclic convolution (2 transforms x 5 N log2 N) + Hamming-492 filtfilt (cosine form) + prefix sums
+    t_hbm = nwin * hbm_mb_per_win * 1e6 / 8e12 * 1e3
+    t_f32 = nwin * f32_mflop_per_win * 1e6 / 157.3e12 * 1e3
+    t_f64 = nwin * f64_mflop_per_win * 1e6 / 78.6e12 * 1e3     # (78.6 TF: AMD's public FP64 vector figure for MI355X; MI355X_MICROARCH.md lists none)
+    t_mix = t_f32 + t_hbm * (1.0 - 190.0 / 1452.0)            # the two pre-filter passes are arithmetic bound, the other seven kernels memory bound
+    warm["bound"] = {
+        "accurate_sync": {"windows": nwin, "launches": 9 * ((runs[0][2] + 63) // 64 + (runs[0][3] + 63) // 64),
+                          "hbm_bytes": int(nwin * hbm_mb_per_win * 1e6), "f32_flop": int(nwin * f32_mflop_per_win * 1e6), "f64_flop": int(nwin * f64_mflop_per_win * 1e6),
+                          "ms_at_8TBs": round(t_hbm, 3), "ms_at_157TF_f32": round(t_f32, 3), "ms_at_78.6TF_f64": round(t_f64, 3),
+                          "ms_sum_of_per_kernel_bounds": round(t_mix, 3), "measured_over_bound": round(accurate / t_mix, 2)},
+        "crude_sync": {"front_end_ms_alone": 0.066, "note": "the decimating front end from raw u8 (k_chain_decim_b, issue bound: extra.side C4 raw_u8_one_chunk) is a "
+                       "tenth of the call; the rest is ~25 float64 launches of 5-50 us over 3.6 M audio samples (envelope in 240 000-sample blocks, two "
+                       "normalised correlations, radix select, candidate scan) and one host synchronisation: launch- and latency-bound at ~2 us per "
+                       "dependent kernel boundary (MI355X_MICROARCH.md, price list 'boundary'), no byte or flop bound within a factor of five"},
+        "source": "profiles/r04_side_traffic.txt (bytes per kernel, PMC), profiles/r05_bench_kernel_stats.csv (launches), DESIGN.md 4.5; not measured in this run"}
     # the reference decodes one file per process (main.py:208-270): the FIRST call of a fresh process is the call.  A child process
     # (started, never exec'ed into) loads the same recording from a scratch file and times its first crude + accurate sync.
     cold = {"config": "C4 end to end 60 s, FIRST call of a fresh process (recording on the host: upload, code objects, tables and plans included)"}

@@ -436,7 +436,7 @@ static int64_t largest_prime_factor(int64_t n) {
 }
 // the chirp-z route pays when the library would run Bluestein itself (radices up to 17 are native) and few bins are kept
 static bool czt_wanted(int64_t n, int64_t num) {
-    static const char* env = getenv("DD_RESAMPLE_CZT");    // tools / tests: 0 = never, 1 = whenever downsampling
+    static const char* env = DD_TUNE_ENV("DD_RESAMPLE_CZT");    // tools / tests: 0 = never, 1 = whenever downsampling
     if (env && atoi(env) == 0) return false;
     if (!(num < n && n >= 256)) return false;
     if (env && atoi(env) == 1) return true;
@@ -569,7 +569,7 @@ static int resample_czt_batch(const void* in, int in_is_f32, const int64_t* in_o
     // convolution length: the smaller of the next 2^a and 3.2^a (measured for config 3, need 86 199, ms per 16 chunks: 98 304 =
     // 3.2^15 0.103, 131 072 0.112, 114 688 = 7.2^14 0.116, 86 400 = the smallest 7-smooth multiple of 16 0.140, 90 112 = 11.2^13
     // 0.147: the library's power-of-two passes beat less data).  DD_CZT_LEN=<n> (tools) forces a length
-    static const char* lenv = getenv("DD_CZT_LEN");
+    static const char* lenv = DD_TUNE_ENV("DD_CZT_LEN");
     const char* oenv = getenv("DD_CZT_OWN");                // tools / tests: 0 = the library's transforms at any length
     int64_t L = 1;
     while (L < nmax + K - 1) L <<= 1;
@@ -1907,7 +1907,7 @@ extern "C" int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int
     // the envelope's pre-filter is hamming(492) (decode_noaa.py:677): a two-term cosine series -- prefix-sum form
     // (dd_filtfilt_kernels.h; DD_SYNC_DIRECT_FIR=1, tools: the 492 multiply-adds per sample of the tiled direct form)
     DDCosFit fit2;
-    static const char* direct_env = getenv("DD_SYNC_DIRECT_FIR");
+    static const char* direct_env = DD_TUNE_ENV("DD_SYNC_DIRECT_FIR");
     const bool cos2 = pre_ntaps && !(direct_env && atoi(direct_env)) && dd_cos_fit_cached(pre_taps_host, pre_ntaps, &fit2) && dd_fc_ok(pre_ntaps, fit2.Q);
     double2* d_tab = (double2*)(base + o_tab);
     if (cos2) {

@@ -1043,7 +1043,7 @@ static int decim_plan(DDChainParams& P, DDDecimPlan& pl) {
                 occ_lds[u8in] = pl.lds_p;
                 occ_val[u8in] = per_cu;
             }
-            static const char* wg_env = getenv("DD_DECIM_WGS_PER_CU");            // tools: fewer persistent workgroups per CU than fit
+            static const char* wg_env = DD_TUNE_ENV("DD_DECIM_WGS_PER_CU");            // tools: fewer persistent workgroups per CU than fit
             if (wg_env && atoi(wg_env) >= 1 && atoi(wg_env) < per_cu) per_cu = atoi(wg_env);
             pl.per_cu = per_cu;
         }

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include "../../include/directdemod_hip.h"
+#include "../../include/directdemod_hip_debug.h"
 
 void dd_set_error(const char* fmt, ...);
 int dd_seam_poll_all(void);         // (dd_chain.hip) chunk-list launches whose in-launch hand-over timed out: DD_OK or DD_ERR_TIMEOUT
@@ -33,6 +34,18 @@ int dd_seam_poll_all(void);         // (dd_chain.hip) chunk-list launches whose 
 #define DD_LAUNCH_CHECK() DD_HIP_CHECK(hipGetLastError())
 
 static inline hipStream_t dd_stream(void* s) { return (hipStream_t)s; }
+
+// Tuning knobs whose sweeps are finished and recorded (tools/README.md names each with its record under profiles/): the product library
+// holds the chosen values as constants and reads none of them from the environment; a -DDD_TUNING build (tools/mkvariant.sh N <unit>
+// -DDD_TUNING, loaded through DD_LIB_PATH) reads them again for a new sweep.  What the product still reads: DD_LIB_PATH (Python side),
+// DD_MFMA_KERNEL (seeds dd_debug_select_kernel once), the route switches the test suite compares (DD_SYNC_HILBERT, DD_SYNC_FRONT,
+// DD_SYNC_BATCH, DD_CZT_OWN, DD_AM_HILBERT), the host-side time stamps DD_CRUDE_TRACE / DD_SYNC_TRACE, DD_POOL_BYTES / DD_RESIDENT_BYTES.
+#ifdef DD_TUNING
+#include <stdlib.h>
+#define DD_TUNE_ENV(name) getenv(name)
+#else
+#define DD_TUNE_ENV(name) ((const char*)nullptr)
+#endif
 
 // Grow-only scratch buffer per (device, stream) for an entry point's intermediates.  An entry point takes the lock,
 // enqueues its copies and kernels on that stream and drops the lock when it returns: the buffer is then protected by

@@ -981,12 +981,12 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     const bool cx = !(P.flags & DD_CHAIN_FM);
     // rows start where `out` starts a line: 16 angles = 64 bytes, 16 complex outputs = 128
     const int a16 = (int)((reinterpret_cast<uintptr_t>(P.out) >> (cx ? 3 : 2)) & 15);
-    static const char* wg_env = getenv("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
+    static const char* wg_env = DD_TUNE_ENV("DD_COS_WGS_PER_CU");            // tools: occupancy experiments
     int grid;
     cos1k_plan(P.L, P.s, a16, dd_cu_count(), wg_env ? atoi(wg_env) : 2, &A.base, &A.nrows, &grid, &A.nwaves);
-    static const char* run_env = getenv("DD_COS_RUN");                 // tools: rows per run of the moving-window map (0 = one run per wave)
+    static const char* run_env = DD_TUNE_ENV("DD_COS_RUN");                 // tools: rows per run of the moving-window map (0 = one run per wave)
     A.run_rows = run_env ? atoi(run_env) : -1;
-    static const char* grid_env = getenv("DD_COS_GRID");               // tools: a fixed number of workgroups
+    static const char* grid_env = DD_TUNE_ENV("DD_COS_GRID");               // tools: a fixed number of workgroups
     if (grid_env && atoi(grid_env) > 0 && (int64_t)atoi(grid_env) * C1_WAVES <= A.nrows) { grid = atoi(grid_env); A.nwaves = grid * C1_WAVES; }
     // runs of 8 rows dealt to the waves in turn once every wave gets at least two of them: the device then walks one moving window of
     // nwaves x 64 KB instead of nwaves streams far apart (memory side alone 5.64 -> 6.05 TB/s, the kernel 0.1455 -> 0.1417 ms in one call,

@@ -1267,7 +1267,7 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     const bool u8 = (P.flags & DD_CHAIN_U8_INPUT) != 0, nco = (P.flags & DD_CHAIN_NCO) != 0, fm = (P.flags & DD_CHAIN_FM) != 0;
     DWPlan pl;
     decimw_plan(P.abs0, P.Ld, P.K, P.M, P.off, dd_cu_count(), pl);
-    static const char* run_env = getenv("DD_DECIMW_RUN");              // tools: rows per run
+    static const char* run_env = DD_TUNE_ENV("DD_DECIMW_RUN");              // tools: rows per run
     if (run_env && atoi(run_env) > 0) {
         pl.run_rows = atoi(run_env);
         pl.nruns = (pl.nrows + pl.run_rows - 1) / pl.run_rows;

@@ -1091,7 +1091,7 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * frac;
         // theta in (-pi, pi]; small -> subtracted from the angle, else applied as a rotation of every product
         const long double th = a > 3.14159265358979323846264338327950288L ? a - 2.0L * 3.14159265358979323846264338327950288L : a;
-        static const char* rot_env = getenv("DD_FFT_ROTATE");          // tools: force the rotation form
+        static const char* rot_env = DD_TUNE_ENV("DD_FFT_ROTATE");          // tools: force the rotation form
         if (fabsl(th) <= 0.25L && th != 0.0L && !(rot_env && atoi(rot_env))) {
             T1.theta_sub = (float)th;
             T1.crot = make_float2((float)cosl(a), (float)-sinl(a));     // (the full-range angle path rotates by it instead)
@@ -1102,7 +1102,7 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     }
     // the block grid is laid so that block b's first angle, out[768 b + base - s], starts a 64-byte line of `out`
     // (DD_FFT_FRAME=0, tools: the grid starts at output 0 whatever the alignment, as before round 4)
-    static const char* frame_env = getenv("DD_FFT_FRAME");
+    static const char* frame_env = DD_TUNE_ENV("DD_FFT_FRAME");
     const bool cxout = !(P.flags & DD_CHAIN_FM);
     {
         const long double frac = nco ? (long double)P.cyc / 18446744073709551616.0L : 0.0L;
@@ -1115,8 +1115,8 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     }
     // float32 angles: 16 per 64-byte line; complex64 outputs: 8 per line (and no demod_fm shift)
     const int a16 = cxout ? (int)((reinterpret_cast<uintptr_t>(P.out) >> 3) & 7) : (int)((reinterpret_cast<uintptr_t>(P.out) >> 2) & 15);
-    static const char* wg_env1 = getenv("DD_FFT_WGS_PER_CU");           // tools: occupancy experiments
-    static const char* rounds_env = getenv("DD_FFT_ROUNDS");            // tools: a fixed number of rounds (1 = round 3's map)
+    static const char* wg_env1 = DD_TUNE_ENV("DD_FFT_WGS_PER_CU");           // tools: occupancy experiments
+    static const char* rounds_env = DD_TUNE_ENV("DD_FFT_ROUNDS");            // tools: a fixed number of rounds (1 = round 3's map)
     DDFft1kPlan pl;
     fft1k_plan(P.L, P.s, (frame_env && atoi(frame_env) == 0) ? P.s : a16, dd_cu_count(), wg_env1 ? atoi(wg_env1) : 3, rounds_env ? atoi(rounds_env) : 0, &pl);
     T1.base = pl.base;

@@ -716,7 +716,7 @@ static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 6 * IIR_M
 static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int ncomp, int carry, hipStream_t s) {
     const int S = h->n - 1;
     int lb = n >= IIR_LONG_FROM ? IIR_LB_LONG : IIR_LB_SHORT;
-    if (const char* e = getenv("DD_IIR_LB")) lb = atoi(e) == IIR_LB_LONG ? IIR_LB_LONG : IIR_LB_SHORT;      // A/B switch
+    if (const char* e = DD_TUNE_ENV("DD_IIR_LB")) lb = atoi(e) == IIR_LB_LONG ? IIR_LB_LONG : IIR_LB_SHORT;      // A/B switch
     // block start states: blocks -> groups of G1 -> (if there are many groups) super-groups of G2 -> one short serial sweep
     const int64_t nb = (n + lb - 1) / lb, ng = (nb + IIR_G1 - 1) / IIR_G1;
     const bool three = ng > 2 * IIR_G2;
@@ -746,7 +746,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     iir_coef(h, &C);
     const unsigned gb = (unsigned)((nb * ncomp + 255) / 256);
     // LDS-staged block kernels need 16-byte aligned buffers (always true for whole device arrays)
-    const bool staged = !(((uintptr_t)in | (uintptr_t)out) & 15) && !getenv("DD_IIR_UNSTAGED");
+    const bool staged = !(((uintptr_t)in | (uintptr_t)out) & 15) && !DD_TUNE_ENV("DD_IIR_UNSTAGED");
     const unsigned gbt = (unsigned)((nb + 256 / ncomp - 1) / (256 / ncomp));
     const size_t lds_t = sizeof(double) * 2 * (256 / ncomp) * iir_lds_row(ncomp);
 #define DD_IIR_BLOCKS(SS, WR, SAVE)                                                                                  \
@@ -767,7 +767,7 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         default: break;                                                                                              \
     }
     // complex128 input: the one-wave LDS-DMA form (DD_IIR_WAVE=0 keeps the 256-thread staged kernels: A/B switch)
-    static const bool wave_env = !(getenv("DD_IIR_WAVE") && atoi(getenv("DD_IIR_WAVE")) == 0);
+    static const bool wave_env = !(DD_TUNE_ENV("DD_IIR_WAVE") && atoi(DD_TUNE_ENV("DD_IIR_WAVE")) == 0);
     const bool wave = staged && ncomp == 2 && wave_env && (lb % IIR_W_CH) == 0;
     const unsigned gbw = (unsigned)((nb + IIR_W_BLOCKS - 1) / IIR_W_BLOCKS);
     const size_t lds_w = (size_t)IIR_W_NB * IIR_W_BUF;

@@ -1027,7 +1027,9 @@ static std::atomic<int> g_kernel_sel{DD_KSEL_UNREAD};
 static int kernel_sel_parse(const char* name) {
     if (!name || !*name || strcmp(name, "auto") == 0) return DD_KSEL_AUTO;
     if (strcmp(name, "ab") == 0) return DD_KSEL_AB;
-    if (strcmp(name, "ws") == 0) return DD_KSEL_WS;
+#ifdef DD_WITH_WS
+    if (strcmp(name, "ws") == 0) return DD_KSEL_WS;            // round 1's y-buffer kernel: only in a -DDD_WITH_WS build (tools/mkvariant.sh)
+#endif
     if (strcmp(name, "fft1k") == 0) return DD_KSEL_FFT1K;
     if (strcmp(name, "cos1k") == 0) return DD_KSEL_COS1K;
     if (strcmp(name, "decimp") == 0) return DD_KSEL_DECIMP;      // M > 1: the tile kernels of rounds 1-4 instead of k_chain_decim_w (M = 1: as "auto")
@@ -1046,7 +1048,8 @@ int dd_kernel_sel_decimp(void) { return kernel_sel() == DD_KSEL_DECIMP ? 1 : 0; 
 extern "C" int dd_debug_select_kernel(const char* name) {
     const int c = kernel_sel_parse(name);
     if (c < 0) {
-        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, ws, fft1k, cos1k, decimp)", name);
+        dd_set_error("dd_debug_select_kernel: unknown kernel '%s' (auto, ab, fft1k, cos1k, decimp; \"ws\" -- k_chain_mfma_ws, round 1 -- is not in the "
+                     "product library since round 6: build a variant with -DDD_WITH_WS)", name);
         return DD_ERR_INVALID;
     }
     g_kernel_sel.store(c, std::memory_order_relaxed);
@@ -1060,10 +1063,12 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     const size_t lds_ws = (size_t)WsGeom<NKS>::LDS_BYTES;
     static DDOncePerDevice attr_set;
     if (attr_set.need()) {
+#ifdef DD_WITH_WS
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+#endif
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_edge<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
@@ -1071,8 +1076,10 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
         DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<NKS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<NKS>::LDS_BYTES));
         if (NKS == 18) {                                    // the instantiations with the in-kernel stamps (DD_STAMPS, tools only)
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ab<18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeom<18>::LDS_BYTES));
+#ifdef DD_WITH_WS
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
             DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_chain_mfma_ws<18, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<18>::LDS_BYTES));
+#endif
         }
         attr_set.mark();
     }
@@ -1083,7 +1090,7 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
     static unsigned long long* stamp_buf = nullptr;
     // DD_STAMPS=<k>: per-wave stage stamps, printed for the k-th launch (k <= 3 -> the 4th: a cold GPU;
     // a few hundred -> the clock the chip holds under sustained load)
-    static const char* stamps_env = getenv("DD_STAMPS");
+    static const char* stamps_env = DD_TUNE_ENV("DD_STAMPS");
     static const int stamps_at = stamps_env ? (atoi(stamps_env) > 3 ? atoi(stamps_env) : 3) : -1;
     static int launches = 0;
     const bool want_stamps_env = stamps_env != nullptr && launches++ == stamps_at;
@@ -1157,8 +1164,14 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
         int grid = (n_int + 3) / 4 < cus ? (n_int + 3) / 4 : cus;
         const bool cx = !(P.flags & DD_CHAIN_FM);
         const dim3 g(grid + n_edge), b(WS_THREADS);
-        // the two-matrix-set kernel (dd_mfma_ab.h); DD_MFMA_KERNEL=ws keeps the y-buffer kernel (A/B runs)
+        // the two-matrix-set kernel (dd_mfma_ab.h).  (k_chain_mfma_ws, round 1's y-buffer kernel, was reachable through
+        // dd_debug_select_kernel("ws") only: since round 6 it is compiled in -DDD_WITH_WS builds alone -- VERDICT r5 item 8)
+#ifdef DD_WITH_WS
         const bool use_ab = !ws_env;
+#else
+        const bool use_ab = true;
+        (void)ws_env; (void)lds_ws;
+#endif
         const size_t lds_ab = (size_t)AbGeom<NKS>::LDS_BYTES;
         if (use_ab) {
             if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ab<NKS, true, true>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
@@ -1167,13 +1180,16 @@ static int mfma_launch_t(DDMfmaState* st, DDChainParams& P, hipStream_t s, int* 
             else if (NKS == 18 && t.stamps)                  // DD_STAMPS (tools): the instantiation with the in-kernel stamps compiled in
                 hipLaunchKernelGGL((k_chain_mfma_ab<18, false, false, true>), g, b, (size_t)AbGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
             else hipLaunchKernelGGL((k_chain_mfma_ab<NKS, false, false>), g, b, lds_ab, s, P, t, t_first, t_last, grid);
-        } else
+        }
+#ifdef DD_WITH_WS
+        else
         if (u8in && cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (u8in) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, true, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else if (NKS == 18 && t.stamps && cx) hipLaunchKernelGGL((k_chain_mfma_ws<18, false, true, true>), g, b, (size_t)WsGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
         else if (NKS == 18 && t.stamps) hipLaunchKernelGGL((k_chain_mfma_ws<18, false, false, true>), g, b, (size_t)WsGeom<18>::LDS_BYTES, s, P, t, t_first, t_last, grid);
         else if (cx) hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, true>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
         else hipLaunchKernelGGL((k_chain_mfma_ws<NKS, false, false>), g, b, lds_ws, s, P, t, t_first, t_last, grid);
+#endif
         DD_LAUNCH_CHECK();
         if (kernel_id) *kernel_id = use_ab ? DD_KERNEL_MFMA_AB : DD_KERNEL_MFMA_WS;
         if (want_stamps) {

@@ -13,10 +13,22 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "directdemod_hip.h")).read()
+def _symbols_of(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _header_symbols():
+    """the public boundary (directdemod_hip.h) plus the diagnostic entry points (directdemod_hip_debug.h, round 6)"""
+    return sorted(set(_symbols_of("directdemod_hip.h")) | set(_symbols_of("directdemod_hip_debug.h")))
+
+
+def test_public_header_holds_no_diagnostic_entry_points():
+    """dd_debug_* live in include/directdemod_hip_debug.h -- the public header is the drop-in boundary only."""
+    pub, dbg = _symbols_of("directdemod_hip.h"), _symbols_of("directdemod_hip_debug.h")
+    assert not [s for s in pub if s.startswith("dd_debug_")]
+    assert dbg and all(s.startswith("dd_debug_") for s in dbg) and len(dbg) >= 8
 
 
 @pytest.fixture(scope="module")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Shader clock and package power (rocm-smi / amd-smi, read-only) sampled while one kernel runs in a loop:
-   KERNEL=fft1k|ab  [LIB=build/variants/lib_N.so]  python tools/debug/clock_power.py"""
+   KERNEL=fft1k|ab|cos1k  [FLAVOUR=u8|cx]  [LIB=build/variants/lib_N.so]  python tools/debug/clock_power.py
+   (FLAVOUR, round 6: the headline chain from raw u8 pairs / with complex64 output instead of angles)"""
 import ctypes as C, os, subprocess, sys, threading, time
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,10 +19,14 @@ x = bench.make_input(torch, n, 0, dev, 3)
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 taps = np.ascontiguousarray(0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(255) / 254))
 os.environ["DD_MFMA_KERNEL"] = os.environ.get("KERNEL", "fft1k")
-out = torch.zeros(n, dtype=torch.float32, device=dev)
+flavour = os.environ.get("FLAVOUR", "")
+flags = _hip.DD_CHAIN_NCO | (0 if flavour == "cx" else _hip.DD_CHAIN_FM)
+if flavour == "u8":
+    x = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
+    flags |= _hip.DD_CHAIN_U8_INPUT
+out = torch.zeros(2 * n if flavour == "cx" else n, dtype=torch.float32, device=dev)
 h = C.c_void_p()
-_hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, _hip.cycles_q64(25000.0, 2400000), 1,
-                               _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM), "create")
+_hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), 255, _hip.cycles_q64(25000.0, 2400000), 1, flags), "create")
 got = C.c_int64(0)
 samples = []
 stop = False

@@ -15,8 +15,9 @@ if not git:
 res = {"method": "rocm-smi --showclocks --showpower every 0.2 s while the kernel loops for 4 s over 2^26 resident samples (tools/debug/clock_power.py); "
                  "dynamic energy = (package power - idle) x time per launch; at the cap a launch cannot take less than dynamic energy / (cap - idle)",
        "idle_W": IDLE_W, "cap_W": CAP_W, "kernels": {}}
-for sel, name in (("cos1k", "k_chain_cos1k"), ("fft1k", "k_chain_fft1k"), ("ab", "k_chain_mfma_ab")):
-    env = dict(os.environ, KERNEL=sel, DUR="4")
+for sel, name, flav in (("cos1k", "k_chain_cos1k", ""), ("fft1k", "k_chain_fft1k", ""), ("ab", "k_chain_mfma_ab", ""),
+                        ("cos1k", "k_chain_cos1k:u8", "u8"), ("cos1k", "k_chain_cos1k:cx", "cx")):        # (round 6: the raw-u8 and complex64-output flavours)
+    env = dict(os.environ, KERNEL=sel, DUR="4", FLAVOUR=flav)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug", "clock_power.py")], capture_output=True, text=True, env=env)
     ms = re.search(r"= ([\d.]+) ms per launch", r.stdout)
     sc, pw = [], []
