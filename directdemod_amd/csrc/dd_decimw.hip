@@ -1218,6 +1218,10 @@ static void decimw_plan(int64_t abs0, int64_t Ld, int K, int M, int off, int ncu
     const int per_wave = (pl.nrows + slots - 1) / slots;
     const int nr = (per_wave + 7) / 8;
     pl.run_rows = nr > 0 ? (per_wave + nr - 1) / nr : 1;
+    // (a run pays for the row before it: with one row per run -- chunks of up to 2^22 samples -- every wave stages and sums two rows to emit
+    //  one.  Two rows per run on half the waves: the sixteen 2^22-sample launches of the C3 chunk loop 0.209 -> 0.189 ms, same call;
+    //  profiles/r06_decimb_notes.txt)
+    if (pl.run_rows < 2 && pl.nrows >= 2) pl.run_rows = 2;
     if (pl.run_rows < 1) pl.run_rows = 1;
     pl.nruns = (pl.nrows + pl.run_rows - 1) / pl.run_rows;
     pl.nwaves = pl.nruns < slots ? pl.nruns : slots;
