@@ -544,13 +544,19 @@ def side_iir_iq(eng, steps=5):
     n = eng.n
     f = filters.butter(2048000, 20000.0, storeState=False)
     src = _hip.DevArray(n, np.complex64, ptr=eng.xin.data_ptr())      # (a view of the bench's resident input: nothing is copied)
+    # (the 1 GiB output is the buffer pool's whole default budget: with anything else parked there it is hipMalloc'ed and hipFree'd on every
+    #  pass -- 30 ms of allocator, seen in one round-6 record -- so the pool is emptied first and only one output is alive at a time)
+    _hip.pool_trim(0)
     y = f.applyOn(src)
     _hip.sync()
+    del y
     t0 = time.perf_counter()
     for _ in range(steps):
         y = f.applyOn(src)
+        del y
     _hip.sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    y = None
     alg = 24.0 * n                                            # 8 B read (complex64) + 16 B written (complex128) per sample
     del y
     return {"config": "filters.butter(2 048 000, 20 000), order 6, over 2^26 complex64 IQ samples (decode_funcube.py:160 shape), complex128 out, through the class",

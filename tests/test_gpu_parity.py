@@ -779,6 +779,38 @@ def test_decimw_kernel_shapes_cuts_and_u8(dd, M, K, fm_on, u8):
         assert np.array_equal(run(np.array([0, L])).view(np.uint32), one.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,K", [(34, 151), (50, 127), (32, 151), (16, 33)])
+def test_a_non_finite_sample_reaches_its_own_outputs_only(dd, M, K):
+    """where does a NaN input sample show?  The reference's lfilter limits it to the outputs whose K-tap window holds it.
+    k_chain_decim_b multiplies a block's samples with zero taps beyond K - 1 (0 x NaN), so the sample reaches the ceil(K / M) outputs whose
+    BLOCKS hold it -- never fewer than the reference's, at most one more -- and nothing else: no gap cell, halo or carried sum spreads it
+    (the padded image's gaps are never read; M = 32 and 16 run the padded image, 16 two passes per row).  Complex64 output, one chunk."""
+    import ctypes as C
+    hip = dd.hip
+    lib = hip.lib()
+    fs, L = 2048000, 40000
+    x = O.grid_c64(O.synth_iq_fm(L, fs, 777 + M, f_carrier=30000.0, f_mod=900.0, dev=3.0)).copy()
+    pos = 20011
+    x[pos] = np.nan + 0j
+    taps = np.ascontiguousarray(O.firwin_lowpass(K, 0.45 / M))
+    h = C.c_void_p()
+    hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), K, hip.cycles_q64(30000.0, fs), M, hip.DD_CHAIN_NCO))
+    src = hip.DevArray.from_host(x, dtype=np.complex64)
+    no = lib.dd_chain_out_count(h, L)
+    o = hip.DevArray(no, np.complex64)
+    got = C.c_int64(0)
+    hip.check(lib.dd_chain_process(h, src.ptr, o.ptr, L, C.byref(got), None))
+    assert lib.dd_chain_last_kernel(h) == hip.DD_KERNEL_DECIM_BLOCKS
+    lib.dd_chain_destroy(h)
+    y = o.to_host()[:got.value]
+    bad = np.nonzero(~np.isfinite(y))[0]
+    kept = np.arange(0, L, M)
+    ref_bad = np.nonzero((kept >= pos) & (kept - (K - 1) <= pos))[0]          # the reference: outputs whose window [n - K + 1, n] holds the sample
+    NI = -(-K // M)
+    assert len(ref_bad) <= len(bad) <= NI and set(ref_bad) <= set(bad), (list(bad), list(ref_bad))
+    assert bad.min() == ref_bad.min() and bad.max() - bad.min() == len(bad) - 1 and bad.max() <= ref_bad.max() + 1
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_decimw_kernel_fuzz(dd, seed):
     """seeded random shapes of k_chain_decim_w: even decimation 8..64 (plain and padded LDS images), 2..256 taps, NCO on / off (a chain without

@@ -44,34 +44,47 @@ for kern, u8 in (("cos1k", False), ("cos1k", True), ("fft1k", False), ("fft1k", 
     print("%s%s: 3000 launches, bit-identical output (checksum %d), %.1f s" % (kern, " (u8 input)" if u8 else "", ref[0], time.time() - t0))
     del x, out
 PY
-timeout 120 python - <<'PY'
+timeout 400 python - <<'PY'
+# round 6: k_chain_decim_b (block sums on the matrix pipe; hand-placed LDS waits) -- the C4 and C3 shapes from complex64 and from raw u8, 3000 launches each: the WHOLE
+# output must be bit-identical from launch to launch (a read that is waited for one instruction too late would show as a changing checksum)
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
-import torch
-from directdemod_amd import _hip, shard
+import torch, scipy.signal as ss
+from directdemod_amd import _hip
 import bench
 _hip.require_gpu()
+lib = _hip.lib()
 dev = torch.device("cuda", 0)
 n = 1 << 26
-x = bench.make_input(torch, n, 0, dev, 7)
-out = torch.empty(n, dtype=torch.float32, device=dev)
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+x = bench.make_input(torch, n, 0, dev, 7)
+x8 = (x + 127.5).round().clamp(0, 255).to(torch.uint8).contiguous()
 k = np.arange(151)
 bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * k / 150) + 0.14128 * np.cos(4 * np.pi * k / 150) - 0.01168 * np.cos(6 * np.pi * k / 150)
-eng = shard.HipChainEngine(bh, 30000.0, 2048000, 34, stream=stream)
-ref = None
-t0 = time.time()
-for i in range(5000):
-    _hip.lib().dd_chain_reset(eng.h, stream)
-    eng.process(x.data_ptr(), out.data_ptr(), n)
-    if i % 1000 == 0:
-        torch.cuda.synchronize()
-        s = float(out[:1000000].double().sum())
-        assert ref is None or s == ref, (i, s, ref)
-        ref = s
-torch.cuda.synchronize()
-print("decimating chain (BH151 /34: k_chain_decim_w) 5000 launches ok, checksum stable, %.1f s" % (time.time() - t0))
+rz = ss.remez(127, [0, 100e3, 150e3, 4999999], [1, 0], fs=1e7)
+for name, taps, M, f, fs in (("C4 BH151 /34", bh, 34, 30000.0, 2048000), ("C3 remez127 /50", rz, 50, 250000.0, 10000000)):
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    for u8 in (False, True):
+        h = C.c_void_p()
+        _hip.check(lib.dd_chain_create(C.byref(h), taps.ctypes.data_as(C.POINTER(C.c_double)), len(taps), _hip.cycles_q64(f, fs), M,
+                                       _hip.DD_CHAIN_NCO | _hip.DD_CHAIN_FM | (_hip.DD_CHAIN_U8_INPUT if u8 else 0)), "create")
+        out = torch.zeros(n // M + 8, dtype=torch.float32, device=dev)
+        src = x8 if u8 else x
+        got = C.c_int64(0)
+        ref = None
+        t0 = time.time()
+        for i in range(3001):
+            lib.dd_chain_reset(h, stream)
+            _hip.check(lib.dd_chain_process(h, src.data_ptr(), out.data_ptr(), n, C.byref(got), stream), "process")
+            if i % 250 == 0:
+                torch.cuda.synchronize()
+                assert lib.dd_chain_last_kernel(h) == _hip.DD_KERNEL_DECIM_BLOCKS
+                sm = (int(out[:got.value].view(torch.int32).to(torch.int64).sum()), int((out[:got.value].view(torch.int32).to(torch.int64) * torch.arange(got.value, device=dev) % 1000003).sum()))
+                assert ref is None or sm == ref, (name, u8, i, sm, ref)
+                ref = sm
+        lib.dd_chain_destroy(h)
+        print("%s%s (k_chain_decim_b): 3000 launches, bit-identical output (checksums %d, %d), %.1f s" % (name, " from raw u8" if u8 else "", ref[0], ref[1], time.time() - t0))
 PY
 timeout 300 python - <<'PY'
 # the chunk-list launch (k_chain_decim_w: the list as one chunk on the absolute sample grid; DD_MFMA_KERNEL=decimp: k_chain_decim_multi, carried state
