@@ -811,7 +811,7 @@ def test_a_non_finite_sample_reaches_its_own_outputs_only(dd, M, K):
     assert bad.min() == ref_bad.min() and bad.max() - bad.min() == len(bad) - 1 and bad.max() <= ref_bad.max() + 1
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(40))
 def test_decimw_kernel_fuzz(dd, seed):
     """seeded random shapes of k_chain_decim_w: even decimation 8..64 (plain and padded LDS images), 2..256 taps, NCO on / off (a chain without
     NCO counts every chunk from zero: the decimation phase, and with it the window alignment, then changes from chunk to chunk), FM or complex64
