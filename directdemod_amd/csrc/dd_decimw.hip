@@ -234,55 +234,19 @@ __device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, con
 // the same through guarded sample-by-sample loads, loads jlo .. 15
 template <bool NCO, bool PAD, bool U8 = false>
 __device__ __forceinline__ void dw_stage_guarded(const DDDecimWArgs& A, float2* buf, const float2* gl, int lane, int jlo, int64_t Brel, const DWPh& pw, const DWMap& mp) {
-    // Four loads' worth of samples at a time, every global load of the batch issued before any of them is looked at: the sample and the history
-    // entry of EVERY position on clamped indices (sixteen loads in flight), the choice between them afterwards.  (Written sample by sample --
-    // `if (n < 0) history else if (n < L) sample` -- each position is a dependent round trip: the row before a chunk's first run was eight of
-    // them on one wave, ~10 us that set the duration of a whole 2^22-sample launch; profiles/r06_decimb_notes.txt.)  Same values as
-    // dw_sample: history entries as they are, samples rotated with the same two roundings, zeros outside both.
-    const int64_t Lm1 = A.L > 0 ? A.L - 1 : 0;
-    const int Km2 = A.K - 2;                                           // (K >= 2: the history has K - 1 >= 1 entries)
-    for (int j0 = jlo; j0 < DW_NL; j0 += 4) {
-        v2f raw[4][2], hist[4][2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            if (j < DW_NL) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int64_t n = Brel + 128 * j + 2 * lane + c;
-                    const int64_t ni = n < 0 ? 0 : (n > Lm1 ? Lm1 : n);
-                    int64_t ti = n + (A.K - 1);
-                    ti = ti < 0 ? 0 : (ti > Km2 ? Km2 : ti);
-                    if (U8) {
-                        const uchar2 b = A.L > 0 ? reinterpret_cast<const uchar2*>(A.in)[ni] : make_uchar2(0, 0);
-                        raw[u][c] = (v2f){(float)b.x - 127.5f, (float)b.y - 127.5f};
-                    } else {
-                        raw[u][c] = A.L > 0 ? dw_v2(reinterpret_cast<const float2*>(A.in)[ni]) : (v2f){0.f, 0.f};
-                    }
-                    hist[u][c] = dw_v2(A.tail_in[ti]);
-                }
-            }
+    // (round 6: a version that issues a batch's loads on clamped indices before looking at any of them -- no dependent round trip per position --
+    //  changed nothing in a chunk loop's time and made the INTERIOR rows of the two-accumulator-set kernels 2-7 % slower by what it did to the
+    //  register allocation of the whole kernel: C4 0.0901 -> 0.0920, raw u8 0.0601 -> 0.0644 ms, same call; profiles/r06_decimb_notes.txt.  Not kept.)
+    for (int j = jlo; j < DW_NL; ++j) {
+        v2f pj = (v2f){1.f, 0.f}, pj1 = (v2f){1.f, 0.f};
+        if (NCO) {
+            const v2f g = dw_v2(gl[2 * j + (lane >> 5)]);
+            pj = dw_cmul(pw.w[0], g);
+            pj1 = dw_cmul(pw.w[1], g);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            if (j < DW_NL) {
-                v2f ph[2] = {(v2f){1.f, 0.f}, (v2f){1.f, 0.f}};
-                if (NCO) {
-                    const v2f g = dw_v2(gl[2 * j + (lane >> 5)]);
-                    ph[0] = dw_cmul(pw.w[0], g);
-                    ph[1] = dw_cmul(pw.w[1], g);
-                }
-                v2f x[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int64_t n = Brel + 128 * j + 2 * lane + c;
-                    const v2f rot = NCO ? dw_cmul(raw[u][c], ph[c]) : raw[u][c];
-                    x[c] = n < 0 ? (n + (A.K - 1) >= 0 ? hist[u][c] : (v2f){0.f, 0.f}) : (n >= A.L ? (v2f){0.f, 0.f} : rot);
-                }
-                *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, A.HP + 128 * j + 2 * lane)) = (v4f){x[0].x, x[0].y, x[1].x, x[1].y};
-            }
-        }
+        const int64_t n = Brel + 128 * j + 2 * lane;
+        const v2f x0 = dw_sample<U8, NCO>(A, n, pj), x1 = dw_sample<U8, NCO>(A, n + 1, pj1);
+        *reinterpret_cast<v4f*>(buf + dw_pos<PAD>(mp, A.HP + 128 * j + 2 * lane)) = (v4f){x0.x, x0.y, x1.x, x1.y};
     }
 }
 
@@ -860,6 +824,7 @@ __device__ __forceinline__ void dw_bsums(const DDDecimWArgs& A, const float2* __
     // every step requests a later one without asking whether the block has it (reads past the block's end -- two steps at most -- stay inside
     // the image and are never used): one wait per step, the same on every path.  Two accumulator sets: a step's 32 products cover the LDS
     // latency, the next step's reads are enough (32 registers); one set: the step after next (48)
+    // (two sets with the step after next requested as well: the same times, same call -- 0.0904 / 0.0969 / 0.0649 against 0.0905 / 0.0969 / 0.0646)
     if constexpr (NG == 2) {
         DWOct<PAD>& b0 = pre.b0;
         DWOct<PAD>& b1 = pre.b1;
