@@ -203,7 +203,10 @@ __device__ __forceinline__ void dw_stage(const DDDecimWArgs& A, float2* buf, con
         for (int jj = 0; jj < NJ; ++jj) g[jj] = dw_v2(gl[2 * (J0 + jj) + (lane >> 5)]);
     }
     // four loads = eight samples at a time: their phasors (pw.w x g) in step, then the rotations in step, then the four 16-byte writes
-    constexpr int NB = NJ < 4 ? NJ : 4;
+#ifndef DW_STAGE_NB
+#define DW_STAGE_NB 4
+#endif
+    constexpr int NB = NJ < DW_STAGE_NB ? NJ : DW_STAGE_NB;
     static_assert(NJ % NB == 0, "loads per staging batch");
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += NB) {
@@ -273,7 +276,7 @@ __device__ __forceinline__ void dw_stage4(const DDDecimWArgs& A, float2* buf, co
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) g[jj] = dw_v2(gl[2 * (J0 + jj) + (lane >> 5)]);
     }
-    constexpr int NB = NJ < 4 ? NJ : 4;
+    constexpr int NB = NJ < DW_STAGE_NB ? NJ : DW_STAGE_NB;
     static_assert(NJ % NB == 0, "loads per staging batch");
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += NB) {
