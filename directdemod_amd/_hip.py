@@ -65,6 +65,7 @@ SIGNATURES = {
     "dd_set_device": (_int, [_int]),
     "dd_get_device": (_int, [C.POINTER(_int)]),
     "dd_copy_warmup": (_int, []),
+    "dd_code_warmup": (_int, []),
     "dd_device_name": (_int, [C.c_char_p, _int]),
     "dd_malloc": (_int, [_pp, _sz]),
     "dd_free": (_int, [_p]),
@@ -143,7 +144,7 @@ SIGNATURES = {
     "dd_noaa_sync_windows_multi": (_int, [_p, _int, _pi64, C.POINTER(_int), _int, _i64, C.c_uint64, C.POINTER(C.c_double), _int,
                                           C.POINTER(C.c_double), _int, C.POINTER(C.c_double), _int, _int, C.c_double,
                                           _pi64, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
-    "dd_noaa_prepare": (_int, [_i64, _i64, _p]),
+    "dd_noaa_prepare": (_int, [_i64, _i64, _i64, _p]),
     "dd_noaa_crude_tail": (_int, [_p, _int, _i64, C.c_double, _i64, C.POINTER(C.c_double), _int, _int, _p,
                                   _pi64, _int, C.POINTER(_int), _p]),
     "dd_afsk_binary_filter_f64": (_int, [_p, _i64, C.POINTER(C.c_double), _int, _p, _p]),
@@ -248,6 +249,7 @@ def require_gpu():
 
 
 _warm = None
+_warm_copy_done = threading.Event()
 
 
 def current_device():
@@ -284,8 +286,13 @@ def _start_copy_warmup():
         try:
             if lib().dd_set_device(dev) == DD_OK:
                 lib().dd_copy_warmup()
+                _warm_copy_done.set()
+                if not os.environ.get("DD_NO_CODE_WARMUP"):
+                    lib().dd_code_warmup()      # (the code objects: 1-4 ms per translation unit that the first launches would pay)
         except Exception:
             pass
+        finally:
+            _warm_copy_done.set()
     # (not a daemon: an interpreter that exits right away waits the few milliseconds this takes instead of tearing the HIP runtime
     #  down under a thread that is inside it)
     _warm = threading.Thread(target=run, name="dd-copy-warmup", daemon=False)
@@ -293,8 +300,9 @@ def _start_copy_warmup():
 
 
 def wait_copy_warmup():
+    """until the warm-up thread's copies are done (its code-object loads may still be running)"""
     if _warm is not None and _warm.is_alive():
-        _warm.join()
+        _warm_copy_done.wait()
 
 
 def device_name():

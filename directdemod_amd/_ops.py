@@ -133,10 +133,11 @@ def find_peaks(cor, samp_rate, needle_len, max_peaks=None):
     return np.array(buf[:n.value], dtype=np.int64)
 
 
-def noaa_prepare(n_audio, block=60000 * 4):
-    """what crude_tail will need for n_audio samples, built ahead (dd_noaa_prepare); errors are left to crude_tail itself"""
+def noaa_prepare(n_audio, block=60000 * 4, window=0):
+    """what crude_tail will need for n_audio samples and the accurate-sync windows for `window` IQ samples each, built ahead
+    (dd_noaa_prepare); errors are left to the calls themselves"""
     try:
-        lib().dd_noaa_prepare(int(n_audio), int(block), None)
+        lib().dd_noaa_prepare(int(n_audio), int(block), int(window), None)
     except Exception:
         pass
 

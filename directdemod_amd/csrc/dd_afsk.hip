@@ -75,3 +75,9 @@ extern "C" int dd_afsk_edges_f64(const double* binary_filter, int64_t n, int spb
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_afsk(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_afsk_binary) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

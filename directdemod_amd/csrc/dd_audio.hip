@@ -157,3 +157,9 @@ void dd_audio_forget_stream(hipStream_t s) {
 #include "dd_audio_xcorr.h"         // X1, X2   dd_xcorr_norm_f64, dd_find_peaks_f64
 #include "dd_audio_sync.h"          // 8f-2  dd_noaa_sync_windows(_multi), dd_noaa_prepare
 #include "dd_audio_crude.h"         // P     dd_noaa_crude_tail
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_audio(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_cvt_f32_f64) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

@@ -356,14 +356,15 @@ static void host_fft_pow2(std::vector<std::complex<double>>& v) {
     }
 }
 // the spectrum of a real kernel image of length M (divided by M): the M/2 + 1 bins the library's real transforms multiply, and -- for the
-// lengths of dd_hconv_kernels.h -- once more behind them in the order its row pass reads (out[N2 k1 + k2] = bin k1 + 512 k2).  One allocation.
-static int kernel_spectrum_upload(const std::vector<double>& img, int64_t M, double2** out, hipStream_t s) {
+// lengths of dd_hconv_kernels.h -- once more behind them in the order its row pass reads (out[N2 k1 + k2] = bin k1 + 512 k2).  Host part:
+// no device call (dd_noaa_prepare runs it while the runtime is still busy with the process's first copy).
+static void kernel_spectrum_host(const std::vector<double>& img, int64_t M, std::vector<double2>& h) {
     std::vector<std::complex<double>> v((size_t)M);
     for (int64_t i = 0; i < M; ++i) v[(size_t)i] = std::complex<double>(img[(size_t)i], 0.0);
     host_fft_pow2(v);
     const int64_t nb = M / 2 + 1;
     const bool own = hc_length_ok(M);
-    std::vector<double2> h((size_t)(nb + (own ? M : 0)));
+    h.resize((size_t)(nb + (own ? M : 0)));
     const double sc = 1.0 / (double)M;
     for (int64_t k = 0; k < nb; ++k) h[(size_t)k] = make_double2(v[(size_t)k].real() * sc, v[(size_t)k].imag() * sc);
     if (own) {
@@ -373,10 +374,13 @@ static int kernel_spectrum_upload(const std::vector<double>& img, int64_t M, dou
             h[(size_t)(nb + i)] = make_double2(v[(size_t)k].real() * sc, v[(size_t)k].imag() * sc);
         }
     }
+}
+// device part: one allocation, one copy
+static int kernel_spectrum_put(const std::vector<double2>& h, double2** out, hipStream_t s) {
     double2* HH = nullptr;
     DD_HIP_CHECK(hipMalloc((void**)&HH, sizeof(double2) * h.size()));
     hipError_t e = hipMemcpyAsync(HH, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);                          // (the staging vector dies with this call)
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                          // (the staging vector dies with the caller)
     if (e != hipSuccess) { (void)hipFree(HH); dd_set_error("Hilbert kernel spectrum: %s", hipGetErrorString(e)); return DD_ERR_HIP; }
     *out = HH;
     return DD_OK;
@@ -392,18 +396,40 @@ static void hilb_cache_put(std::pair<int, int64_t> key, double2* HH) {
     }
     g_hilb[key] = HH;
 }
+// The spectra on the HOST, kept for the life of the process (at most eight, 3-8 MB each).  Two reasons: dd_noaa_prepare builds them ahead
+// without a device call (its thread runs beside the runtime's first copy and the recording's upload; the call that needs one uploads it,
+// 0.3 ms), and a pageable staging vector of a megabyte or more must not be FREED after its copy: the runtime pins such a source in place, and
+// returning pinned pages to the system (free -> munmap of a large block) stalled the next device operation of the process by 25-40 ms
+// (tools/debug/cold_c4_trace.py: the upload of the second spectrum after the first one's vector had died, in the thread that did it or in
+// any other).  Own mutex: prepare fills it without g_sync_mu, the other callers hold g_sync_mu.
+static std::mutex g_hilb_host_mu;
+static std::map<std::pair<int, int64_t>, std::vector<double2>*> g_hilb_host;
+static const std::vector<double2>* hilb_host_find(std::pair<int, int64_t> key) {
+    std::lock_guard<std::mutex> lk(g_hilb_host_mu);
+    auto it = g_hilb_host.find(key);
+    return it == g_hilb_host.end() ? nullptr : it->second;
+}
+static const std::vector<double2>* hilb_host_keep(std::pair<int, int64_t> key, std::vector<double2>& h) {
+    std::lock_guard<std::mutex> lk(g_hilb_host_mu);
+    auto it = g_hilb_host.find(key);
+    if (it != g_hilb_host.end()) return it->second;               // (another thread was first: its copy stays, ours is dropped unused -- never pinned)
+    if (g_hilb_host.size() >= 8) return nullptr;                  // (a process walking through many lengths: the ninth and later are not kept)
+    std::vector<double2>* p = new std::vector<double2>();
+    p->swap(h);
+    g_hilb_host[key] = p;
+    return p;
+}
+static int lg_of(int64_t M) {
+    int lgM = 0;
+    while (((int64_t)1 << lgM) < M) ++lgM;
+    return lgM;
+}
 
 // hh[n] = imag(ifft(h))[n] = (2/N) sum_{k=1..m} sin(2 pi k n / N), m = the number of doubled bins of scipy's mask
 // ((N-1)/2 for odd N, N/2 - 1 for even N) = (2/N) sin(pi m n/N) sin(pi (m+1) n/N) / sin(pi n/N): a closed form, so no
 // length-N (Bluestein) plan is ever built for it; accurate to a few 1e-17 (checked against a long-double sum).
-static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    int lgM = 0;
-    while (((int64_t)1 << lgM) < M) ++lgM;
-    auto key = std::make_pair(dev, (n << 6) | lgM);            // (length and cyclic length)
-    auto it = g_hilb.find(key);
-    if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
+static std::pair<int, int64_t> hilbert_kernel_key(int dev, int64_t n, int64_t M) { return std::make_pair(dev, (n << 6) | lg_of(M)); }      // (length and cyclic length)
+static void hilbert_kernel_host(int64_t n, int64_t M, std::vector<double2>& h) {
     const int64_t m = (n & 1) ? (n - 1) / 2 : n / 2 - 1;
     std::vector<double> host((size_t)M, 0.0);                 // buf[j mod M] = hh[j mod N], j in [-(N-1), N-1]
     for (int64_t j = 1; j < n; ++j) {
@@ -411,8 +437,19 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
         host[(size_t)j] = v;
         host[(size_t)(M - n + j)] = v;
     }
+    kernel_spectrum_host(host, M, h);
+}
+static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hipStream_t s) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    const auto key = hilbert_kernel_key(dev, n, M);
+    auto it = g_hilb.find(key);
+    if (it != g_hilb.end()) { *out = it->second; return DD_OK; }
+    std::vector<double2> h;
+    const std::vector<double2>* hp = hilb_host_find(key);
+    if (!hp) { hilbert_kernel_host(n, M, h); hp = hilb_host_keep(key, h); }
     double2* HH = nullptr;
-    const int rc = kernel_spectrum_upload(host, M, &HH, s);
+    const int rc = kernel_spectrum_put(hp ? *hp : h, &HH, s);
     if (rc != DD_OK) return rc;
     hilb_cache_put(key, HH);
     *out = HH;
@@ -425,14 +462,8 @@ static int hilbert_kernel_spectrum(int64_t n, int64_t M, const double2** out, hi
 // and z = x_even + j x_odd carries both through ONE complex convolution.  decode_noaa.py:647-653 takes the envelope in blocks of 240 000
 // samples: two length-120 000 convolutions fit the cyclic length 2^18 of dd_hconv_kernels.h (>= 2 (N/2) - 1), the block itself does not
 // (it would need 2^19).  This is g's spectrum for that image -- g[j mod N/2] at lags j in [-(N/2 - 1), N/2 - 1] -- in row-pass order.
-static int hilbert_split_spectrum(int64_t N, int64_t M, const double2** out_perm, hipStream_t s) {
-    int dev = 0;
-    DD_HIP_CHECK(hipGetDevice(&dev));
-    int lgM = 0;
-    while (((int64_t)1 << lgM) < M) ++lgM;
-    auto key = std::make_pair(dev, -((N << 6) | lgM));         // (negative: the split kernel of length N, beside the full ones)
-    auto it = g_hilb.find(key);
-    if (it != g_hilb.end()) { *out_perm = it->second + (M / 2 + 1); return DD_OK; }
+static std::pair<int, int64_t> hilbert_split_key(int dev, int64_t N, int64_t M) { return std::make_pair(dev, -((N << 6) | lg_of(M))); }    // (negative: the split kernel of length N, beside the full ones)
+static void hilbert_split_host(int64_t N, int64_t M, std::vector<double2>& h) {
     const int64_t N2 = N / 2;
     std::vector<double> host((size_t)M, 0.0);
     auto g = [&](int64_t j) {                                  // (2/N) cot(pi (2j+1) / N), arguments reduced in integers
@@ -444,8 +475,19 @@ static int hilbert_split_spectrum(int64_t N, int64_t M, const double2** out_perm
         host[(size_t)j] = v;                                   // lag +j
         if (j > 0) host[(size_t)(M - N2 + j)] = v;             // lag j - N/2 (the same circular index)
     }
+    kernel_spectrum_host(host, M, h);
+}
+static int hilbert_split_spectrum(int64_t N, int64_t M, const double2** out_perm, hipStream_t s) {
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    const auto key = hilbert_split_key(dev, N, M);
+    auto it = g_hilb.find(key);
+    if (it != g_hilb.end()) { *out_perm = it->second + (M / 2 + 1); return DD_OK; }
+    std::vector<double2> h;
+    const std::vector<double2>* hp = hilb_host_find(key);
+    if (!hp) { hilbert_split_host(N, M, h); hp = hilb_host_keep(key, h); }
     double2* HH = nullptr;
-    const int rc = kernel_spectrum_upload(host, M, &HH, s);
+    const int rc = kernel_spectrum_put(hp ? *hp : h, &HH, s);
     if (rc != DD_OK) return rc;
     hilb_cache_put(key, HH);
     *out_perm = HH + (M / 2 + 1);
@@ -524,23 +566,47 @@ static int64_t hc_block_len(int64_t N, bool* split) {
 // last block (host transforms: ~20 ms) and the transform's twiddle tables -- built ahead of time.  noaa_sync calls this from a thread of
 // its own when the decoder object is created, so that it overlaps the upload of the recording and the audio chain; the result sits in the
 // cache the crude tail looks in.  Harmless when the lengths turn out different (the crude tail builds what it needs).
-extern "C" int dd_noaa_prepare(int64_t n, int64_t block, void* stream) {
-    DD_REQUIRE(n >= 1 && block >= 2, "arguments");
-    hipStream_t s = dd_stream(stream);
-    int64_t nfull = 0;
-    while ((nfull + 1) * block < n) ++nfull;
-    const int64_t rem = n - nfull * block;
-    std::lock_guard<std::mutex> lk(g_sync_mu);
-    const int64_t lens[2] = {nfull > 0 ? block : 0, rem};
-    for (int i = 0; i < 2; ++i) {
-        bool split = false;
-        const int64_t M = hc_block_len(lens[i], &split);
-        if (!M) continue;
-        const double2 *TA = nullptr, *TB = nullptr, *sp = nullptr;
-        int rc = hc_tables(M == ((int64_t)1 << 18) ? 9 : 8, &TA, &TB);
-        if (rc == DD_OK) rc = split ? hilbert_split_spectrum(lens[i], M, &sp, s) : hilbert_kernel_spectrum(lens[i], M, &sp, s);
-        if (rc != DD_OK) return rc;
+extern "C" int dd_noaa_prepare(int64_t n, int64_t block, int64_t window, void* stream) {
+    DD_REQUIRE(n >= 0 && block >= 2 && window >= 0, "arguments");
+    (void)stream;
+    static const char* tenv = getenv("DD_CRUDE_TRACE");              // tools: host-side time stamps, to stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    int dev = 0;
+    DD_HIP_CHECK(hipGetDevice(&dev));
+    struct Job { std::pair<int, int64_t> key; int64_t len, M; bool split; };
+    std::vector<Job> jobs;
+    if (n >= 1) {
+        int64_t nfull = 0;
+        while ((nfull + 1) * block < n) ++nfull;
+        const int64_t lens[2] = {nfull > 0 ? block : 0, n - nfull * block};
+        for (int i = 0; i < 2; ++i) {
+            bool split = false;
+            const int64_t M = hc_block_len(lens[i], &split);
+            if (M) jobs.push_back(Job{split ? hilbert_split_key(dev, lens[i], M) : hilbert_kernel_key(dev, lens[i], M), lens[i], M, split});
+        }
     }
+    if (window >= 4) {                                               // dd_noaa_sync_windows: L2 = window - 1 angles, cyclic length >= 2 L2 + 2
+        const int64_t L2 = window - 1;
+        int64_t M = 1;
+        while (M < 2 * L2 + 2) M <<= 1;
+        if (hc_length_ok(M)) jobs.push_back(Job{hilbert_kernel_key(dev, L2, M), L2, M, false});
+    }
+    int built = 0;
+    for (const Job& j : jobs) {
+        {
+            std::lock_guard<std::mutex> lk(g_sync_mu);
+            if (g_hilb.count(j.key)) continue;                       // on the device already
+        }
+        if (hilb_host_find(j.key)) continue;
+        // closed forms and a radix-2 transform, outside every lock, no device call: in a fresh process the runtime is still busy with its
+        // first copy (~100 ms, _hip.require_gpu's warm-up thread) and this thread beside it
+        std::vector<double2> h;
+        if (j.split) hilbert_split_host(j.len, j.M, h); else hilbert_kernel_host(j.len, j.M, h);
+        (void)hilb_host_keep(j.key, h);
+        ++built;
+    }
+    if (tenv) fprintf(stderr, "noaa prepare host us (n %ld, window %ld): %d spectra built in %ld\n", (long)n, (long)window, built,
+                      (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
     return DD_OK;
 }
 

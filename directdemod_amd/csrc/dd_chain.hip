@@ -1637,3 +1637,9 @@ extern "C" int dd_chain_prime(dd_chain* c, const void* halo_in, int64_t n_halo, 
     }
     return dd_chain_process(c, halo_in, c->scratch, n_halo, nullptr, stream);
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_chain(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_chain_dense) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

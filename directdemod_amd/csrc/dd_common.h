@@ -87,6 +87,17 @@ static inline int dd_cu_count() {
     }
     return v;
 }
+
+// one per translation unit: names one of its kernels, so that the runtime loads the unit's code object (dd_code_warmup)
+int dd_code_touch_decimw(void);
+int dd_code_touch_audio(void);
+int dd_code_touch_chain(void);
+int dd_code_touch_cosfir(void);
+int dd_code_touch_fftfir(void);
+int dd_code_touch_mfma(void);
+int dd_code_touch_fir(void);
+int dd_code_touch_afsk(void);
+
 #endif
 
 // ---------------------------------------------------------------------------

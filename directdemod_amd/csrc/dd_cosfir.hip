@@ -998,3 +998,9 @@ int dd_cos1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     DD_HIP_CHECK(hipLaunchKernel(cos1k_kernel(u8, nco, cx), g, b, kargs, C1_LDS_BYTES, stream));
     return DD_OK;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_cosfir(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_chain_cos1k<false, true, false>) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

@@ -1358,3 +1358,9 @@ int dd_decimw_launch(const DDChainParams& P, const float* taps_g0, const double*
     if (kernel_id) *kernel_id = pl.bsum ? DD_KERNEL_DECIM_BLOCKS : DD_KERNEL_DECIM_WAVE;
     return DD_OK;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_decimw(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_chain_decim_b<true, true, true, false, 2>) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

@@ -1130,3 +1130,9 @@ int dd_fft1k_launch(void* stv, const DDChainParams& P, hipStream_t stream) {
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_fftfir(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_chain_fft1k<false, false>) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

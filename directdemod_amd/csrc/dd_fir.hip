@@ -884,3 +884,9 @@ extern "C" int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int
     DD_HIP_CHECK(se);
     return DD_OK;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_fir(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_fill_f64) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

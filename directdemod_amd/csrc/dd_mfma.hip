@@ -1264,3 +1264,9 @@ int dd_mfma_launch(void* stv, const DDChainParams& Pin, hipStream_t s, int* kern
     }
     return DD_ERR_UNSUPPORTED;
 }
+
+// dd_code_warmup (dd_runtime.hip): the runtime loads a translation unit's code object when one of its kernels is first named
+int dd_code_touch_mfma(void) {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, (const void*)k_chain_mfma_edge<16>) == hipSuccess ? DD_OK : DD_ERR_HIP;
+}

@@ -211,17 +211,35 @@ extern "C" int dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* str
     if (bytes) DD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dd_stream(stream)));
     return DD_OK;
 }
-// the first host-to-device copy of a process costs ~90 ms inside the runtime whatever its size (tools/debug/first_copy.py): a 4 KB synchronous
-// copy on the CALLING thread's device, for a helper thread to make while the caller opens its recording.  Touches no stream of the
-// library and looks at no seam word (dd_stream_sync does).
+// the first host-to-device copy of a process costs ~90 ms inside the runtime whatever its size (tools/debug/first_copy.py), and the first one of
+// a megabyte or more another 7-8 ms (its other copy path; tools/debug/first_copy2.py: 1 MB 7.5 ms, the 8 MB after it 0.22 ms): a 4 KB and a 1 MB
+// synchronous copy on the CALLING thread's device, for a helper thread to make while the caller opens its recording.  Touches no stream of
+// the library and looks at no seam word (dd_stream_sync does).
 extern "C" int dd_copy_warmup(void) {
+    const size_t big = (size_t)1 << 20;
     void* d = nullptr;
-    DD_HIP_CHECK(hipMalloc(&d, 4096));
-    static const char zeros[4096] = {0};
-    hipError_t e = hipMemcpy(d, zeros, sizeof(zeros), hipMemcpyHostToDevice);
+    DD_HIP_CHECK(hipMalloc(&d, big));
+    std::vector<char> zeros(big, 0);
+    hipError_t e = hipMemcpy(d, zeros.data(), 4096, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d, zeros.data(), big, hipMemcpyHostToDevice);
     (void)hipFree(d);
     DD_HIP_CHECK(e);
     return DD_OK;
+}
+// The runtime loads the code object of a translation unit at the first launch (or query) of one of its kernels: 1-4 ms each, in the caller's
+// first call (the decimating chain's first launch 3.4 ms against 0.2, the crude tail's 2.9 against 0.6, the accurate sync's 8 against 2.5:
+// tools/debug/cold_c4_trace.py).  This names one kernel per unit -- for a helper thread to call once the copy path is up.
+extern "C" int dd_code_warmup(void) {
+    int rc = dd_code_touch_decimw();
+    if (rc == DD_OK) rc = dd_code_touch_audio();
+    if (rc == DD_OK) rc = dd_code_touch_chain();
+    if (rc == DD_OK) rc = dd_code_touch_cosfir();
+    if (rc == DD_OK) rc = dd_code_touch_fftfir();
+    if (rc == DD_OK) rc = dd_code_touch_mfma();
+    if (rc == DD_OK) rc = dd_code_touch_fir();
+    if (rc == DD_OK) rc = dd_code_touch_afsk();
+    if (rc != DD_OK) dd_set_error("dd_code_warmup: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
 }
 extern "C" int dd_stream_create(void** stream) {
     DD_REQUIRE(stream, "stream");

@@ -50,9 +50,11 @@ class noaa_sync:
         self.__syncB = None
         self.__rate = None
         self.__useful = 0
-        # the crude sync's envelope stage needs the Hilbert-kernel spectra of its block lengths (host transforms, ~20 ms): built on a
-        # thread of its own from now on, beside the upload of the recording and the audio chain (dd_noaa_prepare)
+        # the crude sync's envelope stage needs the Hilbert-kernel spectra of its block lengths and the accurate sync that of its window
+        # length (closed forms + host transforms, ~25 ms): built on a thread of its own from now on, beside the runtime's first copy, the
+        # upload of the recording and the audio chain (dd_noaa_prepare)
         self.__prep = None
+        self.__prep_acc = None
         try:
             dec = int(sigsrc.sampFreq / self.__bw)                        # bwLim(NOAA_FMBW): 34 at 2.048 MS/s
             rate1 = int(sigsrc.sampFreq / dec)
@@ -61,8 +63,12 @@ class noaa_sync:
                 if n_audio > 1:
                     import threading
                     from . import _hip
-                    self.__prep = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(n_audio,), daemon=False)   # (joined by getCrudeSync, or by the interpreter at exit)
+                    width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * sigsrc.sampFreq)      # getAccurateSync's windows (:823-825)
+                    # (two threads: getCrudeSync waits for the first only; joined there / by getAccurateSync, or by the interpreter at exit)
+                    self.__prep = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(n_audio, 60000 * 4, 0), daemon=False)
+                    self.__prep_acc = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(0, 60000 * 4, 2 * width), daemon=False)
                     self.__prep.start()
+                    self.__prep_acc.start()
         except Exception:
             self.__prep = None
 
@@ -235,6 +241,9 @@ class noaa_sync:
 
     def getAccurateSync(self, batched=True, resident=True):
         sa, sb = self.getCrudeSync()
+        if self.__prep_acc is not None:
+            self.__prep_acc.join()
+            self.__prep_acc = None
         src = self.__sigsrc
         width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * src.sampFreq)      # :823-825
         if not hasattr(src, "read_raw_u8_into"):

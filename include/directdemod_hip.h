@@ -81,9 +81,12 @@ int  dd_host_unregister(void* hptr);
 int  dd_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int  dd_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int  dd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
-/* one small synchronous host-to-device copy on the calling thread's device (the process's first copy pays ~90 ms of runtime set-up
- * whatever its size): _hip.py makes it on a helper thread when the GPU is first touched.  No reference counterpart. */
+/* a 4 KB and a 1 MB synchronous host-to-device copy on the calling thread's device (the process's first copy pays ~90 ms of runtime set-up
+ * whatever its size, its first large one another ~7 ms): _hip.py makes them on a helper thread when the GPU is first touched.  No reference counterpart. */
 int  dd_copy_warmup(void);
+/* names one kernel of every translation unit of the library, so that the runtime loads the code objects now (1-4 ms each) and not inside the
+ * caller's first launches: _hip.py calls it on the same helper thread, after dd_copy_warmup.  No reference counterpart. */
+int  dd_code_warmup(void);
 int  dd_stream_create(void** stream);
 int  dd_stream_destroy(void* stream);
 int  dd_stream_sync(void* stream);
@@ -322,11 +325,13 @@ int dd_noaa_sync_windows_multi(const void* iq, int iq_kind, const int64_t* start
                                const double* needle_host, int needle_len, int n_needles, double samp_rate,
                                int64_t* peak_host, double* height_host, double* tsync_host, void* stream);
 
-/* dd_noaa_prepare -- builds ahead of time what dd_noaa_crude_tail needs for `n` audio samples in blocks of `block` (decode_noaa.py:647-653): the
- * Hilbert-kernel spectra of the block and of the ragged last block (host transforms, ~20 ms) and the twiddle tables of the float64 transform.
- * Optional: noaa_sync calls it from a thread of its own when the decoder object is created, so that it overlaps the upload and the audio chain.
- * No reference counterpart (the reference's scipy.signal.hilbert plans nothing ahead). */
-int  dd_noaa_prepare(int64_t n, int64_t block, void* stream);
+/* dd_noaa_prepare -- builds ahead of time, ON THE HOST, what dd_noaa_crude_tail needs for `n` audio samples in blocks of `block` (0: nothing;
+ * decode_noaa.py:647-653) and what dd_noaa_sync_windows needs for windows of `window` IQ samples (0: nothing; decode_noaa.py:823-825): the
+ * Hilbert-kernel spectra of the block, of the ragged last block and of the window (closed forms and host transforms, ~12 ms each; no device call --
+ * the call that needs a spectrum uploads it, 0.3 ms).  Optional: noaa_sync calls it from threads of their own when the decoder object is created,
+ * beside the runtime's first copy, the upload and the audio chain.  `stream` is unused.  No reference counterpart (scipy.signal.hilbert plans
+ * nothing ahead). */
+int  dd_noaa_prepare(int64_t n, int64_t block, int64_t window, void* stream);
 /* P -- getCrudeSync's audio-rate tail (decode_noaa.py:781-790) in one host call: the envelope of `audio` (device float32 or
  *      float64, n samples at samp_rate) in `block`-sample blocks by the chunker rule (__getAM :631-657 -> demod_am.py:29),
  *      then for each of n_needles (1 or 2: sync A and sync B, :786 and :790) piecewise-constant needles of m samples

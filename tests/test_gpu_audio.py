@@ -147,6 +147,35 @@ def test_crude_tail_in_one_call_equals_the_staged_route(dd, noaa_inputs):
     assert len(am) == 3 * rate
 
 
+def test_noaa_prepare_builds_on_the_host_what_the_first_calls_take(dd):
+    """dd_noaa_prepare (round 6: host work only -- closed forms + a radix-2 transform per Hilbert-kernel spectrum, kept on the host; the call
+    that needs one uploads it): lengths no other test uses, prepared from a thread as noaa_sync does, then the block envelope
+    (dd_am_envelope_f64: what dd_noaa_crude_tail runs first) against the oracle's block rule (decode_noaa.py:631-657) and one accurate window against the oracle's chain."""
+    import threading
+    rng = np.random.default_rng(77)
+    block = 100002                                     # even: the split (even / odd) kernel of 2^17 points; ragged last block 23457: the plain one
+    n = 3 * block + 23457
+    width = 40001                                      # windows of 80 002 IQ samples -> 80 001 angles, cyclic length 2^18
+    th = [threading.Thread(target=dd.hip.on_callers_device(dd.ops.noaa_prepare), args=(n, block, 0)),
+          threading.Thread(target=dd.hip.on_callers_device(dd.ops.noaa_prepare), args=(0, block, 2 * width))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert dd.hip.lib().dd_noaa_prepare(n, block, 2 * width, None) == 0          # again: nothing left to build
+    a = rng.standard_normal(n)
+    env = dd.demod_am.demod_am().demod_blocks(dd.hip.DevArray.from_host(a), block)      # (the block envelope dd_noaa_crude_tail runs: same spectra)
+    ref = O.am_demod_blocks(a, block)
+    assert np.max(np.abs(env.to_host() - ref)) <= 1e-12 * np.max(ref)
+    raw = O.synth_apt_iq(0.6, 2048000, seed=9)
+    src = dd.source.IQarray(raw, 2048000)
+    ns = dd.noaa.noaa_sync(src, 30000.0)
+    st = 614400 - width
+    idx, pks, tms = ns.accurate_windows([st], 2 * width, dd.constants.NOAA_SYNCA)
+    i, h, t = O.accurate_sync_window(O.read_iq_u8(raw, st, st + 2 * width), 2048000, 30000.0, dd.constants.NOAA_SYNCA)
+    assert idx[0] == i + st and abs(pks[0] - h) < 1e-4
+
+
 def test_crude_tail_many_candidates(dd):
     """Audio without sync words (noise): the peak threshold (decode_noaa.py:723-726) lets a good part of the correlation values
     through -- more than the 24 576 candidates per needle that come back with the counters in the entry's one copy, so the rest is
