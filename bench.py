@@ -561,9 +561,10 @@ def side_iir_iq(eng, steps=5):
     del y
     return {"config": "filters.butter(2 048 000, 20 000), order 6, over 2^26 complex64 IQ samples (decode_funcube.py:160 shape), complex128 out, through the class",
             "ms_per_pass": round(ms, 3), "GS_per_s": round(n / ms / 1e6, 2), "bytes_per_sample": 24.0,
-            "roofline": side_roofline("dd_iir_f64:iq", alg, ms, note="float64 recurrence in three passes over the samples (block end states from zero, the scan of "
-                                      "the block start states, the blocks again from their true states): the passes re-read the input, so ~2.3 x the algorithmic bytes move; "
-                                      "wall clock around the class calls, host side included")}
+            "roofline": side_roofline("dd_iir_c64:iq", alg, ms, note="float64 recurrence in three passes over the samples (block end states from zero, the scan of "
+                                      "the block start states, the blocks again from their true states); round 6: the passes read the complex64 samples as they are "
+                                      "(dd_iir_c64: 8 + 8 + 16 = 32 B per sample move, 1.33 x the algorithmic bytes; 72 through the widened copy before), in 256-byte "
+                                      "pieces per block and step -- 65 536 sequential streams, ~3 TB/s; wall clock around the class calls, host side included")}
 
 
 def side_headline_kernels(eng, steps=10):

@@ -108,6 +108,7 @@ SIGNATURES = {
     "dd_iir_create": (_int, [_pp, C.POINTER(C.c_double), C.POINTER(C.c_double), _int, C.POINTER(C.c_double)]),
     "dd_iir_destroy": (_int, [_p]),
     "dd_iir_f64": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "dd_iir_c64": (_int, [_p, _p, _p, _i64, _int, _p]),
     "dd_iir_filtfilt_f64": (_int, [_p, _p, _p, _i64, _int, _p]),
     "dd_decimate": (_int, [_p, _p, _i64, _int, _int, _int, _pi64, _p]),
     "dd_fm_create": (_int, [_pp]),

@@ -494,6 +494,21 @@ __global__ void __launch_bounds__(256) k_iir_blocks_t(const double* __restrict__
 // the wire while the third is computed.  The lane walks its row exactly as before (same float64 recurrence per
 // sample); outputs overwrite the inputs in LDS and leave as 16-byte stores.  One wave: no barriers, only counted
 // waits (loads, DMAs and stores retire in order on vmcnt).
+// s_waitcnt vmcnt(n) for a wave-uniform n that is a multiple of 8 (the counter holds 63: anything above waits for 63 -- one retirement more than asked)
+__device__ __forceinline__ void iir_wait_vmcnt(int n) {
+    switch (n >> 3) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+typedef double iir_v2d __attribute__((ext_vector_type(2)));      // (a register pair an asm statement can name)
 #define IIR_W_BLOCKS 32
 #define IIR_W_CH 32
 #define IIR_W_NB 3
@@ -509,6 +524,7 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
     double z[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * 2 + c) * IIR_S + k] : 0.0;
+    if (WRITE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the states: before anything below is counted)
     const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;            // samples of this chain's block
     const int nsteps = lb / IIR_W_CH;
     // the counted waits of the write pass assume that every step issues all 16 of its (predicated) stores: true for a
@@ -534,35 +550,60 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
         // step st must have landed.  Younger than its DMAs: the DMA batches of the steps after it and (write pass) the
         // store batches of the iterations since -- 16 instructions each
         const int ahead = nsteps - 1 - st < IIR_W_NB - 1 ? nsteps - 1 - st : IIR_W_NB - 1;       // DMA batches in flight behind step st
-        if (WRITE && partial) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // fewer than 16 stores per step may have issued: nothing to count on
-        } else if (WRITE) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");             // 2 x 16 DMAs + 2 x 16 stores = 64: one more than the counter holds
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // ... and (write pass) the store batches issued since step st's DMAs were: those of the two steps before this one
+        if (WRITE && partial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fewer than 16 stores per step may have issued: nothing to count on
+        else iir_wait_vmcnt(16 * ahead + (WRITE ? 16 * (st < IIR_W_NB - 1 ? st : IIR_W_NB - 1) : 0));              // (2 x 16 DMAs + 2 x 16 stores = 64: one more than the counter holds -> 63)
         char* cur = iir_w_lds + (st % IIR_W_NB) * IIR_W_BUF;
         double* mine = reinterpret_cast<double*>(cur + (bl >> 1) * IIR_W_PAIR + (bl & 1) * (IIR_W_CH * 16)) + c;
         const int left = ilen - st * IIR_W_CH;
+        if (!partial) {                                     // (no per-sample guard where every block exists and is whole: k_iir_blocks_w32)
 #pragma unroll 1
-        for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
-            double x[8];
+            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+                double x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = mine[2 * (u0 + u)];
+                for (int u = 0; u < 8; ++u) x[u] = mine[2 * (u0 + u)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u0 + u < left) {
+                for (int u = 0; u < 8; ++u) {
                     const double y = dd_iir_step_t<S>(C, z, x[u]);
                     if (WRITE) mine[2 * (u0 + u)] = y;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = mine[2 * (u0 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u0 + u < left) {
+                        const double y = dd_iir_step_t<S>(C, z, x[u]);
+                        if (WRITE) mine[2 * (u0 + u)] = y;
+                    }
                 }
             }
         }
         if (WRITE) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // the rows hold the outputs
+#ifndef IIR_W_PLAIN_READS
+            // the rows are read back by instructions the compiler cannot see into: it puts s_waitcnt vmcnt(0) in front of every LDS read that
+            // might touch what a DMA in flight writes -- sixteen drains of the whole queue per step, each store waiting for the one before it
+            // (round 6, the ISA: profiles/r06_iir_notes.txt).  The rows of THIS step landed before the loop above read them.
+            const uint32_t rows = (uint32_t)(uintptr_t)cur + (uint32_t)lane * 16u;          // (LDS: the low 32 bits of the generic address are the byte offset)
+#pragma unroll
+            for (int r0 = 0; r0 < IIR_W_BLOCKS / 2; r0 += 4) {
+                iir_v2d v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[q]) : "v"(rows), "n"((r0 + q) * IIR_W_PAIR));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t bb = b0 + 2 * (r0 + q) + half;
+                    const int64_t idx = bb * lb + (int64_t)st * IIR_W_CH + l32;
+                    if (bb < nb && idx < n) *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+                }
+            }
+#else
 #pragma unroll
             for (int r = 0; r < IIR_W_BLOCKS / 2; ++r) {
                 const int64_t bb = b0 + 2 * r + half;
@@ -572,6 +613,121 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
                 if (bb < nb && idx < n) out[idx] = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // rows read before a later DMA overwrites them
+#endif
+        }
+    }
+    if (!WRITE) {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) blk[(b * 2 + c) * IIR_S + k] = z[k];
+        }
+    } else if (save && live && b == nb - 1) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) state[c * IIR_S + k] = z[k];
+    }
+}
+
+// The same passes for COMPLEX64 input (round 6: decode_funcube.py:160 / decode_meteorm2.py:157 low-pass the IQ stream as the source hands it
+// over -- complex64; lfilter's output is complex128).  The samples come in as they are -- half the bytes of the widened copy the class route
+// made first (8 + 16 B per sample for the copy, then 16 per pass) -- and are widened where a lane picks them up.  One DMA instruction
+// (64 lanes x 16 bytes) now carries a step of FOUR blocks: lane L brings samples 2 (L >> 2), 2 (L >> 2) + 1 of block 4 r + (L & 3), so a
+// block's 32 samples sit in 16-byte pairs 64 bytes apart in the 1 KiB chunk (chunks 64 bytes of padding apart: the rows of chunks r and r + 4
+// share banks -- two-way, on one 4-byte read per 14 float64 operations).  Outputs go through a tile of their
+// own (the rows of k_iir_blocks_w: 512 bytes per block and step) and leave as 16-byte stores.  Ring of three input buffers + the tile =
+// 42.8 KB per wave, three waves per CU.  A 16-byte-aligned 16-byte load never crosses a page: the pair that holds the last sample of an odd-length
+// input reads 8 bytes past it, inside the page of that sample, and nothing looks at them.
+#ifndef IIR_W32_NB
+#define IIR_W32_NB 3
+#endif
+#define IIR_W32_CHUNK (1024 + 64)
+#define IIR_W32_IN ((IIR_W_BLOCKS / 4) * IIR_W32_CHUNK)
+#define IIR_W32_LDS (IIR_W32_NB * IIR_W32_IN + IIR_W_BUF)
+template <int S, bool WRITE>
+__global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict__ in, double2* __restrict__ out, int64_t n, DDIirCoef C,
+                                                       double* __restrict__ blk, int64_t nb, double* __restrict__ state, int save, int lb) {
+    extern __shared__ __attribute__((aligned(16))) char iir_w_lds[];
+    char* const tile = iir_w_lds + IIR_W32_NB * IIR_W32_IN;
+    const int lane = threadIdx.x, bl = lane >> 1, c = lane & 1;
+    const int64_t b0 = (int64_t)blockIdx.x * IIR_W_BLOCKS, b = b0 + bl;
+    const bool live = b < nb;
+    double z[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * 2 + c) * IIR_S + k] : 0.0;
+    if (WRITE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the states: before anything below is counted)
+    const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;
+    const int nsteps = lb / IIR_W_CH;
+    const bool partial = (b0 + IIR_W_BLOCKS > nb) || ((b0 + IIR_W_BLOCKS) * (int64_t)lb > n);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t last_pair = (n - 1) & ~(int64_t)1;
+    auto issue = [&](int step) {
+        char* buf = iir_w_lds + (step % IIR_W32_NB) * IIR_W32_IN;
+#pragma unroll
+        for (int r = 0; r < IIR_W_BLOCKS / 4; ++r) {
+            int64_t idx = (b0 + 4 * r + (lane & 3)) * lb + (int64_t)step * IIR_W_CH + 2 * (lane >> 2);
+            idx = idx < n ? idx : last_pair;                                              // past the end: re-read, never consumed
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + idx),
+                                             (__attribute__((address_space(3))) void*)(buf + r * IIR_W32_CHUNK), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < IIR_W32_NB - 1; ++k)
+        if (k < nsteps) issue(k);
+    double* const mo = reinterpret_cast<double*>(tile + (bl >> 1) * IIR_W_PAIR + (bl & 1) * (IIR_W_CH * 16)) + c;
+    const uint32_t rows = (uint32_t)(uintptr_t)tile + (uint32_t)lane * 16u;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + IIR_W32_NB - 1 < nsteps) issue(st + IIR_W32_NB - 1);
+        // step st must have landed: younger than its DMAs are the DMA batches (8) of the steps after it and (write pass) the store batches
+        // (16) of the NB - 1 steps before this one
+        const int ahead = nsteps - 1 - st < IIR_W32_NB - 1 ? nsteps - 1 - st : IIR_W32_NB - 1;
+        if (WRITE && partial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else iir_wait_vmcnt(8 * ahead + (WRITE ? 16 * (st < IIR_W32_NB - 1 ? st : IIR_W32_NB - 1) : 0));
+        const char* cur = iir_w_lds + (st % IIR_W32_NB) * IIR_W32_IN;
+        const float* mine = reinterpret_cast<const float*>(cur + (bl >> 2) * IIR_W32_CHUNK + (bl & 3) * 16) + c;
+        const int left = ilen - st * IIR_W_CH;
+        if (!partial) {
+            // every block of this wave exists and is whole (all workgroups but the last): no per-sample guard -- a compare, an exec-mask
+            // save / restore and a branch per sample beside fifteen float64 operations, and nothing could move across them
+#pragma unroll 1
+            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = mine[16 * ((u0 + u) >> 1) + 2 * (u & 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double y = dd_iir_step_t<S>(C, z, (double)x[u]);
+                    if (WRITE) mo[2 * (u0 + u)] = y;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = mine[16 * ((u0 + u) >> 1) + 2 * (u & 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u0 + u < left) {
+                        const double y = dd_iir_step_t<S>(C, z, (double)x[u]);
+                        if (WRITE) mo[2 * (u0 + u)] = y;
+                    }
+                }
+            }
+        }
+        if (WRITE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // the tile holds the outputs
+#pragma unroll
+            for (int r0 = 0; r0 < IIR_W_BLOCKS / 2; r0 += 4) {
+                iir_v2d v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[q]) : "v"(rows), "n"((r0 + q) * IIR_W_PAIR));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t bb = b0 + 2 * (r0 + q) + half;
+                    const int64_t idx = bb * lb + (int64_t)st * IIR_W_CH + l32;
+                    if (bb < nb && idx < n) *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+                }
+            }
         }
     }
     if (!WRITE) {
@@ -713,7 +869,8 @@ static void iir_block_matrices(const dd_iir* h, int lb, double* out /* 6 * IIR_M
             }
 }
 
-static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int ncomp, int carry, hipStream_t s) {
+// in32: `in` is complex64 (ncomp == 2, buffers 16-byte aligned: the caller has checked) -- the one-wave kernels k_iir_blocks_w32
+static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int ncomp, int carry, hipStream_t s, bool in32 = false) {
     const int S = h->n - 1;
     int lb = n >= IIR_LONG_FROM ? IIR_LB_LONG : IIR_LB_SHORT;
     if (const char* e = DD_TUNE_ENV("DD_IIR_LB")) lb = atoi(e) == IIR_LB_LONG ? IIR_LB_LONG : IIR_LB_SHORT;      // A/B switch
@@ -789,7 +946,28 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         DD_IIR_BLOCKS_W(13, WR, SAVE) DD_IIR_BLOCKS_W(14, WR, SAVE) DD_IIR_BLOCKS_W(15, WR, SAVE)                           \
         default: break;                                                                                              \
     }
-    if (wave) { DD_IIR_BLOCKS_W_ALL(false, 0) }
+    // (the pass that only reads has no output tile: 26 KB per wave, six waves per CU instead of three)
+#define DD_IIR_BLOCKS_W32(SS, WR, SAVE)                                                                              \
+    case SS: {                                                                                                       \
+        const size_t lds_w32 = (WR) ? (size_t)IIR_W32_LDS : (size_t)(IIR_W32_NB * IIR_W32_IN);                         \
+        static DDOncePerDevice attr_w32;                                                                             \
+        if (attr_w32.need()) {                                                                                       \
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_iir_blocks_w32<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w32)); \
+            attr_w32.mark();                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_iir_blocks_w32<SS, WR>), dim3(gbw), dim3(64), lds_w32, s, reinterpret_cast<const float2*>(in), \
+                           reinterpret_cast<double2*>(out), n, C, blk, nb, h->state, SAVE, lb);                      \
+    } break;
+#define DD_IIR_BLOCKS_W32_ALL(WR, SAVE)                                                                              \
+    switch (S) {                                                                                                     \
+        DD_IIR_BLOCKS_W32(1, WR, SAVE) DD_IIR_BLOCKS_W32(2, WR, SAVE) DD_IIR_BLOCKS_W32(3, WR, SAVE) DD_IIR_BLOCKS_W32(4, WR, SAVE)   \
+        DD_IIR_BLOCKS_W32(5, WR, SAVE) DD_IIR_BLOCKS_W32(6, WR, SAVE) DD_IIR_BLOCKS_W32(7, WR, SAVE) DD_IIR_BLOCKS_W32(8, WR, SAVE)   \
+        DD_IIR_BLOCKS_W32(9, WR, SAVE) DD_IIR_BLOCKS_W32(10, WR, SAVE) DD_IIR_BLOCKS_W32(11, WR, SAVE) DD_IIR_BLOCKS_W32(12, WR, SAVE) \
+        DD_IIR_BLOCKS_W32(13, WR, SAVE) DD_IIR_BLOCKS_W32(14, WR, SAVE) DD_IIR_BLOCKS_W32(15, WR, SAVE)                           \
+        default: break;                                                                                              \
+    }
+    if (in32) { DD_IIR_BLOCKS_W32_ALL(false, 0) }
+    else if (wave) { DD_IIR_BLOCKS_W_ALL(false, 0) }
     else if (staged) { DD_IIR_BLOCKS_ALL(false, 0) }
     else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 0, h->state, 0, lb);
     // the state size is a compile-time constant of the scan kernels: with a run-time S the unrolled
@@ -815,9 +993,12 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
         default: break;
     }
 #undef DD_IIR_SCAN
-    if (wave) { DD_IIR_BLOCKS_W_ALL(true, carry ? 1 : 0) }
+    if (in32) { DD_IIR_BLOCKS_W32_ALL(true, carry ? 1 : 0) }
+    else if (wave) { DD_IIR_BLOCKS_W_ALL(true, carry ? 1 : 0) }
     else if (staged) { DD_IIR_BLOCKS_ALL(true, carry ? 1 : 0) }
     else hipLaunchKernelGGL(k_iir_blocks, dim3(gb), dim3(256), 0, s, in, out, n, ncomp, C, blk, nb, 1, h->state, carry ? 1 : 0, lb);
+#undef DD_IIR_BLOCKS_W32_ALL
+#undef DD_IIR_BLOCKS_W32
 #undef DD_IIR_BLOCKS_W_ALL
 #undef DD_IIR_BLOCKS_W
 #undef DD_IIR_BLOCKS_ALL
@@ -838,6 +1019,34 @@ extern "C" int dd_iir_f64(dd_iir* h, const double* in, double* out, int64_t n, i
         hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, dd_stream(stream), in, out, n, is_complex ? 2 : 1, C, h->state, 1, 0, 0);
     } else {
         hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, dd_stream(stream), in, out, n, is_complex ? 2 : 1, C, h->state, 0, 0, 1);
+    }
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// F4 on complex64 input (round 6): filters.py:75 on what the sources hand over -- decode_funcube.py:160, decode_meteorm2.py:157 low-pass the IQ
+// stream itself.  lfilter gives complex128 for complex64 input (float64 coefficients): `out` is complex128.  Long inputs: the block-parallel
+// passes read the complex64 samples as they are (k_iir_blocks_w32); short or unaligned ones are widened into `out` and filtered there in place.
+__global__ void __launch_bounds__(256) k_iir_widen_c64(const float2* __restrict__ in, double2* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float2 v = in[i]; out[i] = make_double2((double)v.x, (double)v.y); }
+}
+extern "C" int dd_iir_c64(dd_iir* h, const void* in_c64, double* out_c128, int64_t n, int carry, void* stream) {
+    DD_REQUIRE(h && n >= 0, "h/n");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(in_c64 && out_c128 && (const void*)in_c64 != (const void*)out_c128, "buffers");
+    hipStream_t s = dd_stream(stream);
+    const bool aligned = !(((uintptr_t)in_c64 | (uintptr_t)out_c128) & 15);
+    if (n >= 16 * IIR_LB_SHORT && h->n >= 2 && aligned && !DD_TUNE_ENV("DD_IIR_WIDEN"))
+        return iir_parallel(h, (const double*)in_c64, out_c128, n, 2, carry, s, true);
+    hipLaunchKernelGGL(k_iir_widen_c64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float2*)in_c64, (double2*)out_c128, n);
+    DDIirCoef C;
+    iir_coef(h, &C);
+    if (!carry) {
+        for (int k = 0; k < DD_IIR_MAXN; ++k) C.zi[k] = 0.0;
+        hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, s, out_c128, out_c128, n, 2, C, h->state, 1, 0, 0);
+    } else {
+        hipLaunchKernelGGL(k_iir_df2t, dim3(1), dim3(64), 0, s, out_c128, out_c128, n, 2, C, h->state, 0, 0, 1);
     }
     DD_LAUNCH_CHECK();
     return DD_OK;

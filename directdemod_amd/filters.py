@@ -223,6 +223,12 @@ class filter:
         return self.__iir
 
     def _apply_iir(self, d):
+        if d.dtype == _C64 and not self.__zeroPhase and self.__initOut is None:
+            # the IQ stream as the source hands it over (decode_funcube.py:160): complex64 in, complex128 out, no widened copy in between
+            h = self._iir_handle()
+            out = DevArray(d.n, np.complex128)
+            check(lib().dd_iir_c64(h, d.ptr, out.ptr, d.n, 1 if self.__storeState else 0, None), "dd_iir_c64")
+            return out
         if d.dtype == _C64:
             from .comm import _convert
             d = _convert(d, np.complex128)

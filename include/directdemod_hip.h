@@ -153,6 +153,11 @@ int dd_iir_create(dd_iir** h, const double* b, const double* a, int n, const dou
 int dd_iir_destroy(dd_iir* h);
 /* is_complex: 0 = float64, 1 = complex128 (interleaved); carry: keep the final state */
 int dd_iir_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, int carry, void* stream);
+/* the same on complex64 input, complex128 output (what scipy.signal.lfilter returns for a complex64 signal and float64 coefficients): the IQ
+ * stream as source.py hands it over, low-passed before any decimation (decode_funcube.py:160, decode_meteorm2.py:157 -> filters.py:75).  From 4096
+ * samples up the block-parallel passes read the complex64 samples as they are (8 + 8 + 16 bytes per sample move instead of 72 through a widened
+ * copy); shorter or unaligned inputs are widened into `out` and filtered there.  in_c64 != out_c128. */
+int dd_iir_c64(dd_iir* h, const void* in_c64, double* out_c128, int64_t n, int carry, void* stream);
 /* scipy.signal.filtfilt(b, a, x): odd extension 3*n, zi scaled by the first sample of each pass */
 int dd_iir_filtfilt_f64(dd_iir* h, const double* in, double* out, int64_t n, int is_complex, void* stream);
 

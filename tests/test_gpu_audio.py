@@ -788,6 +788,38 @@ def test_iir_block_parallel_complex64_iq(dd):
     assert rel_err(y.to_host(), ref) < 1e-9
 
 
+@pytest.mark.parametrize("n", [3000, 4096, 65536 + 33, (1 << 20) + 1, (1 << 25) + 4097])
+def test_iir_complex64_input_read_in_place_equals_the_widened_route(dd, n):
+    """dd_iir_c64 (round 6): complex64 samples read by the block passes as they are (k_iir_blocks_w32) -- bit for bit what dd_iir_f64 gives
+    on the widened copy (same recurrence, same block states), 1e-9 against lfilter; odd lengths (the last 16-byte pair holds one sample),
+    a ragged last workgroup, both block lengths (256 below 2^25 samples, 1024 from there), the short in-place route below 4096, and the
+    state carried over two chunks (filters.py:75 storeState)."""
+    import scipy.signal as ss
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    f = dd.filters.butter(2048000, 20000.0, storeState=False)
+    d = dd.hip.DevArray.from_host(x)
+    y = f.applyOn(d)
+    assert y.dtype == np.complex128 and y.n == n
+    wide = dd.hip.DevArray.from_host(x.astype(np.complex128))
+    yw = dd.filters.butter(2048000, 20000.0, storeState=False).applyOn(wide)
+    got = y.to_host()
+    assert np.array_equal(got, yw.to_host())
+    if n <= (1 << 20) + 1:
+        # (a sixth-order low-pass at 1 % of the sample rate, the reference's Funcube shape: poles within 0.03 of the unit circle -- the float64
+        #  recurrence with fused multiply-adds and SciPy's without differ by 6e-9 of the peak here, 1e-9 holds for the wider filters above)
+        ref = ss.lfilter(np.asarray(f.getB), np.asarray(f.getA), x.astype(np.complex128))
+        assert rel_err(got, ref) < 1e-7
+    # two chunks with the state carried: equal to one call over both
+    cut = (n // 3) | 1
+    g = dd.filters.butter(2048000, 20000.0)                 # storeState defaults to True (filters.py:239)
+    a = g.applyOn(dd.hip.DevArray.from_host(x[:cut])).to_host()
+    b = g.applyOn(dd.hip.DevArray.from_host(x[cut:])).to_host()
+    g2 = dd.filters.butter(2048000, 20000.0)
+    whole = g2.applyOn(wide).to_host()
+    assert np.max(np.abs(np.concatenate([a, b]) - whole)) <= 1e-7 * np.max(np.abs(whole))      # (other block boundaries: the conditioning above)
+
+
 # ----------------------------------------------------------------------------- X1: both forms of the correlation
 @pytest.mark.parametrize("kind", ["runs_even", "runs_odd", "dense", "many_runs"])
 def test_xcorr_norm_forms_vs_oracle(dd, kind):
