@@ -544,8 +544,8 @@ def side_iir_iq(eng, steps=5):
     n = eng.n
     f = filters.butter(2048000, 20000.0, storeState=False)
     src = _hip.DevArray(n, np.complex64, ptr=eng.xin.data_ptr())      # (a view of the bench's resident input: nothing is copied)
-    # (the 1 GiB output is the buffer pool's whole default budget: with anything else parked there it is hipMalloc'ed and hipFree'd on every
-    #  pass -- 30 ms of allocator, seen in one round-6 record -- so the pool is emptied first and only one output is alive at a time)
+    # (the 1 GiB output was the buffer pool's whole budget until round 6 -- with anything else parked there it was hipMalloc'ed and hipFree'd on
+    #  every pass, 30 ms of allocator in one record; the budget is 16 GiB now, the pool is still emptied first and one output alive at a time)
     _hip.pool_trim(0)
     y = f.applyOn(src)
     _hip.sync()

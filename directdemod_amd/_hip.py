@@ -354,8 +354,9 @@ _DT = {
 # (null stream included), recorded at free time, and whoever takes it out of the pool first waits for
 # those events -- so asynchronous work that still touches the buffer on any stream has finished before
 # a new owner's copy or kernel on another stream can overwrite it.  Without side streams the events are
-# skipped.  At most DD_POOL_BYTES (default 1 GiB) are held; DD_POOL_BYTES=0 disables the pool.
-_POOL_LIMIT = int(os.environ.get("DD_POOL_BYTES", str(1 << 30)))
+# skipped.  At most DD_POOL_BYTES are held (default 16 GiB of the part's 288 GB -- 1 GiB until round 6: two 1 GiB arrays alive in a loop, a complex128
+# copy of 2^26 samples and its filtered output, then cost a hipMalloc + hipFree of 15-30 ms on every pass); DD_POOL_BYTES=0 disables the pool.
+_POOL_LIMIT = int(os.environ.get("DD_POOL_BYTES", str(16 << 30)))
 _pool = {}
 _pool_bytes = 0
 _pool_lock = threading.Lock()

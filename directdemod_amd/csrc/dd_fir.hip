@@ -311,7 +311,9 @@ extern "C" int dd_iir_destroy(dd_iir* h) {
 #define IIR_LONG_FROM ((int64_t)1 << 25)
 #define IIR_G1 32
 #define IIR_G2 32
+#define IIR_GMAX 32             // >= IIR_G1, IIR_G2: the scan kernels hold a group's vectors in registers
 #define IIR_S (DD_IIR_MAXN - 1)
+static_assert(IIR_G1 <= IIR_GMAX && IIR_G2 <= IIR_GMAX, "the scan kernels hold a group in registers");
 #define IIR_MAT (IIR_S * IIR_S)
 
 __device__ __forceinline__ void dd_iir_step(const DDIirCoef& C, int N, double (&z)[DD_IIR_MAXN], double x, double& y) {
@@ -789,14 +791,17 @@ __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, dou
     for (int q = 0; q < S; ++q) { mh[q] = mats[rr * IIR_S + q]; ml[q] = mats[IIR_MAT + rr * IIR_S + q]; }
     double u = (phase == 2) ? grp[t * IIR_S + rr] : 0.0;
     const int64_t b0 = g * G, b1 = b0 + G < nb ? b0 + G : nb;
-    // the chain u <- M u + e is serial; the e vectors are not: the next one is fetched while this step runs
-    double e = blk[(b0 * ncomp + c) * IIR_S + rr];
-    for (int64_t b = b0; b < b1; ++b) {
-        double* slot = blk + (b * ncomp + c) * IIR_S;
-        const double en = blk[((b + 1 < b1 ? b + 1 : b) * ncomp + c) * IIR_S + rr];
-        if (phase == 2 && live && row) slot[r] = u;                    // this block's start state
-        u = dd_iir_affine_row<S>(mh, ml, u, e, base);
-        e = en;
+    // the chain u <- M u + e is serial; the e vectors are not: ALL of the group's (G <= IIR_GMAX) are requested before the first step.
+    // (Round 6: with one fetched a step ahead a step took ~0.5 us -- a memory round trip -- for ~200 cycles of arithmetic; 32 steps 16 -> 4 us.)
+    double ev[IIR_GMAX];
+#pragma unroll
+    for (int i = 0; i < IIR_GMAX; ++i) ev[i] = b0 + i < b1 ? blk[((b0 + i) * ncomp + c) * IIR_S + rr] : 0.0;
+#pragma unroll
+    for (int i = 0; i < IIR_GMAX; ++i) {
+        const bool in = b0 + i < b1;                                   // (false only in the last, short group: every lane takes every step, the result is dropped)
+        if (phase == 2 && live && row && in) blk[((b0 + i) * ncomp + c) * IIR_S + r] = u;      // this block's start state
+        const double un = dd_iir_affine_row<S>(mh, ml, u, ev[i], base);
+        u = in ? un : u;
     }
     if (phase == 0 && live && row) grp[t * IIR_S + r] = u;
 }
@@ -816,13 +821,17 @@ __global__ void __launch_bounds__(64) k_iir_group_sweep(double* __restrict__ grp
 #pragma unroll
     for (int q = 0; q < S; ++q) { mh[q] = mats[rr * IIR_S + q]; ml[q] = mats[IIR_MAT + rr * IIR_S + q]; }
     double u = zero_state ? 0.0 : state[c * IIR_S + rr];
-    double e = grp[c * IIR_S + rr];
-    for (int64_t g = 0; g < ng; ++g) {
-        double* slot = grp + (g * ncomp + c) * IIR_S;
-        const double en = grp[((g + 1 < ng ? g + 1 : g) * ncomp + c) * IIR_S + rr];
-        if (live && row) slot[r] = u;
-        u = dd_iir_affine_row<S>(mh, ml, u, e, base);
-        e = en;
+    for (int64_t g0 = 0; g0 < ng; g0 += IIR_GMAX) {                    // (the e vectors IIR_GMAX at a time, all requested before the first of their steps)
+        double ev[IIR_GMAX];
+#pragma unroll
+        for (int i = 0; i < IIR_GMAX; ++i) ev[i] = g0 + i < ng ? grp[((g0 + i) * ncomp + c) * IIR_S + rr] : 0.0;
+#pragma unroll
+        for (int i = 0; i < IIR_GMAX; ++i) {
+            if (g0 + i < ng) {                                         // (the same for every lane)
+                if (live && row) grp[((g0 + i) * ncomp + c) * IIR_S + r] = u;
+                u = dd_iir_affine_row<S>(mh, ml, u, ev[i], base);
+            }
+        }
     }
 }
 
