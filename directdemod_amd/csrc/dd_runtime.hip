@@ -219,9 +219,12 @@ extern "C" int dd_copy_warmup(void) {
     const size_t big = (size_t)1 << 20;
     void* d = nullptr;
     DD_HIP_CHECK(hipMalloc(&d, big));
-    std::vector<char> zeros(big, 0);
-    hipError_t e = hipMemcpy(d, zeros.data(), 4096, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d, zeros.data(), big, hipMemcpyHostToDevice);
+    // (kept for the life of the process: the runtime pins the source of a copy this large in place, and returning pinned pages to the system
+    //  has stalled later copies -- DESIGN.md 4.5, round 6)
+    static char* const zeros = static_cast<char*>(calloc(1, big));
+    if (!zeros) { (void)hipFree(d); dd_set_error("dd_copy_warmup: out of host memory"); return DD_ERR_NOMEM; }
+    hipError_t e = hipMemcpy(d, zeros, 4096, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d, zeros, big, hipMemcpyHostToDevice);
     (void)hipFree(d);
     DD_HIP_CHECK(e);
     return DD_OK;
