@@ -815,10 +815,13 @@ def side_c4_end_to_end(dur=60.0):
         fd, path = tempfile.mkstemp(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         os.close(fd)
         np.save(path, raw)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_noaa_cold.py"), path], capture_output=True, text=True, timeout=300)
+        # (host-side time stamps inside the library's calls, to stderr: kept in the entry so that a slow first call says where it went)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_noaa_cold.py"), path], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DD_CRUDE_TRACE="1", DD_SYNC_TRACE="1"))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
             cold.update(json.loads(line[-1]))
+            cold["host_time_stamps"] = [ln.strip() for ln in r.stderr.splitlines() if " host us" in ln][:8]
         else:
             cold["error"] = (r.stderr or r.stdout)[-400:]
     except Exception as e:
