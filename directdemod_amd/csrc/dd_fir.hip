@@ -641,14 +641,26 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
 #ifndef IIR_W32_NB
 #define IIR_W32_NB 3
 #endif
-#define IIR_W32_CHUNK (1024 + 64)
-#define IIR_W32_IN ((IIR_W_BLOCKS / 4) * IIR_W32_CHUNK)
-#define IIR_W32_LDS (IIR_W32_NB * IIR_W32_IN + IIR_W_BUF)
-template <int S, bool WRITE>
+#ifndef IIR_W32_READ_CH
+#define IIR_W32_READ_CH 64
+#endif
+// CH = samples per block and step: 32 (a DMA instruction carries a step of four blocks, 256 contiguous bytes each) or -- the pass that only
+// reads -- 64 (two blocks, 512 bytes each: the rate of these passes follows the length of the contiguous pieces, 2.9 TB/s at 256 bytes,
+// 3.9 at the 512 of the complex128 kernel; the write pass keeps 32: its output tile would double)
+template <int CH> struct IirW32 {
+    static constexpr int BPC = 128 / CH;                       // blocks per DMA instruction (64 lanes x 2 samples)
+    static constexpr int NDMA = IIR_W_BLOCKS / BPC;            // DMA instructions per step
+    static constexpr int CHUNK = 1024 + (CH == 32 ? 64 : 32);  // its kilobyte + padding (the rows of chunks a bank period apart share banks: two-way)
+    static constexpr int IN = NDMA * CHUNK;                    // one step of the wave
+};
+#define IIR_W32_LDS(CH, WR) (IIR_W32_NB * IirW32<CH>::IN + ((WR) ? IIR_W_BUF : 0))
+template <int S, bool WRITE, int CH>
 __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict__ in, double2* __restrict__ out, int64_t n, DDIirCoef C,
                                                        double* __restrict__ blk, int64_t nb, double* __restrict__ state, int save, int lb) {
+    static_assert(CH == 32 || (CH == 64 && !WRITE), "the output tile holds 32 samples per block");
+    typedef IirW32<CH> G;
     extern __shared__ __attribute__((aligned(16))) char iir_w_lds[];
-    char* const tile = iir_w_lds + IIR_W32_NB * IIR_W32_IN;
+    char* const tile = iir_w_lds + IIR_W32_NB * G::IN;
     const int lane = threadIdx.x, bl = lane >> 1, c = lane & 1;
     const int64_t b0 = (int64_t)blockIdx.x * IIR_W_BLOCKS, b = b0 + bl;
     const bool live = b < nb;
@@ -657,18 +669,18 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict_
     for (int k = 0; k < S; ++k) z[k] = (WRITE && live) ? blk[(b * 2 + c) * IIR_S + k] : 0.0;
     if (WRITE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the states: before anything below is counted)
     const int ilen = live ? (int)((n - b * lb) < lb ? (n - b * lb) : lb) : 0;
-    const int nsteps = lb / IIR_W_CH;
+    const int nsteps = lb / CH;
     const bool partial = (b0 + IIR_W_BLOCKS > nb) || ((b0 + IIR_W_BLOCKS) * (int64_t)lb > n);
     const int half = lane >> 5, l32 = lane & 31;
     const int64_t last_pair = (n - 1) & ~(int64_t)1;
     auto issue = [&](int step) {
-        char* buf = iir_w_lds + (step % IIR_W32_NB) * IIR_W32_IN;
+        char* buf = iir_w_lds + (step % IIR_W32_NB) * G::IN;
 #pragma unroll
-        for (int r = 0; r < IIR_W_BLOCKS / 4; ++r) {
-            int64_t idx = (b0 + 4 * r + (lane & 3)) * lb + (int64_t)step * IIR_W_CH + 2 * (lane >> 2);
+        for (int r = 0; r < G::NDMA; ++r) {
+            int64_t idx = (b0 + G::BPC * r + (lane & (G::BPC - 1))) * lb + (int64_t)step * CH + 2 * (lane / G::BPC);
             idx = idx < n ? idx : last_pair;                                              // past the end: re-read, never consumed
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + idx),
-                                             (__attribute__((address_space(3))) void*)(buf + r * IIR_W32_CHUNK), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(buf + r * G::CHUNK), 16, 0, 0);
         }
     };
 #pragma unroll
@@ -678,22 +690,23 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict_
     const uint32_t rows = (uint32_t)(uintptr_t)tile + (uint32_t)lane * 16u;
     for (int st = 0; st < nsteps; ++st) {
         if (st + IIR_W32_NB - 1 < nsteps) issue(st + IIR_W32_NB - 1);
-        // step st must have landed: younger than its DMAs are the DMA batches (8) of the steps after it and (write pass) the store batches
+        // step st must have landed: younger than its DMAs are the DMA batches (NDMA) of the steps after it and (write pass) the store batches
         // (16) of the NB - 1 steps before this one
         const int ahead = nsteps - 1 - st < IIR_W32_NB - 1 ? nsteps - 1 - st : IIR_W32_NB - 1;
         if (WRITE && partial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else iir_wait_vmcnt(8 * ahead + (WRITE ? 16 * (st < IIR_W32_NB - 1 ? st : IIR_W32_NB - 1) : 0));
-        const char* cur = iir_w_lds + (st % IIR_W32_NB) * IIR_W32_IN;
-        const float* mine = reinterpret_cast<const float*>(cur + (bl >> 2) * IIR_W32_CHUNK + (bl & 3) * 16) + c;
-        const int left = ilen - st * IIR_W_CH;
+        else iir_wait_vmcnt(G::NDMA * ahead + (WRITE ? 16 * (st < IIR_W32_NB - 1 ? st : IIR_W32_NB - 1) : 0));
+        const char* cur = iir_w_lds + (st % IIR_W32_NB) * G::IN;
+        const float* mine = reinterpret_cast<const float*>(cur + (bl / G::BPC) * G::CHUNK + (bl & (G::BPC - 1)) * 16) + c;
+        constexpr int PS = 4 * G::BPC;                                                    // floats from a pair of a block to its next one
+        const int left = ilen - st * CH;
         if (!partial) {
             // every block of this wave exists and is whole (all workgroups but the last): no per-sample guard -- a compare, an exec-mask
             // save / restore and a branch per sample beside fifteen float64 operations, and nothing could move across them
 #pragma unroll 1
-            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+            for (int u0 = 0; u0 < CH; u0 += 8) {
                 float x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = mine[16 * ((u0 + u) >> 1) + 2 * (u & 1)];
+                for (int u = 0; u < 8; ++u) x[u] = mine[PS * ((u0 + u) >> 1) + 2 * (u & 1)];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const double y = dd_iir_step_t<S>(C, z, (double)x[u]);
@@ -702,10 +715,10 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict_
             }
         } else {
 #pragma unroll 1
-            for (int u0 = 0; u0 < IIR_W_CH; u0 += 8) {
+            for (int u0 = 0; u0 < CH; u0 += 8) {
                 float x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = mine[16 * ((u0 + u) >> 1) + 2 * (u & 1)];
+                for (int u = 0; u < 8; ++u) x[u] = mine[PS * ((u0 + u) >> 1) + 2 * (u & 1)];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (u0 + u < left) {
@@ -958,13 +971,14 @@ static int iir_parallel(dd_iir* h, const double* in, double* out, int64_t n, int
     // (the pass that only reads has no output tile: 26 KB per wave, six waves per CU instead of three)
 #define DD_IIR_BLOCKS_W32(SS, WR, SAVE)                                                                              \
     case SS: {                                                                                                       \
-        const size_t lds_w32 = (WR) ? (size_t)IIR_W32_LDS : (size_t)(IIR_W32_NB * IIR_W32_IN);                         \
+        constexpr int CHW = (WR) ? 32 : IIR_W32_READ_CH;                                                             \
+        const size_t lds_w32 = (size_t)IIR_W32_LDS(CHW, WR);                                                         \
         static DDOncePerDevice attr_w32;                                                                             \
         if (attr_w32.need()) {                                                                                       \
-            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_iir_blocks_w32<SS, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w32)); \
+            DD_HIP_CHECK(hipFuncSetAttribute((const void*)k_iir_blocks_w32<SS, WR, CHW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w32)); \
             attr_w32.mark();                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_iir_blocks_w32<SS, WR>), dim3(gbw), dim3(64), lds_w32, s, reinterpret_cast<const float2*>(in), \
+        hipLaunchKernelGGL((k_iir_blocks_w32<SS, WR, CHW>), dim3(gbw), dim3(64), lds_w32, s, reinterpret_cast<const float2*>(in), \
                            reinterpret_cast<double2*>(out), n, C, blk, nb, h->state, SAVE, lb);                      \
     } break;
 #define DD_IIR_BLOCKS_W32_ALL(WR, SAVE)                                                                              \
