@@ -129,3 +129,5 @@ for name, bounds in (("16 x 2^22", [i << 22 for i in range(17)]), ("ragged", [0,
     lib.dd_chain_destroy(h)
     print("chunk list %s: 4000 launches, every checked output bit-identical to the chunk loop, %.1f s" % (name, time.time() - t0))
 PY
+# round 6: the IIR block passes (counted vmcnt waits around LDS-DMA steps): outputs bit-identical from launch to launch
+timeout 600 python tools/debug/iir_soak.py
