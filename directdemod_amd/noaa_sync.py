@@ -39,6 +39,9 @@ def _window_taps():
     return bh, pre
 
 
+_prepared = set()           # (device, kind, length) dd_noaa_prepare has been started for in this process
+
+
 class noaa_sync:
     '''Sync detection of a NOAA APT recording (crude @ ~60 kS/s, accurate @ IQ rate)'''
 
@@ -64,11 +67,18 @@ class noaa_sync:
                     import threading
                     from . import _hip
                     width = int(3 * constants.NOAA_T * len(constants.NOAA_SYNCA) * sigsrc.sampFreq)      # getAccurateSync's windows (:823-825)
-                    # (two threads: getCrudeSync waits for the first only; joined there / by getAccurateSync, or by the interpreter at exit)
-                    self.__prep = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(n_audio, 60000 * 4, 0), daemon=False)
-                    self.__prep_acc = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(0, 60000 * 4, 2 * width), daemon=False)
-                    self.__prep.start()
-                    self.__prep_acc.start()
+                    # (two threads: getCrudeSync waits for the first only; joined there / by getAccurateSync, or by the interpreter at exit.
+                    #  Lengths this process has prepared before -- a second decoder object on a recording of the same length -- start none:
+                    #  starting and joining a thread is 0.1 ms, more than the warm calls' own host work)
+                    dev = _hip.current_device()
+                    if (dev, "audio", n_audio) not in _prepared:
+                        _prepared.add((dev, "audio", n_audio))
+                        self.__prep = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(n_audio, 60000 * 4, 0), daemon=False)
+                        self.__prep.start()
+                    if (dev, "window", 2 * width) not in _prepared:
+                        _prepared.add((dev, "window", 2 * width))
+                        self.__prep_acc = threading.Thread(target=_hip.on_callers_device(_ops.noaa_prepare), args=(0, 60000 * 4, 2 * width), daemon=False)
+                        self.__prep_acc.start()
         except Exception:
             self.__prep = None
 
