@@ -766,13 +766,38 @@ template <int S>
 struct IirRows {
     static constexpr int RP = S <= 8 ? 8 : 16;
 };
+// every element of x[] in its register before anything after this statement starts (an empty asm that names them all as read-write operands)
+template <int S>
+__device__ __forceinline__ void iir_tie(double (&x)[S]) {
+    if constexpr (S == 1) asm volatile("" : "+v"(x[0]));
+    else if constexpr (S == 2) asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+    else if constexpr (S == 3) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+    else if constexpr (S == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else if constexpr (S == 5) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]));
+    else if constexpr (S == 6) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+    else if constexpr (S == 7) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+    else if constexpr (S == 8) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    else if constexpr (S == 9) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]));
+    else if constexpr (S == 10) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]));
+    else if constexpr (S == 11) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]));
+    else if constexpr (S == 12) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+    else if constexpr (S == 13) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]));
+    else if constexpr (S == 14) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]));
+    else if constexpr (S == 15) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]));
+}
 template <int S>
 __device__ __forceinline__ double dd_iir_affine_row(const double (&mh)[S], const double (&ml)[S], double u, double e, int base) {
 #pragma clang fp contract(off)      // error-free transformations below: no fusing of their multiplies and adds
+    // all S components first (round 6: fetched one by one inside the loop below every shuffle was followed by a wait -- S LDS round trips per
+    // step of the chain, 720 of a step's 1080 cycles)
+    double xs[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) xs[q] = __shfl(u, base + q);
+    iir_tie<S>(xs);                 // (left to itself the compiler still issues half of them one by one between the sums)
     double ah = e, al = 0.0;
 #pragma unroll
     for (int q = 0; q < S; ++q) {
-        const double x = __shfl(u, base + q);
+        const double x = xs[q];
         const double m = mh[q];
         const double p = m * x;
         const double pe = fma(m, x, -p) + ml[q] * x;                   // exact product tail + low limb
@@ -787,7 +812,7 @@ __device__ __forceinline__ double dd_iir_affine_row(const double (&mh)[S], const
 
 // phase 0: group end vectors from zero (grp[]); phase 2: block start states written over blk[]
 template <int S>
-__global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, double* __restrict__ grp, int64_t nb, int ncomp,
+__global__ void __launch_bounds__(64, 1) k_iir_groups(double* __restrict__ blk, double* __restrict__ grp, int64_t nb, int ncomp,
                                                    const double* __restrict__ mats, int phase, int G) {
     constexpr int RP = IirRows<S>::RP;
     const int64_t ng = (nb + G - 1) / G;
@@ -821,7 +846,7 @@ __global__ void __launch_bounds__(64) k_iir_groups(double* __restrict__ blk, dou
 
 // phase 1: sequential sweep over the groups (one chain per component): grp[g] <- start state of group g
 template <int S>
-__global__ void __launch_bounds__(64) k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, const double* __restrict__ mats,
+__global__ void __launch_bounds__(64, 1) k_iir_group_sweep(double* __restrict__ grp, int64_t ng, int ncomp, const double* __restrict__ mats,
                                                         const double* __restrict__ state, int zero_state) {
     constexpr int RP = IirRows<S>::RP;
     const int lane = threadIdx.x, r = lane % RP, base = lane - r;
