@@ -521,7 +521,14 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
                                                      double* __restrict__ blk, int64_t nb, double* __restrict__ state, int save, int lb) {
     extern __shared__ __attribute__((aligned(16))) char iir_w_lds[];
     const int lane = threadIdx.x, bl = lane >> 1, c = lane & 1;
+#ifndef IIR_WRITE_FORWARD
+    // the pass that writes takes the workgroups' blocks from the END of the input -- what the read pass touched last is what the memory-side cache (256 MB)
+    // still holds -- and its stores are non-temporal, so that the 16 bytes written per sample do not push the 8 still to be read out of it (round 6, same call:
+    // write pass 360 -> 327 us, the call 0.644 -> 0.591 ms; reversed alone 347 us, non-temporal alone 351 us)
+    const int64_t b0 = (int64_t)(WRITE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * IIR_W_BLOCKS, b = b0 + bl;
+#else
     const int64_t b0 = (int64_t)blockIdx.x * IIR_W_BLOCKS, b = b0 + bl;
+#endif
     const bool live = b < nb;
     double z[S];
 #pragma unroll
@@ -602,7 +609,13 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w(const double2* __restrict__
                 for (int q = 0; q < 4; ++q) {
                     const int64_t bb = b0 + 2 * (r0 + q) + half;
                     const int64_t idx = bb * lb + (int64_t)st * IIR_W_CH + l32;
-                    if (bb < nb && idx < n) *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+                    if (bb < nb && idx < n) {
+#ifndef IIR_WRITE_PLAIN
+                        __builtin_nontemporal_store(v[q], reinterpret_cast<iir_v2d*>(out + idx));
+#else
+                        *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+#endif
+                    }
                 }
             }
 #else
@@ -662,7 +675,14 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict_
     extern __shared__ __attribute__((aligned(16))) char iir_w_lds[];
     char* const tile = iir_w_lds + IIR_W32_NB * G::IN;
     const int lane = threadIdx.x, bl = lane >> 1, c = lane & 1;
+#ifndef IIR_WRITE_FORWARD
+    // the pass that writes takes the workgroups' blocks from the END of the input -- what the read pass touched last is what the memory-side cache (256 MB)
+    // still holds -- and its stores are non-temporal, so that the 16 bytes written per sample do not push the 8 still to be read out of it (round 6, same call:
+    // write pass 360 -> 327 us, the call 0.644 -> 0.591 ms; reversed alone 347 us, non-temporal alone 351 us)
+    const int64_t b0 = (int64_t)(WRITE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * IIR_W_BLOCKS, b = b0 + bl;
+#else
     const int64_t b0 = (int64_t)blockIdx.x * IIR_W_BLOCKS, b = b0 + bl;
+#endif
     const bool live = b < nb;
     double z[S];
 #pragma unroll
@@ -740,7 +760,13 @@ __global__ void __launch_bounds__(64) k_iir_blocks_w32(const float2* __restrict_
                 for (int q = 0; q < 4; ++q) {
                     const int64_t bb = b0 + 2 * (r0 + q) + half;
                     const int64_t idx = bb * lb + (int64_t)st * IIR_W_CH + l32;
-                    if (bb < nb && idx < n) *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+                    if (bb < nb && idx < n) {
+#ifndef IIR_WRITE_PLAIN
+                        __builtin_nontemporal_store(v[q], reinterpret_cast<iir_v2d*>(out + idx));
+#else
+                        *reinterpret_cast<iir_v2d*>(out + idx) = v[q];
+#endif
+                    }
                 }
             }
         }
